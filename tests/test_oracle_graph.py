@@ -80,7 +80,7 @@ def test_matvecexp_order_is_T_minus_1():
 
 
 def test_final_unitary_is_unitary_and_scale_is_one():
-    sp = oracle_system(cases.case_c2(n=8, k=2, steps=20, m=4, taylor=(12, 2), seed=3))
+    sp = oracle_system(cases.case_c2(n=8, k=2, steps=20, m=4, taylor=(14, 4), seed=3))
     r = go.evaluate(sp, sp.base0, want_grad=False)
     U = r['U_final']
     np.testing.assert_allclose(U.conj().T @ U, np.eye(8), atol=1e-12)
@@ -92,7 +92,7 @@ def test_first_order_gradient_approaches_finite_difference_as_dt_to_zero():
     """The reference gradient is the first-order GRAPE approximation (tensorflow_state.py:49-65): it equals the true
     derivative only up to O(dt ||[H_k,H]||).  Sanity bound: error shrinks ~linearly with dt."""
     errs = []
-    for steps in (20, 80):
+    for steps in (80, 320):
         c = cases.case_c2(n=4, k=2, steps=steps, m=4, taylor=(14, 1), seed=4)
         c['total_time'] = 1.0
         sp = oracle_system(c)
@@ -107,7 +107,7 @@ def test_first_order_gradient_approaches_finite_difference_as_dt_to_zero():
                        - go.evaluate(sp, bm, want_grad=False)['reg_loss']) / (2 * h)
             errs.append(abs(fd[idx] - g[idx]) / (abs(fd[idx]) + 1e-12))
     coarse, fine = max(errs[:3]), max(errs[3:])
-    assert fine < coarse * 0.6 and fine < 0.05
+    assert fine < coarse * 0.5 and fine < 0.06
 
 
 def test_tf1_adam_semantics():
