@@ -1,0 +1,152 @@
+/*
+ * qoc.h -- C ABI of the MI355X-native GRAPE engine (libqoc_hip.so).
+ *
+ * The reference (SchusterLab/quantum-optimal-control, Python + TensorFlow 1.x) has no FFI: its "operator API" is the
+ * set of tensors that core/run_session.py and core/analysis.py fetch from the TensorflowState graph.
+ * Every entry point below replaces one of those fetches / feeds; the file:line cited is the reference call site,
+ * relative to /root/reference/quantum_optimal_control/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every host buffer; the engine copies inputs to HBM at
+ *     qoc_create() and owns device memory until qoc_destroy(); outputs are written into caller buffers.
+ *   - complex arrays are C-order interleaved (re, im) float64, i.e. numpy complex128.
+ *   - all per-seed arrays have a leading n_seeds dimension (independent random-restart control sets that share the
+ *     Hamiltonians; the reference has exactly one seed per Grape() call).
+ *   - every function returns QOC_OK (0) or a negative status; qoc_last_error() gives the message (thread-local).
+ *   - a handle is not thread-safe; one HIP stream per handle; one process per GPU.
+ */
+#ifndef QOC_H
+#define QOC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QOC_OK 0
+#define QOC_ERR_INVALID (-1)   /* bad argument / unsupported configuration */
+#define QOC_ERR_HIP (-2)       /* HIP runtime error (message has the hipError string) */
+#define QOC_ERR_NOMEM (-3)
+#define QOC_ERR_STATE (-4)     /* call sequence error (e.g. adam step before any evaluation) */
+
+#define QOC_PATH_AUTO 0
+#define QOC_PATH_GENERIC 1     /* any n: workgroup-cooperative complex-fp64 products from HBM/L2 */
+#define QOC_PATH_MFMA 2        /* n <= 32, unitary mode: register-resident v_mfma_f64_16x16x4 chain kernels */
+
+typedef struct qoc_engine* qoc_handle;
+
+/* Static problem description == what SystemParameters hands to TensorflowState
+ * (core/system_parameters.py:12-86 -> core/tensorflow_state.py:13-15). */
+typedef struct qoc_config {
+    int32_t n;              /* state_num                       system_parameters.py:165 */
+    int32_t k;              /* ops_len                         system_parameters.py:202 */
+    int32_t steps;          /*                                 system_parameters.py:164 */
+    int32_t m;              /* len(states_concerned_list)      system_parameters.py:171 */
+    int32_t taylor_terms;   /* exp_terms                       system_parameters.py:226-230 */
+    int32_t scaling;        /* scaling (squarings)             system_parameters.py:226-230 */
+    int32_t state_transfer; /* 0: unitary (matexp_op chain), 1: state transfer (matvecexp_op)  tensorflow_state.py:374-383 */
+    int32_t n_seeds;        /* >= 1 */
+    double dt;              /* total_time / steps */
+    double total_time;
+    /* get_reg_loss terms (core/regularization_functions.py:7-97): presence flag + coefficient (un-normalised,
+     * the engine divides by steps as the reference does). */
+    int32_t has_amplitude, has_envelope, has_dwdt, has_d2wdt2, has_speed_up, has_bandpass;
+    double c_amplitude, c_envelope, c_dwdt, c_d2wdt2, c_speed_up, c_bandpass;
+    int32_t band_lo, band_hi;   /* band_id = (band*total_time).astype(int)   regularization_functions.py:61 */
+    int32_t n_forbidden;        /* len(forbidden_coeff_list)                 regularization_functions.py:71-85 */
+    int32_t forbid_dressed;     /* rotate inter_vecs by sort_ev(v_c)^dagger  regularization_functions.py:73-80 */
+    int32_t device;             /* HIP device ordinal */
+    int32_t path;               /* QOC_PATH_* */
+    int32_t chunks;             /* MFMA path: time chunks per seed (0 = auto) */
+    int32_t reserved[7];
+} qoc_config;
+
+/* Adam loop hyper-parameters == Convergence (core/convergence.py:16-49). */
+typedef struct qoc_adam_params {
+    double rate;                /* convergence['rate']                 default 0.01  */
+    double learning_rate_decay; /* convergence['learning_rate_decay']  default 2500   */
+    double conv_target;         /* convergence['conv_target']          default 1e-8   */
+    double min_grad;            /* convergence['min_grad']             default 1e-25  */
+    int32_t max_iterations;     /* convergence['max_iterations']       default 5000   */
+    int32_t poll_every;         /* host checks the device-side done flags every this many iterations (>=1) */
+} qoc_adam_params;
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------------
+ * qoc_create replaces TensorflowState(sys_para).build_graph() + tf.Session init
+ * (main_grape/grape.py:113-114, core/run_session.py:27-29): constants are copied to HBM once.
+ *   Hs   [(k+1)][n][n] complex : -i*dt*H0, -i*dt*Hops[k]     (matrix_list[:k+1] un-embedded, system_parameters.py:197-204)
+ *   U0   [n][n] complex        : initial unitary              (tensorflow_state.py:162); ignored in state transfer
+ *   V    [n][m] complex        : initial vectors as columns   (tensorflow_state.py:150-156)
+ *   W    [n][m] complex        : target vectors as columns, U_target*V in unitary mode (tensorflow_state.py:158-166)
+ *   maxA [k]                   : ops_max_amp                  (tensorflow_state.py:178)
+ *   one_minus_gauss [k][steps] : envelope constant            (tensorflow_state.py:146-147); may be NULL if !has_envelope
+ *   forbidden_states [n_forbidden], forbidden_coeffs [n_forbidden] (regularization_functions.py:81)
+ *   Vs   [n][n] complex        : sort_ev(v_c, dressed_id), NULL unless forbid_dressed
+ */
+int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const double* V, const double* W,
+               const double* maxA, const double* one_minus_gauss, const int32_t* forbidden_states,
+               const double* forbidden_coeffs, const double* Vs, qoc_handle* out);
+int qoc_destroy(qoc_handle h);
+
+/* ---- the trainable variable -------------------------------------------------------------------------------------
+ * ops_weight_base [n_seeds][k][steps]  (tensorflow_state.py:174; ops_weight_base.assign, run_session.py:121).
+ * qoc_set_base also resets the Adam slots and the per-seed iteration counters / done flags. */
+int qoc_set_base(qoc_handle h, const double* base);
+int qoc_get_base(qoc_handle h, double* base);
+
+/* ---- one evaluation == session.run([grad_pack, loss, reg_loss, unitary_scale, grad_squared])
+ * (run_session.py:53-54 and get_error :119-127).  Arrays are [n_seeds]; grad is [n_seeds][k][steps] =
+ * d reg_loss / d ops_weight_base with the reference's first-order GRAPE gradient (tensorflow_state.py:49-65,
+ * 100-133); any output pointer may be NULL. */
+int qoc_eval(qoc_handle h, double* loss, double* reg_loss, double* grad_squared, double* unitary_scale,
+             double* grad);
+
+/* ---- one optimizer application == session.run([optimizer], {learning_rate: lr}) (run_session.py:66-69):
+ * TF1 Adam (beta1 .9, beta2 .999, eps 1e-8 outside the bias correction) on the gradient of the last evaluation
+ * (the reference recomputes it at the same parameters, which is numerically the same).  lr is [n_seeds]. */
+int qoc_adam_step(qoc_handle h, const double* lr);
+
+/* ---- device-resident optimisation loop == run_session.start_adam_optimizer (run_session.py:47-69), per seed:
+ * evaluate; stop if loss < conv_target or grad_squared < min_grad or iterations >= max_iterations; otherwise
+ * iterations += 1, lr = rate*exp(-iterations/decay), Adam step.  Stop decisions are taken on the device per seed
+ * (finished seeds freeze); the host only polls.  iterations_out is [n_seeds] (may be NULL). */
+int qoc_run_adam(qoc_handle h, const qoc_adam_params* p, int32_t* iterations_out);
+
+/* Enqueue exactly `iters` loop iterations (same per-seed semantics as qoc_run_adam) without any host
+ * synchronisation; used by bench.py between two qoc_sync() calls. */
+int qoc_iterate(qoc_handle h, const qoc_adam_params* p, int32_t iters);
+int qoc_sync(qoc_handle h);
+
+/* Last evaluation's per-seed scalars [n_seeds] each (any pointer may be NULL). */
+int qoc_get_scalars(qoc_handle h, double* loss, double* reg_loss, double* grad_squared, double* unitary_scale,
+                    int32_t* iterations, int32_t* done);
+
+/* ---- read-back == Analysis (core/analysis.py:18-41) and run_session.Get_uks (run_session.py:112-117) ----------
+ * uks   [n_seeds][k][steps]          : maxA[k] * sin(base)
+ * Uf    [n_seeds][n][n] complex      : RtoCMat(final_state) of the last evaluation (unitary mode only)
+ * inter [n_seeds][steps+1][n][m] cplx: inter_vecs (tau = 0 is the initial vectors) of the last evaluation */
+int qoc_get_uks(qoc_handle h, double* uks);
+int qoc_get_final_unitary(qoc_handle h, double* Uf);
+int qoc_get_inter_vecs(qoc_handle h, double* inter);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------------------------
+ * With profiling enabled every launch of the dominant kernel is bracketed by hipEvents on the engine's stream.
+ * qoc_profile_read returns the number of bracketed launches and their summed duration in milliseconds. */
+int qoc_profile_enable(qoc_handle h, int32_t on);
+int qoc_profile_read(qoc_handle h, const char** kernel_name, int64_t* launches, double* total_ms);
+/* Elapsed milliseconds (hipEvents on the engine stream) around `iters` iterations, after a sync. */
+int qoc_time_iterations(qoc_handle h, const qoc_adam_params* p, int32_t iters, double* elapsed_ms);
+
+/* ---- introspection ---------------------------------------------------------------------------------------------*/
+int qoc_path_in_use(qoc_handle h);        /* QOC_PATH_GENERIC or QOC_PATH_MFMA */
+int qoc_chunks_in_use(qoc_handle h);
+int qoc_device_count(void);
+int qoc_device_info(int32_t device, char* name, int32_t name_len, int32_t* compute_units, int64_t* hbm_bytes);
+const char* qoc_last_error(void);
+const char* qoc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QOC_H */

@@ -1,0 +1,93 @@
+// qoc_common.h -- device-side problem description and complex-fp64 helpers shared by all kernels.
+// gfx950 only: no CUDA shims, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double2 cplx;   // (x = re, y = im), layout-compatible with numpy complex128
+
+__device__ __forceinline__ cplx cmake(double r, double i) { cplx c; c.x = r; c.y = i; return c; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cplx cconj(cplx a) { return cmake(a.x, -a.y); }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+// acc += a*b
+__device__ __forceinline__ void cfma(cplx& acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+}
+// acc += conj(a)*b
+__device__ __forceinline__ void cfma_conj(cplx& acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x); acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y); acc.y = fma(-a.y, b.x, acc.y);
+}
+
+#define QOC_MAX_FORBIDDEN 16
+#define QOC_BLOCK 256
+
+// Everything a kernel needs, passed by value (kernarg segment -> SGPRs).
+struct QocDev {
+    int n, k, steps, m, T, s, B;
+    int state_transfer;
+    double dt;
+    // regularisers (coefficients already divided by steps, regularization_functions.py:16,22,32,...)
+    int has_amp, has_env, has_dwdt, has_d2wdt2, has_speed, has_band;
+    double a_amp, a_env, a_dwdt, a_d2wdt2, a_speed, a_band;
+    int band_lo, band_hi;
+    int n_forb, forbid_dressed;
+    int forb_state[QOC_MAX_FORBIDDEN];
+    double forb_a[QOC_MAX_FORBIDDEN];
+    // constants in HBM
+    const cplx* Hs;      // [k+1][n][n]
+    const cplx* U0;      // [n][n]
+    const cplx* V;       // [n][m]
+    const cplx* W;       // [n][m]
+    const cplx* Psi0;    // [n][m] = U0*V (unitary mode start vector); = V in state transfer
+    const cplx* Vs;      // [n][n] or null
+    const double* maxA;  // [k]
+    const double* omg;   // [k][steps] or null
+    // trainable + optimizer state
+    double* base;        // [B][k][steps]
+    double* adam_m;
+    double* adam_v;
+    int* adam_t;         // [B]
+    int* iters;          // [B]
+    int* done;           // [B]
+    // per-evaluation intermediates
+    double* w;           // [B][k][steps] sin(base)
+    double* u;           // [B][k][steps] maxA*w
+    double* dLdu;        // [B][k][steps]
+    double* grad;        // [B][k][steps] d reg_loss / d base
+    cplx* inter;         // [B][steps+1][n][m]
+    cplx* Xfinal;        // [B][n][n]
+    cplx* ztau;          // [B][steps+1] per-time-step overlap (speed_up)
+    cplx* zfin;          // [B]
+    double* su_resid;    // [B] (steps+1 - value) of speed_up
+    double* loss;        // [B]
+    double* reg_state;   // [B]
+    double* reg_loss;    // [B]
+    double* g2;          // [B]
+    double* uscale;      // [B]
+    cplx* band_ph;       // [B][k][steps] scratch for the bandpass gradient
+};
+
+// Adam loop parameters handed to the finishing kernel.
+struct QocAdamDev {
+    int mode;            // 0: evaluation only; 1: loop iteration (decide + update on device); 2: explicit step with lr[]
+    double rate, decay, conv_target, min_grad;
+    int max_iterations;
+    const double* lr;    // mode 2
+};
+
+// Deterministic workgroup reduction (sum) of one double per thread; result valid in every thread.
+__device__ __forceinline__ double block_sum(double v, double* red /* >= QOC_BLOCK/64 + 1 doubles of LDS */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}

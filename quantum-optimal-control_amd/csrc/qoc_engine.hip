@@ -1,0 +1,521 @@
+// qoc_engine.hip -- host side of libqoc_hip.so: the C ABI of include/qoc.h over the HIP kernels.
+//
+// One engine handle == one GRAPE problem (shared Hamiltonians, n_seeds independent control sets) resident in the
+// HBM of one MI355X, one HIP stream.  One iteration is a fixed sequence of kernel launches on that stream; the
+// stop rule, learning-rate schedule and Adam update run on the device, so the host never has to synchronise
+// inside the optimisation loop (it only polls the done flags every `poll_every` iterations).
+#include "../../include/qoc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qoc_common.h"
+#include "qoc_kernels_finish.h"
+#include "qoc_kernels_generic.h"
+#include "qoc_kernels_mfma.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(QOC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                              \
+    } while (0)
+
+struct qoc_engine {
+    qoc_config cfg;
+    QocDev d;
+    int path;
+    int chunks;
+    hipStream_t stream;
+    std::vector<void*> allocs;
+    // generic path
+    cplx* K = nullptr;          // [B][steps][n][n]
+    cplx* expm_scratch = nullptr;
+    int expm_grid = 0;
+    cplx* seed_scratch = nullptr;
+    // mfma path
+    QocMfma mf;
+    bool evaluated = false;
+    // profiling of the dominant kernel
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t ev_used = 0;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+template <typename T>
+static int dev_alloc(qoc_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    if (count == 0) count = 1;
+    hipError_t err = hipMalloc(&q, count * sizeof(T));
+    if (err != hipSuccess) return fail(QOC_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(err));
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return QOC_OK;
+}
+
+template <typename T>
+static int dev_upload(qoc_engine* e, const T** p, const T* host, size_t count) {
+    T* q = nullptr;
+    int rc = dev_alloc(e, &q, count);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(q, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *p = q;
+    return QOC_OK;
+}
+
+#define TRY(expr)          \
+    do {                   \
+        int rc_ = (expr);  \
+        if (rc_) return rc_; \
+    } while (0)
+
+static int prof_begin(qoc_engine* e) {
+    if (!e->profiling) return QOC_OK;
+    if (e->ev_used + 2 > e->ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t x;
+            HIP_TRY(hipEventCreate(&x));
+            e->ev.push_back(x);
+        }
+    }
+    HIP_TRY(hipEventRecord(e->ev[e->ev_used], e->stream));
+    return QOC_OK;
+}
+static int prof_end(qoc_engine* e) {
+    if (!e->profiling) return QOC_OK;
+    HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
+    e->ev_used += 2;
+    return QOC_OK;
+}
+static int prof_collect(qoc_engine* e) {
+    if (e->ev_used == 0) return QOC_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < e->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+        e->prof_ms += ms;
+        e->prof_launches += 1;
+    }
+    e->ev_used = 0;
+    return QOC_OK;
+}
+
+// ---- one evaluation (+ optional on-device stop rule / Adam), enqueued on the engine stream ------------------------
+static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
+    const QocDev& d = e->d;
+    const int total = d.B * d.k * d.steps;
+    int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
+    if (cgrid > 2048) cgrid = 2048;
+    hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
+    if (e->path == QOC_PATH_MFMA) {
+        TRY(prof_begin(e));
+        qoc_mfma_launch_expm(e->mf, d, e->stream);
+        TRY(prof_end(e));
+        qoc_mfma_launch_forward(e->mf, d, e->stream);
+        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        qoc_mfma_launch_backward(e->mf, d, e->stream);
+    } else if (!d.state_transfer) {
+        TRY(prof_begin(e));
+        hipLaunchKernelGGL(k_expm_generic, dim3(e->expm_grid), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->expm_scratch);
+        TRY(prof_end(e));
+        hipLaunchKernelGGL(k_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->seed_scratch);
+        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        hipLaunchKernelGGL(k_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->seed_scratch);
+    } else {
+        TRY(prof_begin(e));
+        hipLaunchKernelGGL(k_st_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
+        TRY(prof_end(e));
+        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        hipLaunchKernelGGL(k_st_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
+    }
+    hipLaunchKernelGGL(k_finish, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, ap);
+    HIP_TRY(hipGetLastError());
+    e->evaluated = true;
+    return QOC_OK;
+}
+
+static QocAdamDev loop_params(const qoc_adam_params* p) {
+    QocAdamDev ap;
+    ap.mode = 1;
+    ap.rate = p->rate;
+    ap.decay = p->learning_rate_decay;
+    ap.conv_target = p->conv_target;
+    ap.min_grad = p->min_grad;
+    ap.max_iterations = p->max_iterations;
+    ap.lr = nullptr;
+    return ap;
+}
+
+extern "C" {
+
+const char* qoc_last_error(void) { return g_err.c_str(); }
+const char* qoc_version(void) { return "qoc-hip 0.1 (gfx950)"; }
+
+int qoc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int qoc_device_info(int32_t device, char* name, int32_t name_len, int32_t* compute_units, int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return QOC_OK;
+}
+
+int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const double* V, const double* W,
+               const double* maxA, const double* one_minus_gauss, const int32_t* forbidden_states,
+               const double* forbidden_coeffs, const double* Vs, qoc_handle* out) {
+    if (!cfg || !Hs || !V || !W || !maxA || !out) return fail(QOC_ERR_INVALID, "qoc_create: null argument");
+    if (cfg->n < 1 || cfg->k < 1 || cfg->steps < 1 || cfg->m < 1 || cfg->n_seeds < 1)
+        return fail(QOC_ERR_INVALID, "qoc_create: n, k, steps, m, n_seeds must be >= 1");
+    if (cfg->taylor_terms < 1 || cfg->scaling < 0 || cfg->scaling > 30)
+        return fail(QOC_ERR_INVALID, "qoc_create: bad taylor_terms/scaling (%d, %d)", cfg->taylor_terms, cfg->scaling);
+    if (!cfg->state_transfer && !U0) return fail(QOC_ERR_INVALID, "qoc_create: U0 required in unitary mode");
+    if (cfg->n_forbidden < 0 || cfg->n_forbidden > QOC_MAX_FORBIDDEN)
+        return fail(QOC_ERR_INVALID, "qoc_create: n_forbidden must be in [0, %d]", QOC_MAX_FORBIDDEN);
+    if (cfg->n_forbidden > 0 && (!forbidden_states || !forbidden_coeffs))
+        return fail(QOC_ERR_INVALID, "qoc_create: forbidden lists missing");
+    if (cfg->forbid_dressed && cfg->n_forbidden > 0 && !Vs)
+        return fail(QOC_ERR_INVALID, "qoc_create: forbid_dressed needs Vs");
+    if (cfg->has_envelope && !one_minus_gauss) return fail(QOC_ERR_INVALID, "qoc_create: envelope constant missing");
+    if (cfg->has_d2wdt2 && !cfg->has_dwdt)
+        return fail(QOC_ERR_INVALID, "qoc_create: d2wdt2 needs dwdt (reference: NameError new_weights)");
+    for (int f = 0; f < cfg->n_forbidden; ++f)
+        if (forbidden_states[f] < 0 || forbidden_states[f] >= cfg->n)
+            return fail(QOC_ERR_INVALID, "qoc_create: forbidden state %d out of range", forbidden_states[f]);
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0)
+        return fail(QOC_ERR_HIP, "qoc_create: no HIP device visible (%s) -- this engine has no CPU fallback",
+                    de == hipSuccess ? "count = 0" : hipGetErrorString(de));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(QOC_ERR_INVALID, "qoc_create: device %d of %d", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    qoc_engine* e = new qoc_engine();
+    e->cfg = *cfg;
+    QocDev& d = e->d;
+    memset(&d, 0, sizeof d);
+    const int n = cfg->n, k = cfg->k, steps = cfg->steps, m = cfg->m, B = cfg->n_seeds;
+    d.n = n; d.k = k; d.steps = steps; d.m = m; d.T = cfg->taylor_terms; d.s = cfg->state_transfer ? 0 : cfg->scaling;
+    d.B = B; d.state_transfer = cfg->state_transfer; d.dt = cfg->dt;
+    const double inv_steps = 1.0 / (double)steps;
+    d.has_amp = cfg->has_amplitude; d.a_amp = cfg->c_amplitude * inv_steps;
+    d.has_env = cfg->has_envelope; d.a_env = cfg->c_envelope * inv_steps;
+    d.has_dwdt = cfg->has_dwdt; d.a_dwdt = cfg->c_dwdt * inv_steps;
+    d.has_d2wdt2 = cfg->has_d2wdt2; d.a_d2wdt2 = cfg->c_d2wdt2 * inv_steps;
+    d.has_speed = cfg->has_speed_up; d.a_speed = cfg->c_speed_up * inv_steps;
+    d.has_band = cfg->has_bandpass; d.a_band = cfg->c_bandpass * inv_steps;
+    d.band_lo = cfg->band_lo; d.band_hi = cfg->band_hi;
+    d.n_forb = cfg->n_forbidden; d.forbid_dressed = cfg->forbid_dressed && cfg->n_forbidden > 0;
+    for (int f = 0; f < cfg->n_forbidden; ++f) {
+        d.forb_state[f] = forbidden_states[f];
+        d.forb_a[f] = forbidden_coeffs[f] * inv_steps;
+    }
+    int rc = QOC_OK;
+    auto bail = [&](int code) { qoc_destroy(e); return code; };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QOC_ERR_HIP, "hipStreamCreate failed"));
+    hipEventCreate(&e->t0);
+    hipEventCreate(&e->t1);
+
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, ks = (size_t)k * steps;
+    // U0*V on the host (tiny): start vector of the thin forward recursion
+    std::vector<double> psi0(2 * nm);
+    for (int a = 0; a < n; ++a)
+        for (int j = 0; j < m; ++j) {
+            double re = 0, im = 0;
+            if (cfg->state_transfer) {
+                re = V[2 * (a * m + j)]; im = V[2 * (a * m + j) + 1];
+            } else {
+                for (int c = 0; c < n; ++c) {
+                    const double ur = U0[2 * (a * n + c)], ui = U0[2 * (a * n + c) + 1];
+                    const double vr = V[2 * (c * m + j)], vi = V[2 * (c * m + j) + 1];
+                    re += ur * vr - ui * vi;
+                    im += ur * vi + ui * vr;
+                }
+            }
+            psi0[2 * (a * m + j)] = re; psi0[2 * (a * m + j) + 1] = im;
+        }
+    std::vector<double> ident;
+    if (!U0) {
+        ident.assign(2 * nn, 0.0);
+        for (int a = 0; a < n; ++a) ident[2 * (a * n + a)] = 1.0;
+        U0 = ident.data();
+    }
+    if ((rc = dev_upload(e, &d.Hs, (const cplx*)Hs, (size_t)(k + 1) * nn))) return bail(rc);
+    if ((rc = dev_upload(e, &d.U0, (const cplx*)U0, nn))) return bail(rc);
+    if ((rc = dev_upload(e, &d.V, (const cplx*)V, nm))) return bail(rc);
+    if ((rc = dev_upload(e, &d.W, (const cplx*)W, nm))) return bail(rc);
+    if ((rc = dev_upload(e, &d.Psi0, (const cplx*)psi0.data(), nm))) return bail(rc);
+    if (d.forbid_dressed && (rc = dev_upload(e, &d.Vs, (const cplx*)Vs, nn))) return bail(rc);
+    if ((rc = dev_upload(e, &d.maxA, maxA, (size_t)k))) return bail(rc);
+    if (one_minus_gauss && (rc = dev_upload(e, &d.omg, one_minus_gauss, ks))) return bail(rc);
+
+#define ALLOC(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
+    ALLOC(d.base, B * ks); ALLOC(d.adam_m, B * ks); ALLOC(d.adam_v, B * ks);
+    ALLOC(d.adam_t, (size_t)B); ALLOC(d.iters, (size_t)B); ALLOC(d.done, (size_t)B);
+    ALLOC(d.w, B * ks); ALLOC(d.u, B * ks); ALLOC(d.dLdu, B * ks); ALLOC(d.grad, B * ks);
+    ALLOC(d.inter, (size_t)B * (steps + 1) * nm);
+    ALLOC(d.Xfinal, (size_t)B * nn);
+    ALLOC(d.ztau, (size_t)B * (steps + 1));
+    ALLOC(d.zfin, (size_t)B); ALLOC(d.su_resid, (size_t)B);
+    ALLOC(d.loss, (size_t)B); ALLOC(d.reg_state, (size_t)B); ALLOC(d.reg_loss, (size_t)B);
+    ALLOC(d.g2, (size_t)B); ALLOC(d.uscale, (size_t)B);
+    if (d.has_band) ALLOC(d.band_ph, B * ks);
+    hipMemset(d.base, 0, B * ks * sizeof(double));
+    hipMemset(d.adam_m, 0, B * ks * sizeof(double));
+    hipMemset(d.adam_v, 0, B * ks * sizeof(double));
+    hipMemset(d.adam_t, 0, B * sizeof(int));
+    hipMemset(d.iters, 0, B * sizeof(int));
+    hipMemset(d.done, 0, B * sizeof(int));
+    hipMemset(d.su_resid, 0, B * sizeof(double));
+    hipMemset(d.uscale, 0, B * sizeof(double));
+    hipMemset(d.Xfinal, 0, (size_t)B * nn * sizeof(cplx));
+
+    // ---- path selection -----------------------------------------------------------------------------------------
+    int path = cfg->path;
+    const bool mfma_ok = qoc_mfma_supported(d);
+    if (path == QOC_PATH_AUTO) path = mfma_ok ? QOC_PATH_MFMA : QOC_PATH_GENERIC;
+    if (path == QOC_PATH_MFMA && !mfma_ok)
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 32, m <= 16, T >= 2 (n=%d m=%d)", n, m));
+    if (path != QOC_PATH_MFMA && path != QOC_PATH_GENERIC) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
+    e->path = path;
+    e->chunks = 1;
+    if (path == QOC_PATH_MFMA) {
+        std::string msg;
+        rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
+        if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
+        e->chunks = e->mf.C;
+    } else if (!cfg->state_transfer) {
+        ALLOC(e->K, (size_t)B * steps * nn);
+        int grid = B * steps;
+        if (grid > 4096) grid = 4096;
+        e->expm_grid = grid;
+        ALLOC(e->expm_scratch, (size_t)grid * 3 * nn);
+        ALLOC(e->seed_scratch, (size_t)B * (2 * nn + 2 * nm));
+    } else {
+        ALLOC(e->seed_scratch, (size_t)B * (nn + 3 * nm));
+    }
+#undef ALLOC
+    HIP_TRY(hipDeviceSynchronize());
+    *out = e;
+    return QOC_OK;
+}
+
+int qoc_destroy(qoc_handle e) {
+    if (!e) return QOC_OK;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) hipFree(p);
+    for (hipEvent_t x : e->ev) hipEventDestroy(x);
+    if (e->t0) hipEventDestroy(e->t0);
+    if (e->t1) hipEventDestroy(e->t1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return QOC_OK;
+}
+
+#define CHECK_H(h) if (!(h)) return fail(QOC_ERR_INVALID, "null handle"); HIP_TRY(hipSetDevice((h)->cfg.device))
+
+int qoc_set_base(qoc_handle e, const double* base) {
+    CHECK_H(e);
+    if (!base) return fail(QOC_ERR_INVALID, "qoc_set_base: null base");
+    const QocDev& d = e->d;
+    const size_t cnt = (size_t)d.B * d.k * d.steps;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(d.base, base, cnt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d.adam_m, 0, cnt * sizeof(double)));
+    HIP_TRY(hipMemset(d.adam_v, 0, cnt * sizeof(double)));
+    HIP_TRY(hipMemset(d.adam_t, 0, d.B * sizeof(int)));
+    HIP_TRY(hipMemset(d.iters, 0, d.B * sizeof(int)));
+    HIP_TRY(hipMemset(d.done, 0, d.B * sizeof(int)));
+    e->evaluated = false;
+    return QOC_OK;
+}
+
+int qoc_get_base(qoc_handle e, double* base) {
+    CHECK_H(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(base, e->d.base, (size_t)e->d.B * e->d.k * e->d.steps * sizeof(double), hipMemcpyDeviceToHost));
+    return QOC_OK;
+}
+
+int qoc_get_scalars(qoc_handle e, double* loss, double* reg_loss, double* grad_squared, double* unitary_scale,
+                    int32_t* iterations, int32_t* done) {
+    CHECK_H(e);
+    const QocDev& d = e->d;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t sz = (size_t)d.B * sizeof(double);
+    if (loss) HIP_TRY(hipMemcpy(loss, d.loss, sz, hipMemcpyDeviceToHost));
+    if (reg_loss) HIP_TRY(hipMemcpy(reg_loss, d.reg_loss, sz, hipMemcpyDeviceToHost));
+    if (grad_squared) HIP_TRY(hipMemcpy(grad_squared, d.g2, sz, hipMemcpyDeviceToHost));
+    if (unitary_scale) HIP_TRY(hipMemcpy(unitary_scale, d.uscale, sz, hipMemcpyDeviceToHost));
+    if (iterations) HIP_TRY(hipMemcpy(iterations, d.iters, d.B * sizeof(int), hipMemcpyDeviceToHost));
+    if (done) HIP_TRY(hipMemcpy(done, d.done, d.B * sizeof(int), hipMemcpyDeviceToHost));
+    return QOC_OK;
+}
+
+int qoc_eval(qoc_handle e, double* loss, double* reg_loss, double* grad_squared, double* unitary_scale, double* grad) {
+    CHECK_H(e);
+    QocAdamDev ap;
+    memset(&ap, 0, sizeof ap);
+    ap.mode = 0;
+    TRY(enqueue_iteration(e, ap));
+    TRY(qoc_get_scalars(e, loss, reg_loss, grad_squared, unitary_scale, nullptr, nullptr));
+    if (grad) HIP_TRY(hipMemcpy(grad, e->d.grad, (size_t)e->d.B * e->d.k * e->d.steps * sizeof(double), hipMemcpyDeviceToHost));
+    return QOC_OK;
+}
+
+int qoc_adam_step(qoc_handle e, const double* lr) {
+    CHECK_H(e);
+    if (!lr) return fail(QOC_ERR_INVALID, "qoc_adam_step: null lr");
+    if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_adam_step: no evaluation since the last qoc_set_base");
+    double* dlr = nullptr;
+    HIP_TRY(hipMalloc((void**)&dlr, e->d.B * sizeof(double)));
+    hipMemcpy(dlr, lr, e->d.B * sizeof(double), hipMemcpyHostToDevice);
+    QocAdamDev ap;
+    memset(&ap, 0, sizeof ap);
+    ap.mode = 2;
+    ap.lr = dlr;
+    // the reference re-evaluates the gradient at the same parameters inside session.run([optimizer]) (run_session.py:69)
+    int rc = enqueue_iteration(e, ap);
+    hipStreamSynchronize(e->stream);
+    hipFree(dlr);
+    return rc;
+}
+
+int qoc_iterate(qoc_handle e, const qoc_adam_params* p, int32_t iters) {
+    CHECK_H(e);
+    if (!p) return fail(QOC_ERR_INVALID, "qoc_iterate: null params");
+    const QocAdamDev ap = loop_params(p);
+    for (int i = 0; i < iters; ++i) TRY(enqueue_iteration(e, ap));
+    return QOC_OK;
+}
+
+int qoc_sync(qoc_handle e) {
+    CHECK_H(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QOC_OK;
+}
+
+int qoc_run_adam(qoc_handle e, const qoc_adam_params* p, int32_t* iterations_out) {
+    CHECK_H(e);
+    if (!p) return fail(QOC_ERR_INVALID, "qoc_run_adam: null params");
+    const QocAdamDev ap = loop_params(p);
+    const int poll = p->poll_every > 0 ? p->poll_every : 1;
+    std::vector<int> done(e->d.B);
+    // at most max_iterations updates + the evaluation that trips the stop rule
+    const long long budget = (long long)p->max_iterations + 1;
+    long long launched = 0;
+    while (true) {
+        int burst = poll;
+        if (launched + burst > budget) burst = (int)(budget - launched);
+        for (int i = 0; i < burst; ++i) TRY(enqueue_iteration(e, ap));
+        launched += burst;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemcpy(done.data(), e->d.done, e->d.B * sizeof(int), hipMemcpyDeviceToHost));
+        bool all = true;
+        for (int b = 0; b < e->d.B; ++b) all = all && done[b];
+        if (all) break;
+        if (launched >= budget) return fail(QOC_ERR_STATE, "qoc_run_adam: seeds not finished after %lld evaluations", launched);
+    }
+    if (iterations_out) HIP_TRY(hipMemcpy(iterations_out, e->d.iters, e->d.B * sizeof(int), hipMemcpyDeviceToHost));
+    return QOC_OK;
+}
+
+int qoc_get_uks(qoc_handle e, double* uks) {
+    CHECK_H(e);
+    const QocDev& d = e->d;
+    const size_t ks = (size_t)d.k * d.steps;
+    std::vector<double> base((size_t)d.B * ks), maxA(d.k);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(base.data(), d.base, base.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(maxA.data(), d.maxA, d.k * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < d.B; ++b)
+        for (int kk = 0; kk < d.k; ++kk)
+            for (int t = 0; t < d.steps; ++t) {
+                const size_t o = (size_t)b * ks + (size_t)kk * d.steps + t;
+                uks[o] = maxA[kk] * sin(base[o]);                                // run_session.py:112-117
+            }
+    return QOC_OK;
+}
+
+int qoc_get_final_unitary(qoc_handle e, double* Uf) {
+    CHECK_H(e);
+    if (e->d.state_transfer) return fail(QOC_ERR_STATE, "qoc_get_final_unitary: state-transfer mode has no final unitary");
+    if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_final_unitary: nothing evaluated yet");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(Uf, e->d.Xfinal, (size_t)e->d.B * e->d.n * e->d.n * sizeof(cplx), hipMemcpyDeviceToHost));
+    return QOC_OK;
+}
+
+int qoc_get_inter_vecs(qoc_handle e, double* inter) {
+    CHECK_H(e);
+    if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_inter_vecs: nothing evaluated yet");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(inter, e->d.inter, (size_t)e->d.B * (e->d.steps + 1) * e->d.n * e->d.m * sizeof(cplx), hipMemcpyDeviceToHost));
+    return QOC_OK;
+}
+
+int qoc_profile_enable(qoc_handle e, int32_t on) {
+    CHECK_H(e);
+    TRY(prof_collect(e));
+    e->profiling = on != 0;
+    e->prof_ms = 0.0;
+    e->prof_launches = 0;
+    return QOC_OK;
+}
+
+int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, double* total_ms) {
+    CHECK_H(e);
+    TRY(prof_collect(e));
+    if (kernel_name)
+        *kernel_name = e->path == QOC_PATH_MFMA ? "k_mfma_expm_chunk" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic");
+    if (launches) *launches = e->prof_launches;
+    if (total_ms) *total_ms = e->prof_ms;
+    return QOC_OK;
+}
+
+int qoc_time_iterations(qoc_handle e, const qoc_adam_params* p, int32_t iters, double* elapsed_ms) {
+    CHECK_H(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipEventRecord(e->t0, e->stream));
+    TRY(qoc_iterate(e, p, iters));
+    HIP_TRY(hipEventRecord(e->t1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->t1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->t0, e->t1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return QOC_OK;
+}
+
+int qoc_path_in_use(qoc_handle e) { return e ? e->path : QOC_ERR_INVALID; }
+int qoc_chunks_in_use(qoc_handle e) { return e ? e->chunks : QOC_ERR_INVALID; }
+
+}  // extern "C"

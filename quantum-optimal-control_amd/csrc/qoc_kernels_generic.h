@@ -1,0 +1,340 @@
+// qoc_kernels_generic.h -- any-n complex-fp64 kernels (workgroup-cooperative products straight from HBM/L2).
+// This is the correctness-first path for every (n, m, mode); the register-resident MFMA path
+// (qoc_kernels_mfma.h) replaces the propagator kernels when n <= 32 in unitary mode.
+//
+// Reference call sites are cited as file:line relative to /root/reference/quantum_optimal_control/.
+#pragma once
+#include "qoc_common.h"
+
+// C[MxN] = op(A)[MxKd] * B[KdxN]; row-major operands in global memory; all threads of the workgroup cooperate.
+// No barrier inside: the caller synchronises before C is read.
+template <bool CONJ_T_A>
+__device__ __forceinline__ void wg_mm(int M, int N, int Kd, const cplx* __restrict__ A, int lda,
+                                      const cplx* __restrict__ Bm, int ldb, cplx* __restrict__ C, int ldc) {
+    for (int o = threadIdx.x; o < M * N; o += blockDim.x) {
+        const int i = o / N, j = o - i * N;
+        cplx acc = cmake(0.0, 0.0);
+        for (int c = 0; c < Kd; ++c) {
+            const cplx a = CONJ_T_A ? cconj(A[(size_t)c * lda + i]) : A[(size_t)i * lda + c];
+            cfma(acc, a, Bm[(size_t)c * ldb + j]);
+        }
+        C[(size_t)i * ldc + j] = acc;
+    }
+}
+
+// w = sin(base), u = maxA*w                                   core/tensorflow_state.py:176-178
+__global__ void k_controls(QocDev d) {
+    const int total = d.B * d.k * d.steps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int kk = (i / d.steps) % d.k;
+        const double w = sin(d.base[i]);
+        d.w[i] = w;
+        d.u[i] = d.maxA[kk] * w;
+    }
+}
+
+// H_t = sum_ii (uks[ii]/2^s) * H_all[ii]                       tensorflow_state.py:30-33 (scaled) / :83-86 (s = 0)
+__device__ __forceinline__ void wg_assemble(const QocDev& d, int b, int t, double inv_scale, double sign,
+                                            cplx* __restrict__ A) {
+    const int nn = d.n * d.n;
+    const double* ub = d.u + (size_t)b * d.k * d.steps + t;
+    for (int o = threadIdx.x; o < nn; o += blockDim.x) {
+        cplx acc = cscale(d.Hs[o], sign * inv_scale);
+        for (int kk = 0; kk < d.k; ++kk) {
+            const double c = sign * (ub[(size_t)kk * d.steps] * inv_scale);
+            const cplx h = d.Hs[(size_t)(kk + 1) * nn + o];
+            acc.x = fma(c, h.x, acc.x);
+            acc.y = fma(c, h.y, acc.y);
+        }
+        A[o] = acc;
+    }
+}
+
+// K_t = (sum_{j<=T} A^j/j!)^(2^s)   -- matexp_op                tensorflow_state.py:25-46, 70-75
+// grid-stride over (seed, t); scratch: 2 n x n matrices per workgroup.
+__global__ void __launch_bounds__(QOC_BLOCK) k_expm_generic(QocDev d, cplx* __restrict__ Kout, cplx* __restrict__ scratch) {
+    const int nn = d.n * d.n;
+    cplx* A = scratch + (size_t)blockIdx.x * 3 * nn;
+    cplx* P = A + nn;
+    cplx* Q = P + nn;
+    const double inv_scale = 1.0 / (double)(1 << d.s);
+    for (int item = blockIdx.x; item < d.B * d.steps; item += gridDim.x) {
+        const int b = item / d.steps, t = item - b * d.steps;
+        cplx* Kt = Kout + (size_t)item * nn;
+        wg_assemble(d, b, t, inv_scale, 1.0, A);
+        __syncthreads();
+        for (int o = threadIdx.x; o < nn; o += blockDim.x) {       // ii = 1: matexp = I + H/1 ; H_n = H
+            const cplx a = A[o];
+            P[o] = a;
+            const int i = o / d.n, j = o - i * d.n;
+            Kt[o] = cmake(a.x + (i == j ? 1.0 : 0.0), a.y);
+        }
+        __syncthreads();
+        double fact = 1.0;
+        for (int ii = 2; ii <= d.T; ++ii) {
+            wg_mm<false>(d.n, d.n, d.n, A, d.n, P, d.n, Q, d.n);     // H_n = H * H_n            :41
+            __syncthreads();
+            fact *= (double)ii;
+            for (int o = threadIdx.x; o < nn; o += blockDim.x) {    // matexp += H_n / factorial :40
+                const cplx q = Q[o];
+                cplx kv = Kt[o];
+                kv.x += q.x / fact; kv.y += q.y / fact;
+                Kt[o] = kv;
+            }
+            cplx* tmp = P; P = Q; Q = tmp;
+            __syncthreads();
+        }
+        for (int sq = 0; sq < d.s; ++sq) {                          // squaring                  :43-44
+            wg_mm<false>(d.n, d.n, d.n, Kt, d.n, Kt, d.n, Q, d.n);
+            __syncthreads();
+            for (int o = threadIdx.x; o < nn; o += blockDim.x) Kt[o] = Q[o];
+            __syncthreads();
+        }
+    }
+}
+
+// Forward chain, one workgroup per seed:  X_t = K_t X_{t-1},  Psi_t = K_t Psi_{t-1} (= X_t V)
+// tensorflow_state.py:204-227 (propagator), :229-242 (inter vectors). scratch: 2 n x n per seed.
+__global__ void __launch_bounds__(QOC_BLOCK) k_fwd_generic(QocDev d, const cplx* __restrict__ Kin, cplx* __restrict__ scratch) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, n = d.n, m = d.m, nn = n * n, nm = n * m;
+    cplx* Xa = scratch + (size_t)b * 2 * nn;
+    cplx* Xb = Xa + nn;
+    cplx* iv = d.inter + (size_t)b * (d.steps + 1) * nm;
+    for (int o = threadIdx.x; o < nn; o += blockDim.x) Xa[o] = d.U0[o];
+    for (int o = threadIdx.x; o < nm; o += blockDim.x) iv[o] = d.V[o];
+    __syncthreads();
+    const cplx* psi_prev = d.Psi0;
+    for (int t = 0; t < d.steps; ++t) {
+        const cplx* Kt = Kin + ((size_t)b * d.steps + t) * nn;
+        cplx* psi = iv + (size_t)(t + 1) * nm;
+        wg_mm<false>(n, m, n, Kt, n, psi_prev, m, psi, m);
+        wg_mm<false>(n, n, n, Kt, n, Xa, n, Xb, n);
+        __syncthreads();
+        cplx* tmp = Xa; Xa = Xb; Xb = tmp;
+        psi_prev = psi;
+    }
+    // final_state and unitary_scale = (1/n) sum_ab Re (X^dagger X)_ab = (1/n) sum_c |sum_a X[c][a]|^2   :223-225
+    double part = 0.0;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        cplx rs = cmake(0.0, 0.0);
+        for (int a = 0; a < n; ++a) rs = cadd(rs, Xa[c * n + a]);
+        part += rs.x * rs.x + rs.y * rs.y;
+    }
+    for (int o = threadIdx.x; o < nn; o += blockDim.x) d.Xfinal[(size_t)b * nn + o] = Xa[o];
+    const double tot = block_sum(part, red);
+    if (threadIdx.x == 0) d.uscale[b] = tot / (double)n;
+}
+
+// State-transfer forward, one workgroup per seed: psi_{t+1} = sum_{j<T} B_t^j psi_t / j!  (matvecexp_op)
+// tensorflow_state.py:77-97, 244-261.  scratch per seed: n*n (B_t) + 2*n*m.
+__global__ void __launch_bounds__(QOC_BLOCK) k_st_fwd_generic(QocDev d, cplx* __restrict__ scratch) {
+    const int b = blockIdx.x, n = d.n, m = d.m, nn = n * n, nm = n * m;
+    cplx* Bt = scratch + (size_t)b * (nn + 2 * nm);
+    cplx* pa = Bt + nn;
+    cplx* pb = pa + nm;
+    cplx* iv = d.inter + (size_t)b * (d.steps + 1) * nm;
+    for (int o = threadIdx.x; o < nm; o += blockDim.x) iv[o] = d.V[o];
+    __syncthreads();
+    for (int t = 0; t < d.steps; ++t) {
+        const cplx* psi = iv + (size_t)t * nm;
+        cplx* out = iv + (size_t)(t + 1) * nm;
+        wg_assemble(d, b, t, 1.0, 1.0, Bt);
+        for (int o = threadIdx.x; o < nm; o += blockDim.x) { pa[o] = psi[o]; out[o] = psi[o]; }
+        __syncthreads();
+        double fact = 1.0;
+        for (int ii = 1; ii < d.T; ++ii) {
+            wg_mm<false>(n, m, n, Bt, n, pa, m, pb, m);              // psi_n = H psi_n           :94
+            __syncthreads();
+            fact *= (double)ii;
+            for (int o = threadIdx.x; o < nm; o += blockDim.x) {    // matvecexp += psi_n/fact   :95
+                cplx v = out[o];
+                v.x += pb[o].x / fact; v.y += pb[o].y / fact;
+                out[o] = v;
+            }
+            cplx* tmp = pa; pa = pb; pb = tmp;
+            __syncthreads();
+        }
+    }
+}
+
+// Fidelity, state-side regulariser values and everything the sources need; one workgroup per seed.
+// tensorflow_state.py:282-340, regularization_functions.py:71-95.
+__global__ void __launch_bounds__(QOC_BLOCK) k_loss(QocDev d) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, n = d.n, m = d.m, nm = n * m;
+    const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * nm;
+    const cplx* fin = iv + (size_t)d.steps * nm;
+    double zr = 0.0, zi = 0.0, nrm = 0.0;
+    for (int o = threadIdx.x; o < nm; o += blockDim.x) {
+        const cplx f = fin[o], w = d.W[o];
+        zr += f.x * w.x + f.y * w.y;        // f * conj(w)
+        zi += f.y * w.x - f.x * w.y;
+        nrm += f.x * f.x + f.y * f.y;
+    }
+    zr = block_sum(zr, red); zi = block_sum(zi, red); nrm = block_sum(nrm, red);
+    const double mm = (double)m * (double)m;
+    double reg_state = 0.0;
+    if (d.has_speed) {                                                           // :88-95
+        double val = 0.0;
+        for (int tau = 0; tau <= d.steps; ++tau) {
+            double tr = 0.0, ti = 0.0;
+            const cplx* p = iv + (size_t)tau * nm;
+            for (int o = threadIdx.x; o < nm; o += blockDim.x) {
+                const cplx f = p[o], w = d.W[o];
+                tr += f.x * w.x + f.y * w.y;
+                ti += f.y * w.x - f.x * w.y;
+            }
+            tr = block_sum(tr, red); ti = block_sum(ti, red);
+            if (threadIdx.x == 0) d.ztau[(size_t)b * (d.steps + 1) + tau] = cmake(tr, ti);
+            val += (tr * tr + ti * ti) / mm;
+        }
+        const double resid = (double)(d.steps + 1) - val;
+        if (threadIdx.x == 0) d.su_resid[b] = resid;
+        reg_state += d.a_speed * 0.5 * resid * resid;
+    }
+    if (d.n_forb > 0) {                                                          // :71-85
+        double acc = 0.0;
+        const int total = (d.steps + 1) * m;
+        for (int o = threadIdx.x; o < total; o += blockDim.x) {
+            const int tau = o / m, j = o - tau * m;
+            const cplx* p = iv + (size_t)tau * nm;
+            for (int f = 0; f < d.n_forb; ++f) {
+                const int st = d.forb_state[f];
+                cplx phi;
+                if (d.forbid_dressed) {
+                    phi = cmake(0.0, 0.0);
+                    for (int c = 0; c < n; ++c) cfma_conj(phi, d.Vs[c * n + st], p[c * m + j]);
+                } else {
+                    phi = p[st * m + j];
+                }
+                const double pop = phi.x * phi.x + phi.y * phi.y;
+                acc += d.forb_a[f] * 0.5 * pop * pop;
+            }
+        }
+        reg_state += block_sum(acc, red);
+    }
+    if (threadIdx.x == 0) {
+        d.zfin[b] = cmake(zr, zi);
+        d.loss[b] = 1.0 - (zr * zr + zi * zi) / mm;
+        d.reg_state[b] = reg_state;
+        if (d.state_transfer) d.uscale[b] = nrm * nrm / mm;                      // tensorflow_state.py:335
+    }
+}
+
+// S[tau][a][j] = d(state regularisers)/dPsi_tau   (G = d/dRe + i d/dIm)
+__device__ __forceinline__ cplx source_at(const QocDev& d, int b, int tau, int a, int j) {
+    cplx s = cmake(0.0, 0.0);
+    const int n = d.n, m = d.m;
+    const cplx* p = d.inter + ((size_t)b * (d.steps + 1) + tau) * n * m;
+    for (int f = 0; f < d.n_forb; ++f) {
+        const int st = d.forb_state[f];
+        if (d.forbid_dressed) {
+            cplx phi = cmake(0.0, 0.0);
+            for (int c = 0; c < n; ++c) cfma_conj(phi, d.Vs[c * n + st], p[c * m + j]);
+            const double pop = phi.x * phi.x + phi.y * phi.y;
+            cfma(s, d.Vs[a * n + st], cscale(phi, 2.0 * d.forb_a[f] * pop));
+        } else if (a == st) {
+            const cplx phi = p[st * m + j];
+            const double pop = phi.x * phi.x + phi.y * phi.y;
+            s = cadd(s, cscale(phi, 2.0 * d.forb_a[f] * pop));
+        }
+    }
+    if (d.has_speed) {
+        const double coef = -d.a_speed * d.su_resid[b] * 2.0 / ((double)m * (double)m);
+        const cplx z = d.ztau[(size_t)b * (d.steps + 1) + tau];
+        s = cadd(s, cscale(cmul(z, d.W[a * m + j]), coef));
+    }
+    return s;
+}
+
+// dL/du_{k,t} = Re <Lambda_t, H_k' Psi_t>                      tensorflow_state.py:61-63 / :112-114
+__device__ __forceinline__ void wg_control_grads(const QocDev& d, int b, int t, const cplx* __restrict__ lam,
+                                                 const cplx* __restrict__ psi, double* red) {
+    const int n = d.n, m = d.m, nm = n * m, nn = n * n;
+    for (int kk = 0; kk < d.k; ++kk) {
+        const cplx* Hk = d.Hs + (size_t)(kk + 1) * nn;
+        double part = 0.0;
+        for (int o = threadIdx.x; o < nm; o += blockDim.x) {
+            const int i = o / m, j = o - i * m;
+            cplx y = cmake(0.0, 0.0);
+            for (int c = 0; c < n; ++c) cfma(y, Hk[i * n + c], psi[c * m + j]);
+            part += lam[o].x * y.x + lam[o].y * y.y;                  // Re(conj(lam) * y)
+        }
+        const double g = block_sum(part, red);
+        if (threadIdx.x == 0) d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = g;
+    }
+}
+
+__device__ __forceinline__ void wg_terminal_costate(const QocDev& d, int b, bool need_src, cplx* __restrict__ lam) {
+    const int nm = d.n * d.m;
+    const cplx z = d.zfin[b];
+    const double c0 = -2.0 / ((double)d.m * (double)d.m);
+    for (int o = threadIdx.x; o < nm; o += blockDim.x) {
+        cplx v = cscale(cmul(z, d.W[o]), c0);
+        if (need_src) v = cadd(v, source_at(d, b, d.steps, o / d.m, o % d.m));
+        lam[o] = v;
+    }
+}
+
+// Backward sweep (unitary mode), one workgroup per seed: Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1}.
+__global__ void __launch_bounds__(QOC_BLOCK) k_bwd_generic(QocDev d, const cplx* __restrict__ Kin, cplx* __restrict__ scratch) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, n = d.n, m = d.m, nn = n * n, nm = n * m;
+    cplx* la = scratch + (size_t)b * 2 * nm;
+    cplx* lb = la + nm;
+    const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * nm;
+    const bool need_src = d.n_forb > 0 || d.has_speed;
+    wg_terminal_costate(d, b, need_src, la);
+    __syncthreads();
+    for (int t = d.steps - 1; t >= 0; --t) {
+        wg_control_grads(d, b, t, la, iv + (size_t)(t + 1) * nm, red);
+        if (t == 0) break;
+        const cplx* Kt = Kin + ((size_t)b * d.steps + t) * nn;
+        wg_mm<true>(n, m, n, Kt, n, la, m, lb, m);
+        __syncthreads();
+        if (need_src) {
+            for (int o = threadIdx.x; o < nm; o += blockDim.x) lb[o] = cadd(lb[o], source_at(d, b, t, o / m, o % m));
+        }
+        cplx* tmp = la; la = lb; lb = tmp;
+        __syncthreads();
+    }
+}
+
+// Backward sweep (state transfer): lambda_t = sum_{j<T} (-B_t)^j lambda_{t+1} / j! + S_t   tensorflow_state.py:100-133
+__global__ void __launch_bounds__(QOC_BLOCK) k_st_bwd_generic(QocDev d, cplx* __restrict__ scratch) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, n = d.n, m = d.m, nn = n * n, nm = n * m;
+    cplx* Bt = scratch + (size_t)b * (nn + 3 * nm);
+    cplx* lam = Bt + nn;
+    cplx* pa = lam + nm;
+    cplx* pb = pa + nm;
+    const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * nm;
+    const bool need_src = d.n_forb > 0 || d.has_speed;
+    wg_terminal_costate(d, b, need_src, lam);
+    __syncthreads();
+    for (int t = d.steps - 1; t >= 0; --t) {
+        wg_control_grads(d, b, t, lam, iv + (size_t)(t + 1) * nm, red);
+        if (t == 0) break;
+        wg_assemble(d, b, t, 1.0, -1.0, Bt);                         // H = sum (-uks) H_all      :121-123
+        for (int o = threadIdx.x; o < nm; o += blockDim.x) pa[o] = lam[o];
+        __syncthreads();
+        double fact = 1.0;
+        for (int ii = 1; ii < d.T; ++ii) {
+            wg_mm<false>(n, m, n, Bt, n, pa, m, pb, m);
+            __syncthreads();
+            fact *= (double)ii;
+            for (int o = threadIdx.x; o < nm; o += blockDim.x) {
+                cplx v = lam[o];
+                v.x += pb[o].x / fact; v.y += pb[o].y / fact;
+                lam[o] = v;
+            }
+            cplx* tmp = pa; pa = pb; pb = tmp;
+            __syncthreads();
+        }
+        if (need_src) {
+            for (int o = threadIdx.x; o < nm; o += blockDim.x) lam[o] = cadd(lam[o], source_at(d, b, t, o / m, o % m));
+            __syncthreads();
+        }
+    }
+}

@@ -1,0 +1,154 @@
+"""Optimiser drivers over the HIP engine (reference: core/run_session.py:11-199).
+
+ADAM        device-resident loop (stop rule, LR schedule and Adam update run on the GPU; the host polls every
+            update_step iterations to print the reference's progress line)
+EVOLVE      one evaluation at the initial controls
+anything else is handed to scipy.optimize.minimize with (reg_loss, gradient) from the engine, as the reference does.
+"""
+import time
+
+import numpy as np
+from scipy.optimize import minimize
+
+
+class run_session(object):
+
+    def __init__(self, tfs, graph, conv, sys_para, method, show_plots=True, single_simulation=False, use_gpu=True):
+        self.tfs = tfs
+        self.graph = graph
+        self.engine = tfs.engine
+        self.conv = conv
+        self.sys_para = sys_para
+        self.update_step = conv.update_step
+        self.iterations = 0
+        self.method = method.upper()
+        self.show_plots = show_plots
+        self.target = False
+        self.end = False
+        self.seed = 0          # which control set the scalar attributes (l, rl, ...) report
+        print("Initialized")
+        if self.method == 'EVOLVE':
+            self.start_time = time.time()
+            self.l, self.rl, self.grads, self.metric, self.g_squared = self.get_error(self.sys_para.ops_weight_base)
+            self.get_end_results()
+        elif self.method == 'ADAM':
+            self.start_adam_optimizer()
+        else:
+            self.bfgs_optimize(method=self.method)
+
+    # ---- Adam ---------------------------------------------------------------------------------------------------
+    def start_adam_optimizer(self):
+        eng, conv = self.engine, self.conv
+        self.start_time = time.time()
+        params = eng.adam_params(rate=conv.rate, learning_rate_decay=conv.learning_rate_decay,
+                                 conv_target=conv.conv_target, min_grad=conv.min_grad,
+                                 max_iterations=conv.max_iterations, poll_every=max(1, int(conv.update_step)))
+        budget = int(conv.max_iterations) + 1          # evaluations: one per update + the one that trips the stop rule
+        launched = 0
+        burst = max(1, int(conv.update_step))
+        first = True
+        while True:
+            n = 1 if first else min(burst, budget - launched)   # first line is printed at iteration 0 like the reference
+            first = False
+            eng.iterate(params, n)
+            launched += n
+            s = eng.scalars()
+            self._take_scalars(s)
+            self.end = bool(np.all(s['done']))
+            if self.end or launched >= budget:
+                break
+            self.save_data()
+            self.display()
+        self.end = True
+        self.get_end_results()
+
+    def _take_scalars(self, s):
+        b = self.seed
+        self.l, self.rl = float(s['loss'][b]), float(s['reg_loss'][b])
+        self.g_squared, self.metric = float(s['grad_squared'][b]), float(s['unitary_scale'][b])
+        if 'iterations' in s:
+            self.iterations = int(s['iterations'][b])
+        self.conv.record(self.iterations, self.l, self.rl)
+
+    # ---- results ------------------------------------------------------------------------------------------------
+    def get_end_results(self):
+        self.save_data()
+        self.display()
+        self.uks = self.Get_uks()
+        if not self.sys_para.state_transfer:
+            self.Uf = self.engine.get_final_unitary()[self.seed]
+        else:
+            self.Uf = []
+
+    def Get_uks(self):
+        return self.engine.get_uks()[self.seed]
+
+    def get_error(self, uks):
+        """Loss, regularised loss, flattened gradient, unitary metric and grad_squared at controls `uks`
+        (the variable is the pre-sin base, exactly as in the reference where get_error assigns ops_weight_base)."""
+        eng = self.engine
+        base = np.broadcast_to(np.reshape(np.asarray(uks, dtype=np.float64), (eng.k, eng.steps)),
+                               (eng.n_seeds, eng.k, eng.steps))
+        adam_state_reset = base      # set_base resets the optimiser slots, irrelevant for scipy drivers
+        eng.set_base(adam_state_reset)
+        r = eng.evaluate(want_grad=True)
+        b = self.seed
+        g = np.reshape(r['grad'][b], (eng.k * eng.steps))
+        return float(r['loss'][b]), float(r['reg_loss'][b]), g, float(r['unitary_scale'][b]), float(r['grad_squared'][b])
+
+    def save_data(self):
+        if self.sys_para.save:
+            from quantum_optimal_control.helper_functions.data_management import H5File
+            self.elapsed = time.time() - self.start_time
+            with H5File(self.sys_para.file_path) as hf:
+                hf.append('error', np.array(self.l))
+                hf.append('reg_error', np.array(self.rl))
+                hf.append('uks', np.array(self.Get_uks()))
+                hf.append('iteration', np.array(self.iterations))
+                hf.append('run_time', np.array(self.elapsed))
+                hf.append('unitary_scale', np.array(self.metric))
+
+    def display(self):
+        self.elapsed = time.time() - self.start_time
+        print('Error = :%1.2e; Runtime: %.1fs; Iterations = %d, grads =  %10.3e, unitary_metric = %.5f' % (
+            self.l, self.elapsed, self.iterations, self.g_squared, self.metric))
+
+    # ---- scipy drivers ------------------------------------------------------------------------------------------
+    def minimize_opt_fun(self, x):
+        k = len(self.sys_para.ops_c)
+        self.l, self.rl, self.grads, self.metric, self.g_squared = self.get_error(np.reshape(x, (k, len(x) // k)))
+        if self.l < self.conv.conv_target:
+            self.conv_time = time.time() - self.start_time
+            self.conv_iter = self.iterations
+            self.end = True
+            print('Target fidelity reached')
+            self.grads = 0 * self.grads          # zero gradient terminates the scipy optimisation
+        if not self.end:
+            if self.iterations % self.conv.update_step == 0:
+                self.save_data()
+                self.display()
+            self.iterations += 1
+        return np.float64(self.rl), np.asarray(self.grads, dtype=np.float64)
+
+    def bfgs_optimize(self, method='L-BFGS-B', jac=True, options=None):
+        self.conv.reset_convergence()
+        self.first = True
+        self.conv_time = 0.
+        self.conv_iter = 0
+        self.end = False
+        print("Starting " + self.method + " Optimization")
+        self.start_time = time.time()
+        x0 = np.reshape(self.sys_para.ops_weight_base, -1)
+        if method == 'L-BFGS-B':
+            options = {'maxfun': self.conv.max_iterations, 'gtol': self.conv.min_grad, 'disp': False, 'maxls': 40}
+        else:
+            options = {'gtol': self.conv.min_grad, 'disp': False, 'maxiter': self.conv.max_iterations}
+        res = minimize(self.minimize_opt_fun, x0, method=method, jac=jac, options=options)
+        k = len(self.sys_para.ops_c)
+        self.l, self.rl, self.grads, self.metric, self.g_squared = self.get_error(np.reshape(res['x'], (k, len(res['x']) // k)))
+        print(self.method + ' optimization done')
+        if not self.sys_para.show_plots:
+            print(res.message)
+            print("Error = %1.2e" % self.l)
+            print("Total time is " + str(time.time() - self.start_time))
+        self.get_end_results()

@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/qoc.h declares,
+and refuses to run without a HIP device (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'qoc.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(qoc_[a-z_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from quantum_optimal_control.core import hip_engine
+    lib = hip_engine.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), 'libqoc_hip.so does not export %s' % name
+    # and the Python binding declares a prototype for each of them
+    assert sorted(hip_engine.EXPORTED_SYMBOLS) == declared
+    assert b'gfx950' in lib.qoc_version()
+
+
+def test_config_struct_layout_matches_header():
+    from quantum_optimal_control.core import hip_engine
+    # 8 int32 + 2 double + 6 int32 + 6 double + 7 int32 + 7 reserved int32, natural alignment
+    assert ctypes.sizeof(hip_engine.QocConfig) == 8 * 4 + 2 * 8 + 6 * 4 + 6 * 8 + 14 * 4
+    assert ctypes.sizeof(hip_engine.QocAdamParams) == 4 * 8 + 2 * 4
+
+
+def test_no_cpu_fallback_without_gpu():
+    from quantum_optimal_control.core import hip_engine
+    if hip_engine.device_count() > 0:
+        pytest.skip('a HIP device is visible')
+    n, k, m, steps = 2, 1, 2, 4
+    Hs = np.zeros((k + 1, n, n), dtype=np.complex128)
+    with pytest.raises(hip_engine.QocError, match='no HIP device'):
+        hip_engine.HipEngine(Hs, np.eye(n), np.eye(n)[:, :m], np.eye(n)[:, :m], [1.0], 0.1, 0.4, steps, 3, 0,
+                             reg_coeffs={})
+
+
+def test_product_path_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, 'quantum-optimal-control_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('no CPU fallback', ''), '%s mentions the oracle' % f
+
+
+def test_grape_argument_errors_match_reference():
+    from quantum_optimal_control.main_grape.grape import Grape
+    H0 = np.zeros((2, 2)); Hops = [np.eye(2)]
+    with pytest.raises(ValueError, match='file_name, is not specified'):
+        Grape(H0, Hops, ['x'], np.eye(2), 1.0, 4, [0, 1])                       # save=True default
+    with pytest.raises(ValueError, match='data_path, is not specified'):
+        Grape(H0, Hops, ['x'], np.eye(2), 1.0, 4, [0, 1], file_name='a')
+    with pytest.raises(KeyError):
+        Grape(H0, Hops, ['x'], np.eye(2), 1.0, 4, [0, 1], save=False, freq_unit='THz')
+    with pytest.raises(ValueError, match='Initial guess has strength > max_amp'):
+        Grape(H0 + np.eye(2), Hops, ['x'], np.eye(2), 1.0, 4, [0, 1], save=False, maxA=[0.1],
+              initial_guess=np.ones((1, 4)), reg_coeffs={})

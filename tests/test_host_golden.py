@@ -1,0 +1,76 @@
+"""Host-side mirror of the reference interface (rows a1-a5, a17) vs fixtures captured from the reference."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from quantum_optimal_control.core.convergence import Convergence
+from quantum_optimal_control.core.system_parameters import SystemParameters
+from quantum_optimal_control.helper_functions import grape_functions as gf
+from tests.golden import cases
+from tests.helpers import load_golden, resolve_dressed
+
+
+def build_sys_para(c, fx=None):
+    n = len(c['H0'])
+    U0 = np.identity(n) if c['U0'] is None else c['U0']
+    if c['maxA'] is None:
+        maxA = (4 * np.ones(len(c['Hops'])) if c['initial_guess'] is None
+                else 1.5 * np.max(np.abs(c['initial_guess'])) * np.ones(len(c['Hops'])))
+    else:
+        maxA = c['maxA']
+    np.random.seed(c['np_seed'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        return SystemParameters(c['H0'], c['Hops'], c['Hnames'], c['U'], U0, c['total_time'], c['steps'],
+                                c['states_concerned_list'], resolve_dressed(c, fx), maxA, None, c['initial_guess'],
+                                False, 1e-4, c['state_transfer'], False, c['reg_coeffs'], False, None,
+                                c['Taylor_terms'], True, True, False, False, False)
+
+
+@pytest.mark.parametrize('name', list(cases.ALL_CASES))
+def test_system_parameters_bit_exact(name):
+    c = cases.ALL_CASES[name]()
+    fx = load_golden('sysparams_%s.npz' % name)
+    S = build_sys_para(c, fx)
+    assert S.dt == float(fx['dt']) and S.state_num == int(fx['state_num'])
+    assert (S.exp_terms, S.scaling) == (int(fx['exp_terms']), int(fx['scaling']))
+    if c['Taylor_terms'] is None:
+        assert list(S.exps) == list(fx['exps']) and list(S.scalings) == list(fx['scalings'])
+    np.testing.assert_array_equal(S.matrix_list, fx['matrix_list'])
+    np.testing.assert_array_equal(np.array(S.initial_vectors), fx['initial_vectors'])
+    np.testing.assert_array_equal(S.initial_unitary, fx['initial_unitary'])
+    np.testing.assert_array_equal(S.one_minus_gauss, fx['one_minus_gauss'])
+    np.testing.assert_array_equal(S.ops_weight_base, fx['ops_weight_base'])
+    if c['state_transfer']:
+        np.testing.assert_array_equal(np.array(S.target_vectors), fx['target_vectors'])
+    else:
+        np.testing.assert_array_equal(S.target_unitary, fx['target_unitary'])
+    if c['initial_guess'] is not None:
+        np.testing.assert_array_equal(S.u0_base, fx['u0_base'])
+    # complex stack handed to the engine is the un-embedded matrix_list
+    Hs, U0, V, W, Vs = S.engine_inputs()
+    n = S.state_num
+    for i in range(len(Hs)):
+        np.testing.assert_array_equal(gf.c_to_r_mat(Hs[i]), fx['matrix_list'][i])
+
+
+def test_helper_functions_match_reference():
+    fx = load_golden('helpers.npz')
+    np.testing.assert_array_equal(gf.c_to_r_mat(fx['in_M']), fx['c_to_r_mat'])
+    np.testing.assert_array_equal(gf.c_to_r_vec(fx['in_v']), fx['c_to_r_vec'])
+    did = [int(i) for i in fx['dressed_id']]
+    np.testing.assert_array_equal(gf.sort_ev(fx['dressed_v'], did), fx['sort_ev'])
+    assert gf.get_state_index(2, did) == int(fx['state_index_2'])
+    np.testing.assert_allclose(gf.dressed_unitary(fx['in_Ugate'], fx['dressed_v'], did), fx['dressed_unitary'], atol=1e-15)
+    w, v, d2 = gf.get_dressed_info(fx['in_Hd'])
+    assert d2 == did
+    np.testing.assert_allclose(np.sort(w.real), np.sort(fx['dressed_w'].real), atol=1e-12)
+
+
+def test_convergence_defaults():
+    conv = Convergence(None, 'ns', {})
+    assert (conv.rate, conv.update_step, conv.evol_save_step, conv.conv_target, conv.max_iterations,
+            conv.learning_rate_decay, conv.min_grad) == (0.01, 100, 100, 1e-8, 5000, 2500, 1e-25)
+    conv = Convergence(None, 'ns', {'rate': 0.5, 'min_grad': 1e-9})
+    assert conv.rate == 0.5 and conv.min_grad == 1e-9 and conv.max_iterations == 5000
