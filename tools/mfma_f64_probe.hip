@@ -28,6 +28,22 @@ __global__ void __launch_bounds__(256) k_rate(double* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+__global__ void __launch_bounds__(256) k_cycles(double* out, long long* cyc, int iters) {
+    d4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    const long long t1 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 __global__ void __launch_bounds__(256) k_fma(double* out, int iters) {
     double x[16];
     for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 1e-3 + i;
@@ -76,6 +92,18 @@ int main() {
     bench("mfma_f64 1acc 1wave/SIMD (dependent)", [&] { hipLaunchKernelGGL(k_rate<1>, dim3(blocks), dim3(256), 0, 0, dout, iters); }, 1 * 4 * 2048.0, blocks, 256);
     bench("mfma_f64 2acc 1wave/SIMD", [&] { hipLaunchKernelGGL(k_rate<2>, dim3(blocks), dim3(256), 0, 0, dout, iters); }, 2 * 4 * 2048.0, blocks, 256);
     bench("mfma_f64 4acc 2waves/SIMD", [&] { hipLaunchKernelGGL(k_rate<4>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0, blocks * 2, 256);
+    bench("mfma_f64 4acc 4waves/SIMD", [&] { hipLaunchKernelGGL(k_rate<4>, dim3(blocks * 4), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0, blocks * 4, 256);
+    bench("mfma_f64 2acc 8waves/SIMD", [&] { hipLaunchKernelGGL(k_rate<2>, dim3(blocks * 8), dim3(256), 0, 0, dout, iters); }, 2 * 4 * 2048.0, blocks * 8, 256);
+    {   // in-kernel shader-clock cycles per MFMA (s_memtime ticks = shader cycles) and effective clock
+        long long* dcyc; hipMalloc(&dcyc, sizeof(long long) * 2);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_cycles, dim3(blocks), dim3(256), 0, 0, dout, dcyc, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        long long hc[2]; hipMemcpy(hc, dcyc, sizeof hc, hipMemcpyDeviceToHost);
+        printf("in-kernel: %.1f memtime ticks per MFMA (4 acc, 1 wave/SIMD); ticks/s = %.3f GHz over %.3f ms\n",
+               (double)hc[0] / (iters * 4.0), (double)hc[0] / (ms * 1e-3) * 1e-9, ms);
+    }
     bench("v_fma_f64 16chains 1wave/SIMD", [&] { hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(256), 0, 0, dout, iters); }, 16 * 256 * 2.0, blocks, 256);
     bench("v_fma_f64 16chains 4waves/SIMD", [&] { hipLaunchKernelGGL(k_fma, dim3(blocks * 4), dim3(256), 0, 0, dout, iters); }, 16 * 256 * 2.0, blocks * 4, 256);
     // cycles per MFMA on one SIMD assuming the reported clock
