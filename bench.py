@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py -- GRAPE iterations/s (forward chain + first-order backward + regularisers + Adam) on N MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line from rank 0.
+  * workload (BASELINE.json configs[1] / SURVEY.md 8d "C2"): n=32, k=4, time slices=500, m=8, (T,s)=(5,3), fp64
+    complex, synthetic Hamiltonians from numpy.random.default_rng(0); SEEDS_PER_GPU independent random-restart control
+    sets per GPU (config 4: 512 seeds / 8 GPUs = 64 per GPU) -> weak scaling, no data-path collective; the final
+    per-seed fidelities are all-gathered once over RCCL after the last iteration (inside the timed region).
+  * a "step" = one GRAPE iteration of every seed on the GPU (all inputs resident in HBM).
+  * value = (seeds on all GPUs) * K / wall time, wall = max over ranks, barrier + device sync on both sides.
+  * roofline: dominant kernel (k_mfma_expm_chunk: matrix exponentials + chunk products) timed with hipEvents on the
+    engine's stream in a separate short pass; algorithmic FLOPs per launch from SURVEY.md 8d.
+  * cpu_baseline: the CPU oracle (NumPy complex128 port of the reference's op sequence, ONE evaluation per
+    iteration) timed on a bounded sample on this host -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'quantum-optimal-control_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+N, K_OPS, SLICES, M, TAYLOR = 32, 4, 500, 8, (5, 3)
+SEEDS_PER_GPU = 64
+FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X public fp64 matrix (= vector) peak; MI355X_MICROARCH.md lists no fp64 row
+
+
+def build_problem():
+    from tests.golden import cases
+    c = cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0)
+    H0, Hops, U = c['H0'], c['Hops'], c['U']
+    dt = c['total_time'] / SLICES
+    Hs = np.stack([-1j * dt * H0] + [-1j * dt * h for h in Hops])
+    V = np.eye(N, dtype=complex)[:, :M]
+    W = U @ V
+    return c, Hs, np.eye(N, dtype=complex), V, W, dt
+
+
+def seed_bases(first, count):
+    return np.stack([np.random.default_rng(1000 + first + i).normal(0, 1 / np.sqrt(SLICES), (K_OPS, SLICES))
+                     for i in range(count)])
+
+
+def cpu_baseline(budget_s=12.0):
+    """Oracle (port) timed on a bounded sample: whole iterations (evaluate + Adam) of ONE seed of the same workload."""
+    from oracle import grape_oracle as go
+    from tests.helpers import oracle_system
+    from tests.golden import cases
+    sp = oracle_system(cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0))
+    base = seed_bases(0, 1)[0]
+    opt = go.Adam(base.shape)
+    go.evaluate(sp, base)                       # warm-up
+    t0 = time.perf_counter()
+    its = 0
+    while True:
+        r = go.evaluate(sp, base)
+        base = opt.step(base, r['grad'], 0.01)
+        its += 1
+        if time.perf_counter() - t0 > budget_s or its >= 200:
+            break
+    el = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = 1
+    return {'value': its / el, 'unit': 'GRAPE iterations/s', 'cores': int(threads), 'kind': 'port',
+            'sample': '%d iterations of 1 seed of the same C2 workload in %.1f s (NumPy complex128 oracle, one '
+                      'evaluation per iteration; host has %d logical CPUs)' % (its, el, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--seeds-per-gpu', type=int, default=SEEDS_PER_GPU)
+    ap.add_argument('--chunks', type=int, default=0)
+    ap.add_argument('--path', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from quantum_optimal_control.core import hip_engine
+    from quantum_optimal_control.parallel_seeds import SeedShard
+
+    c, Hs, U0, V, W, dt = build_problem()
+    B = args.seeds_per_gpu
+    shard = SeedShard(total_seeds=B * world, rank=rank, world=world)
+    eng = hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], SLICES, TAYLOR[0], TAYLOR[1],
+                               reg_coeffs={}, n_seeds=shard.count, device=local_rank, path=args.path,
+                               chunks=args.chunks)
+    eng.set_base(seed_bases(shard.first, shard.count))
+    params = eng.adam_params(rate=0.01, learning_rate_decay=2500, conv_target=1e-8, min_grad=1e-25,
+                             max_iterations=10 ** 9, poll_every=10 ** 9)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    eng.iterate(params, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    eng.iterate(params, args.steps)
+    eng.sync()
+    sc = eng.scalars()
+    fidelity = shard.all_gather(1.0 - sc['loss'], dist)          # RCCL all-gather of the final fidelities
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    assert int(np.sum(sc['done'])) == 0 and np.all(sc['iterations'] == args.warmup + args.steps), \
+        'a seed stopped early: timed work would be incomplete'
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel, hipEvents on the engine stream (separate pass, rank 0) -----------------
+    roof = None
+    single = None
+    if rank == 0:
+        eng.profile_enable(True)
+        eng.iterate(params, min(10, args.steps))
+        pr = eng.profile_read()
+        eng.profile_enable(False)
+        T, s = TAYLOR
+        flops_per_launch = shard.count * SLICES * ((T - 1 + s) + 1) * 8.0 * N ** 3   # expm GEMMs + chain GEMM, SURVEY 8d
+        avg_ms = pr['total_ms'] / max(1, pr['launches'])
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': pr['kernel'], 'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                'avg_launch_ms': avg_ms, 'launches': pr['launches'], 'flops_per_launch': flops_per_launch,
+                'measured_mfma_f64_ceiling_TFLOPs': 48.2}
+    total_seeds = B * world
+    value = total_seeds * args.steps / elapsed
+    if rank == 0:
+        out = {
+            'metric': 'GRAPE iterations/sec (fwd+bwd+Adam) at n=32 k=4 steps=500', 'value': value,
+            'unit': 'GRAPE iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C2 3-transmon-size unitary gate: n=32 k=4 steps=500 m=8 Taylor(T,s)=(5,3), '
+                                   '%d independent control seeds per GPU (aggregate over seeds), reg_coeffs={}' % B,
+                       'seeds_per_gpu': B, 'total_seeds': total_seeds, 'path': eng.path, 'chunks': eng.chunks,
+                       'parallelism': 'seed-sharded x%d, RCCL all-gather of final fidelities' % world},
+            'per_seed_iterations_per_s': args.steps / elapsed,
+            'best_fidelity': float(np.max(fidelity)),
+            'roofline': roof,
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
