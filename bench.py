@@ -94,8 +94,15 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # test hook: QOC_BENCH_BACKEND=gloo + QOC_BENCH_SAME_DEVICE=1 runs N ranks on ONE GPU to exercise this code path
+        backend = os.environ.get('QOC_BENCH_BACKEND', 'nccl')
+        if os.environ.get('QOC_BENCH_SAME_DEVICE') == '1':
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from quantum_optimal_control.core import hip_engine
     from quantum_optimal_control.parallel_seeds import SeedShard
@@ -133,13 +140,12 @@ def main():
         'a seed stopped early: timed work would be incomplete'
     if dist is not None:
         import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # ---- roofline of the dominant kernel, hipEvents on the engine stream (separate pass, rank 0) -----------------
     roof = None
-    single = None
     if rank == 0:
         eng.profile_enable(True)
         eng.iterate(params, min(10, args.steps))
