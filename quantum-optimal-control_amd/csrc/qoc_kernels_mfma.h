@@ -6,11 +6,18 @@
 //    which is *also* the B-operand layout of K-slice r.  A left-multiplication chain  P <- A * P  therefore never
 //    moves P out of registers: the D output of one product is the B operand of the next.
 //  * Left-multiplication acts on column blocks independently, so one wavefront owns ONE 16-column half (J) of a
-//    32x32 matrix through the whole Taylor (Horner) recursion: 64 MFMAs per product per wave, 4 independent
-//    accumulator chains, ~150 VGPRs -> >= 2 waves per SIMD.
+//    32x32 matrix through the whole Taylor (Horner) recursion.
+//  * Complex products use the 3-multiplication form  T1 = Ar Br, T2 = Ai Bi, T3 = (Ar+Ai)(Br+Bi),
+//    Re = T1 - T2, Im = T3 - T1 - T2 :  48 MFMAs per 32x32x16 complex product per wave instead of 64,
+//    6 independent accumulator chains.
 //  * Only squaring (and handing K_t to the running chunk product) needs the matrix as a LEFT operand, i.e. in the
 //    A-fragment layout (lane l <-> element (row = l&15, k = l>>4)) = the transposed D layout.  The two waves of a
 //    matrix exchange their halves through a padded, transposed LDS image (one barrier per exchange, two buffers).
+//  * HBM format "fragD(M)": 16 fragments f = cb*8 + q of 64 lanes x complex (1 KB each, perfectly coalesced),
+//    lane l of fragment (cb, q) = M[4q + (l>>4)][16cb + (l&15)].  D-layout register (row block Ib, reg r) of column
+//    block J is fragment J*8 + 4Ib + r; the A-operand (I, q) for a left product by M^dagger is conj(fragD(M)[I*8+q])
+//    and for a left product by M it is fragD(M^T)[I*8+q].  K_t and the chunk products are stored as fragD(K) and
+//    fragD(K^T), so every global access of these kernels is  uniform base + lane*16 + immediate.
 //  * Time is cut into C chunks per seed.  k_mfma_expm_chunk computes K_t for its chunk AND the chunk product
 //    P_c = prod K_t; the thin sweeps (Psi_t = K_t Psi_{t-1}, Lambda_{t-1} = K_t^dagger Lambda_t) rebuild their chunk
 //    boundary from the P_c's (<= C thin products) and then run their chunk -- every kernel has B*C-way parallelism.
@@ -24,6 +31,7 @@
 #define QOC_NP 32                 // padded matrix dimension
 #define QOC_LDR 33                // padded leading dimension of the transposed LDS image (complex elements)
 #define QOC_MAXC 64               // max time chunks per seed
+#define QOC_FRAG 1024             // complex elements per fragD matrix (16 fragments x 64 lanes)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define QMFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -34,93 +42,82 @@ struct AFrag { double re[2][8], im[2][8]; };      // 32x32 complex LEFT operand:
 struct QocMfma {
     int C = 1;                // chunks per seed
     int L = 1;                // steps per chunk
-    cplx* Hs_pad = nullptr;   // [k+1][32][32]  -i dt H, zero padded
-    cplx* HsT_pad = nullptr;  // [k+1][32][32]  transposed
-    cplx* U0_pad = nullptr;   // [32][32] zero padded
-    cplx* K = nullptr;        // [B][steps][32][32]
-    cplx* Pc = nullptr;       // [B][C][32][32] chunk products
+    int mq = 4;               // ceil(m / 4): k-slices of the rank-m outer product
+    cplx* HfD = nullptr;      // [k+1] fragD(-i dt H), zero padded
+    cplx* HfT = nullptr;      // [k+1] fragD((-i dt H)^T)
+    cplx* U0fD = nullptr;     // fragD(U0), zero padded
+    cplx* KfD = nullptr;      // [B][steps] fragD(K_t)
+    cplx* KfT = nullptr;      // [B][steps] fragD(K_t^T)
+    cplx* PfD = nullptr;      // [B][C] fragD(P_c)
+    cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
     size_t bwd_lds = 0;
     bool h_in_lds = true;
 };
 
 // ---- fragment helpers ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ cplx ldg_c(const cplx* p) { return *p; }
-
-// A-layout fragments of M from its TRANSPOSE stored plain row-major [32][32] (coalesced: 4 x 256 B per instruction).
-__device__ __forceinline__ void afrag_from_transposed(const cplx* __restrict__ Mt, int lane, AFrag& A) {
+// A-operand fragments from a fragD matrix (pass fragD(M^T) to multiply by M, fragD(M) with CONJ to multiply by M^dagger)
+template <bool CONJ>
+__device__ __forceinline__ void afrag_load(const cplx* __restrict__ F, int lane, AFrag& A) {
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const cplx v = Mt[(4 * q + (lane >> 4)) * QOC_NP + 16 * I + (lane & 15)];
-            A.re[I][q] = v.x; A.im[I][q] = v.y;
+            const cplx v = F[(I * 8 + q) * 64 + lane];
+            A.re[I][q] = v.x; A.im[I][q] = CONJ ? -v.y : v.y;
         }
 }
-// A-layout fragments of M^dagger from M stored plain row-major (same coalesced pattern, conjugated).
-__device__ __forceinline__ void afrag_dagger(const cplx* __restrict__ M, int lane, AFrag& A) {
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const cplx v = M[(4 * q + (lane >> 4)) * QOC_NP + 16 * I + (lane & 15)];
-            A.re[I][q] = v.x; A.im[I][q] = -v.y;
-        }
-}
-// A-layout fragments of M from M stored plain row-major (gather: 16 rows x 64 B per instruction).
-__device__ __forceinline__ void afrag_gather(const cplx* __restrict__ M, int lane, AFrag& A) {
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const cplx v = M[(16 * I + (lane & 15)) * QOC_NP + 4 * q + (lane >> 4)];
-            A.re[I][q] = v.x; A.im[I][q] = v.y;
-        }
-}
-
-// out[I] = sum_k A[I,k] * p[k]   for one 16-column block: 64 MFMAs, 4 independent accumulator chains.
-__device__ __forceinline__ void mm_colblock(const AFrag& A, const CTile p[2], CTile out[2]) {
-    d4 r0 = {0, 0, 0, 0}, i0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, i1 = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const double br = p[q >> 2].re[q & 3], bi = p[q >> 2].im[q & 3], nbi = -bi;
-        r0 = QMFMA(A.re[0][q], br, r0);
-        i0 = QMFMA(A.re[0][q], bi, i0);
-        r1 = QMFMA(A.re[1][q], br, r1);
-        i1 = QMFMA(A.re[1][q], bi, i1);
-        r0 = QMFMA(A.im[0][q], nbi, r0);
-        i0 = QMFMA(A.im[0][q], br, i0);
-        r1 = QMFMA(A.im[1][q], nbi, r1);
-        i1 = QMFMA(A.im[1][q], br, i1);
-    }
-    out[0].re = r0; out[0].im = i0; out[1].re = r1; out[1].im = i1;
-}
-
-// D-layout column block J of a plain row-major [32][32] matrix.
-__device__ __forceinline__ void colblock_load(const cplx* __restrict__ M, int J, int lane, CTile p[2]) {
+// D-layout column block J from / to a fragD matrix
+__device__ __forceinline__ void colblock_load(const cplx* __restrict__ F, int J, int lane, CTile p[2]) {
 #pragma unroll
     for (int Ib = 0; Ib < 2; ++Ib)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const cplx v = M[(16 * Ib + (lane >> 4) + 4 * r) * QOC_NP + 16 * J + (lane & 15)];
+            const cplx v = F[(J * 8 + 4 * Ib + r) * 64 + lane];
             p[Ib].re[r] = v.x; p[Ib].im[r] = v.y;
         }
 }
-__device__ __forceinline__ void colblock_store(cplx* __restrict__ M, int J, int lane, const CTile p[2]) {
+__device__ __forceinline__ void colblock_store(cplx* __restrict__ F, int J, int lane, const CTile p[2]) {
 #pragma unroll
     for (int Ib = 0; Ib < 2; ++Ib)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            M[(16 * Ib + (lane >> 4) + 4 * r) * QOC_NP + 16 * J + (lane & 15)] = cmake(p[Ib].re[r], p[Ib].im[r]);
+        for (int r = 0; r < 4; ++r) F[(J * 8 + 4 * Ib + r) * 64 + lane] = cmake(p[Ib].re[r], p[Ib].im[r]);
+}
+// the I = J half of an A-layout matrix is the J-th half of fragD(M^T)
+__device__ __forceinline__ void afrag_store_half(cplx* __restrict__ F, int J, int lane, const AFrag& A) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const double re = J ? A.re[1][q] : A.re[0][q], im = J ? A.im[1][q] : A.im[0][q];
+        F[(J * 8 + q) * 64 + lane] = cmake(re, im);
+    }
 }
 __device__ __forceinline__ void colblock_identity(int J, int lane, CTile p[2]) {
+    const int dlt = (lane & 15) - (lane >> 4);
 #pragma unroll
     for (int Ib = 0; Ib < 2; ++Ib)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 16 * Ib + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
-            p[Ib].re[r] = (row == col) ? 1.0 : 0.0; p[Ib].im[r] = 0.0;
+            p[Ib].re[r] = (Ib == J && dlt == 4 * r) ? 1.0 : 0.0; p[Ib].im[r] = 0.0;
         }
+}
+
+// out[I] = sum_k A[I,k] * p[k] for one 16-column block, 3-multiplication complex arithmetic:
+// 48 MFMAs, 6 independent accumulator chains.
+__device__ __forceinline__ void mm_colblock(const AFrag& A, const CTile p[2], CTile out[2]) {
+    d4 a0 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, c0 = {0, 0, 0, 0};
+    d4 a1 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const double br = p[q >> 2].re[q & 3], bi = p[q >> 2].im[q & 3], bs = br + bi;
+        a0 = QMFMA(A.re[0][q], br, a0);
+        a1 = QMFMA(A.re[1][q], br, a1);
+        b0 = QMFMA(A.im[0][q], bi, b0);
+        b1 = QMFMA(A.im[1][q], bi, b1);
+        c0 = QMFMA(A.re[0][q] + A.im[0][q], bs, c0);
+        c1 = QMFMA(A.re[1][q] + A.im[1][q], bs, c1);
+    }
+    out[0].re = a0 - b0; out[0].im = c0 - a0 - b0;
+    out[1].re = a1 - b1; out[1].im = c1 - a1 - b1;
 }
 
 // Write a column block into the transposed LDS image img[col][row] (leading dimension QOC_LDR, complex).
@@ -150,8 +147,8 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
     const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
-    const int NN = QOC_NP * QOC_NP;
     const double inv_scale = 1.0 / (double)(1 << d.s);
+    const int dlt = (lane & 15) - (lane >> 4);     // identity: tile Ib == J, register r, lanes with dlt == 4r
     int flip = 0;
     CTile R[2];
     colblock_identity(J, lane, R);
@@ -160,30 +157,24 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
         AFrag A;
         CTile P[2];
         {
+            afrag_load<false>(mf.HfT, lane, A);
+            colblock_load(mf.HfD, J, lane, P);
 #pragma unroll
             for (int I = 0; I < 2; ++I)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const cplx h0 = mf.HsT_pad[(4 * q + (lane >> 4)) * QOC_NP + 16 * I + (lane & 15)];
-                    A.re[I][q] = h0.x * inv_scale; A.im[I][q] = h0.y * inv_scale;
-                }
+                for (int q = 0; q < 8; ++q) { A.re[I][q] *= inv_scale; A.im[I][q] *= inv_scale; }
 #pragma unroll
-            for (int Ib = 0; Ib < 2; ++Ib)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const cplx h0 = mf.Hs_pad[(16 * Ib + (lane >> 4) + 4 * r) * QOC_NP + 16 * J + (lane & 15)];
-                    P[Ib].re[r] = h0.x * inv_scale; P[Ib].im[r] = h0.y * inv_scale;
-                }
+            for (int Ib = 0; Ib < 2; ++Ib) { P[Ib].re *= inv_scale; P[Ib].im *= inv_scale; }
 #pragma unroll 1
             for (int kk = 0; kk < d.k; ++kk) {
                 const double ck = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale;
-                const cplx* __restrict__ HT = mf.HsT_pad + (size_t)(kk + 1) * NN;
-                const cplx* __restrict__ HP = mf.Hs_pad + (size_t)(kk + 1) * NN;
+                const cplx* __restrict__ HT = mf.HfT + (size_t)(kk + 1) * QOC_FRAG;
+                const cplx* __restrict__ HD = mf.HfD + (size_t)(kk + 1) * QOC_FRAG;
 #pragma unroll
                 for (int I = 0; I < 2; ++I)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const cplx h = HT[(4 * q + (lane >> 4)) * QOC_NP + 16 * I + (lane & 15)];
+                        const cplx h = HT[(I * 8 + q) * 64 + lane];
                         A.re[I][q] = fma(ck, h.x, A.re[I][q]);
                         A.im[I][q] = fma(ck, h.y, A.im[I][q]);
                     }
@@ -191,15 +182,13 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
                 for (int Ib = 0; Ib < 2; ++Ib)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const cplx h = HP[(16 * Ib + (lane >> 4) + 4 * r) * QOC_NP + 16 * J + (lane & 15)];
+                        const cplx h = HD[(J * 8 + 4 * Ib + r) * 64 + lane];
                         P[Ib].re[r] = fma(ck, h.x, P[Ib].re[r]);
                         P[Ib].im[r] = fma(ck, h.y, P[Ib].im[r]);
                     }
             }
         }
         // ---- Horner: P_{T-1} = I + A/T ; P_{j-1} = I + (A P_j)/j  -> sum_{j<=T} A^j/j!   (tensorflow_state.py:37-41)
-        // identity on this wave's column block: tile Ib == J, register r, lanes with (l&15) - (l>>4) == 4r
-        const int dlt = (lane & 15) - (lane >> 4);
         {
             const double invT = 1.0 / (double)d.T;
 #pragma unroll
@@ -232,17 +221,25 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
             mm_colblock(A, P, acc);
             P[0] = acc[0]; P[1] = acc[1];
         }
-        // ---- K_t out; running chunk product R <- K_t R ------------------------------------------------------------
-        colblock_store(mf.K + ((size_t)b * d.steps + t) * NN, J, lane, P);
+        // ---- K_t out (both operand forms); running chunk product R <- K_t R ----------------------------------------
+        const size_t item = (size_t)b * d.steps + t;
+        colblock_store(mf.KfD + item * QOC_FRAG, J, lane, P);
         lds_put_colblock(img[flip], 16 * J, lane, P);
         __syncthreads();
         lds_get_afrag(img[flip], lane, A);
         flip ^= 1;
+        afrag_store_half(mf.KfT + item * QOC_FRAG, J, lane, A);
         CTile acc[2];
         mm_colblock(A, R, acc);
         R[0] = acc[0]; R[1] = acc[1];
     }
-    colblock_store(mf.Pc + ((size_t)b * mf.C + c) * NN, J, lane, R);
+    const size_t pitem = (size_t)b * mf.C + c;
+    colblock_store(mf.PfD + pitem * QOC_FRAG, J, lane, R);
+    lds_put_colblock(img[flip], 16 * J, lane, R);
+    __syncthreads();
+    AFrag A;
+    lds_get_afrag(img[flip], lane, A);
+    afrag_store_half(mf.PfT + pitem * QOC_FRAG, J, lane, A);
 }
 
 // ---- kernel F: thin forward sweep  Psi_t = K_t Psi_{t-1}  (inter vectors) + final unitary ------------------------
@@ -250,7 +247,6 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
 __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NN = QOC_NP * QOC_NP;
     const int n_sweep = d.B * mf.C;
     if (item < n_sweep) {
         const int b = item / mf.C, c = item - b * mf.C;
@@ -271,13 +267,13 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
         }
         AFrag A;
         for (int cc = 0; cc < c; ++cc) {                                // chunk boundary from the chunk products
-            afrag_gather(mf.Pc + ((size_t)b * mf.C + cc) * NN, lane, A);
+            afrag_load<false>(mf.PfT + ((size_t)b * mf.C + cc) * QOC_FRAG, lane, A);
             CTile acc[2];
             mm_colblock(A, Psi, acc);
             Psi[0] = acc[0]; Psi[1] = acc[1];
         }
         for (int t = t0; t < t1; ++t) {
-            afrag_gather(mf.K + ((size_t)b * d.steps + t) * NN, lane, A);
+            afrag_load<false>(mf.KfT + ((size_t)b * d.steps + t) * QOC_FRAG, lane, A);
             CTile acc[2];
             mm_colblock(A, Psi, acc);
             Psi[0] = acc[0]; Psi[1] = acc[1];
@@ -294,10 +290,10 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w >> 1, J = w & 1;
         CTile X[2];
-        colblock_load(mf.U0_pad, J, lane, X);
+        colblock_load(mf.U0fD, J, lane, X);
         AFrag A;
         for (int cc = 0; cc < mf.C; ++cc) {
-            afrag_gather(mf.Pc + ((size_t)b * mf.C + cc) * NN, lane, A);
+            afrag_load<false>(mf.PfT + ((size_t)b * mf.C + cc) * QOC_FRAG, lane, A);
             CTile acc[2];
             mm_colblock(A, X, acc);
             X[0] = acc[0]; X[1] = acc[1];
@@ -331,24 +327,19 @@ __global__ void __launch_bounds__(64) k_mfma_uscale(QocDev d) {
 // ---- kernel B: thin backward sweep  Lambda_{t-1} = K_t^dagger Lambda_t  + control gradients ----------------------
 // dL/du_{k,t} = Re sum_ab H_k'[a][b] Q_t[a][b],  Q_t = conj(Lambda_t) Psi_t^T  (rank-m outer product on the MFMA),
 // which equals Re <Lambda_t, H_k' Psi_t> of the reference's matexp_op_grad (tensorflow_state.py:61-63).
-// 4 waves per workgroup; LDS: D-layout image of the k control Hamiltonians (shared) + one transposition pad per wave.
+// 4 waves per workgroup; LDS: fragD image of the k control Hamiltonians (shared) + one transposition pad per wave.
 template <bool H_IN_LDS>
 __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int single_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NN = QOC_NP * QOC_NP;
-    cplx* Hl = (cplx*)smem;                                                     // [k][4 tiles][4 regs][64 lanes]
-    cplx* pad = (cplx*)(smem + (H_IN_LDS ? (size_t)d.k * NN * sizeof(cplx) : 0)) + (size_t)wv * 16 * QOC_LDR;
+    cplx* Hl = (cplx*)smem;                                                     // [k] fragD(H_k')
+    cplx* pad = (cplx*)(smem + (H_IN_LDS ? (size_t)d.k * QOC_FRAG * sizeof(cplx) : 0)) + (size_t)wv * 16 * QOC_LDR;
     if (H_IN_LDS) {
-        for (int o = threadIdx.x; o < d.k * NN; o += blockDim.x) {
-            // o = ((kk*4 + tile)*4 + r)*64 + l  ->  element (row, col) of H_{kk+1}'
-            const int l = o & 63, r = (o >> 6) & 3, tile = (o >> 8) & 3, kk = o >> 10;
-            const int row = 16 * (tile >> 1) + (l >> 4) + 4 * r, col = 16 * (tile & 1) + (l & 15);
-            Hl[o] = mf.Hs_pad[(size_t)(kk + 1) * NN + row * QOC_NP + col];
-        }
+        for (int o = threadIdx.x; o < d.k * QOC_FRAG; o += blockDim.x) Hl[o] = mf.HfD[QOC_FRAG + o];
         __syncthreads();
     }
+    const cplx* Hsrc = H_IN_LDS ? Hl : (mf.HfD + QOC_FRAG);
     const int CC = single_chunk ? 1 : mf.C;
     const int item = blockIdx.x * 4 + wv;
     if (item >= d.B * CC) return;
@@ -376,7 +367,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     AFrag A;
     if (!single_chunk) {
         for (int cc = mf.C - 1; cc > c; --cc) {                          // Lambda at the end of this chunk
-            afrag_dagger(mf.Pc + ((size_t)b * mf.C + cc) * NN, lane, A);
+            afrag_load<true>(mf.PfD + ((size_t)b * mf.C + cc) * QOC_FRAG, lane, A);
             CTile acc[2];
             mm_colblock(A, Lam, acc);
             Lam[0] = acc[0]; Lam[1] = acc[1];
@@ -384,7 +375,8 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     }
     const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
     for (int t = t1 - 1; t >= t0; --t) {
-        // ---- Q = conj(Lambda_t) Psi_t^T ---------------------------------------------------------------------------
+        // ---- Q = conj(Lambda_t) Psi_t^T, 3-multiplication form:  Qr = T1 + T2, Qi = T3 - T1 + T2 with
+        //      T1 = Lr Pr, T2 = Li Pi, T3 = (Lr - Li)(Pr + Pi) ------------------------------------------------------
         lds_put_colblock(pad, 0, lane, Lam);                             // wave-private image: pad[j][row]
         double lr[2][4], li[2][4], pr[2][4], pi[2][4];
         const cplx* psi = iv + (size_t)(t + 1) * d.n * d.m;
@@ -392,12 +384,16 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
         for (int I = 0; I < 2; ++I)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = 16 * I + (lane & 15), j = 4 * q + (lane >> 4);
-                const cplx lv = pad[j * QOC_LDR + row];
-                lr[I][q] = lv.x; li[I][q] = lv.y;
-                cplx pv = cmake(0.0, 0.0);
-                if (row < d.n && j < d.m) pv = psi[row * d.m + j];
-                pr[I][q] = pv.x; pi[I][q] = pv.y;
+                lr[I][q] = 0.0; li[I][q] = 0.0; pr[I][q] = 0.0; pi[I][q] = 0.0;
+                if (q < mf.mq) {
+                    const int row = 16 * I + (lane & 15), j = 4 * q + (lane >> 4);
+                    const cplx lv = pad[j * QOC_LDR + row];
+                    lr[I][q] = lv.x; li[I][q] = lv.y;
+                    if (row < d.n && j < d.m) {
+                        const cplx pv = psi[row * d.m + j];
+                        pr[I][q] = pv.x; pi[I][q] = pv.y;
+                    }
+                }
             }
         double g[8];
 #pragma unroll
@@ -406,28 +402,23 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
         for (int I = 0; I < 2; ++I)
 #pragma unroll
             for (int Jp = 0; Jp < 2; ++Jp) {
-                d4 qr = {0, 0, 0, 0}, qi = {0, 0, 0, 0};
+                d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    qr = QMFMA(lr[I][q], pr[Jp][q], qr);
-                    qi = QMFMA(lr[I][q], pi[Jp][q], qi);
-                    qr = QMFMA(li[I][q], pi[Jp][q], qr);
-                    qi = QMFMA(-li[I][q], pr[Jp][q], qi);
+                    if (q < mf.mq) {
+                        t1v = QMFMA(lr[I][q], pr[Jp][q], t1v);
+                        t2v = QMFMA(li[I][q], pi[Jp][q], t2v);
+                        t3v = QMFMA(lr[I][q] - li[I][q], pr[Jp][q] + pi[Jp][q], t3v);
+                    }
                 }
-                const int tile = I * 2 + Jp;
+                const d4 qr = t1v + t2v, qi = t3v - t1v + t2v;
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     if (kk >= d.k) continue;
                     double acc = 0.0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cplx h;
-                        if (H_IN_LDS) {
-                            h = Hl[((kk * 4 + tile) * 4 + r) * 64 + lane];
-                        } else {
-                            const int row = 16 * I + (lane >> 4) + 4 * r, col = 16 * Jp + (lane & 15);
-                            h = mf.Hs_pad[(size_t)(kk + 1) * NN + row * QOC_NP + col];
-                        }
+                        const cplx h = Hsrc[(size_t)kk * QOC_FRAG + (Jp * 8 + 4 * I + r) * 64 + lane];
                         acc = fma(h.x, qr[r], acc);
                         acc = fma(-h.y, qi[r], acc);
                     }
@@ -444,7 +435,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
         }
         if (t == 0) break;
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t (+ S_{t-1}) ---------------------------------------------------------
-        afrag_dagger(mf.K + ((size_t)b * d.steps + t) * NN, lane, A);
+        afrag_load<true>(mf.KfD + ((size_t)b * d.steps + t) * QOC_FRAG, lane, A);
         CTile acc[2];
         mm_colblock(A, Lam, acc);
         Lam[0] = acc[0]; Lam[1] = acc[1];
@@ -469,9 +460,21 @@ static inline bool qoc_mfma_supported(const QocDev& d) {
     return !d.state_transfer && d.n <= QOC_NP && d.m <= 16 && d.k <= 8 && d.T >= 1;
 }
 
+// host: fragD image of a zero-padded n x n matrix (transpose optionally)
+static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F) {
+    for (int f = 0; f < 16; ++f)
+        for (int l = 0; l < 64; ++l) {
+            const int cb = f >> 3, q = f & 7;
+            int row = 4 * q + (l >> 4), col = 16 * cb + (l & 15);
+            if (transpose) { const int tmp = row; row = col; col = tmp; }
+            cplx v; v.x = 0.0; v.y = 0.0;
+            if (row < n && col < n) v = M[(size_t)row * n + col];
+            F[f * 64 + l] = v;
+        }
+}
+
 static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
                                  std::vector<void*>& allocs, std::string& msg) {
-    const int NP = QOC_NP, NN = NP * NP;
     int C = chunks_req;
     if (C <= 0) {
         C = (1024 + d.B - 1) / d.B;                  // ~2 waves per SIMD for the expm kernel (2 waves per chunk)
@@ -483,21 +486,15 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     int L = (d.steps + C - 1) / C;
     C = (d.steps + L - 1) / L;                       // no empty chunks
     mf.C = C; mf.L = L;
-    std::vector<cplx> hp((size_t)(d.k + 1) * NN), ht((size_t)(d.k + 1) * NN), u0((size_t)NN);
-    for (auto& v : hp) { v.x = 0; v.y = 0; }
-    ht = hp;
-    for (auto& v : u0) { v.x = 0; v.y = 0; }
-    for (int kk = 0; kk <= d.k; ++kk)
-        for (int a = 0; a < d.n; ++a)
-            for (int bcol = 0; bcol < d.n; ++bcol) {
-                const cplx v = Hs_host[(size_t)kk * d.n * d.n + a * d.n + bcol];
-                hp[(size_t)kk * NN + a * NP + bcol] = v;
-                ht[(size_t)kk * NN + bcol * NP + a] = v;
-            }
+    mf.mq = (d.m + 3) / 4;
+    std::vector<cplx> hd((size_t)(d.k + 1) * QOC_FRAG), ht((size_t)(d.k + 1) * QOC_FRAG), u0(QOC_FRAG);
+    for (int kk = 0; kk <= d.k; ++kk) {
+        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, false, hd.data() + (size_t)kk * QOC_FRAG);
+        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, true, ht.data() + (size_t)kk * QOC_FRAG);
+    }
     std::vector<cplx> u0h((size_t)d.n * d.n);
     if (hipMemcpy(u0h.data(), d.U0, u0h.size() * sizeof(cplx), hipMemcpyDeviceToHost) != hipSuccess) { msg = "U0 readback failed"; return -2; }
-    for (int a = 0; a < d.n; ++a)
-        for (int bcol = 0; bcol < d.n; ++bcol) u0[a * NP + bcol] = u0h[a * d.n + bcol];
+    qoc_to_fragD(u0h.data(), d.n, false, u0.data());
     auto up = [&](cplx** dst, const std::vector<cplx>& src) -> bool {
         void* p = nullptr;
         if (hipMalloc(&p, src.size() * sizeof(cplx)) != hipSuccess) return false;
@@ -506,7 +503,7 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         *dst = (cplx*)p;
         return true;
     };
-    if (!up(&mf.Hs_pad, hp) || !up(&mf.HsT_pad, ht) || !up(&mf.U0_pad, u0)) { msg = "MFMA path: constant upload failed"; return -3; }
+    if (!up(&mf.HfD, hd) || !up(&mf.HfT, ht) || !up(&mf.U0fD, u0)) { msg = "MFMA path: constant upload failed"; return -3; }
     auto al = [&](cplx** dst, size_t count) -> bool {
         void* p = nullptr;
         if (hipMalloc(&p, count * sizeof(cplx)) != hipSuccess) return false;
@@ -514,9 +511,10 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         *dst = (cplx*)p;
         return true;
     };
-    if (!al(&mf.K, (size_t)d.B * d.steps * NN) || !al(&mf.Pc, (size_t)d.B * C * NN)) { msg = "MFMA path: out of device memory"; return -3; }
+    const size_t nk = (size_t)d.B * d.steps * QOC_FRAG, np = (size_t)d.B * C * QOC_FRAG;
+    if (!al(&mf.KfD, nk) || !al(&mf.KfT, nk) || !al(&mf.PfD, np) || !al(&mf.PfT, np)) { msg = "MFMA path: out of device memory"; return -3; }
     const size_t pads = (size_t)4 * 16 * QOC_LDR * sizeof(cplx);
-    const size_t hbytes = (size_t)d.k * NN * sizeof(cplx);
+    const size_t hbytes = (size_t)d.k * QOC_FRAG * sizeof(cplx);
     mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
     mf.bwd_lds = pads + (mf.h_in_lds ? hbytes : 0);
     if (mf.h_in_lds) {
