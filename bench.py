@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--chunks', type=int, default=0)
     ap.add_argument('--path', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--groups', type=int, default=1, help='split the seeds of this GPU over G engines/streams')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -110,26 +111,48 @@ def main():
     c, Hs, U0, V, W, dt = build_problem()
     B = args.seeds_per_gpu
     shard = SeedShard(total_seeds=B * world, rank=rank, world=world)
-    eng = hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], SLICES, TAYLOR[0], TAYLOR[1],
-                               reg_coeffs={}, n_seeds=shard.count, device=local_rank, path=args.path,
-                               chunks=args.chunks)
-    eng.set_base(seed_bases(shard.first, shard.count))
+    G = max(1, args.groups)
+    gsh = [SeedShard(shard.count, g, G) for g in range(G)]
+    engs = []
+    for g in range(G):
+        e = hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], SLICES, TAYLOR[0], TAYLOR[1],
+                                 reg_coeffs={}, n_seeds=gsh[g].count, device=local_rank, path=args.path,
+                                 chunks=args.chunks)
+        e.set_base(seed_bases(shard.first + gsh[g].first, gsh[g].count))
+        engs.append(e)
+    eng = engs[0]
     params = eng.adam_params(rate=0.01, learning_rate_decay=2500, conv_target=1e-8, min_grad=1e-25,
                              max_iterations=10 ** 9, poll_every=10 ** 9)
 
+    class _Multi(object):
+        def iterate(self, p, n):
+            for _ in range(n):
+                for e in engs:
+                    e.iterate(p, 1)
+
+        def sync(self):
+            for e in engs:
+                e.sync()
+
+        def scalars(self):
+            parts = [e.scalars() for e in engs]
+            return {k: np.concatenate([q[k] for q in parts]) for k in parts[0]}
+
+    multi = _Multi()
+
     def barrier():
-        eng.sync()
+        multi.sync()
         if dist is not None:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
 
-    eng.iterate(params, args.warmup)
+    multi.iterate(params, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    eng.iterate(params, args.steps)
-    eng.sync()
-    sc = eng.scalars()
+    multi.iterate(params, args.steps)
+    multi.sync()
+    sc = multi.scalars()
     fidelity = shard.all_gather(1.0 - sc['loss'], dist)          # RCCL all-gather of the final fidelities
     if dist is not None:
         import torch
@@ -152,7 +175,7 @@ def main():
         pr = eng.profile_read()
         eng.profile_enable(False)
         T, s = TAYLOR
-        flops_per_launch = shard.count * SLICES * ((T - 1 + s) + 1) * 8.0 * N ** 3   # expm GEMMs + chain GEMM, SURVEY 8d
+        flops_per_launch = gsh[0].count * SLICES * ((T - 1 + s) + 1) * 8.0 * N ** 3   # expm GEMMs + chain GEMM, SURVEY 8d
         avg_ms = pr['total_ms'] / max(1, pr['launches'])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'kernel': pr['kernel'], 'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS,
@@ -170,6 +193,7 @@ def main():
             'config': {'workload': 'C2 3-transmon-size unitary gate: n=32 k=4 steps=500 m=8 Taylor(T,s)=(5,3), '
                                    '%d independent control seeds per GPU (aggregate over seeds), reg_coeffs={}' % B,
                        'seeds_per_gpu': B, 'total_seeds': total_seeds, 'path': eng.path, 'chunks': eng.chunks,
+                       'stream_groups': G,
                        'parallelism': 'seed-sharded x%d, RCCL all-gather of final fidelities' % world},
             'per_seed_iterations_per_s': args.steps / elapsed,
             'best_fidelity': float(np.max(fidelity)),
@@ -178,7 +202,8 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -43,6 +43,7 @@ struct QocMfma {
     int C = 1;                // chunks per seed
     int L = 1;                // steps per chunk
     int mq = 4;               // ceil(m / 4): k-slices of the rank-m outer product
+    double invfact[24];       // 1/j!
     cplx* HfD = nullptr;      // [k+1] fragD(-i dt H), zero padded
     cplx* HfT = nullptr;      // [k+1] fragD((-i dt H)^T)
     cplx* U0fD = nullptr;     // fragD(U0), zero padded
@@ -188,28 +189,61 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
                     }
             }
         }
-        // ---- Horner: P_{T-1} = I + A/T ; P_{j-1} = I + (A P_j)/j  -> sum_{j<=T} A^j/j!   (tensorflow_state.py:37-41)
-        {
-            const double invT = 1.0 / (double)d.T;
+        // ---- order-T Taylor polynomial sum_{j<=T} A^j/j! (tensorflow_state.py:37-41), Paterson-Stockmeyer form in
+        //      A2 = A*A with blocks B_i = c_{2i} I + c_{2i+1} A:  S = B_m ; S = B_i + A2*S  -> 1 + ceil(T/2) - 1 products
+        //      instead of T-1 (T=5: 3 instead of 4).  c_j = 1/j! from mf.invfact.
+        if (d.T >= 2) {
+            CTile AJ[2];
+            AJ[0] = P[0]; AJ[1] = P[1];
+            CTile A2J[2];
+            mm_colblock(A, AJ, A2J);
+            lds_put_colblock(img[flip], 16 * J, lane, A2J);
+            __syncthreads();
+            lds_get_afrag(img[flip], lane, A);                      // A now holds the left-operand fragments of A2
+            flip ^= 1;
+            const int mm = d.T >> 1;
+            int i;
+            if ((d.T & 1) == 0) {                                   // top block is c_T I: S = B_{m-1} + c_T A2
+                const double c0 = mf.invfact[2 * mm - 2], c1 = mf.invfact[2 * mm - 1], cT = mf.invfact[d.T];
+#pragma unroll
+                for (int Ib = 0; Ib < 2; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
+                        P[Ib].re[r] = one + c1 * AJ[Ib].re[r] + cT * A2J[Ib].re[r];
+                        P[Ib].im[r] = c1 * AJ[Ib].im[r] + cT * A2J[Ib].im[r];
+                    }
+                i = mm - 2;
+            } else {                                                // S = B_m = c_{2m} I + c_{2m+1} A
+                const double c0 = mf.invfact[2 * mm], c1 = mf.invfact[2 * mm + 1];
+#pragma unroll
+                for (int Ib = 0; Ib < 2; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
+                        P[Ib].re[r] = one + c1 * AJ[Ib].re[r];
+                        P[Ib].im[r] = c1 * AJ[Ib].im[r];
+                    }
+                i = mm - 1;
+            }
+            for (; i >= 0; --i) {
+                CTile acc[2];
+                mm_colblock(A, P, acc);
+                const double c0 = mf.invfact[2 * i], c1 = mf.invfact[2 * i + 1];
+#pragma unroll
+                for (int Ib = 0; Ib < 2; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
+                        P[Ib].re[r] = one + c1 * AJ[Ib].re[r] + acc[Ib].re[r];
+                        P[Ib].im[r] = c1 * AJ[Ib].im[r] + acc[Ib].im[r];
+                    }
+            }
+        } else {                                                    // T == 1: I + A
 #pragma unroll
             for (int Ib = 0; Ib < 2; ++Ib)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double one = (Ib == J && dlt == 4 * r) ? 1.0 : 0.0;
-                    P[Ib].re[r] = one + P[Ib].re[r] * invT; P[Ib].im[r] = P[Ib].im[r] * invT;
-                }
-        }
-        for (int j = d.T - 1; j >= 1; --j) {
-            CTile acc[2];
-            mm_colblock(A, P, acc);
-            const double invj = 1.0 / (double)j;
-#pragma unroll
-            for (int Ib = 0; Ib < 2; ++Ib)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double one = (Ib == J && dlt == 4 * r) ? 1.0 : 0.0;
-                    P[Ib].re[r] = one + acc[Ib].re[r] * invj; P[Ib].im[r] = acc[Ib].im[r] * invj;
-                }
+                for (int r = 0; r < 4; ++r) P[Ib].re[r] += (Ib == J && dlt == 4 * r) ? 1.0 : 0.0;
         }
         // ---- squaring: M <- M*M, s times (:43-44); the left operand comes back through the LDS image -----------
         for (int sq = 0; sq < d.s; ++sq) {
@@ -457,7 +491,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
 // ---- host side ----------------------------------------------------------------------------------------------------
 
 static inline bool qoc_mfma_supported(const QocDev& d) {
-    return !d.state_transfer && d.n <= QOC_NP && d.m <= 16 && d.k <= 8 && d.T >= 1;
+    return !d.state_transfer && d.n <= QOC_NP && d.m <= 16 && d.k <= 8 && d.T >= 1 && d.T <= 22;
 }
 
 // host: fragD image of a zero-padded n x n matrix (transpose optionally)
@@ -487,6 +521,10 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     C = (d.steps + L - 1) / L;                       // no empty chunks
     mf.C = C; mf.L = L;
     mf.mq = (d.m + 3) / 4;
+    {
+        double f = 1.0;
+        for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; mf.invfact[j] = 1.0 / f; }
+    }
     std::vector<cplx> hd((size_t)(d.k + 1) * QOC_FRAG), ht((size_t)(d.k + 1) * QOC_FRAG), u0(QOC_FRAG);
     for (int kk = 0; kk <= d.k; ++kk) {
         qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, false, hd.data() + (size_t)kk * QOC_FRAG);
