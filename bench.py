@@ -47,15 +47,40 @@ def seed_bases(first, count):
                      for i in range(count)])
 
 
-def cpu_baseline(budget_s=12.0):
-    """Oracle (port) timed on a bounded sample: whole iterations (evaluate + Adam) of ONE seed of the same workload."""
-    from oracle import grape_oracle as go
+def cpu_baseline(budget_s=15.0):
+    """CPU oracle timed on a bounded sample of the same workload: whole iterations (evaluate + Adam) of one seed per
+    thread, all host threads busy (seeds are the parallel axis on the CPU too).  Compiled C port (oracle/qoc_oracle.c)
+    when its .so is present, else the NumPy oracle on one thread."""
     from tests.helpers import oracle_system
     from tests.golden import cases
     sp = oracle_system(cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0))
+    try:
+        from oracle import c_port
+        threads = c_port.max_threads()
+        bases = seed_bases(0, threads)
+        t0 = time.perf_counter()
+        c_port.iterate(sp, bases, 1, nthreads=threads)                      # calibration + warm-up
+        per_it = time.perf_counter() - t0
+        iters = int(max(2, min(200, budget_s / max(per_it, 1e-3))))
+        t0 = time.perf_counter()
+        c_port.iterate(sp, bases, iters, nthreads=threads)
+        el = time.perf_counter() - t0
+        return {'value': threads * iters / el, 'unit': 'GRAPE iterations/s', 'cores': int(threads), 'kind': 'port',
+                'sample': '%d iterations x %d seeds (one seed per thread, OpenMP) of the same C2 workload in %.1f s; '
+                          'compiled C restatement oracle/qoc_oracle.c, one evaluation per iteration, fp64 complex; '
+                          'host has %d logical CPUs' % (iters, threads, el, os.cpu_count()),
+                'per_thread_value': iters / el}
+    except OSError:
+        pass
+    from oracle import grape_oracle as go
+    try:
+        import threadpoolctl
+        ctx = threadpoolctl.threadpool_limits(limits=1)
+    except Exception:
+        ctx = None
     base = seed_bases(0, 1)[0]
     opt = go.Adam(base.shape)
-    go.evaluate(sp, base)                       # warm-up
+    go.evaluate(sp, base)
     t0 = time.perf_counter()
     its = 0
     while True:
@@ -65,14 +90,9 @@ def cpu_baseline(budget_s=12.0):
         if time.perf_counter() - t0 > budget_s or its >= 200:
             break
     el = time.perf_counter() - t0
-    try:
-        import threadpoolctl
-        threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        threads = 1
-    return {'value': its / el, 'unit': 'GRAPE iterations/s', 'cores': int(threads), 'kind': 'port',
-            'sample': '%d iterations of 1 seed of the same C2 workload in %.1f s (NumPy complex128 oracle, one '
-                      'evaluation per iteration; host has %d logical CPUs)' % (its, el, os.cpu_count())}
+    return {'value': its / el, 'unit': 'GRAPE iterations/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d iterations of 1 seed of the same C2 workload in %.1f s (NumPy complex128 oracle, BLAS limited '
+                      'to one thread)' % (its, el)}
 
 
 def main():

@@ -51,6 +51,7 @@ struct QocMfma {
     cplx* KfT = nullptr;      // [B][steps] fragD(K_t^T)
     cplx* PfD = nullptr;      // [B][C] fragD(P_c)
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
+    cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
     size_t bwd_lds = 0;
     bool h_in_lds = true;
 };
@@ -358,6 +359,37 @@ __global__ void __launch_bounds__(64) k_mfma_uscale(QocDev d) {
     if (lane == 0) d.uscale[b] = part / (double)n;
 }
 
+// ---- kernel B0: affine offsets of the backward recursion when state regularisers add a source at every slice --------
+// Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1} is affine; over chunk c it maps the chunk-end costate E to
+// P_c^dagger E + a_c with a_c = result of running the chunk from a ZERO costate.  One wave per (seed, chunk >= 1).
+__global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (item >= d.B * mf.C) return;
+    const int b = item / mf.C, c = item - b * mf.C;
+    if (c == 0) return;                                               // a_0 is never used
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    CTile Z[2];
+#pragma unroll
+    for (int Ib = 0; Ib < 2; ++Ib) { Z[Ib].re = (d4){0, 0, 0, 0}; Z[Ib].im = (d4){0, 0, 0, 0}; }
+    AFrag A;
+    for (int t = t1 - 1; t >= t0; --t) {
+        afrag_load<true>(mf.KfD + ((size_t)b * d.steps + t) * QOC_FRAG, lane, A);
+        CTile acc[2];
+        mm_colblock(A, Z, acc);
+#pragma unroll
+        for (int Ib = 0; Ib < 2; ++Ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
+                cplx sv = cmake(0.0, 0.0);
+                if (row < d.n && col < d.m) sv = source_at(d, b, t, row, col);
+                Z[Ib].re[r] = acc[Ib].re[r] + sv.x; Z[Ib].im[r] = acc[Ib].im[r] + sv.y;
+            }
+    }
+    colblock_store(mf.Aoff + ((size_t)b * mf.C + c) * 512, 0, lane, Z);
+}
+
 // ---- kernel B: thin backward sweep  Lambda_{t-1} = K_t^dagger Lambda_t  + control gradients ----------------------
 // dL/du_{k,t} = Re sum_ab H_k'[a][b] Q_t[a][b],  Q_t = conj(Lambda_t) Psi_t^T  (rank-m outer product on the MFMA),
 // which equals Re <Lambda_t, H_k' Psi_t> of the reference's matexp_op_grad (tensorflow_state.py:61-63).
@@ -405,6 +437,12 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
             CTile acc[2];
             mm_colblock(A, Lam, acc);
             Lam[0] = acc[0]; Lam[1] = acc[1];
+            if (need_src) {                                              // E_{cc-1} = P_cc^dagger E_cc + a_cc
+                CTile off[2];
+                colblock_load(mf.Aoff + ((size_t)b * mf.C + cc) * 512, 0, lane, off);
+#pragma unroll
+                for (int Ib = 0; Ib < 2; ++Ib) { Lam[Ib].re += off[Ib].re; Lam[Ib].im += off[Ib].im; }
+            }
         }
     }
     const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
@@ -550,7 +588,7 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         return true;
     };
     const size_t nk = (size_t)d.B * d.steps * QOC_FRAG, np = (size_t)d.B * C * QOC_FRAG;
-    if (!al(&mf.KfD, nk) || !al(&mf.KfT, nk) || !al(&mf.PfD, np) || !al(&mf.PfT, np)) { msg = "MFMA path: out of device memory"; return -3; }
+    if (!al(&mf.KfD, nk) || !al(&mf.KfT, nk) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 512)) { msg = "MFMA path: out of device memory"; return -3; }
     const size_t pads = (size_t)4 * 16 * QOC_LDR * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * QOC_FRAG * sizeof(cplx);
     mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
@@ -573,11 +611,11 @@ static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStre
     hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
 }
 static inline void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    // state regularisers add a source at every step (affine recursion): run those sequentially per seed for now
-    const int single = (d.n_forb > 0 || d.has_speed) ? 1 : 0;
-    const int items = d.B * (single ? 1 : mf.C);
+    const int items = d.B * mf.C;
+    if ((d.n_forb > 0 || d.has_speed) && mf.C > 1)
+        hipLaunchKernelGGL(k_mfma_bwd_offsets, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     if (mf.h_in_lds)
-        hipLaunchKernelGGL(k_mfma_backward<true>, dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, single);
+        hipLaunchKernelGGL(k_mfma_backward<true>, dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
     else
-        hipLaunchKernelGGL(k_mfma_backward<false>, dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, single);
+        hipLaunchKernelGGL(k_mfma_backward<false>, dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
 }

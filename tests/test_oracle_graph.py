@@ -135,3 +135,26 @@ def test_d2wdt2_without_dwdt_raises_like_reference():
     sp = oracle_system(c)
     with pytest.raises(NameError):
         go.evaluate(sp, sp.base0)
+
+
+def test_c_port_matches_numpy_oracle():
+    """oracle/qoc_oracle.c (cpu_baseline leg of bench.py) restates the same unitary-mode iteration."""
+    import os
+    from oracle import c_port
+    if not os.path.exists(c_port.LIB):
+        pytest.skip('oracle/_build/libqoc_oracle.so not built (run __graft_entry__.build())')
+    c = cases.case_c2(n=12, k=3, steps=25, m=5, taylor=(6, 2), seed=8)
+    sp = oracle_system(c)
+    bases = np.stack([sp.base0, -2.0 * sp.base0])
+    r = c_port.evaluate(sp, bases, nthreads=2)
+    for b in range(2):
+        o = go.evaluate(sp, bases[b])
+        assert abs(r['loss'][b] - o['loss']) < 1e-13
+        assert abs(r['unitary_scale'][b] - o['unitary_scale']) < 1e-12
+        np.testing.assert_allclose(r['grad'][b], o['grad'], atol=1e-13 * max(1, np.max(np.abs(o['grad']))))
+        np.testing.assert_allclose(r['U_final'][b], o['U_final'], atol=1e-13)
+    # the loop: same TF1-Adam / LR schedule as run_adam
+    conv = dict(rate=0.02, max_iterations=7, learning_rate_decay=50, conv_target=-1.0, min_grad=-1.0)
+    ref = go.run_adam(sp, conv, base=sp.base0)
+    out, loss = c_port.iterate(sp, sp.base0[None], 7, rate=0.02, decay=50.0, nthreads=1)
+    np.testing.assert_allclose(out[0], ref['base'], atol=1e-12)
