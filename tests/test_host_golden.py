@@ -74,3 +74,26 @@ def test_convergence_defaults():
             conv.learning_rate_decay, conv.min_grad) == (0.01, 100, 100, 1e-8, 5000, 2500, 1e-25)
     conv = Convergence(None, 'ns', {'rate': 0.5, 'min_grad': 1e-9})
     assert conv.rate == 0.5 and conv.min_grad == 1e-9 and conv.max_iterations == 5000
+
+
+def test_builder_helpers_match_reference():
+    """Row f2: caller-side builders vs outputs of the reference's own functions (tests/golden/helpers.npz)."""
+    fx = load_golden('helpers.npz')
+    np.testing.assert_allclose(gf.qft(2), fx['qft2'], atol=1e-15)
+    np.testing.assert_array_equal(gf.Hadamard(2), fx['hadamard2'])
+    assert gf.concerned(2, 3) == list(fx['concerned_2_3'])
+    cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=complex)
+    np.testing.assert_array_equal(gf.transmon_gate(cnot, 3), fx['transmon_gate_cnot_3'])
+    np.testing.assert_array_equal(np.array(gf.rz(0.7)), fx['rz'])
+    np.testing.assert_array_equal(np.array(gf.rx(0.7)), fx['rx'])
+    sx = np.array([[0, 1], [1, 0]], dtype=float)
+    np.testing.assert_array_equal(gf.kron_all(sx, 3, np.eye(2)), fx['kron_all'])
+    np.testing.assert_array_equal(gf.multi_kron(sx, 3), fx['multi_kron'])
+    a3 = np.diag(np.sqrt(np.arange(1, 3)), 1)
+    np.testing.assert_array_equal(gf.nn_chain_kron(a3 + a3.T, np.eye(3), 3, 3), fx['nn_chain_kron'])
+    Hops, Hnames, amps = gf.append_separate_krons(a3 + a3.T, 'x', 2, 3, [], [], [], amp=2.5)
+    np.testing.assert_array_equal(np.array(Hops), fx['sep_kron_ops'])
+    assert list(Hnames) == [str(s) for s in fx['sep_kron_names']] and list(amps) == list(fx['sep_kron_amps'])
+    assert gf.Bin(5, 6) == str(fx['bin_5_6']) and gf.Basis(7, 3, 3) == str(fx['basis_7_3_3'])
+    assert gf.baseN(11, 3) == str(fx['baseN_11_3']) and gf.baseN(0, 5) == '0'
+    assert gf.hamming_distance(0b101101) == 4

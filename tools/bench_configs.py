@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Secondary configs of BASELINE.json (not the bench.py line): C1, C3 (state transfer), forbidden-regularised C2, n=64 unitary.
+Prints iterations/s per config through the same C ABI."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'quantum-optimal-control_amd'))
+import numpy as np  # noqa: E402
+
+from quantum_optimal_control.core import hip_engine  # noqa: E402
+from tests.golden import cases  # noqa: E402
+from tests.helpers import oracle_system  # noqa: E402
+
+
+def run(name, c, n_seeds, iters, path=0):
+    sp = oracle_system(c)
+    eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms,
+                               sp.scaling, state_transfer=sp.state_transfer, reg_coeffs=sp.reg_coeffs,
+                               one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=n_seeds, path=path)
+    rng = np.random.default_rng(0)
+    eng.set_base(rng.normal(0, 1 / np.sqrt(sp.steps), (n_seeds, sp.k, sp.steps)))
+    p = eng.adam_params(max_iterations=10 ** 9, conv_target=-1.0, min_grad=-1.0)
+    eng.iterate(p, 2); eng.sync()
+    t0 = time.perf_counter()
+    eng.iterate(p, iters); eng.sync()
+    el = time.perf_counter() - t0
+    s = eng.scalars()
+    print('%-34s n=%-3d k=%d steps=%-4d m=%d seeds=%-3d path=%d chunks=%-2d : %9.1f it/s aggregate, %8.3f ms/iteration-batch, loss[0]=%.6f'
+          % (name, sp.n, sp.k, sp.steps, sp.m, n_seeds, eng.path, eng.chunks, n_seeds * iters / el, el / iters * 1e3, s['loss'][0]))
+    eng.close()
+
+
+if __name__ == '__main__':
+    run('C1 single qubit', cases.case_c1(), 1, 50)
+    run('C1 single qubit x64 seeds', cases.case_c1(), 64, 50)
+    run('C2 single seed (latency)', cases.case_c2(), 1, 20)
+    run('C2 x64', cases.case_c2(), 64, 20)
+    c = cases.case_c2(); c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [30, 31]}
+    run('C2 x64 + dwdt + forbidden', c, 64, 20)
+    run('C3 state transfer', cases.case_c3(), 1, 5)
+    run('C3 state transfer x64 seeds', cases.case_c3(), 64, 5)
+    run('n=64 unitary (generic) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 3)
