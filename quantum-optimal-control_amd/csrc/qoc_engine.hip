@@ -19,6 +19,7 @@
 #include "qoc_kernels_finish.h"
 #include "qoc_kernels_generic.h"
 #include "qoc_kernels_mfma.h"
+#include "qoc_kernels_st.h"
 
 static thread_local std::string g_err;
 
@@ -142,6 +143,12 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         hipLaunchKernelGGL(k_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->seed_scratch);
         hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
         hipLaunchKernelGGL(k_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->seed_scratch);
+    } else if (e->path == QOC_PATH_ST_FUSED) {
+        TRY(prof_begin(e));
+        st_fused_launch(d, e->stream, true);
+        TRY(prof_end(e));
+        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        st_fused_launch(d, e->stream, false);
     } else {
         TRY(prof_begin(e));
         hipLaunchKernelGGL(k_st_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
@@ -301,10 +308,14 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // ---- path selection -----------------------------------------------------------------------------------------
     int path = cfg->path;
     const bool mfma_ok = qoc_mfma_supported(d);
-    if (path == QOC_PATH_AUTO) path = mfma_ok ? QOC_PATH_MFMA : QOC_PATH_GENERIC;
+    const bool st_ok = st_fused_supported(d);
+    if (path == QOC_PATH_AUTO) path = mfma_ok ? QOC_PATH_MFMA : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC);
     if (path == QOC_PATH_MFMA && !mfma_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 32, m <= 16, T >= 2 (n=%d m=%d)", n, m));
-    if (path != QOC_PATH_MFMA && path != QOC_PATH_GENERIC) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 32, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
+    if (path == QOC_PATH_ST_FUSED && !st_ok)
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
+    if (path != QOC_PATH_MFMA && path != QOC_PATH_GENERIC && path != QOC_PATH_ST_FUSED)
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
     if (path == QOC_PATH_MFMA) {
@@ -319,7 +330,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         e->expm_grid = grid;
         ALLOC(e->expm_scratch, (size_t)grid * 3 * nn);
         ALLOC(e->seed_scratch, (size_t)B * (2 * nn + 2 * nm));
-    } else {
+    } else if (path == QOC_PATH_GENERIC) {
         ALLOC(e->seed_scratch, (size_t)B * (nn + 3 * nm));
     }
 #undef ALLOC
@@ -496,7 +507,8 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     CHECK_H(e);
     TRY(prof_collect(e));
     if (kernel_name)
-        *kernel_name = e->path == QOC_PATH_MFMA ? "k_mfma_expm_chunk" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic");
+        *kernel_name = e->path == QOC_PATH_MFMA ? "k_mfma_expm_chunk"
+                       : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;
     return QOC_OK;

@@ -105,6 +105,36 @@ def test_mfma_path_parity(chunks, variant):
     eng.close()
 
 
+@pytest.mark.parametrize('variant', ['c3_small', 'allreg_m2', 'n64_m1', 'n5_m2', 'm4_T1'])
+def test_fused_state_transfer_parity(variant):
+    """Register-resident state-transfer kernels (path 3) against the oracle."""
+    if variant == 'c3_small':
+        c = cases.ALL_CASES['c3_small']()
+    elif variant == 'allreg_m2':
+        c = cases.case_state_small()
+        c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [5.0, 5.0], 'states_forbidden_list': [3, 4],
+                           'speed_up': 0.3, 'amplitude': 0.2}
+        c['Taylor_terms'] = [7, 0]
+    elif variant == 'n64_m1':
+        c = cases.case_c3(n=64, k=6, steps=30, taylor=(10, 0))
+    elif variant == 'n5_m2':
+        c = cases.case_state_small()
+    else:
+        c = cases.case_state_small(); c['Taylor_terms'] = [1, 0]
+        rng = np.random.default_rng(3)
+        vs = [rng.normal(size=5) + 1j * rng.normal(size=5) for _ in range(8)]
+        c['states_concerned_list'] = [v / np.linalg.norm(v) for v in vs[:4]]
+        c['U'] = [v / np.linalg.norm(v) for v in vs[4:]]
+    sp = oracle_system(c)
+    rng = np.random.default_rng(11)
+    bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1]
+    eng = make_engine(sp, n_seeds=2, path=3)
+    assert eng.path == 3
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
+
+
 def test_mfma_and_generic_paths_agree_in_the_loop():
     c = cases.case_c2(n=32, k=4, steps=30, m=8, taylor=(5, 3), seed=0)
     sp = oracle_system(c)
