@@ -20,6 +20,7 @@
 #include "qoc_kernels_generic.h"
 #include "qoc_kernels_mfma.h"
 #include "qoc_kernels_st.h"
+#include "qoc_kernels_gemm.h"
 
 static thread_local std::string g_err;
 
@@ -54,6 +55,7 @@ struct qoc_engine {
     cplx* seed_scratch = nullptr;
     // mfma path
     QocMfma mf;
+    QocGemm gm;
     bool evaluated = false;
     // profiling of the dominant kernel
     bool profiling = false;
@@ -136,6 +138,13 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         qoc_mfma_launch_forward(e->mf, d, e->stream);
         hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
         qoc_mfma_launch_backward(e->mf, d, e->stream);
+    } else if (e->path == QOC_PATH_GEMM) {
+        TRY(prof_begin(e));
+        qoc_gemm_expm(e->gm, d, e->stream);
+        TRY(prof_end(e));
+        qoc_gemm_forward(e->gm, d, e->stream);
+        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        qoc_gemm_backward(e->gm, d, e->stream);
     } else if (!d.state_transfer) {
         TRY(prof_begin(e));
         hipLaunchKernelGGL(k_expm_generic, dim3(e->expm_grid), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->expm_scratch);
@@ -309,13 +318,15 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     int path = cfg->path;
     const bool mfma_ok = qoc_mfma_supported(d);
     const bool st_ok = st_fused_supported(d);
-    if (path == QOC_PATH_AUTO) path = mfma_ok ? QOC_PATH_MFMA : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC);
+    const bool gemm_ok = qoc_gemm_supported(d);
+    if (path == QOC_PATH_AUTO) path = mfma_ok ? QOC_PATH_MFMA : (st_ok ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));
     if (path == QOC_PATH_MFMA && !mfma_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 32, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
-    if (path != QOC_PATH_MFMA && path != QOC_PATH_GENERIC && path != QOC_PATH_ST_FUSED)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
+    if (path == QOC_PATH_GEMM && !gemm_ok)
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: GEMM path needs unitary mode and m <= 32 (m=%d)", m));
+    if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
     if (path == QOC_PATH_MFMA) {
@@ -323,6 +334,10 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         e->chunks = e->mf.C;
+    } else if (path == QOC_PATH_GEMM) {
+        std::string msg;
+        rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, e->allocs, msg);
+        if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
     } else if (!cfg->state_transfer) {
         ALLOC(e->K, (size_t)B * steps * nn);
         int grid = B * steps;
@@ -507,7 +522,7 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     CHECK_H(e);
     TRY(prof_collect(e));
     if (kernel_name)
-        *kernel_name = e->path == QOC_PATH_MFMA ? "k_mfma_expm_chunk"
+        *kernel_name = e->path == QOC_PATH_GEMM ? "k_zgemm32 (batched matexp sequence)" : e->path == QOC_PATH_MFMA ? "k_mfma_expm_chunk"
                        : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;

@@ -1,0 +1,356 @@
+// qoc_kernels_gemm.h -- "GEMM path": unitary mode for any n > 32 (and m <= 32), e.g. BASELINE config C5 (n = 512).
+//
+// Matrices are zero-padded to N = 32*ceil(n/32) and stay in HBM/L2 as plain row-major complex128; every product is a
+// launch of k_zgemm32: ONE wavefront per 32x32 output tile, v_mfma_f64_16x16x4_f64 with the 3-multiplication complex
+// form (12 MFMAs per 4-deep k-slice, 12 independent accumulator chains), operand fragments loaded straight from
+// global memory in the MFMA A/B lane layouts (B rows are coalesced 256-byte segments; A is a 16-row x 64-byte gather
+// that L1/L2 absorb), no LDS and no barriers.  The host sequences the launches:
+//   * matrix exponentials: batched over ALL (seed, slice) pairs -- Horner form of the Taylor series + squarings;
+//   * forward chain: one launch per slice on the concatenation [X | Psi] (N x (N+32)), i.e. X_t = K_t X_{t-1} and
+//     Psi_t = K_t Psi_{t-1} together;
+//   * backward chain: one launch per slice, Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1} (epilogue adds the sources);
+//   * control gradients: for each control k ONE batched launch over all (seed, slice): the tile of H_k' Psi_t is
+//     contracted with conj(Lambda_t) in the epilogue (deterministic per-tile partial sums, reduced by k_gemm_grad_reduce).
+// Reference semantics: core/tensorflow_state.py:25-46, 49-65, 204-242.
+#pragma once
+#include <string>
+#include <vector>
+#include "qoc_common.h"
+
+typedef double gd4 __attribute__((ext_vector_type(4)));
+#define GMFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define QOC_TW 32          // thin (vector block) width
+
+struct GemmArgs {
+    const cplx* A; long long sA; int lda;      // left operand  (batch stride in elements; 0 = shared)
+    const cplx* Bm; long long sB; int ldb;     // right operand
+    cplx* C; long long sC; int ldc;            // output
+    const cplx* E; long long sE; int lde;      // optional addend (nullptr = none)
+    double alpha, beta, gamma;                 // C = alpha*op(A)*B + beta*E + gamma*I
+    int Kdim;                                  // inner dimension (multiple of 4)
+    int tiles_m, tiles_n;                      // output tiles per matrix
+    int batch;
+    // dot epilogue (EPI = 1): partial[batch][tile_m] = Re sum conj(L)*(A*B) over the tile
+    const cplx* L; long long sL; int ldl;
+    double* partial; int partial_stride;       // partial[(batch*partial_stride) + offset + tile_m]
+    int partial_offset;
+};
+
+template <bool CONJT, int EPI>
+__global__ void __launch_bounds__(64) k_zgemm32(GemmArgs g) {
+    const int lane = threadIdx.x;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int bt = blockIdx.x / tiles, tile = blockIdx.x - bt * tiles;
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int r0 = tm * 32, c0 = tn * 32;
+    const cplx* __restrict__ A = g.A + (size_t)bt * g.sA;
+    const cplx* __restrict__ Bm = g.Bm + (size_t)bt * g.sB;
+    gd4 t1[2][2], t2[2][2], t3[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) { t1[I][J] = (gd4){0, 0, 0, 0}; t2[I][J] = (gd4){0, 0, 0, 0}; t3[I][J] = (gd4){0, 0, 0, 0}; }
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int k0 = 0; k0 < g.Kdim; k0 += 8) {                       // two k-slices per trip: 8 loads in flight
+        cplx a[2][2], b[2][2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int kk = k0 + 4 * qq + lk;
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                if (CONJT) a[qq][I] = A[(size_t)kk * g.lda + r0 + 16 * I + lr];
+                else a[qq][I] = A[(size_t)(r0 + 16 * I + lr) * g.lda + kk];
+            }
+#pragma unroll
+            for (int J = 0; J < 2; ++J) b[qq][J] = Bm[(size_t)kk * g.ldb + c0 + 16 * J + lr];
+        }
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const double ar = a[qq][I].x, ai = CONJT ? -a[qq][I].y : a[qq][I].y, as = ar + ai;
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    const double br = b[qq][J].x, bi = b[qq][J].y;
+                    t1[I][J] = GMFMA(ar, br, t1[I][J]);
+                    t2[I][J] = GMFMA(ai, bi, t2[I][J]);
+                    t3[I][J] = GMFMA(as, br + bi, t3[I][J]);
+                }
+            }
+    }
+    // D layout: register r of tile (I, J) <-> (row = r0 + 16I + (lane>>4) + 4r, col = c0 + 16J + (lane&15))
+    double part = 0.0;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 16 * I + lk + 4 * r, col = c0 + 16 * J + lr;
+                const double re = t1[I][J][r] - t2[I][J][r], im = t3[I][J][r] - t1[I][J][r] - t2[I][J][r];
+                if (EPI == 0) {
+                    cplx v = cmake(g.alpha * re, g.alpha * im);
+                    if (g.E) {
+                        const cplx e = g.E[(size_t)bt * g.sE + (size_t)row * g.lde + col];
+                        v.x = fma(g.beta, e.x, v.x); v.y = fma(g.beta, e.y, v.y);
+                    }
+                    if (row == col) v.x += g.gamma;
+                    g.C[(size_t)bt * g.sC + (size_t)row * g.ldc + col] = v;
+                } else {
+                    const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
+                    part = fma(l.x, re, part); part = fma(l.y, im, part);      // Re(conj(l) * y)
+                }
+            }
+    if (EPI == 1) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if (lane == 0) g.partial[(size_t)bt * g.partial_stride + g.partial_offset + tm] = part;
+    }
+}
+
+// A_t = (H0' + sum_k u_k H_k') / 2^s for every (seed, slice), padded N x N           tensorflow_state.py:30-33
+__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N) {
+    const size_t NN = (size_t)N * N;
+    const size_t total = (size_t)d.B * d.steps * NN;
+    const double inv = 1.0 / (double)(1 << d.s);
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t item = o / NN, e = o - item * NN;
+        const int b = (int)(item / d.steps), t = (int)(item - (size_t)b * d.steps);
+        cplx acc = cscale(HsP[e], inv);
+        for (int kk = 0; kk < d.k; ++kk) {
+            const double c = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv;
+            const cplx h = HsP[(size_t)(kk + 1) * NN + e];
+            acc.x = fma(c, h.x, acc.x); acc.y = fma(c, h.y, acc.y);
+        }
+        Aout[o] = acc;
+    }
+}
+// P = I + A / T (first Horner step)
+__global__ void __launch_bounds__(256) k_gemm_horner_init(const cplx* __restrict__ A, cplx* __restrict__ P, size_t count, int N, double invT) {
+    const size_t NN = (size_t)N * N;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < count; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = o % NN;
+        const int row = (int)(e / N), col = (int)(e - (size_t)row * N);
+        const cplx a = A[o];
+        P[o] = cmake(a.x * invT + (row == col ? 1.0 : 0.0), a.y * invT);
+    }
+}
+// Y[b] = [U0 | Psi0] padded (N x (N+32)); inter[b][0] = V
+__global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restrict__ Y, int N) {
+    const int ld = N + QOC_TW;
+    const size_t per = (size_t)N * ld;
+    const size_t total = (size_t)d.B * per;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = o % per;
+        const int row = (int)(e / ld), col = (int)(e - (size_t)row * ld);
+        cplx v = cmake(0.0, 0.0);
+        if (row < d.n) {
+            if (col < d.n) v = d.U0[row * d.n + col];
+            else if (col >= N && col - N < d.m) v = d.Psi0[row * d.m + (col - N)];
+        }
+        Y[o] = v;
+    }
+    const size_t nm = (size_t)d.n * d.m;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * nm; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = o / nm, e = o - b * nm;
+        d.inter[b * (size_t)(d.steps + 1) * nm + e] = d.V[e];
+    }
+}
+// copy the thin block of Y (columns N..N+31) into interP[b][tau] (padded) and inter[b][tau] (API layout)
+__global__ void __launch_bounds__(256) k_gemm_take_psi(QocDev d, const cplx* __restrict__ Y, cplx* __restrict__ interP, int N, int tau) {
+    const int ld = N + QOC_TW;
+    const size_t per = (size_t)N * QOC_TW;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * per; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = o / per, e = o - b * per;
+        const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
+        const cplx v = Y[b * (size_t)N * ld + (size_t)row * ld + N + col];
+        interP[(b * (size_t)(d.steps + 1) + tau) * per + e] = v;
+        if (row < d.n && col < d.m) d.inter[(b * (size_t)(d.steps + 1) + tau) * d.n * d.m + (size_t)row * d.m + col] = v;
+    }
+}
+// final_state, unitary_scale from the X block of Y                                     tensorflow_state.py:223-225
+__global__ void __launch_bounds__(256) k_gemm_take_final(QocDev d, const cplx* __restrict__ Y, int N) {
+    __shared__ double red[8];
+    const int b = blockIdx.x, ld = N + QOC_TW, n = d.n;
+    const cplx* X = Y + (size_t)b * N * ld;
+    double part = 0.0;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        cplx rs = cmake(0.0, 0.0);
+        for (int a = 0; a < n; ++a) rs = cadd(rs, X[(size_t)c * ld + a]);
+        part += rs.x * rs.x + rs.y * rs.y;
+    }
+    for (int o = threadIdx.x; o < n * n; o += blockDim.x) d.Xfinal[(size_t)b * n * n + o] = X[(size_t)(o / n) * ld + (o % n)];
+    const double tot = block_sum(part, red);
+    if (threadIdx.x == 0) d.uscale[b] = tot / (double)n;
+}
+// sources S[b][tau] (padded thin) for every tau, and the terminal costate LamP[b][steps-1]
+__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ LamP, int N) {
+    const size_t per = (size_t)N * QOC_TW;
+    const bool need_src = d.n_forb > 0 || d.has_speed;
+    const size_t total = (size_t)d.B * (d.steps + 1) * per;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bt = o / per, e = o - bt * per;
+        const int b = (int)(bt / (d.steps + 1)), tau = (int)(bt - (size_t)b * (d.steps + 1));
+        const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
+        cplx s = cmake(0.0, 0.0);
+        const bool valid = row < d.n && col < d.m;
+        if (valid && need_src && tau >= 1) s = source_at(d, b, tau, row, col);
+        if (need_src) SrcP[o] = s;
+        if (tau == d.steps) {                                            // Lambda_{steps-1} = -(2/m^2) z W + S_steps
+            cplx v = cmake(0.0, 0.0);
+            if (valid) {
+                const double c0 = -2.0 / ((double)d.m * (double)d.m);
+                v = cadd(cscale(cmul(d.zfin[b], d.W[row * d.m + col]), c0), s);
+            }
+            LamP[((size_t)b * d.steps + (d.steps - 1)) * per + e] = v;
+        }
+    }
+}
+// dLdu[b][k][t] = sum over row tiles of the partial dots
+__global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double* __restrict__ partial, int tiles_m) {
+    const size_t total = (size_t)d.B * d.steps * d.k;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bt = o / d.k;
+        const int kk = (int)(o - bt * d.k);
+        const int b = (int)(bt / d.steps), t = (int)(bt - (size_t)b * d.steps);
+        const double* p = partial + (bt * d.k + kk) * tiles_m;
+        double s = 0.0;
+        for (int i = 0; i < tiles_m; ++i) s += p[i];
+        d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = s;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+struct QocGemm {
+    int N = 0;
+    cplx* HsP = nullptr;      // [k+1][N][N]
+    cplx *A = nullptr, *P = nullptr, *K = nullptr;     // [B*steps][N][N]
+    cplx *Y0 = nullptr, *Y1 = nullptr;                               // [B][N][N+32]
+    cplx* interP = nullptr;   // [B][steps+1][N][32]
+    cplx* LamP = nullptr;     // [B][steps][N][32]
+    cplx* SrcP = nullptr;     // [B][steps+1][N][32] (state regularisers only)
+    double* partial = nullptr; // [B*steps][k][N/32]
+};
+
+static inline bool qoc_gemm_supported(const QocDev& d) { return !d.state_transfer && d.m <= QOC_TW && d.T >= 1; }
+
+static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg) {
+    const int N = ((d.n + 31) / 32) * 32;
+    gm.N = N;
+    const size_t NN = (size_t)N * N, BS = (size_t)d.B * d.steps, thin = (size_t)N * QOC_TW;
+    std::vector<cplx> hp((size_t)(d.k + 1) * NN);
+    for (auto& v : hp) { v.x = 0; v.y = 0; }
+    for (int kk = 0; kk <= d.k; ++kk)
+        for (int a = 0; a < d.n; ++a)
+            for (int c = 0; c < d.n; ++c) hp[(size_t)kk * NN + (size_t)a * N + c] = Hs_host[(size_t)kk * d.n * d.n + (size_t)a * d.n + c];
+    auto al = [&](void** dst, size_t bytes) -> bool {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return false;
+        allocs.push_back(p);
+        *dst = p;
+        return true;
+    };
+    const bool need_src = d.n_forb > 0 || d.has_speed;
+    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.A, BS * NN * sizeof(cplx)) &&
+              al((void**)&gm.P, BS * NN * sizeof(cplx)) &&
+              al((void**)&gm.K, BS * NN * sizeof(cplx)) && al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
+              al((void**)&gm.Y1, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
+              al((void**)&gm.interP, (size_t)d.B * (d.steps + 1) * thin * sizeof(cplx)) &&
+              al((void**)&gm.LamP, BS * thin * sizeof(cplx)) &&
+              al((void**)&gm.partial, BS * d.k * (N / 32) * sizeof(double));
+    if (ok && need_src) ok = al((void**)&gm.SrcP, (size_t)d.B * (d.steps + 1) * thin * sizeof(cplx));
+    if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
+    if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+    hipMemset(gm.interP, 0, (size_t)d.B * (d.steps + 1) * thin * sizeof(cplx));
+    return 0;
+}
+
+static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
+    const unsigned blocks = (unsigned)((size_t)g.batch * g.tiles_m * g.tiles_n);
+    if (epi == 0) {
+        if (conjt) hipLaunchKernelGGL((k_zgemm32<true, 0>), dim3(blocks), dim3(64), 0, s, g);
+        else hipLaunchKernelGGL((k_zgemm32<false, 0>), dim3(blocks), dim3(64), 0, s, g);
+    } else {
+        hipLaunchKernelGGL((k_zgemm32<false, 1>), dim3(blocks), dim3(64), 0, s, g);
+    }
+}
+
+static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
+
+// K_t for all (seed, slice): the dominant part of the path (bracketed by the profiling events of the engine)
+static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    const int N = gm.N;
+    const size_t NN = (size_t)N * N, BS = (size_t)d.B * d.steps;
+    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N);
+    // result of the Taylor/squaring sequence must land in gm.K: count the remaining products to pick the start buffer
+    const int products = (d.T - 1) + d.s;
+    cplx* cur = (products % 2 == 0) ? gm.K : gm.P;          // buffers alternate cur -> other on every product
+    cplx* oth = (products % 2 == 0) ? gm.P : gm.K;
+    hipLaunchKernelGGL(k_gemm_horner_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, cur, BS * NN, N, 1.0 / (double)d.T);
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.lda = g.ldb = g.ldc = N; g.sA = g.sB = g.sC = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.batch = (int)BS;
+    for (int j = d.T - 1; j >= 1; --j) {                     // P <- I + (A P)/j            tensorflow_state.py:37-41
+        g.A = gm.A; g.Bm = cur; g.C = oth; g.E = nullptr; g.alpha = 1.0 / (double)j; g.beta = 0.0; g.gamma = 1.0;
+        qoc_gemm_launch(false, 0, g, s);
+        cplx* t = cur; cur = oth; oth = t;
+    }
+    for (int sq = 0; sq < d.s; ++sq) {                       // M <- M M                    tensorflow_state.py:43-44
+        g.A = cur; g.Bm = cur; g.C = oth; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
+        qoc_gemm_launch(false, 0, g, s);
+        cplx* t = cur; cur = oth; oth = t;
+    }
+    (void)cur;                                               // == gm.K by construction
+}
+
+static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    const int N = gm.N, ld = N + QOC_TW;
+    const size_t NN = (size_t)N * N;
+    hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, N);
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.lda = N; g.sA = (long long)NN * d.steps; g.ldb = g.ldc = ld; g.sB = g.sC = (long long)N * ld;
+    g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = ld / 32; g.batch = d.B; g.alpha = 1.0;
+    cplx *cur = gm.Y0, *oth = gm.Y1;
+    for (int t = 0; t < d.steps; ++t) {                      // [X | Psi]_t = K_t [X | Psi]_{t-1}  tensorflow_state.py:214-238
+        g.A = gm.K + (size_t)t * NN; g.Bm = cur; g.C = oth;
+        qoc_gemm_launch(false, 0, g, s);
+        hipLaunchKernelGGL(k_gemm_take_psi, dim3(gemm_grid((size_t)d.B * N * QOC_TW)), dim3(256), 0, s, d, oth, gm.interP, N, t + 1);
+        cplx* x = cur; cur = oth; oth = x;
+    }
+    hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
+}
+
+static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    const int N = gm.N;
+    const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
+    const bool need_src = d.n_forb > 0 || d.has_speed;
+    hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (d.steps + 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.LamP, N);
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.lda = N; g.sA = (long long)NN * d.steps; g.ldb = g.ldc = g.lde = QOC_TW;
+    g.sB = g.sC = (long long)thin * d.steps; g.sE = (long long)thin * (d.steps + 1);
+    g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = 1; g.batch = d.B; g.alpha = 1.0; g.beta = 1.0;
+    for (int t = d.steps - 1; t >= 1; --t) {                 // Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1}
+        g.A = gm.K + (size_t)t * NN; g.Bm = gm.LamP + (size_t)t * thin; g.C = gm.LamP + (size_t)(t - 1) * thin;
+        g.E = need_src ? gm.SrcP + (size_t)t * thin : nullptr;           // S index tau = t  <->  Psi_{t-1}
+        qoc_gemm_launch(true, 0, g, s);
+    }
+    // gradients: for each control one batched product H_k' Psi_t contracted with conj(Lambda_t)   tensorflow_state.py:61-63
+    GemmArgs h;
+    memset(&h, 0, sizeof h);
+    h.lda = N; h.sA = 0; h.ldb = QOC_TW; h.ldl = QOC_TW; h.Kdim = N; h.tiles_m = N / 32; h.tiles_n = 1;
+    h.partial = gm.partial; h.partial_stride = d.k * (N / 32);
+    for (int b = 0; b < d.B; ++b) {
+        h.batch = d.steps;
+        h.Bm = gm.interP + ((size_t)b * (d.steps + 1) + 1) * thin; h.sB = (long long)thin;       // Psi_t = interP[tau = t+1]
+        h.L = gm.LamP + (size_t)b * d.steps * thin; h.sL = (long long)thin;
+        for (int kk = 0; kk < d.k; ++kk) {
+            h.A = gm.HsP + (size_t)(kk + 1) * NN;
+            h.partial = gm.partial + (size_t)b * d.steps * h.partial_stride;
+            h.partial_offset = kk * (N / 32);
+            qoc_gemm_launch(false, 1, h, s);
+        }
+    }
+    hipLaunchKernelGGL(k_gemm_grad_reduce, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, N / 32);
+}

@@ -135,6 +135,31 @@ def test_fused_state_transfer_parity(variant):
     eng.close()
 
 
+@pytest.mark.parametrize('variant', ['n40', 'n64_sources', 'n33_m20', 'n20_forced', 'n96_short'])
+def test_gemm_path_parity(variant):
+    """Tiled-MFMA GEMM path (path 4: any n, m <= 32) against the oracle."""
+    if variant == 'n40':
+        c = cases.case_c2(n=40, k=3, steps=12, m=6, taylor=(6, 2), seed=21)
+    elif variant == 'n64_sources':
+        c = cases.case_c2(n=64, k=2, steps=9, m=4, taylor=(5, 3), seed=22)
+        c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [3.0, 2.0], 'states_forbidden_list': [63, 62],
+                           'speed_up': 0.4, 'amplitude': 0.2}
+    elif variant == 'n33_m20':
+        c = cases.case_c2(n=33, k=2, steps=7, m=20, taylor=(4, 1), seed=23)
+    elif variant == 'n20_forced':
+        c = cases.case_c2(n=20, k=3, steps=10, m=5, taylor=(1, 2), seed=24)
+    else:
+        c = cases.case_c2(n=96, k=2, steps=5, m=8, taylor=(6, 3), seed=25)
+    sp = oracle_system(c)
+    rng = np.random.default_rng(5)
+    bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2]
+    eng = make_engine(sp, n_seeds=len(bases), path=4)
+    assert eng.path == 4
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
+
+
 def test_mfma_and_generic_paths_agree_in_the_loop():
     c = cases.case_c2(n=32, k=4, steps=30, m=8, taylor=(5, 3), seed=0)
     sp = oracle_system(c)

@@ -42,4 +42,7 @@ if __name__ == '__main__':
     run('C2 x64 + dwdt + forbidden', c, 64, 20)
     run('C3 state transfer', cases.case_c3(), 1, 5)
     run('C3 state transfer x64 seeds', cases.case_c3(), 64, 5)
-    run('n=64 unitary (generic) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 3)
+    run('n=64 unitary (generic path) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 3, path=1)
+    run('n=64 unitary (GEMM path) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 5)
+    run('n=128 unitary (GEMM path) x4', cases.case_c2(n=128, k=6, steps=500, m=8, taylor=(5, 3), seed=2), 4, 3)
+    run('C5 n=512 k=8 steps=2000 (GEMM path)', cases.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2), 1, 2)
