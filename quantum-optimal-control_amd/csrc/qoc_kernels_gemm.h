@@ -36,9 +36,13 @@ struct GemmArgs {
     int partial_offset;
 };
 
-template <bool CONJT, int EPI>
-__global__ void __launch_bounds__(64) k_zgemm32(GemmArgs g) {
-    const int lane = threadIdx.x;
+// SK wavefronts of a workgroup split the inner dimension of ONE tile (small-batch chain launches are latency-bound when
+// a single wave walks all of K); partial (re, im) tiles meet in LDS (16 KB per extra wave), wave 0 runs the epilogue.
+template <bool CONJT, int EPI, int SK>
+__global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double sk_part[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = g.tiles_m * g.tiles_n;
     const int bt = blockIdx.x / tiles, tile = blockIdx.x - bt * tiles;
     const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
@@ -51,7 +55,8 @@ __global__ void __launch_bounds__(64) k_zgemm32(GemmArgs g) {
 #pragma unroll
         for (int J = 0; J < 2; ++J) { t1[I][J] = (gd4){0, 0, 0, 0}; t2[I][J] = (gd4){0, 0, 0, 0}; t3[I][J] = (gd4){0, 0, 0, 0}; }
     const int lr = lane & 15, lk = lane >> 4;
-    for (int k0 = 0; k0 < g.Kdim; k0 += 8) {                       // two k-slices per trip: 8 loads in flight
+    const int kspan = g.Kdim / SK;
+    for (int k0 = wv * kspan; k0 < (wv + 1) * kspan; k0 += 8) {     // two k-slices per trip: 8 loads in flight
         cplx a[2][2], b[2][2];
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
@@ -78,6 +83,41 @@ __global__ void __launch_bounds__(64) k_zgemm32(GemmArgs g) {
                 }
             }
     }
+    // combine the 3-multiplication accumulators (linear, so partial K ranges simply add)
+    gd4 re[2][2], im[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) { re[I][J] = t1[I][J] - t2[I][J]; im[I][J] = t3[I][J] - t1[I][J] - t2[I][J]; }
+    if (SK > 1) {
+        if (wv > 0) {
+            double* dst = sk_part + (size_t)(wv - 1) * 2048 + lane;             // [32 values][64 lanes]
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dst[(((I * 2 + J) * 4 + r) * 2 + 0) * 64] = re[I][J][r];
+                        dst[(((I * 2 + J) * 4 + r) * 2 + 1) * 64] = im[I][J][r];
+                    }
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 1; w < SK; ++w) {
+            const double* src = sk_part + (size_t)(w - 1) * 2048 + lane;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        re[I][J][r] += src[(((I * 2 + J) * 4 + r) * 2 + 0) * 64];
+                        im[I][J][r] += src[(((I * 2 + J) * 4 + r) * 2 + 1) * 64];
+                    }
+        }
+    }
     // D layout: register r of tile (I, J) <-> (row = r0 + 16I + (lane>>4) + 4r, col = c0 + 16J + (lane&15))
     double part = 0.0;
 #pragma unroll
@@ -87,9 +127,9 @@ __global__ void __launch_bounds__(64) k_zgemm32(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = r0 + 16 * I + lk + 4 * r, col = c0 + 16 * J + lr;
-                const double re = t1[I][J][r] - t2[I][J][r], im = t3[I][J][r] - t1[I][J][r] - t2[I][J][r];
+                const double vre = re[I][J][r], vim = im[I][J][r];
                 if (EPI == 0) {
-                    cplx v = cmake(g.alpha * re, g.alpha * im);
+                    cplx v = cmake(g.alpha * vre, g.alpha * vim);
                     if (g.E) {
                         const cplx e = g.E[(size_t)bt * g.sE + (size_t)row * g.lde + col];
                         v.x = fma(g.beta, e.x, v.x); v.y = fma(g.beta, e.y, v.y);
@@ -98,7 +138,7 @@ __global__ void __launch_bounds__(64) k_zgemm32(GemmArgs g) {
                     g.C[(size_t)bt * g.sC + (size_t)row * g.ldc + col] = v;
                 } else {
                     const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
-                    part = fma(l.x, re, part); part = fma(l.y, im, part);      // Re(conj(l) * y)
+                    part = fma(l.x, vre, part); part = fma(l.y, vim, part);      // Re(conj(l) * y)
                 }
             }
     if (EPI == 1) {
@@ -265,13 +305,38 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     return 0;
 }
 
+template <bool CONJT, int EPI, int SK>
+static inline void qoc_gemm_launch_sk(const GemmArgs& g, unsigned blocks, hipStream_t s) {
+    const size_t lds = SK > 1 ? (size_t)(SK - 1) * 2048 * sizeof(double) : 0;
+    if (SK > 2) {
+        static bool once = false;
+        if (!once) { hipFuncSetAttribute((const void*)k_zgemm32<CONJT, EPI, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    }
+    hipLaunchKernelGGL((k_zgemm32<CONJT, EPI, SK>), dim3(blocks), dim3(64 * SK), lds, s, g);
+}
+// picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small
 static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
-    const unsigned blocks = (unsigned)((size_t)g.batch * g.tiles_m * g.tiles_n);
-    if (epi == 0) {
-        if (conjt) hipLaunchKernelGGL((k_zgemm32<true, 0>), dim3(blocks), dim3(64), 0, s, g);
-        else hipLaunchKernelGGL((k_zgemm32<false, 0>), dim3(blocks), dim3(64), 0, s, g);
+    const size_t tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
+    const unsigned blocks = (unsigned)tiles;
+    int sk = 1;
+    if (tiles * 2 <= 2048 && (g.Kdim / 2) % 8 == 0) sk = 2;
+    if (tiles * 4 <= 2048 && (g.Kdim / 4) % 8 == 0) sk = 4;
+    if (tiles * 8 <= 2048 && (g.Kdim / 8) % 8 == 0) sk = 8;
+    if (epi == 1) {
+        if (sk == 8) qoc_gemm_launch_sk<false, 1, 8>(g, blocks, s);
+        else if (sk == 4) qoc_gemm_launch_sk<false, 1, 4>(g, blocks, s);
+        else if (sk == 2) qoc_gemm_launch_sk<false, 1, 2>(g, blocks, s);
+        else qoc_gemm_launch_sk<false, 1, 1>(g, blocks, s);
+    } else if (conjt) {
+        if (sk == 8) qoc_gemm_launch_sk<true, 0, 8>(g, blocks, s);
+        else if (sk == 4) qoc_gemm_launch_sk<true, 0, 4>(g, blocks, s);
+        else if (sk == 2) qoc_gemm_launch_sk<true, 0, 2>(g, blocks, s);
+        else qoc_gemm_launch_sk<true, 0, 1>(g, blocks, s);
     } else {
-        hipLaunchKernelGGL((k_zgemm32<false, 1>), dim3(blocks), dim3(64), 0, s, g);
+        if (sk == 8) qoc_gemm_launch_sk<false, 0, 8>(g, blocks, s);
+        else if (sk == 4) qoc_gemm_launch_sk<false, 0, 4>(g, blocks, s);
+        else if (sk == 2) qoc_gemm_launch_sk<false, 0, 2>(g, blocks, s);
+        else qoc_gemm_launch_sk<false, 0, 1>(g, blocks, s);
     }
 }
 
