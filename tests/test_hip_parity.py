@@ -283,3 +283,41 @@ def test_large_size_properties_c2():
     np.testing.assert_allclose(Uf[0], o['U_final'], atol=1e-11)
     assert np.max(np.abs(r['grad'][0] - o['grad'])) <= 1e-10 * np.max(np.abs(o['grad']))
     eng.close()
+
+
+def test_large_size_properties_c5():
+    """BASELINE config C5 at full size (n=512, k=8, steps=2000) on the GEMM path: the oracle cannot run this in
+    reasonable time, so the check is through size-independent properties + an oracle comparison of the first slices and
+    of the last-slice gradient (which only needs the final vectors)."""
+    c = cases.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2)
+    sp = oracle_system(c)
+    eng = make_engine(sp, n_seeds=1)
+    assert eng.path == 4
+    eng.set_base(sp.base0[None])
+    r = eng.evaluate()
+    Uf = eng.get_final_unitary()[0]
+    inter = eng.get_inter_vecs()[0]
+    n, m = 512, 8
+    dev = np.max(np.abs(Uf.conj().T @ Uf - np.eye(n)))
+    assert dev < 1e-2                                            # order-5 / 3-squaring series, 2000 slices
+    assert abs(r['unitary_scale'][0] - np.sum((Uf.conj().T @ Uf).real) / n) < 1e-10
+    np.testing.assert_allclose(inter[-1], Uf[:, :m], atol=1e-11)
+    np.testing.assert_array_equal(inter[0], sp.V)
+    z = np.sum(inter[-1] * np.conj(sp.W))
+    assert abs(r['loss'][0] - (1 - abs(z) ** 2 / m ** 2)) < 1e-12
+    assert abs(r['grad_squared'][0] - 0.5 * np.sum(r['grad'][0] ** 2)) < 1e-12 * max(1.0, r['grad_squared'][0])
+    # first two slices against the oracle's matexp
+    u = sp.maxA[:, None] * np.sin(sp.base0)
+    psi = sp.V
+    for t in range(2):
+        A = (sp.Hs[0] + np.tensordot(u[:, t], sp.Hs[1:], axes=1)) / 2 ** sp.scaling
+        psi = go.matexp(A, sp.exp_terms, sp.scaling) @ psi
+        np.testing.assert_allclose(inter[t + 1], psi, atol=1e-12)
+    # last-slice gradient: Lambda_{steps-1} = -(2/m^2) z W, dL/du_k = Re <Lambda, H_k' Psi_final>
+    lam = (-2.0 / m ** 2) * z * sp.W
+    t = sp.steps - 1
+    for kk in range(sp.k):
+        g = np.real(np.sum(np.conj(lam) * (sp.Hs[kk + 1] @ inter[-1])))
+        expect = np.cos(sp.base0[kk, t]) * sp.maxA[kk] * g
+        assert abs(r['grad'][0][kk, t] - expect) < 1e-10 * max(1.0, abs(expect))
+    eng.close()
