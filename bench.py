@@ -198,8 +198,19 @@ def main():
         flops_per_launch = gsh[0].count * SLICES * ((T - 1 + s) + 1) * 8.0 * N ** 3   # expm GEMMs + chain GEMM, SURVEY 8d
         avg_ms = pr['total_ms'] / max(1, pr['launches'])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so the value comes from the committed PMC pass of
+        # this same command (profiles/r01_pmc_traffic.json) when the workload matches; null otherwise
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            w = pm['workload']
+            if (w['seeds_per_gpu'], w['chunks'], pm['kernel']) == (gsh[0].count, eng.chunks, pr['kernel']):
+                traffic = pm['hbm_bytes_per_launch']
+        except Exception:
+            traffic = None
         roof = {'bound': 'mfma', 'kernel': pr['kernel'], 'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
+                'traffic_unit': 'bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.txt)',
                 'avg_launch_ms': avg_ms, 'launches': pr['launches'], 'flops_per_launch': flops_per_launch,
                 'measured_mfma_f64_ceiling_TFLOPs': 48.2}
     total_seeds = B * world
