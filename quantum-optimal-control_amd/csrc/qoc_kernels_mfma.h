@@ -461,10 +461,10 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
                     const int row = 16 * I + (lane & 15), j = 4 * q + (lane >> 4);
                     const cplx lv = pad[j * QOC_LDR + row];
                     lr[I][q] = lv.x; li[I][q] = lv.y;
-                    // clamped address + select (no per-element branch around the load)
-                    const cplx pv = psi[min(row, d.n - 1) * d.m + min(j, d.m - 1)];
-                    const bool ok = row < d.n && j < d.m;
-                    pr[I][q] = ok ? pv.x : 0.0; pi[I][q] = ok ? pv.y : 0.0;
+                    if (row < d.n && j < d.m) {
+                        const cplx pv = psi[row * d.m + j];
+                        pr[I][q] = pv.x; pi[I][q] = pv.y;
+                    }
                 }
             }
         double g[8];
