@@ -54,7 +54,14 @@ struct QocMfma {
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
     size_t bwd_lds = 0;
     bool h_in_lds = true;
+    int skew_c = 0, skew_b = 0;   // element skews per chunk / per seed that break the power-of-two strides of K storage
 };
+
+// element offset of K_t of seed b in KfD / KfT: consecutive slices are 16 KB apart; concurrent wavefronts differ in
+// (seed, chunk), whose natural strides (L*16 KB, steps*16 KB) are powers of two for the usual sizes and alias HBM channels
+__device__ __forceinline__ size_t kitem(const QocMfma& mf, int steps, int b, int t) {
+    return (size_t)b * ((size_t)steps * QOC_FRAG + (size_t)mf.C * mf.skew_c + mf.skew_b) + (size_t)t * QOC_FRAG + (size_t)(t / mf.L) * mf.skew_c;
+}
 
 // ---- fragment helpers ---------------------------------------------------------------------------------------------
 
@@ -257,13 +264,13 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
             P[0] = acc[0]; P[1] = acc[1];
         }
         // ---- K_t out (both operand forms); running chunk product R <- K_t R ----------------------------------------
-        const size_t item = (size_t)b * d.steps + t;
-        colblock_store(mf.KfD + item * QOC_FRAG, J, lane, P);
+        const size_t item = kitem(mf, d.steps, b, t);
+        colblock_store(mf.KfD + item, J, lane, P);
         lds_put_colblock(img[flip], 16 * J, lane, P);
         __syncthreads();
         lds_get_afrag(img[flip], lane, A);
         flip ^= 1;
-        afrag_store_half(mf.KfT + item * QOC_FRAG, J, lane, A);
+        afrag_store_half(mf.KfT + item, J, lane, A);
         CTile acc[2];
         mm_colblock(A, R, acc);
         R[0] = acc[0]; R[1] = acc[1];
@@ -308,7 +315,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
             Psi[0] = acc[0]; Psi[1] = acc[1];
         }
         for (int t = t0; t < t1; ++t) {
-            afrag_load<false>(mf.KfT + ((size_t)b * d.steps + t) * QOC_FRAG, lane, A);
+            afrag_load<false>(mf.KfT + kitem(mf, d.steps, b, t), lane, A);
             CTile acc[2];
             mm_colblock(A, Psi, acc);
             Psi[0] = acc[0]; Psi[1] = acc[1];
@@ -374,7 +381,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
     for (int Ib = 0; Ib < 2; ++Ib) { Z[Ib].re = (d4){0, 0, 0, 0}; Z[Ib].im = (d4){0, 0, 0, 0}; }
     AFrag A;
     for (int t = t1 - 1; t >= t0; --t) {
-        afrag_load<true>(mf.KfD + ((size_t)b * d.steps + t) * QOC_FRAG, lane, A);
+        afrag_load<true>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
         CTile acc[2];
         mm_colblock(A, Z, acc);
 #pragma unroll
@@ -507,7 +514,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
         }
         if (t == 0) break;
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t (+ S_{t-1}) ---------------------------------------------------------
-        afrag_load<true>(mf.KfD + ((size_t)b * d.steps + t) * QOC_FRAG, lane, A);
+        afrag_load<true>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
         CTile acc[2];
         mm_colblock(A, Lam, acc);
         Lam[0] = acc[0]; Lam[1] = acc[1];
@@ -587,7 +594,9 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         *dst = (cplx*)p;
         return true;
     };
-    const size_t nk = (size_t)d.B * d.steps * QOC_FRAG, np = (size_t)d.B * C * QOC_FRAG;
+    mf.skew_c = 5 * 16;                            // 1280 B per chunk
+    mf.skew_b = 3 * 16;                            //  768 B per seed
+    const size_t nk = (size_t)d.B * ((size_t)d.steps * QOC_FRAG + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * QOC_FRAG;
     if (!al(&mf.KfD, nk) || !al(&mf.KfT, nk) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 512)) { msg = "MFMA path: out of device memory"; return -3; }
     const size_t pads = (size_t)4 * 16 * QOC_LDR * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * QOC_FRAG * sizeof(cplx);
