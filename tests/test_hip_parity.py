@@ -350,3 +350,55 @@ def test_seed_batching_is_bitwise_deterministic():
     # and the run is repeatable
     again = run([0, 1, 2, 3, 4])
     assert np.array_equal(again[0], whole[0])
+
+
+def edge_cases():
+    out = []
+    out.append(('n1_scalar', cases.case_c2(n=1, k=1, steps=5, m=1, taylor=(6, 1), seed=31), 0))
+    out.append(('mfma_m16_k8', cases.case_c2(n=24, k=8, steps=6, m=16, taylor=(3, 1), seed=32), 2))
+    out.append(('mfma_T22_s0', cases.case_c2(n=9, k=2, steps=4, m=3, taylor=(22, 0), seed=33), 2))
+    out.append(('mfma_T2_s5', cases.case_c2(n=32, k=1, steps=3, m=8, taylor=(2, 5), seed=34), 2))
+    out.append(('gemm_m32', cases.case_c2(n=32, k=2, steps=4, m=32, taylor=(4, 1), seed=35), 0))
+    out.append(('gemm_n65', cases.case_c2(n=65, k=2, steps=3, m=2, taylor=(3, 2), seed=36), 0))
+    out.append(('gemm_k9', cases.case_c2(n=8, k=9, steps=4, m=3, taylor=(4, 1), seed=37), 0))
+    c = cases.case_state_small(); c['Taylor_terms'] = [9, 0]
+    rng = np.random.default_rng(3)
+    vs = [rng.normal(size=5) + 1j * rng.normal(size=5) for _ in range(10)]
+    c['states_concerned_list'] = [v / np.linalg.norm(v) for v in vs[:5]]
+    c['U'] = [v / np.linalg.norm(v) for v in vs[5:]]
+    out.append(('st_m5_generic', c, 0))
+    c = cases.case_state_small(); c['Taylor_terms'] = [5, 0]
+    c['states_concerned_list'] = [v / np.linalg.norm(v) for v in vs[:3]]
+    c['U'] = [v / np.linalg.norm(v) for v in vs[5:8]]
+    out.append(('st_m3_fused', c, 3))
+    out.append(('st_n65_generic', cases.case_c3(n=65, k=2, steps=4, taylor=(4, 0)), 0))
+    return out
+
+
+@pytest.mark.parametrize('name,c,path', edge_cases(), ids=[e[0] for e in edge_cases()])
+def test_edge_cases_all_paths(name, c, path):
+    """Limits of every fast path and the automatic fall-through to the next one (sizes 1, maximum m/k/T, n just past a
+    tile boundary, vector counts the fused kernels do not cover)."""
+    if name == 'st_n65_generic':
+        c['reg_coeffs'] = {'dwdt': 0.1}
+    sp = oracle_system(c)
+    bases = [sp.base0, -1.5 * sp.base0 + 0.05]
+    eng = make_engine(sp, n_seeds=2, path=path)
+    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'st_m5_generic': 1, 'st_n65_generic': 1}
+    if name in expect:
+        assert eng.path == expect[name], (name, eng.path)
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
+
+
+def test_unsupported_path_requests_fail_loudly():
+    from quantum_optimal_control.core import hip_engine
+    sp = oracle_system(cases.case_c2(n=40, k=2, steps=3, m=2, taylor=(3, 1), seed=1))
+    with pytest.raises(hip_engine.QocError, match='MFMA path needs'):
+        make_engine(sp, path=2)
+    sp = oracle_system(cases.case_state_small())
+    with pytest.raises(hip_engine.QocError, match='GEMM path needs unitary'):
+        make_engine(sp, path=4)
+    with pytest.raises(hip_engine.QocError, match='unknown path'):
+        make_engine(sp, path=9)
