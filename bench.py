@@ -230,7 +230,7 @@ def main():
             'best_fidelity': float(np.max(fidelity)),
             'roofline': roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (contract)
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     for e in engs:
