@@ -477,18 +477,16 @@ int qoc_run_adam(qoc_handle e, const qoc_adam_params* p, int32_t* iterations_out
 
 int qoc_get_uks(qoc_handle e, double* uks) {
     CHECK_H(e);
+    if (!uks) return fail(QOC_ERR_INVALID, "qoc_get_uks: null output");
     const QocDev& d = e->d;
-    const size_t ks = (size_t)d.k * d.steps;
-    std::vector<double> base((size_t)d.B * ks), maxA(d.k);
+    // uks = maxA[k] * sin(base) of the CURRENT variable (run_session.py:112-117), evaluated on the device
+    const int total = d.B * d.k * d.steps;
+    int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
+    if (cgrid > 2048) cgrid = 2048;
+    hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(base.data(), d.base, base.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(maxA.data(), d.maxA, d.k * sizeof(double), hipMemcpyDeviceToHost));
-    for (int b = 0; b < d.B; ++b)
-        for (int kk = 0; kk < d.k; ++kk)
-            for (int t = 0; t < d.steps; ++t) {
-                const size_t o = (size_t)b * ks + (size_t)kk * d.steps + t;
-                uks[o] = maxA[kk] * sin(base[o]);                                // run_session.py:112-117
-            }
+    HIP_TRY(hipMemcpy(uks, d.u, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
     return QOC_OK;
 }
 
