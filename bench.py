@@ -95,6 +95,28 @@ def cpu_baseline(budget_s=15.0):
                       'to one thread)' % (its, el)}
 
 
+def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
+    """BASELINE.md "B-faithful": the reference's own op sequence -- real-embedded 2n x 2n float32 matrices, one Defun per
+    slice with recompute inside the gradient function, TWO graph evaluations per iteration (run_session.py:53-54, 69) --
+    emulated node for node in torch-CPU (oracle/tf_graph_emulation.py).  Not TensorFlow (absent)."""
+    import torch
+    from oracle import tf_graph_emulation as tfe
+    from tests.helpers import oracle_system
+    from tests.golden import cases
+    sp = oracle_system(cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0))
+    base = seed_bases(0, 1)[0]
+    tfe.evaluate_graph(sp, base, dtype=torch.float32)               # warm-up
+    t0 = time.perf_counter()
+    evals = 0
+    while evals < max_evals and time.perf_counter() - t0 < budget_s:
+        tfe.evaluate_graph(sp, base, dtype=torch.float32)
+        evals += 1
+    el = time.perf_counter() - t0
+    return {'value': evals / el / 2.0, 'unit': 'GRAPE iterations/s', 'cores': int(torch.get_num_threads()),
+            'kind': 'port', 'sample': '%d fp32 real-embedded graph evaluations (fwd + custom-gradient bwd) of 1 seed of C2 in '
+                                      '%.1f s; 2 evaluations per reference iteration; torch-CPU emulation of the TF graph' % (evals, el)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -232,6 +254,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (contract)
             out['cpu_baseline'] = cpu_baseline()
+            try:
+                out['cpu_baseline_reference_ops'] = cpu_baseline_reference_ops()
+            except Exception as exc:                         # torch missing etc.: the primary baseline stands
+                out['cpu_baseline_reference_ops'] = {'error': repr(exc)}
         print(json.dumps(out))
     for e in engs:
         e.close()
