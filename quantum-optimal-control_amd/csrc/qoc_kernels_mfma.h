@@ -1,7 +1,8 @@
 // qoc_kernels_mfma.h -- register-resident v_mfma_f64_16x16x4_f64 path for n <= 32, unitary mode (gfx950 / CDNA4).
 //
 // Design ("MFMA path"):
-//  * Every matrix is zero-padded to NP = 32 and lives as 16x16 fp64 tiles in the MFMA C/D fragment layout
+//  * Every matrix is zero-padded to NP = 16*NT (NT = 1 for n <= 16, NT = 2 for n <= 32; the kernels are templated on
+//    NT and the comments below describe NT = 2) and lives as 16x16 fp64 tiles in the MFMA C/D fragment layout
 //      lane l, reg r  <->  element (row = (l>>4) + 4r, col = l&15)
 //    which is *also* the B-operand layout of K-slice r.  A left-multiplication chain  P <- A * P  therefore never
 //    moves P out of registers: the D output of one product is the B operand of the next.
@@ -28,21 +29,27 @@
 #include <vector>
 #include "qoc_common.h"
 
-#define QOC_NP 32                 // padded matrix dimension
-#define QOC_LDR 33                // padded leading dimension of the transposed LDS image (complex elements)
+#define QOC_NP 32                 // largest padded matrix dimension (NT = 2)
 #define QOC_MAXC 64               // max time chunks per seed
-#define QOC_FRAG 1024             // complex elements per fragD matrix (16 fragments x 64 lanes)
+// per-NT constants: NP = 16 NT (padded size), QS = 4 NT (k-slices), LDR = NP + 1 (LDS image leading dimension),
+// FR = 256 NT^2 (complex elements of one fragD matrix = NT*QS fragments x 64 lanes)
+#define QNP (16 * NT)
+#define QQS (4 * NT)
+#define QLDR (16 * NT + 1)
+#define QFR (256 * NT * NT)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define QMFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 struct CTile { d4 re, im; };                      // 16x16 complex tile, D layout
-struct AFrag { double re[2][8], im[2][8]; };      // 32x32 complex LEFT operand: [row block I][k-slice q], A layout
+template <int NT> struct AFragT { double re[NT][4 * NT], im[NT][4 * NT]; };   // LEFT operand: [row block I][k-slice q], A layout
 
 struct QocMfma {
     int C = 1;                // chunks per seed
     int L = 1;                // steps per chunk
     int mq = 4;               // ceil(m / 4): k-slices of the rank-m outer product
+    int NT = 2;               // 16x16 tiles per matrix dimension (1: n <= 16, 2: n <= 32)
+    int FR = 1024;            // complex elements per fragD matrix = 256 NT^2
     double invfact[24];       // 1/j!
     cplx* HfD = nullptr;      // [k+1] fragD(-i dt H), zero padded
     cplx* HfT = nullptr;      // [k+1] fragD((-i dt H)^T)
@@ -60,50 +67,57 @@ struct QocMfma {
 // element offset of K_t of seed b in KfD / KfT: consecutive slices are 16 KB apart; concurrent wavefronts differ in
 // (seed, chunk), whose natural strides (L*16 KB, steps*16 KB) are powers of two for the usual sizes and alias HBM channels
 __device__ __forceinline__ size_t kitem(const QocMfma& mf, int steps, int b, int t) {
-    return (size_t)b * ((size_t)steps * QOC_FRAG + (size_t)mf.C * mf.skew_c + mf.skew_b) + (size_t)t * QOC_FRAG + (size_t)(t / mf.L) * mf.skew_c;
+    return (size_t)b * ((size_t)steps * mf.FR + (size_t)mf.C * mf.skew_c + mf.skew_b) + (size_t)t * mf.FR + (size_t)(t / mf.L) * mf.skew_c;
 }
 
 // ---- fragment helpers ---------------------------------------------------------------------------------------------
 
 // A-operand fragments from a fragD matrix (pass fragD(M^T) to multiply by M, fragD(M) with CONJ to multiply by M^dagger)
-template <bool CONJ>
-__device__ __forceinline__ void afrag_load(const cplx* __restrict__ F, int lane, AFrag& A) {
+template <int NT, bool CONJ>
+__device__ __forceinline__ void afrag_load(const cplx* __restrict__ F, int lane, AFragT<NT>& A) {
 #pragma unroll
-    for (int I = 0; I < 2; ++I)
+    for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const cplx v = F[(I * 8 + q) * 64 + lane];
+        for (int q = 0; q < QQS; ++q) {
+            const cplx v = F[(I * QQS + q) * 64 + lane];
             A.re[I][q] = v.x; A.im[I][q] = CONJ ? -v.y : v.y;
         }
 }
 // D-layout column block J from / to a fragD matrix
-__device__ __forceinline__ void colblock_load(const cplx* __restrict__ F, int J, int lane, CTile p[2]) {
+template <int NT>
+__device__ __forceinline__ void colblock_load(const cplx* __restrict__ F, int J, int lane, CTile p[NT]) {
 #pragma unroll
-    for (int Ib = 0; Ib < 2; ++Ib)
+    for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const cplx v = F[(J * 8 + 4 * Ib + r) * 64 + lane];
+            const cplx v = F[(J * QQS + 4 * Ib + r) * 64 + lane];
             p[Ib].re[r] = v.x; p[Ib].im[r] = v.y;
         }
 }
-__device__ __forceinline__ void colblock_store(cplx* __restrict__ F, int J, int lane, const CTile p[2]) {
+template <int NT>
+__device__ __forceinline__ void colblock_store(cplx* __restrict__ F, int J, int lane, const CTile p[NT]) {
 #pragma unroll
-    for (int Ib = 0; Ib < 2; ++Ib)
+    for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) F[(J * 8 + 4 * Ib + r) * 64 + lane] = cmake(p[Ib].re[r], p[Ib].im[r]);
+        for (int r = 0; r < 4; ++r) F[(J * QQS + 4 * Ib + r) * 64 + lane] = cmake(p[Ib].re[r], p[Ib].im[r]);
 }
 // the I = J half of an A-layout matrix is the J-th half of fragD(M^T)
-__device__ __forceinline__ void afrag_store_half(cplx* __restrict__ F, int J, int lane, const AFrag& A) {
+template <int NT>
+__device__ __forceinline__ void afrag_store_half(cplx* __restrict__ F, int J, int lane, const AFragT<NT>& A) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const double re = J ? A.re[1][q] : A.re[0][q], im = J ? A.im[1][q] : A.im[0][q];
-        F[(J * 8 + q) * 64 + lane] = cmake(re, im);
+    for (int q = 0; q < QQS; ++q) {
+        double re = A.re[0][q], im = A.im[0][q];
+#pragma unroll
+        for (int Jc = 1; Jc < NT; ++Jc)
+            if (Jc == J) { re = A.re[Jc][q]; im = A.im[Jc][q]; }
+        F[(J * QQS + q) * 64 + lane] = cmake(re, im);
     }
 }
-__device__ __forceinline__ void colblock_identity(int J, int lane, CTile p[2]) {
+template <int NT>
+__device__ __forceinline__ void colblock_identity(int J, int lane, CTile p[NT]) {
     const int dlt = (lane & 15) - (lane >> 4);
 #pragma unroll
-    for (int Ib = 0; Ib < 2; ++Ib)
+    for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             p[Ib].re[r] = (Ib == J && dlt == 4 * r) ? 1.0 : 0.0; p[Ib].im[r] = 0.0;
@@ -111,47 +125,52 @@ __device__ __forceinline__ void colblock_identity(int J, int lane, CTile p[2]) {
 }
 
 // out[I] = sum_k A[I,k] * p[k] for one 16-column block, 3-multiplication complex arithmetic:
-// 48 MFMAs, 6 independent accumulator chains.
-__device__ __forceinline__ void mm_colblock(const AFrag& A, const CTile p[2], CTile out[2]) {
-    d4 a0 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, c0 = {0, 0, 0, 0};
-    d4 a1 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+// 12 NT^2 MFMAs (48 for NT = 2), 3 NT independent accumulator chains.
+template <int NT>
+__device__ __forceinline__ void mm_colblock(const AFragT<NT>& A, const CTile p[NT], CTile out[NT]) {
+    d4 a[NT], b[NT], c[NT];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int I = 0; I < NT; ++I) { a[I] = (d4){0, 0, 0, 0}; b[I] = (d4){0, 0, 0, 0}; c[I] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+    for (int q = 0; q < QQS; ++q) {
         const double br = p[q >> 2].re[q & 3], bi = p[q >> 2].im[q & 3], bs = br + bi;
-        a0 = QMFMA(A.re[0][q], br, a0);
-        a1 = QMFMA(A.re[1][q], br, a1);
-        b0 = QMFMA(A.im[0][q], bi, b0);
-        b1 = QMFMA(A.im[1][q], bi, b1);
-        c0 = QMFMA(A.re[0][q] + A.im[0][q], bs, c0);
-        c1 = QMFMA(A.re[1][q] + A.im[1][q], bs, c1);
+#pragma unroll
+        for (int I = 0; I < NT; ++I) a[I] = QMFMA(A.re[I][q], br, a[I]);
+#pragma unroll
+        for (int I = 0; I < NT; ++I) b[I] = QMFMA(A.im[I][q], bi, b[I]);
+#pragma unroll
+        for (int I = 0; I < NT; ++I) c[I] = QMFMA(A.re[I][q] + A.im[I][q], bs, c[I]);
     }
-    out[0].re = a0 - b0; out[0].im = c0 - a0 - b0;
-    out[1].re = a1 - b1; out[1].im = c1 - a1 - b1;
+#pragma unroll
+    for (int I = 0; I < NT; ++I) { out[I].re = a[I] - b[I]; out[I].im = c[I] - a[I] - b[I]; }
 }
 
 // Write a column block into the transposed LDS image img[col][row] (leading dimension QOC_LDR, complex).
-__device__ __forceinline__ void lds_put_colblock(cplx* img, int Jcol0, int lane, const CTile p[2]) {
+template <int NT>
+__device__ __forceinline__ void lds_put_colblock(cplx* img, int Jcol0, int lane, const CTile p[NT]) {
 #pragma unroll
-    for (int Ib = 0; Ib < 2; ++Ib)
+    for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            img[(Jcol0 + (lane & 15)) * QOC_LDR + 16 * Ib + (lane >> 4) + 4 * r] = cmake(p[Ib].re[r], p[Ib].im[r]);
+            img[(Jcol0 + (lane & 15)) * QLDR + 16 * Ib + (lane >> 4) + 4 * r] = cmake(p[Ib].re[r], p[Ib].im[r]);
 }
 // Read the A-layout fragments of the full 32x32 matrix held in the transposed image.
-__device__ __forceinline__ void lds_get_afrag(const cplx* img, int lane, AFrag& A) {
+template <int NT>
+__device__ __forceinline__ void lds_get_afrag(const cplx* img, int lane, AFragT<NT>& A) {
 #pragma unroll
-    for (int I = 0; I < 2; ++I)
+    for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const cplx v = img[(4 * q + (lane >> 4)) * QOC_LDR + 16 * I + (lane & 15)];
+        for (int q = 0; q < QQS; ++q) {
+            const cplx v = img[(4 * q + (lane >> 4)) * QLDR + 16 * I + (lane & 15)];
             A.re[I][q] = v.x; A.im[I][q] = v.y;
         }
 }
 
 // ---- kernel E: K_t = matexp for every t of one chunk + chunk product P_c ---------------------------------------
 // One workgroup = 2 waves = the two 16-column halves of the matrices of chunk (b, c).
-__global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf) {
-    __shared__ __attribute__((aligned(16))) cplx img[2][QOC_NP * QOC_LDR];
+template <int NT>
+__global__ void __launch_bounds__(64 * NT, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf) {
+    __shared__ __attribute__((aligned(16))) cplx img[2][QNP * QLDR];
     const int lane = threadIdx.x & 63;
     const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
@@ -159,39 +178,39 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
     const double inv_scale = 1.0 / (double)(1 << d.s);
     const int dlt = (lane & 15) - (lane >> 4);     // identity: tile Ib == J, register r, lanes with dlt == 4r
     int flip = 0;
-    CTile R[2];
-    colblock_identity(J, lane, R);
+    CTile R[NT];
+    colblock_identity<NT>(J, lane, R);
     for (int t = t0; t < t1; ++t) {
         // ---- A_t = (H0' + sum_k u_k H_k') / 2^s : left-operand fragments + this wave's column block -----------
-        AFrag A;
-        CTile P[2];
+        AFragT<NT> A;
+        CTile P[NT];
         {
-            afrag_load<false>(mf.HfT, lane, A);
-            colblock_load(mf.HfD, J, lane, P);
+            afrag_load<NT, false>(mf.HfT, lane, A);
+            colblock_load<NT>(mf.HfD, J, lane, P);
 #pragma unroll
-            for (int I = 0; I < 2; ++I)
+            for (int I = 0; I < NT; ++I)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { A.re[I][q] *= inv_scale; A.im[I][q] *= inv_scale; }
+                for (int q = 0; q < QQS; ++q) { A.re[I][q] *= inv_scale; A.im[I][q] *= inv_scale; }
 #pragma unroll
-            for (int Ib = 0; Ib < 2; ++Ib) { P[Ib].re *= inv_scale; P[Ib].im *= inv_scale; }
+            for (int Ib = 0; Ib < NT; ++Ib) { P[Ib].re *= inv_scale; P[Ib].im *= inv_scale; }
 #pragma unroll 1
             for (int kk = 0; kk < d.k; ++kk) {
                 const double ck = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale;
-                const cplx* __restrict__ HT = mf.HfT + (size_t)(kk + 1) * QOC_FRAG;
-                const cplx* __restrict__ HD = mf.HfD + (size_t)(kk + 1) * QOC_FRAG;
+                const cplx* __restrict__ HT = mf.HfT + (size_t)(kk + 1) * QFR;
+                const cplx* __restrict__ HD = mf.HfD + (size_t)(kk + 1) * QFR;
 #pragma unroll
-                for (int I = 0; I < 2; ++I)
+                for (int I = 0; I < NT; ++I)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const cplx h = HT[(I * 8 + q) * 64 + lane];
+                    for (int q = 0; q < QQS; ++q) {
+                        const cplx h = HT[(I * QQS + q) * 64 + lane];
                         A.re[I][q] = fma(ck, h.x, A.re[I][q]);
                         A.im[I][q] = fma(ck, h.y, A.im[I][q]);
                     }
 #pragma unroll
-                for (int Ib = 0; Ib < 2; ++Ib)
+                for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const cplx h = HD[(J * 8 + 4 * Ib + r) * 64 + lane];
+                        const cplx h = HD[(J * QQS + 4 * Ib + r) * 64 + lane];
                         P[Ib].re[r] = fma(ck, h.x, P[Ib].re[r]);
                         P[Ib].im[r] = fma(ck, h.y, P[Ib].im[r]);
                     }
@@ -201,20 +220,20 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
         //      A2 = A*A with blocks B_i = c_{2i} I + c_{2i+1} A:  S = B_m ; S = B_i + A2*S  -> 1 + ceil(T/2) - 1 products
         //      instead of T-1 (T=5: 3 instead of 4).  c_j = 1/j! from mf.invfact.
         if (d.T >= 2) {
-            CTile AJ[2];
-            AJ[0] = P[0]; AJ[1] = P[1];
-            CTile A2J[2];
-            mm_colblock(A, AJ, A2J);
-            lds_put_colblock(img[flip], 16 * J, lane, A2J);
+            CTile AJ[NT];
+            for (int Ib = 0; Ib < NT; ++Ib) AJ[Ib] = P[Ib];
+            CTile A2J[NT];
+            mm_colblock<NT>(A, AJ, A2J);
+            lds_put_colblock<NT>(img[flip], 16 * J, lane, A2J);
             __syncthreads();
-            lds_get_afrag(img[flip], lane, A);                      // A now holds the left-operand fragments of A2
+            lds_get_afrag<NT>(img[flip], lane, A);                      // A now holds the left-operand fragments of A2
             flip ^= 1;
             const int mm = d.T >> 1;
             int i;
             if ((d.T & 1) == 0) {                                   // top block is c_T I: S = B_{m-1} + c_T A2
                 const double c0 = mf.invfact[2 * mm - 2], c1 = mf.invfact[2 * mm - 1], cT = mf.invfact[d.T];
 #pragma unroll
-                for (int Ib = 0; Ib < 2; ++Ib)
+                for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
@@ -225,7 +244,7 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
             } else {                                                // S = B_m = c_{2m} I + c_{2m+1} A
                 const double c0 = mf.invfact[2 * mm], c1 = mf.invfact[2 * mm + 1];
 #pragma unroll
-                for (int Ib = 0; Ib < 2; ++Ib)
+                for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
@@ -235,11 +254,11 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
                 i = mm - 1;
             }
             for (; i >= 0; --i) {
-                CTile acc[2];
-                mm_colblock(A, P, acc);
+                CTile acc[NT];
+                mm_colblock<NT>(A, P, acc);
                 const double c0 = mf.invfact[2 * i], c1 = mf.invfact[2 * i + 1];
 #pragma unroll
-                for (int Ib = 0; Ib < 2; ++Ib)
+                for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
@@ -249,43 +268,44 @@ __global__ void __launch_bounds__(128, 2) k_mfma_expm_chunk(QocDev d, QocMfma mf
             }
         } else {                                                    // T == 1: I + A
 #pragma unroll
-            for (int Ib = 0; Ib < 2; ++Ib)
+            for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) P[Ib].re[r] += (Ib == J && dlt == 4 * r) ? 1.0 : 0.0;
         }
         // ---- squaring: M <- M*M, s times (:43-44); the left operand comes back through the LDS image -----------
         for (int sq = 0; sq < d.s; ++sq) {
-            lds_put_colblock(img[flip], 16 * J, lane, P);
+            lds_put_colblock<NT>(img[flip], 16 * J, lane, P);
             __syncthreads();
-            lds_get_afrag(img[flip], lane, A);
+            lds_get_afrag<NT>(img[flip], lane, A);
             flip ^= 1;
-            CTile acc[2];
-            mm_colblock(A, P, acc);
-            P[0] = acc[0]; P[1] = acc[1];
+            CTile acc[NT];
+            mm_colblock<NT>(A, P, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) P[Ib] = acc[Ib];
         }
         // ---- K_t out (both operand forms); running chunk product R <- K_t R ----------------------------------------
         const size_t item = kitem(mf, d.steps, b, t);
-        colblock_store(mf.KfD + item, J, lane, P);
-        lds_put_colblock(img[flip], 16 * J, lane, P);
+        colblock_store<NT>(mf.KfD + item, J, lane, P);
+        lds_put_colblock<NT>(img[flip], 16 * J, lane, P);
         __syncthreads();
-        lds_get_afrag(img[flip], lane, A);
+        lds_get_afrag<NT>(img[flip], lane, A);
         flip ^= 1;
-        afrag_store_half(mf.KfT + item, J, lane, A);
-        CTile acc[2];
-        mm_colblock(A, R, acc);
-        R[0] = acc[0]; R[1] = acc[1];
+        afrag_store_half<NT>(mf.KfT + item, J, lane, A);
+        CTile acc[NT];
+        mm_colblock<NT>(A, R, acc);
+        for (int Ib = 0; Ib < NT; ++Ib) R[Ib] = acc[Ib];
     }
     const size_t pitem = (size_t)b * mf.C + c;
-    colblock_store(mf.PfD + pitem * QOC_FRAG, J, lane, R);
-    lds_put_colblock(img[flip], 16 * J, lane, R);
+    colblock_store<NT>(mf.PfD + pitem * QFR, J, lane, R);
+    lds_put_colblock<NT>(img[flip], 16 * J, lane, R);
     __syncthreads();
-    AFrag A;
-    lds_get_afrag(img[flip], lane, A);
-    afrag_store_half(mf.PfT + pitem * QOC_FRAG, J, lane, A);
+    AFragT<NT> A;
+    lds_get_afrag<NT>(img[flip], lane, A);
+    afrag_store_half<NT>(mf.PfT + pitem * QFR, J, lane, A);
 }
 
 // ---- kernel F: thin forward sweep  Psi_t = K_t Psi_{t-1}  (inter vectors) + final unitary ------------------------
 // grid.x = B*C sweep waves + B*2 final-unitary waves, 4 waves per workgroup, no LDS, no barriers.
+template <int NT>
 __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,9 +313,9 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
     if (item < n_sweep) {
         const int b = item / mf.C, c = item - b * mf.C;
         const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
-        CTile Psi[2];
+        CTile Psi[NT];
 #pragma unroll
-        for (int Ib = 0; Ib < 2; ++Ib)
+        for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
@@ -307,42 +327,42 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
         if (c == 0) {                                                   // inter[0] = V  (tensorflow_state.py:232-233)
             for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
         }
-        AFrag A;
+        AFragT<NT> A;
         for (int cc = 0; cc < c; ++cc) {                                // chunk boundary from the chunk products
-            afrag_load<false>(mf.PfT + ((size_t)b * mf.C + cc) * QOC_FRAG, lane, A);
-            CTile acc[2];
-            mm_colblock(A, Psi, acc);
-            Psi[0] = acc[0]; Psi[1] = acc[1];
+            afrag_load<NT, false>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, Psi, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) Psi[Ib] = acc[Ib];
         }
         for (int t = t0; t < t1; ++t) {
-            afrag_load<false>(mf.KfT + kitem(mf, d.steps, b, t), lane, A);
-            CTile acc[2];
-            mm_colblock(A, Psi, acc);
-            Psi[0] = acc[0]; Psi[1] = acc[1];
+            afrag_load<NT, false>(mf.KfT + kitem(mf, d.steps, b, t), lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, Psi, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) Psi[Ib] = acc[Ib];
             cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
 #pragma unroll
-            for (int Ib = 0; Ib < 2; ++Ib)
+            for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
                     if (row < d.n && col < d.m) out[row * d.m + col] = cmake(Psi[Ib].re[r], Psi[Ib].im[r]);
                 }
         }
-    } else if (item < n_sweep + d.B * 2) {
+    } else if (item < n_sweep + d.B * NT) {
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
-        const int w = item - n_sweep, b = w >> 1, J = w & 1;
-        CTile X[2];
-        colblock_load(mf.U0fD, J, lane, X);
-        AFrag A;
+        const int w = item - n_sweep, b = w / NT, J = w - b * NT;
+        CTile X[NT];
+        colblock_load<NT>(mf.U0fD, J, lane, X);
+        AFragT<NT> A;
         for (int cc = 0; cc < mf.C; ++cc) {
-            afrag_load<false>(mf.PfT + ((size_t)b * mf.C + cc) * QOC_FRAG, lane, A);
-            CTile acc[2];
-            mm_colblock(A, X, acc);
-            X[0] = acc[0]; X[1] = acc[1];
+            afrag_load<NT, false>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, X, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) X[Ib] = acc[Ib];
         }
         cplx* Xf = d.Xfinal + (size_t)b * d.n * d.n;
 #pragma unroll
-        for (int Ib = 0; Ib < 2; ++Ib)
+        for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * Ib + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
@@ -369,6 +389,7 @@ __global__ void __launch_bounds__(64) k_mfma_uscale(QocDev d) {
 // ---- kernel B0: affine offsets of the backward recursion when state regularisers add a source at every slice --------
 // Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1} is affine; over chunk c it maps the chunk-end costate E to
 // P_c^dagger E + a_c with a_c = result of running the chunk from a ZERO costate.  One wave per (seed, chunk >= 1).
+template <int NT>
 __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -376,16 +397,16 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
     const int b = item / mf.C, c = item - b * mf.C;
     if (c == 0) return;                                               // a_0 is never used
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
-    CTile Z[2];
+    CTile Z[NT];
 #pragma unroll
-    for (int Ib = 0; Ib < 2; ++Ib) { Z[Ib].re = (d4){0, 0, 0, 0}; Z[Ib].im = (d4){0, 0, 0, 0}; }
-    AFrag A;
+    for (int Ib = 0; Ib < NT; ++Ib) { Z[Ib].re = (d4){0, 0, 0, 0}; Z[Ib].im = (d4){0, 0, 0, 0}; }
+    AFragT<NT> A;
     for (int t = t1 - 1; t >= t0; --t) {
-        afrag_load<true>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
-        CTile acc[2];
-        mm_colblock(A, Z, acc);
+        afrag_load<NT, true>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
+        CTile acc[NT];
+        mm_colblock<NT>(A, Z, acc);
 #pragma unroll
-        for (int Ib = 0; Ib < 2; ++Ib)
+        for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
@@ -394,25 +415,25 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
                 Z[Ib].re[r] = acc[Ib].re[r] + sv.x; Z[Ib].im[r] = acc[Ib].im[r] + sv.y;
             }
     }
-    colblock_store(mf.Aoff + ((size_t)b * mf.C + c) * 512, 0, lane, Z);
+    colblock_store<NT>(mf.Aoff + ((size_t)b * mf.C + c) * (QQS * 64), 0, lane, Z);
 }
 
 // ---- kernel B: thin backward sweep  Lambda_{t-1} = K_t^dagger Lambda_t  + control gradients ----------------------
 // dL/du_{k,t} = Re sum_ab H_k'[a][b] Q_t[a][b],  Q_t = conj(Lambda_t) Psi_t^T  (rank-m outer product on the MFMA),
 // which equals Re <Lambda_t, H_k' Psi_t> of the reference's matexp_op_grad (tensorflow_state.py:61-63).
 // 4 waves per workgroup; LDS: fragD image of the k control Hamiltonians (shared) + one transposition pad per wave.
-template <bool H_IN_LDS>
+template <int NT, bool H_IN_LDS>
 __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int single_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     cplx* Hl = (cplx*)smem;                                                     // [k] fragD(H_k')
-    cplx* pad = (cplx*)(smem + (H_IN_LDS ? (size_t)d.k * QOC_FRAG * sizeof(cplx) : 0)) + (size_t)wv * 16 * QOC_LDR;
+    cplx* pad = (cplx*)(smem + (H_IN_LDS ? (size_t)d.k * QFR * sizeof(cplx) : 0)) + (size_t)wv * 16 * QLDR;
     if (H_IN_LDS) {
-        for (int o = threadIdx.x; o < d.k * QOC_FRAG; o += blockDim.x) Hl[o] = mf.HfD[QOC_FRAG + o];
+        for (int o = threadIdx.x; o < d.k * QFR; o += blockDim.x) Hl[o] = mf.HfD[QFR + o];
         __syncthreads();
     }
-    const cplx* Hsrc = H_IN_LDS ? Hl : (mf.HfD + QOC_FRAG);
+    const cplx* Hsrc = H_IN_LDS ? Hl : (mf.HfD + QFR);
     const int CC = single_chunk ? 1 : mf.C;
     const int item = blockIdx.x * 4 + wv;
     if (item >= d.B * CC) return;
@@ -420,12 +441,12 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     const int t0 = single_chunk ? 0 : c * mf.L, t1 = single_chunk ? d.steps : min(t0 + mf.L, d.steps);
     const bool need_src = d.n_forb > 0 || d.has_speed;
     // terminal costate: -(2/m^2) z W (+ S_steps)
-    CTile Lam[2];
+    CTile Lam[NT];
     {
         const cplx z = d.zfin[b];
         const double c0 = -2.0 / ((double)d.m * (double)d.m);
 #pragma unroll
-        for (int Ib = 0; Ib < 2; ++Ib)
+        for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
@@ -437,18 +458,18 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
                 Lam[Ib].re[r] = v.x; Lam[Ib].im[r] = v.y;
             }
     }
-    AFrag A;
+    AFragT<NT> A;
     if (!single_chunk) {
         for (int cc = mf.C - 1; cc > c; --cc) {                          // Lambda at the end of this chunk
-            afrag_load<true>(mf.PfD + ((size_t)b * mf.C + cc) * QOC_FRAG, lane, A);
-            CTile acc[2];
-            mm_colblock(A, Lam, acc);
-            Lam[0] = acc[0]; Lam[1] = acc[1];
+            afrag_load<NT, true>(mf.PfD + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, Lam, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) Lam[Ib] = acc[Ib];
             if (need_src) {                                              // E_{cc-1} = P_cc^dagger E_cc + a_cc
-                CTile off[2];
-                colblock_load(mf.Aoff + ((size_t)b * mf.C + cc) * 512, 0, lane, off);
+                CTile off[NT];
+                colblock_load<NT>(mf.Aoff + ((size_t)b * mf.C + cc) * (QQS * 64), 0, lane, off);
 #pragma unroll
-                for (int Ib = 0; Ib < 2; ++Ib) { Lam[Ib].re += off[Ib].re; Lam[Ib].im += off[Ib].im; }
+                for (int Ib = 0; Ib < NT; ++Ib) { Lam[Ib].re += off[Ib].re; Lam[Ib].im += off[Ib].im; }
             }
         }
     }
@@ -456,17 +477,17 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     for (int t = t1 - 1; t >= t0; --t) {
         // ---- Q = conj(Lambda_t) Psi_t^T, 3-multiplication form:  Qr = T1 + T2, Qi = T3 - T1 + T2 with
         //      T1 = Lr Pr, T2 = Li Pi, T3 = (Lr - Li)(Pr + Pi) ------------------------------------------------------
-        lds_put_colblock(pad, 0, lane, Lam);                             // wave-private image: pad[j][row]
-        double lr[2][4], li[2][4], pr[2][4], pi[2][4];
+        lds_put_colblock<NT>(pad, 0, lane, Lam);                             // wave-private image: pad[j][row]
+        double lr[NT][4], li[NT][4], pr[NT][4], pi[NT][4];
         const cplx* psi = iv + (size_t)(t + 1) * d.n * d.m;
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < NT; ++I)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 lr[I][q] = 0.0; li[I][q] = 0.0; pr[I][q] = 0.0; pi[I][q] = 0.0;
                 if (q < mf.mq) {
                     const int row = 16 * I + (lane & 15), j = 4 * q + (lane >> 4);
-                    const cplx lv = pad[j * QOC_LDR + row];
+                    const cplx lv = pad[j * QLDR + row];
                     lr[I][q] = lv.x; li[I][q] = lv.y;
                     if (row < d.n && j < d.m) {
                         const cplx pv = psi[row * d.m + j];
@@ -478,9 +499,9 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) g[kk] = 0.0;
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < NT; ++I)
 #pragma unroll
-            for (int Jp = 0; Jp < 2; ++Jp) {
+            for (int Jp = 0; Jp < NT; ++Jp) {
                 d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -497,7 +518,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
                     double acc = 0.0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const cplx h = Hsrc[(size_t)kk * QOC_FRAG + (Jp * 8 + 4 * I + r) * 64 + lane];
+                        const cplx h = Hsrc[(size_t)kk * QFR + (Jp * QQS + 4 * I + r) * 64 + lane];
                         acc = fma(h.x, qr[r], acc);
                         acc = fma(-h.y, qi[r], acc);
                     }
@@ -514,13 +535,13 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
         }
         if (t == 0) break;
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t (+ S_{t-1}) ---------------------------------------------------------
-        afrag_load<true>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
-        CTile acc[2];
-        mm_colblock(A, Lam, acc);
-        Lam[0] = acc[0]; Lam[1] = acc[1];
+        afrag_load<NT, true>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
+        CTile acc[NT];
+        mm_colblock<NT>(A, Lam, acc);
+        for (int Ib = 0; Ib < NT; ++Ib) Lam[Ib] = acc[Ib];
         if (need_src) {
 #pragma unroll
-            for (int Ib = 0; Ib < 2; ++Ib)
+            for (int Ib = 0; Ib < NT; ++Ib)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
@@ -539,11 +560,12 @@ static inline bool qoc_mfma_supported(const QocDev& d) {
     return !d.state_transfer && d.n <= QOC_NP && d.m <= 16 && d.k <= 8 && d.T >= 1 && d.T <= 22;
 }
 
-// host: fragD image of a zero-padded n x n matrix (transpose optionally)
-static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F) {
-    for (int f = 0; f < 16; ++f)
+// host: fragD image of a zero-padded n x n matrix (transpose optionally) for NT tiles per dimension
+static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, int NT) {
+    const int QS = 4 * NT;
+    for (int f = 0; f < NT * QS; ++f)
         for (int l = 0; l < 64; ++l) {
-            const int cb = f >> 3, q = f & 7;
+            const int cb = f / QS, q = f - cb * QS;
             int row = 4 * q + (l >> 4), col = 16 * cb + (l & 15);
             if (transpose) { const int tmp = row; row = col; col = tmp; }
             cplx v; v.x = 0.0; v.y = 0.0;
@@ -554,9 +576,12 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F) {
 
 static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
                                  std::vector<void*>& allocs, std::string& msg) {
+    const int NT = d.n <= 16 ? 1 : 2;
+    const int FR = 256 * NT * NT;
+    mf.NT = NT; mf.FR = FR;
     int C = chunks_req;
     if (C <= 0) {
-        C = (1024 + d.B - 1) / d.B;                  // ~2 waves per SIMD for the expm kernel (2 waves per chunk)
+        C = (1024 + d.B - 1) / d.B;                  // ~2 waves per SIMD for the expm kernel (NT waves per chunk)
         if (C > 32) C = 32;
     }
     if (C > d.steps) C = d.steps;
@@ -570,14 +595,14 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         double f = 1.0;
         for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; mf.invfact[j] = 1.0 / f; }
     }
-    std::vector<cplx> hd((size_t)(d.k + 1) * QOC_FRAG), ht((size_t)(d.k + 1) * QOC_FRAG), u0(QOC_FRAG);
+    std::vector<cplx> hd((size_t)(d.k + 1) * FR), ht((size_t)(d.k + 1) * FR), u0(FR);
     for (int kk = 0; kk <= d.k; ++kk) {
-        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, false, hd.data() + (size_t)kk * QOC_FRAG);
-        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, true, ht.data() + (size_t)kk * QOC_FRAG);
+        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, false, hd.data() + (size_t)kk * FR, NT);
+        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, true, ht.data() + (size_t)kk * FR, NT);
     }
     std::vector<cplx> u0h((size_t)d.n * d.n);
     if (hipMemcpy(u0h.data(), d.U0, u0h.size() * sizeof(cplx), hipMemcpyDeviceToHost) != hipSuccess) { msg = "U0 readback failed"; return -2; }
-    qoc_to_fragD(u0h.data(), d.n, false, u0.data());
+    qoc_to_fragD(u0h.data(), d.n, false, u0.data(), NT);
     auto up = [&](cplx** dst, const std::vector<cplx>& src) -> bool {
         void* p = nullptr;
         if (hipMalloc(&p, src.size() * sizeof(cplx)) != hipSuccess) return false;
@@ -596,14 +621,16 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     };
     mf.skew_c = 5 * 16;                            // 1280 B per chunk
     mf.skew_b = 3 * 16;                            //  768 B per seed
-    const size_t nk = (size_t)d.B * ((size_t)d.steps * QOC_FRAG + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * QOC_FRAG;
-    if (!al(&mf.KfD, nk) || !al(&mf.KfT, nk) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 512)) { msg = "MFMA path: out of device memory"; return -3; }
-    const size_t pads = (size_t)4 * 16 * QOC_LDR * sizeof(cplx);
-    const size_t hbytes = (size_t)d.k * QOC_FRAG * sizeof(cplx);
+    const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
+    if (!al(&mf.KfD, nk) || !al(&mf.KfT, nk) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
+    const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
+    const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
     mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
     mf.bwd_lds = pads + (mf.h_in_lds ? hbytes : 0);
     if (mf.h_in_lds) {
-        if (hipFuncSetAttribute((const void*)k_mfma_backward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds) != hipSuccess) {
+        const hipError_t e1 = hipFuncSetAttribute((const void*)k_mfma_backward<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
+        const hipError_t e2 = hipFuncSetAttribute((const void*)k_mfma_backward<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
+        if ((NT == 1 ? e1 : e2) != hipSuccess) {
             msg = "MFMA path: cannot reserve LDS for the backward kernel";
             return -2;
         }
@@ -611,20 +638,29 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     return 0;
 }
 
+template <int NT>
+static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    hipLaunchKernelGGL(k_mfma_expm_chunk<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
+}
 static inline void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    hipLaunchKernelGGL(k_mfma_expm_chunk, dim3(d.B * mf.C), dim3(128), 0, s, d, mf);
+    if (mf.NT == 1) qoc_mfma_launch_all_expm<1>(mf, d, s); else qoc_mfma_launch_all_expm<2>(mf, d, s);
 }
 static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    const int items = d.B * mf.C + d.B * 2;
-    hipLaunchKernelGGL(k_mfma_forward, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    const int items = d.B * mf.C + d.B * mf.NT;
+    if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    else hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
 }
-static inline void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
+template <int NT>
+static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const int items = d.B * mf.C;
     if ((d.n_forb > 0 || d.has_speed) && mf.C > 1)
-        hipLaunchKernelGGL(k_mfma_bwd_offsets, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     if (mf.h_in_lds)
-        hipLaunchKernelGGL(k_mfma_backward<true>, dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
+        hipLaunchKernelGGL((k_mfma_backward<NT, true>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
     else
-        hipLaunchKernelGGL(k_mfma_backward<false>, dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
+        hipLaunchKernelGGL((k_mfma_backward<NT, false>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
+}
+static inline void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else qoc_mfma_launch_all_backward<2>(mf, d, s);
 }
