@@ -32,7 +32,7 @@ extern "C" {
 
 #define QOC_PATH_AUTO 0
 #define QOC_PATH_GENERIC 1     /* any n: workgroup-cooperative complex-fp64 products from HBM/L2 */
-#define QOC_PATH_MFMA 2        /* n <= 32, unitary mode: register-resident v_mfma_f64_16x16x4 chain kernels */
+#define QOC_PATH_MFMA 2        /* n <= 64, unitary mode: register-resident v_mfma_f64_16x16x4 chain kernels (NP = 16/32/48/64) */
 #define QOC_PATH_ST_FUSED 3    /* state transfer, n <= 64, m <= 4: register-resident generator, LDS vectors */
 #define QOC_PATH_GEMM 4        /* unitary mode, any n (m <= 32): tiled MFMA complex GEMM launches from HBM/L2 (n = 512) */
 

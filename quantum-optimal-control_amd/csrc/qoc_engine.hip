@@ -319,9 +319,13 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const bool mfma_ok = qoc_mfma_supported(d);
     const bool st_ok = st_fused_supported(d);
     const bool gemm_ok = qoc_gemm_supported(d);
-    if (path == QOC_PATH_AUTO) path = mfma_ok ? QOC_PATH_MFMA : (st_ok ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));
+    // 48 < n <= 64 runs the register-resident kernels with spills: they win on latency (few seeds), the GEMM path ties
+    // or wins on throughput from ~64 seeds on
+    const bool prefer_gemm = gemm_ok && n > 48 && B >= 64;
+    if (path == QOC_PATH_AUTO)
+        path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (st_ok ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));
     if (path == QOC_PATH_MFMA && !mfma_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 48, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 64, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_GEMM && !gemm_ok)

@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
 // ---- host side ----------------------------------------------------------------------------------------------------
 
 static inline bool qoc_mfma_supported(const QocDev& d) {
-    return !d.state_transfer && d.n <= 48 && d.m <= 16 && d.k <= 8 && d.T >= 1 && d.T <= 22;
+    return !d.state_transfer && d.n <= 64 && d.m <= 16 && d.k <= 8 && d.T >= 1 && d.T <= 22;
 }
 
 // host: fragD image of a zero-padded n x n matrix (transpose optionally) for NT tiles per dimension
@@ -576,7 +576,7 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
 
 static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
                                  std::vector<void*>& allocs, std::string& msg) {
-    const int NT = d.n <= 16 ? 1 : (d.n <= 32 ? 2 : 3);
+    const int NT = d.n <= 16 ? 1 : (d.n <= 32 ? 2 : (d.n <= 48 ? 3 : 4));
     const int FR = 256 * NT * NT;
     mf.NT = NT; mf.FR = FR;
     int C = chunks_req;
@@ -631,7 +631,8 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         const hipError_t e1 = hipFuncSetAttribute((const void*)k_mfma_backward<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
         const hipError_t e2 = hipFuncSetAttribute((const void*)k_mfma_backward<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
         const hipError_t e3 = hipFuncSetAttribute((const void*)k_mfma_backward<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
-        if ((NT == 1 ? e1 : (NT == 2 ? e2 : e3)) != hipSuccess) {
+        const hipError_t e4 = hipFuncSetAttribute((const void*)k_mfma_backward<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
+        if ((NT == 1 ? e1 : (NT == 2 ? e2 : (NT == 3 ? e3 : e4))) != hipSuccess) {
             msg = "MFMA path: cannot reserve LDS for the backward kernel";
             return -2;
         }
@@ -644,13 +645,14 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     hipLaunchKernelGGL(k_mfma_expm_chunk<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
 }
 static inline void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    if (mf.NT == 1) qoc_mfma_launch_all_expm<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_expm<2>(mf, d, s); else qoc_mfma_launch_all_expm<3>(mf, d, s);
+    if (mf.NT == 1) qoc_mfma_launch_all_expm<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_expm<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_expm<3>(mf, d, s); else qoc_mfma_launch_all_expm<4>(mf, d, s);
 }
 static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const int items = d.B * mf.C + d.B * mf.NT;
     if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    else hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
 }
 template <int NT>
@@ -664,5 +666,5 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
         hipLaunchKernelGGL((k_mfma_backward<NT, false>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
 }
 static inline void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_backward<2>(mf, d, s); else qoc_mfma_launch_all_backward<3>(mf, d, s);
+    if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_backward<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_backward<3>(mf, d, s); else qoc_mfma_launch_all_backward<4>(mf, d, s);
 }

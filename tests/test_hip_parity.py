@@ -82,7 +82,7 @@ def test_eval_parity(name, c, path):
 
 
 @pytest.mark.parametrize('chunks', [1, 3, 7, 40])
-@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'U0_dressed', 'n40_nt3', 'n48_k4_sources_nt3'])
+@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'U0_dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n57_k1_nt4'])
 def test_mfma_path_parity(chunks, variant):
     """Register-resident MFMA path (n <= 32, unitary mode) for several time-chunk counts, incl. ragged last chunk."""
     if variant == 'plain':
@@ -98,6 +98,11 @@ def test_mfma_path_parity(chunks, variant):
     elif variant == 'n48_k4_sources_nt3':
         c = cases.case_c2(n=48, k=4, steps=14, m=11, taylor=(4, 3), seed=13)
         c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [3.0, 2.0], 'states_forbidden_list': [47, 40], 'speed_up': 0.4}
+    elif variant == 'n64_nt4':
+        c = cases.case_c2(n=64, k=3, steps=11, m=8, taylor=(5, 2), seed=14)
+        c['reg_coeffs'] = {'forbidden_coeff_list': [3.0], 'states_forbidden_list': [63], 'amplitude': 0.1}
+    elif variant == 'n57_k1_nt4':
+        c = cases.case_c2(n=57, k=1, steps=9, m=3, taylor=(4, 1), seed=15)
     else:
         c = cases.case_dressed()
     sp = oracle_system(c)
@@ -399,7 +404,7 @@ def test_edge_cases_all_paths(name, c, path):
 
 def test_unsupported_path_requests_fail_loudly():
     from quantum_optimal_control.core import hip_engine
-    sp = oracle_system(cases.case_c2(n=50, k=2, steps=3, m=2, taylor=(3, 1), seed=1))
+    sp = oracle_system(cases.case_c2(n=66, k=2, steps=3, m=2, taylor=(3, 1), seed=1))
     with pytest.raises(hip_engine.QocError, match='MFMA path needs'):
         make_engine(sp, path=2)
     sp = oracle_system(cases.case_state_small())
