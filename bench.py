@@ -104,6 +104,7 @@ def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
     from tests.helpers import oracle_system
     from tests.golden import cases
     sp = oracle_system(cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0))
+    torch.set_num_threads(min(16, torch.get_num_threads()))        # 2n x 2n = 64 x 64 matmuls: more threads only thrash
     base = seed_bases(0, 1)[0]
     tfe.evaluate_graph(sp, base, dtype=torch.float32)               # warm-up
     t0 = time.perf_counter()
