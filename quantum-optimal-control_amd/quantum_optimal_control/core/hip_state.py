@@ -39,8 +39,13 @@ class HipState(object):
             one_minus_gauss=sp.one_minus_gauss if 'envelope' in rc else None, Vs=Vs,
             n_seeds=self.n_seeds, device=self.device, path=self.path, chunks=self.chunks)
         base = np.asarray(sp.ops_weight_base, dtype=np.float64)
-        if base.ndim == 2:
-            base = np.broadcast_to(base, (self.n_seeds,) + base.shape)
+        if base.ndim == 2 and self.n_seeds > 1:
+            # seed 0 = the reference's own starting point; the rest are independent random restarts
+            from quantum_optimal_control.parallel_seeds import restart_guesses
+            extra = restart_guesses(base.shape[0], base.shape[1], 1, self.n_seeds - 1)
+            base = np.concatenate([base[None], extra], axis=0)
+        elif base.ndim == 2:
+            base = base[None]
         self.engine.set_base(base)
         print("Graph built!")
         return self.engine

@@ -72,6 +72,10 @@ class run_session(object):
 
     # ---- results ------------------------------------------------------------------------------------------------
     def get_end_results(self):
+        if self.engine.n_seeds > 1:                       # report / return the best restart
+            s = self.engine.scalars()
+            self.seed = int(np.argmin(s['loss']))
+            self._take_scalars(s)
         self.save_data()
         self.display()
         self.uks = self.Get_uks()

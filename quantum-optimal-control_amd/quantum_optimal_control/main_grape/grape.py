@@ -52,7 +52,10 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
           dressed_info=None, maxA=None, use_gpu=True, sparse_H=True, sparse_U=False, sparse_K=False, draw=None,
           initial_guess=None, show_plots=True, unitary_error=1e-4, method='Adam', state_transfer=False,
           no_scaling=False, freq_unit='GHz', file_name=None, save=True, data_path=None, Taylor_terms=None,
-          use_inter_vecs=True):
+          use_inter_vecs=True, restarts=1):
+    """Reference signature (main_grape/grape.py:19) plus one optional extension: ``restarts=B`` optimises B control sets at
+    once on the GPU -- the first is the reference's own initial guess (same NumPy RNG draw / ``initial_guess``), the others
+    are independent N(0, 1/sqrt(steps)) restarts -- and returns the (uks, U_final) of the best final fidelity."""
     grape_start_time = time.time()
     time_unit = _TIME_UNITS[freq_unit]                  # KeyError on an unknown unit, as in the reference
     if use_gpu:
@@ -86,7 +89,7 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
                                 maxAmp, draw, initial_guess, show_plots, unitary_error, state_transfer, no_scaling,
                                 reg_coeffs, save, file_path, Taylor_terms, use_gpu, use_inter_vecs, sparse_H, sparse_U,
                                 sparse_K)
-    tfs = HipState(sys_para)                            # constants -> HBM (was: TF graph construction)
+    tfs = HipState(sys_para, n_seeds=max(1, int(restarts)))   # constants -> HBM (was: TF graph construction)
     graph = tfs.build_graph()
     conv = Convergence(sys_para, time_unit, convergence)
     try:

@@ -412,3 +412,22 @@ def test_unsupported_path_requests_fail_loudly():
         make_engine(sp, path=4)
     with pytest.raises(hip_engine.QocError, match='unknown path'):
         make_engine(sp, path=9)
+
+
+def test_grape_restarts_extension_returns_best_seed():
+    """Optional `restarts=B`: seed 0 reproduces the plain call bit for bit; the returned pulse is the best of the batch."""
+    from quantum_optimal_control.main_grape.grape import Grape
+    c = cases.case_c1()
+    conv = {'rate': 0.05, 'update_step': 10, 'max_iterations': 25, 'conv_target': 1e-12, 'learning_rate_decay': 100}
+    np.random.seed(c['np_seed'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        uks1, Uf1 = Grape(convergence=conv, method='Adam', **grape_kwargs(c))
+    np.random.seed(c['np_seed'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        uksB, UfB = Grape(convergence=conv, method='Adam', restarts=6, **grape_kwargs(c))
+    sp = oracle_system(c)
+
+    def loss(U):
+        return 1 - abs(np.trace(sp.U_target.conj().T @ U)) ** 2 / 4
+    assert loss(UfB) <= loss(Uf1) + 1e-15
+    assert uksB.shape == uks1.shape and UfB.shape == Uf1.shape
