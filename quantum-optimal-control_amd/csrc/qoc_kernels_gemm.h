@@ -175,6 +175,19 @@ __global__ void __launch_bounds__(256) k_gemm_horner_init(const cplx* __restrict
         P[o] = cmake(a.x * invT + (row == col ? 1.0 : 0.0), a.y * invT);
     }
 }
+// S = c0*I + c1*A (+ cT*A2): top block of the Paterson-Stockmeyer recursion
+__global__ void __launch_bounds__(256) k_gemm_ps_init(const cplx* __restrict__ A, const cplx* __restrict__ A2, cplx* __restrict__ S,
+                                                       size_t count, int N, double c0, double c1, double cT) {
+    const size_t NN = (size_t)N * N;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < count; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = o % NN;
+        const int row = (int)(e / N), col = (int)(e - (size_t)row * N);
+        const cplx a = A[o];
+        cplx v = cmake(c1 * a.x + (row == col ? c0 : 0.0), c1 * a.y);
+        if (A2) { const cplx a2 = A2[o]; v.x = fma(cT, a2.x, v.x); v.y = fma(cT, a2.y, v.y); }
+        S[o] = v;
+    }
+}
 // Y[b] = [U0 | Psi0] padded (N x (N+32)); inter[b][0] = V
 __global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restrict__ Y, int N) {
     const int ld = N + QOC_TW;
@@ -264,7 +277,7 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
 struct QocGemm {
     int N = 0;
     cplx* HsP = nullptr;      // [k+1][N][N]
-    cplx *A = nullptr, *P = nullptr, *K = nullptr;     // [B*steps][N][N]
+    cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*steps][N][N]
     cplx *Y0 = nullptr, *Y1 = nullptr;                               // [B][N][N+32]
     cplx* interP = nullptr;   // [B][steps+1][N][32]
     cplx* LamP = nullptr;     // [B][steps][N][32]
@@ -292,7 +305,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     };
     const bool need_src = d.n_forb > 0 || d.has_speed;
     bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.A, BS * NN * sizeof(cplx)) &&
-              al((void**)&gm.P, BS * NN * sizeof(cplx)) &&
+              al((void**)&gm.P, BS * NN * sizeof(cplx)) && al((void**)&gm.A2, BS * NN * sizeof(cplx)) &&
               al((void**)&gm.K, BS * NN * sizeof(cplx)) && al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.Y1, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.interP, (size_t)d.B * (d.steps + 1) * thin * sizeof(cplx)) &&
@@ -347,18 +360,33 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N;
     const size_t NN = (size_t)N * N, BS = (size_t)d.B * d.steps;
     hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N);
-    // result of the Taylor/squaring sequence must land in gm.K: count the remaining products to pick the start buffer
-    const int products = (d.T - 1) + d.s;
-    cplx* cur = (products % 2 == 0) ? gm.K : gm.P;          // buffers alternate cur -> other on every product
-    cplx* oth = (products % 2 == 0) ? gm.P : gm.K;
-    hipLaunchKernelGGL(k_gemm_horner_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, cur, BS * NN, N, 1.0 / (double)d.T);
+    // Taylor polynomial sum_{j<=T} A^j/j! (tensorflow_state.py:37-41) in Paterson-Stockmeyer form over A2 = A*A:
+    // S = B_m ; S = B_i + A2*S with B_i = c_{2i} I + c_{2i+1} A  (T = 5: 3 products instead of 4); then s squarings.
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.lda = g.ldb = g.ldc = N; g.sA = g.sB = g.sC = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.batch = (int)BS;
-    for (int j = d.T - 1; j >= 1; --j) {                     // P <- I + (A P)/j            tensorflow_state.py:37-41
-        g.A = gm.A; g.Bm = cur; g.C = oth; g.E = nullptr; g.alpha = 1.0 / (double)j; g.beta = 0.0; g.gamma = 1.0;
-        qoc_gemm_launch(false, 0, g, s);
-        cplx* t = cur; cur = oth; oth = t;
+    g.lda = g.ldb = g.ldc = g.lde = N; g.sA = g.sB = g.sC = g.sE = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.batch = (int)BS;
+    double invf[24];
+    { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; invf[j] = 1.0 / f; } }
+    const int mm = d.T >> 1;
+    const bool even = (d.T & 1) == 0;
+    const int horner = d.T >= 2 ? (even ? mm - 1 : mm) : 0;      // products after A2
+    const int products = horner + d.s;                           // buffer flips until the result
+    cplx* cur = (products % 2 == 0) ? gm.K : gm.P;               // buffers alternate cur -> other on every product
+    cplx* oth = (products % 2 == 0) ? gm.P : gm.K;
+    if (d.T >= 2) {
+        g.A = gm.A; g.Bm = gm.A; g.C = gm.A2; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
+        qoc_gemm_launch(false, 0, g, s);                         // A2 = A*A
+        if (even) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, gm.A2, cur, BS * NN, N,
+                                     invf[2 * mm - 2], invf[2 * mm - 1], invf[d.T]);
+        else hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N,
+                                invf[2 * mm], invf[2 * mm + 1], 0.0);
+        for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {    // S <- c_{2i} I + c_{2i+1} A + A2*S
+            g.A = gm.A2; g.Bm = cur; g.C = oth; g.E = gm.A; g.alpha = 1.0; g.beta = invf[2 * i + 1]; g.gamma = invf[2 * i];
+            qoc_gemm_launch(false, 0, g, s);
+            cplx* t = cur; cur = oth; oth = t;
+        }
+    } else {
+        hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N, 1.0, 1.0, 0.0);
     }
     for (int sq = 0; sq < d.s; ++sq) {                       // M <- M M                    tensorflow_state.py:43-44
         g.A = cur; g.Bm = cur; g.C = oth; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
