@@ -149,30 +149,24 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
 }
 
 // A_t = (H0' + sum_k u_k H_k') / 2^s for every (seed, slice), padded N x N           tensorflow_state.py:30-33
-__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N) {
+// Slices are padded to SP = NC*S per seed; a padded slice gets A = 0, i.e. K = I exactly.
+__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP) {
     const size_t NN = (size_t)N * N;
-    const size_t total = (size_t)d.B * d.steps * NN;
+    const size_t total = (size_t)d.B * SP * NN;
     const double inv = 1.0 / (double)(1 << d.s);
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         const size_t item = o / NN, e = o - item * NN;
-        const int b = (int)(item / d.steps), t = (int)(item - (size_t)b * d.steps);
-        cplx acc = cscale(HsP[e], inv);
-        for (int kk = 0; kk < d.k; ++kk) {
-            const double c = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv;
-            const cplx h = HsP[(size_t)(kk + 1) * NN + e];
-            acc.x = fma(c, h.x, acc.x); acc.y = fma(c, h.y, acc.y);
+        const int b = (int)(item / SP), t = (int)(item - (size_t)b * SP);
+        cplx acc = cmake(0.0, 0.0);
+        if (t < d.steps) {
+            acc = cscale(HsP[e], inv);
+            for (int kk = 0; kk < d.k; ++kk) {
+                const double c = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv;
+                const cplx h = HsP[(size_t)(kk + 1) * NN + e];
+                acc.x = fma(c, h.x, acc.x); acc.y = fma(c, h.y, acc.y);
+            }
         }
         Aout[o] = acc;
-    }
-}
-// P = I + A / T (first Horner step)
-__global__ void __launch_bounds__(256) k_gemm_horner_init(const cplx* __restrict__ A, cplx* __restrict__ P, size_t count, int N, double invT) {
-    const size_t NN = (size_t)N * N;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < count; o += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = o % NN;
-        const int row = (int)(e / N), col = (int)(e - (size_t)row * N);
-        const cplx a = A[o];
-        P[o] = cmake(a.x * invT + (row == col ? 1.0 : 0.0), a.y * invT);
     }
 }
 // S = c0*I + c1*A (+ cT*A2): top block of the Paterson-Stockmeyer recursion
@@ -188,13 +182,13 @@ __global__ void __launch_bounds__(256) k_gemm_ps_init(const cplx* __restrict__ A
         S[o] = v;
     }
 }
-// Y[b] = [U0 | Psi0] padded (N x (N+32)); inter[b][0] = V
-__global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restrict__ Y, int N) {
+// Y[b] = [U0 | Psi0] padded (N x (N+32)); Psibnd[b][0] = Psi0 padded; inter[b][0] = V
+__global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restrict__ Y, cplx* __restrict__ Psibnd, int N, int NC) {
     const int ld = N + QOC_TW;
     const size_t per = (size_t)N * ld;
     const size_t total = (size_t)d.B * per;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
-        const size_t e = o % per;
+        const size_t bb = o / per, e = o - bb * per;
         const int row = (int)(e / ld), col = (int)(e - (size_t)row * ld);
         cplx v = cmake(0.0, 0.0);
         if (row < d.n) {
@@ -202,23 +196,33 @@ __global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restr
             else if (col >= N && col - N < d.m) v = d.Psi0[row * d.m + (col - N)];
         }
         Y[o] = v;
+        if (col >= N) Psibnd[(bb * NC) * (size_t)N * QOC_TW + (size_t)row * QOC_TW + (col - N)] = v;
     }
     const size_t nm = (size_t)d.n * d.m;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * nm; o += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = o / nm, e = o - b * nm;
-        d.inter[b * (size_t)(d.steps + 1) * nm + e] = d.V[e];
+        const size_t bb = o / nm, e = o - bb * nm;
+        d.inter[bb * (size_t)(d.steps + 1) * nm + e] = d.V[e];
     }
 }
-// copy the thin block of Y (columns N..N+31) into interP[b][tau] (padded) and inter[b][tau] (API layout)
-__global__ void __launch_bounds__(256) k_gemm_take_psi(QocDev d, const cplx* __restrict__ Y, cplx* __restrict__ interP, int N, int tau) {
+// copy the thin block of Y (columns N..N+31) into Psibnd[b][c]
+__global__ void __launch_bounds__(256) k_gemm_take_bnd(QocDev d, const cplx* __restrict__ Y, cplx* __restrict__ Psibnd, int N, int NC, int c) {
     const int ld = N + QOC_TW;
     const size_t per = (size_t)N * QOC_TW;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * per; o += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = o / per, e = o - b * per;
+        const size_t bb = o / per, e = o - bb * per;
         const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
-        const cplx v = Y[b * (size_t)N * ld + (size_t)row * ld + N + col];
-        interP[(b * (size_t)(d.steps + 1) + tau) * per + e] = v;
-        if (row < d.n && col < d.m) d.inter[(b * (size_t)(d.steps + 1) + tau) * d.n * d.m + (size_t)row * d.m + col] = v;
+        Psibnd[(bb * NC + c) * per + e] = Y[bb * (size_t)N * ld + (size_t)row * ld + N + col];
+    }
+}
+// inter[b][t+1] (API layout) from interP[b][t] (padded thin), t < steps
+__global__ void __launch_bounds__(256) k_gemm_unpad_inter(QocDev d, const cplx* __restrict__ interP, int N, int SP) {
+    const size_t nm = (size_t)d.n * d.m, per = (size_t)N * QOC_TW;
+    const size_t total = (size_t)d.B * d.steps * nm;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bt = o / nm, e = o - bt * nm;
+        const size_t bb = bt / d.steps, t = bt - bb * d.steps;
+        const int row = (int)(e / d.m), col = (int)(e - (size_t)row * d.m);
+        d.inter[(bb * (size_t)(d.steps + 1) + t + 1) * nm + e] = interP[(bb * SP + t) * per + (size_t)row * QOC_TW + col];
     }
 }
 // final_state, unitary_scale from the X block of Y                                     tensorflow_state.py:223-225
@@ -236,27 +240,40 @@ __global__ void __launch_bounds__(256) k_gemm_take_final(QocDev d, const cplx* _
     const double tot = block_sum(part, red);
     if (threadIdx.x == 0) d.uscale[b] = tot / (double)n;
 }
-// sources S[b][tau] (padded thin) for every tau, and the terminal costate LamP[b][steps-1]
-__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ LamP, int N) {
+// sources SrcP[b][tau] (padded thin, tau = 0..SP-1; zero for tau = 0 and tau > steps) and the costate at the END of the
+// last chunk Ebnd[b][NC-1]: -(2/m^2) z W, plus S_steps when there is no padded slice to add it through the recursion
+__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ Ebnd, int N, int SP, int NC) {
     const size_t per = (size_t)N * QOC_TW;
     const bool need_src = d.n_forb > 0 || d.has_speed;
-    const size_t total = (size_t)d.B * (d.steps + 1) * per;
+    const size_t total = (size_t)d.B * (need_src ? SP : 1) * per;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         const size_t bt = o / per, e = o - bt * per;
-        const int b = (int)(bt / (d.steps + 1)), tau = (int)(bt - (size_t)b * (d.steps + 1));
+        const int per_seed = need_src ? SP : 1;
+        const int b = (int)(bt / per_seed), tau = (int)(bt - (size_t)b * per_seed);
         const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
-        cplx s = cmake(0.0, 0.0);
         const bool valid = row < d.n && col < d.m;
-        if (valid && need_src && tau >= 1) s = source_at(d, b, tau, row, col);
-        if (need_src) SrcP[o] = s;
-        if (tau == d.steps) {                                            // Lambda_{steps-1} = -(2/m^2) z W + S_steps
+        if (need_src) {
+            cplx s = cmake(0.0, 0.0);
+            if (valid && tau >= 1 && tau <= d.steps) s = source_at(d, b, tau, row, col);
+            SrcP[o] = s;
+        }
+        if (tau == 0) {
             cplx v = cmake(0.0, 0.0);
             if (valid) {
                 const double c0 = -2.0 / ((double)d.m * (double)d.m);
-                v = cadd(cscale(cmul(d.zfin[b], d.W[row * d.m + col]), c0), s);
+                v = cscale(cmul(d.zfin[b], d.W[row * d.m + col]), c0);
+                if (need_src && SP == d.steps) v = cadd(v, source_at(d, b, d.steps, row, col));
             }
-            LamP[((size_t)b * d.steps + (d.steps - 1)) * per + e] = v;
+            Ebnd[((size_t)b * NC + (NC - 1)) * per + e] = v;
         }
+    }
+}
+// LamP[b][(c+1)S-1] = (Ebnd ? Ebnd[b][c] : 0): costate at the end of every chunk
+__global__ void __launch_bounds__(256) k_gemm_set_chunk_ends(QocDev d, cplx* __restrict__ LamP, const cplx* __restrict__ Ebnd, int N, int S, int NC) {
+    const size_t per = (size_t)N * QOC_TW;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * NC * per; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bc = o / per, e = o - bc * per;
+        LamP[(bc * S + (S - 1)) * per + e] = Ebnd ? Ebnd[o] : cmake(0.0, 0.0);
     }
 }
 // dLdu[b][k][t] = sum over row tiles of the partial dots
@@ -274,14 +291,20 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
+// Time is cut into NC chunks of S = 2^L slices (padded with identity slices to SP = NC*S).  A pairwise product tree over
+// the K_t gives the chunk products at the batched-GEMM rate; the sequential part of each chain shrinks from `steps`
+// launches to NC (chunk boundaries) + S (all chunks swept in parallel).
 struct QocGemm {
-    int N = 0;
+    int N = 0, S = 1, L = 0, NC = 1, SP = 1;
     cplx* HsP = nullptr;      // [k+1][N][N]
-    cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*steps][N][N]
+    cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
+    cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
+    size_t tree_off[8];
     cplx *Y0 = nullptr, *Y1 = nullptr;                               // [B][N][N+32]
-    cplx* interP = nullptr;   // [B][steps+1][N][32]
-    cplx* LamP = nullptr;     // [B][steps][N][32]
-    cplx* SrcP = nullptr;     // [B][steps+1][N][32] (state regularisers only)
+    cplx* interP = nullptr;   // [B][SP][N][32]   Psi_t
+    cplx* LamP = nullptr;     // [B][SP][N][32]   Lambda_t
+    cplx* SrcP = nullptr;     // [B][SP][N][32]   S_tau (state regularisers only)
+    cplx *Psibnd = nullptr, *Ebnd = nullptr, *Aoff = nullptr;        // [B][NC][N][32] chunk-start Psi, chunk-end Lambda, affine offsets
     double* partial = nullptr; // [B*steps][k][N/32]
 };
 
@@ -290,7 +313,12 @@ static inline bool qoc_gemm_supported(const QocDev& d) { return !d.state_transfe
 static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg) {
     const int N = ((d.n + 31) / 32) * 32;
     gm.N = N;
-    const size_t NN = (size_t)N * N, BS = (size_t)d.B * d.steps, thin = (size_t)N * QOC_TW;
+    int L = 0;
+    while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
+    gm.L = L; gm.S = 1 << L;
+    gm.NC = (d.steps + gm.S - 1) / gm.S;
+    gm.SP = gm.NC * gm.S;
+    const size_t NN = (size_t)N * N, BSP = (size_t)d.B * gm.SP, thin = (size_t)N * QOC_TW;
     std::vector<cplx> hp((size_t)(d.k + 1) * NN);
     for (auto& v : hp) { v.x = 0; v.y = 0; }
     for (int kk = 0; kk <= d.k; ++kk)
@@ -298,23 +326,27 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
             for (int c = 0; c < d.n; ++c) hp[(size_t)kk * NN + (size_t)a * N + c] = Hs_host[(size_t)kk * d.n * d.n + (size_t)a * d.n + c];
     auto al = [&](void** dst, size_t bytes) -> bool {
         void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return false;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return false;
         allocs.push_back(p);
         *dst = p;
         return true;
     };
     const bool need_src = d.n_forb > 0 || d.has_speed;
-    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.A, BS * NN * sizeof(cplx)) &&
-              al((void**)&gm.P, BS * NN * sizeof(cplx)) && al((void**)&gm.A2, BS * NN * sizeof(cplx)) &&
-              al((void**)&gm.K, BS * NN * sizeof(cplx)) && al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
+    size_t tree_elems = 0;
+    for (int l = 1; l <= L; ++l) { gm.tree_off[l] = tree_elems; tree_elems += (size_t)d.B * (gm.SP >> l) * NN; }
+    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.A, BSP * NN * sizeof(cplx)) &&
+              al((void**)&gm.P, BSP * NN * sizeof(cplx)) && al((void**)&gm.A2, BSP * NN * sizeof(cplx)) &&
+              al((void**)&gm.K, BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
+              al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.Y1, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
-              al((void**)&gm.interP, (size_t)d.B * (d.steps + 1) * thin * sizeof(cplx)) &&
-              al((void**)&gm.LamP, BS * thin * sizeof(cplx)) &&
-              al((void**)&gm.partial, BS * d.k * (N / 32) * sizeof(double));
-    if (ok && need_src) ok = al((void**)&gm.SrcP, (size_t)d.B * (d.steps + 1) * thin * sizeof(cplx));
+              al((void**)&gm.interP, BSP * thin * sizeof(cplx)) && al((void**)&gm.LamP, BSP * thin * sizeof(cplx)) &&
+              al((void**)&gm.Psibnd, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
+              al((void**)&gm.Ebnd, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
+              al((void**)&gm.Aoff, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
+              al((void**)&gm.partial, (size_t)d.B * d.steps * d.k * (N / 32) * sizeof(double));
+    if (ok && need_src) ok = al((void**)&gm.SrcP, BSP * thin * sizeof(cplx));
     if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
-    hipMemset(gm.interP, 0, (size_t)d.B * (d.steps + 1) * thin * sizeof(cplx));
     return 0;
 }
 
@@ -358,8 +390,8 @@ static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; retu
 // K_t for all (seed, slice): the dominant part of the path (bracketed by the profiling events of the engine)
 static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N;
-    const size_t NN = (size_t)N * N, BS = (size_t)d.B * d.steps;
-    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N);
+    const size_t NN = (size_t)N * N, BS = (size_t)d.B * gm.SP;
+    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N, gm.SP);
     // Taylor polynomial sum_{j<=T} A^j/j! (tensorflow_state.py:37-41) in Paterson-Stockmeyer form over A2 = A*A:
     // S = B_m ; S = B_i + A2*S with B_i = c_{2i} I + c_{2i+1} A  (T = 5: 3 products instead of 4); then s squarings.
     GemmArgs g;
@@ -394,50 +426,102 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         cplx* t = cur; cur = oth; oth = t;
     }
     (void)cur;                                               // == gm.K by construction
+    // pairwise product tree: T_l[i] = T_{l-1}[2i+1] * T_{l-1}[2i]  (later slice on the left), T_0 = K
+    const cplx* prev = gm.K;
+    for (int l = 1; l <= gm.L; ++l) {
+        cplx* out = gm.tree + gm.tree_off[l];
+        g.A = prev + NN; g.sA = 2 * (long long)NN; g.Bm = prev; g.sB = 2 * (long long)NN; g.C = out; g.sC = (long long)NN;
+        g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0; g.batch = (int)((size_t)d.B * (gm.SP >> l));
+        qoc_gemm_launch(false, 0, g, s);
+        prev = out;
+    }
 }
 
+static inline const cplx* qoc_gemm_chunk_products(const QocGemm& gm) { return gm.L > 0 ? gm.tree + gm.tree_off[gm.L] : gm.K; }
+
 static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s) {
-    const int N = gm.N, ld = N + QOC_TW;
-    const size_t NN = (size_t)N * N;
-    hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, N);
+    const int N = gm.N, ld = N + QOC_TW, S = gm.S, NC = gm.NC;
+    const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
+    const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
+    hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC);
+    // chunk boundaries: [X | Psi] <- P_c [X | Psi]   (X for final_state, Psi for the chunk starts)      :214-238
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.lda = N; g.sA = (long long)NN * d.steps; g.ldb = g.ldc = ld; g.sB = g.sC = (long long)N * ld;
+    g.lda = N; g.sA = (long long)NN * NC; g.ldb = g.ldc = ld; g.sB = g.sC = (long long)N * ld;
     g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = ld / 32; g.batch = d.B; g.alpha = 1.0;
     cplx *cur = gm.Y0, *oth = gm.Y1;
-    for (int t = 0; t < d.steps; ++t) {                      // [X | Psi]_t = K_t [X | Psi]_{t-1}  tensorflow_state.py:214-238
-        g.A = gm.K + (size_t)t * NN; g.Bm = cur; g.C = oth;
+    for (int c = 0; c < NC; ++c) {
+        g.A = Pc + (size_t)c * NN; g.Bm = cur; g.C = oth;
         qoc_gemm_launch(false, 0, g, s);
-        hipLaunchKernelGGL(k_gemm_take_psi, dim3(gemm_grid((size_t)d.B * N * QOC_TW)), dim3(256), 0, s, d, oth, gm.interP, N, t + 1);
+        if (c + 1 < NC)
+            hipLaunchKernelGGL(k_gemm_take_bnd, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, oth, gm.Psibnd, N, NC, c + 1);
         cplx* x = cur; cur = oth; oth = x;
     }
     hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
+    // all chunks swept together: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}, one launch per j, batch = B*NC
+    GemmArgs h;
+    memset(&h, 0, sizeof h);
+    h.lda = N; h.sA = (long long)NN * S; h.ldb = h.ldc = QOC_TW; h.Kdim = N; h.tiles_m = N / 32; h.tiles_n = 1;
+    h.batch = d.B * NC; h.alpha = 1.0; h.sC = (long long)thin * S;
+    for (int j = 0; j < S; ++j) {
+        h.A = gm.K + (size_t)j * NN;
+        if (j == 0) { h.Bm = gm.Psibnd; h.sB = (long long)thin; }
+        else { h.Bm = gm.interP + (size_t)(j - 1) * thin; h.sB = (long long)thin * S; }
+        h.C = gm.interP + (size_t)j * thin;
+        qoc_gemm_launch(false, 0, h, s);
+    }
+    hipLaunchKernelGGL(k_gemm_unpad_inter, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.SP);
+}
+
+// one backward pass over all chunks in parallel: Lambda_{cS+j-1} = K_{cS+j}^dagger Lambda_{cS+j} + S_{cS+j}, j = S-1 .. 1;
+// the j = 0 product (result belongs to the previous chunk's end) goes to `first_out` [B][NC] when requested
+static inline void qoc_gemm_bwd_sweep(QocGemm& gm, const QocDev& d, hipStream_t s, bool need_src, cplx* first_out) {
+    const int N = gm.N, S = gm.S, NC = gm.NC;
+    const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.lda = N; g.sA = (long long)NN * S; g.ldb = g.ldc = g.lde = QOC_TW; g.sB = (long long)thin * S; g.sE = (long long)thin * S;
+    g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = 1; g.batch = d.B * NC; g.alpha = 1.0; g.beta = 1.0;
+    for (int j = S - 1; j >= (first_out ? 0 : 1); --j) {
+        g.A = gm.K + (size_t)j * NN; g.Bm = gm.LamP + (size_t)j * thin;
+        g.E = need_src ? gm.SrcP + (size_t)j * thin : nullptr;
+        if (j > 0) { g.C = gm.LamP + (size_t)(j - 1) * thin; g.sC = (long long)thin * S; }
+        else { g.C = first_out; g.sC = (long long)thin; }
+        qoc_gemm_launch(true, 0, g, s);
+    }
 }
 
 static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s) {
-    const int N = gm.N;
+    const int N = gm.N, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const bool need_src = d.n_forb > 0 || d.has_speed;
-    hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (d.steps + 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.LamP, N);
+    const cplx* Pc = qoc_gemm_chunk_products(gm);
+    hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC);
+    if (need_src && NC > 1) {                                // affine offsets a_c: every chunk run from a zero costate
+        hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)nullptr, N, S, NC);
+        qoc_gemm_bwd_sweep(gm, d, s, true, gm.Aoff);
+    }
+    // chunk-end costates: E_{c-1} = P_c^dagger E_c + a_c
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.lda = N; g.sA = (long long)NN * d.steps; g.ldb = g.ldc = g.lde = QOC_TW;
-    g.sB = g.sC = (long long)thin * d.steps; g.sE = (long long)thin * (d.steps + 1);
+    g.lda = N; g.sA = (long long)NN * NC; g.ldb = g.ldc = g.lde = QOC_TW; g.sB = g.sC = g.sE = (long long)thin * NC;
     g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = 1; g.batch = d.B; g.alpha = 1.0; g.beta = 1.0;
-    for (int t = d.steps - 1; t >= 1; --t) {                 // Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1}
-        g.A = gm.K + (size_t)t * NN; g.Bm = gm.LamP + (size_t)t * thin; g.C = gm.LamP + (size_t)(t - 1) * thin;
-        g.E = need_src ? gm.SrcP + (size_t)t * thin : nullptr;           // S index tau = t  <->  Psi_{t-1}
+    for (int c = NC - 1; c >= 1; --c) {
+        g.A = Pc + (size_t)c * NN; g.Bm = gm.Ebnd + (size_t)c * thin; g.C = gm.Ebnd + (size_t)(c - 1) * thin;
+        g.E = need_src ? gm.Aoff + (size_t)c * thin : nullptr;
         qoc_gemm_launch(true, 0, g, s);
     }
+    hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)gm.Ebnd, N, S, NC);
+    qoc_gemm_bwd_sweep(gm, d, s, need_src, nullptr);
     // gradients: for each control one batched product H_k' Psi_t contracted with conj(Lambda_t)   tensorflow_state.py:61-63
     GemmArgs h;
     memset(&h, 0, sizeof h);
     h.lda = N; h.sA = 0; h.ldb = QOC_TW; h.ldl = QOC_TW; h.Kdim = N; h.tiles_m = N / 32; h.tiles_n = 1;
-    h.partial = gm.partial; h.partial_stride = d.k * (N / 32);
+    h.partial_stride = d.k * (N / 32);
     for (int b = 0; b < d.B; ++b) {
         h.batch = d.steps;
-        h.Bm = gm.interP + ((size_t)b * (d.steps + 1) + 1) * thin; h.sB = (long long)thin;       // Psi_t = interP[tau = t+1]
-        h.L = gm.LamP + (size_t)b * d.steps * thin; h.sL = (long long)thin;
+        h.Bm = gm.interP + (size_t)b * gm.SP * thin; h.sB = (long long)thin;
+        h.L = gm.LamP + (size_t)b * gm.SP * thin; h.sL = (long long)thin;
         for (int kk = 0; kk < d.k; ++kk) {
             h.A = gm.HsP + (size_t)(kk + 1) * NN;
             h.partial = gm.partial + (size_t)b * d.steps * h.partial_stride;
