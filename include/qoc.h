@@ -125,10 +125,13 @@ int qoc_get_scalars(qoc_handle h, double* loss, double* reg_loss, double* grad_s
                     int32_t* iterations, int32_t* done);
 
 /* ---- read-back == Analysis (core/analysis.py:18-41) and run_session.Get_uks (run_session.py:112-117) ----------
- * uks   [n_seeds][k][steps]          : maxA[k] * sin(base)
+ * uks   [n_seeds][k][steps]          : maxA[k] * sin(base) of the current variable
  * Uf    [n_seeds][n][n] complex      : RtoCMat(final_state) of the last evaluation (unitary mode only)
  * inter [n_seeds][steps+1][n][m] cplx: inter_vecs (tau = 0 is the initial vectors) of the last evaluation */
 int qoc_get_uks(qoc_handle h, double* uks);
+/* uks the LAST EVALUATION ran on (inside the Adam loop the variable has already moved one step further; the reference
+ * logs loss, final_state and uks of the same evaluation, run_session.py:75-91,130-138). */
+int qoc_get_uks_evaluated(qoc_handle h, double* uks);
 int qoc_get_final_unitary(qoc_handle h, double* Uf);
 int qoc_get_inter_vecs(qoc_handle h, double* inter);
 

@@ -319,9 +319,9 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const bool mfma_ok = qoc_mfma_supported(d);
     const bool st_ok = st_fused_supported(d);
     const bool gemm_ok = qoc_gemm_supported(d);
-    // 48 < n <= 64 runs the register-resident kernels with spills: they win on latency (few seeds), the GEMM path ties
-    // or wins on throughput from ~64 seeds on
-    const bool prefer_gemm = gemm_ok && n > 48 && B >= 64;
+    // 48 < n <= 64 would run the register-resident kernels with spills (NT = 4): the tree-chunked GEMM path is 1.4-2.4x
+    // faster there for every seed count and slice count measured (tools/path_sweep.py), so AUTO hands n > 48 to it
+    const bool prefer_gemm = gemm_ok && n > 48;
     if (path == QOC_PATH_AUTO)
         path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (st_ok ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));
     if (path == QOC_PATH_MFMA && !mfma_ok)
@@ -491,6 +491,16 @@ int qoc_get_uks(qoc_handle e, double* uks) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(uks, d.u, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
+    return QOC_OK;
+}
+
+int qoc_get_uks_evaluated(qoc_handle e, double* uks) {
+    CHECK_H(e);
+    if (!uks) return fail(QOC_ERR_INVALID, "qoc_get_uks_evaluated: null output");
+    if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_uks_evaluated: nothing evaluated yet");
+    // d.u still holds the controls the last evaluation ran on (an Adam step only moves `base`)
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(uks, e->d.u, (size_t)e->d.B * e->d.k * e->d.steps * sizeof(double), hipMemcpyDeviceToHost));
     return QOC_OK;
 }
 

@@ -24,6 +24,13 @@ class Convergence(object):
         self.last_iter = 0
         self.accumulate_rate = 1.00
 
+    def save_evol(self, anly):
+        """Snapshot of the propagation at this point of the run (convergence.py:62-66); with save=True the Analysis
+        calls append final_state / inter_vecs_* to the run log."""
+        if not self.sys_para.state_transfer:
+            self.final_state = anly.get_final_state()
+        self.inter_vecs = anly.get_inter_vecs()
+
     def record(self, iteration, cost, reg_cost):
         self.iterations.append(iteration)
         self.costs.append(cost)

@@ -50,6 +50,7 @@ _SIGNATURES = {
     'qoc_sync': (C.c_int, [C.c_void_p]),
     'qoc_get_scalars': (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, _IP, _IP]),
     'qoc_get_uks': (C.c_int, [C.c_void_p, _DP]),
+    'qoc_get_uks_evaluated': (C.c_int, [C.c_void_p, _DP]),
     'qoc_get_final_unitary': (C.c_int, [C.c_void_p, _DP]),
     'qoc_get_inter_vecs': (C.c_int, [C.c_void_p, _DP]),
     'qoc_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
@@ -246,9 +247,11 @@ class HipEngine(object):
         return dict(loss=loss, reg_loss=reg, grad_squared=g2, unitary_scale=us, iterations=its, done=done)
 
     # -- read-back ------------------------------------------------------------------------------------------------
-    def get_uks(self):
+    def get_uks(self, evaluated=False):
+        """maxA*sin(base) of the current variable, or (evaluated=True) the controls the last evaluation ran on."""
         out = np.empty(self._seed_shape())
-        _check(self._lib.qoc_get_uks(self._h, _dp(out)))
+        fn = self._lib.qoc_get_uks_evaluated if evaluated else self._lib.qoc_get_uks
+        _check(fn(self._h, _dp(out)))
         return out
 
     def get_final_unitary(self):

@@ -10,6 +10,8 @@ import time
 import numpy as np
 from scipy.optimize import minimize
 
+from quantum_optimal_control.core.analysis import Analysis
+
 
 class run_session(object):
 
@@ -57,8 +59,7 @@ class run_session(object):
             self.end = bool(np.all(s['done']))
             if self.end or launched >= budget:
                 break
-            self.save_data()
-            self.display()
+            self.update_and_save()
         self.end = True
         self.get_end_results()
 
@@ -67,8 +68,19 @@ class run_session(object):
         self.l, self.rl = float(s['loss'][b]), float(s['reg_loss'][b])
         self.g_squared, self.metric = float(s['grad_squared'][b]), float(s['unitary_scale'][b])
         if 'iterations' in s:
-            self.iterations = int(s['iterations'][b])
+            # the device counter is already one past the evaluation these scalars belong to, unless that evaluation
+            # tripped the stop rule (run_session.py:53-60 evaluates, checks, then increments)
+            self.iterations = int(s['iterations'][b]) - (0 if int(s['done'][b]) else 1)
         self.conv.record(self.iterations, self.l, self.rl)
+
+    def update_and_save(self):
+        """Host poll at a multiple of update_step (run_session.py:75-91): progress line, run-log row, and every
+        evol_save_step iterations the propagation snapshot."""
+        self.anly = Analysis(self.sys_para, self.engine, self.seed)
+        self.save_data()
+        self.display()
+        if self.iterations % max(1, int(self.conv.evol_save_step)) == 0:
+            self.conv.save_evol(self.anly)
 
     # ---- results ------------------------------------------------------------------------------------------------
     def get_end_results(self):
@@ -76,16 +88,20 @@ class run_session(object):
             s = self.engine.scalars()
             self.seed = int(np.argmin(s['loss']))
             self._take_scalars(s)
+        self.anly = Analysis(self.sys_para, self.engine, self.seed)
         self.save_data()
         self.display()
+        self.conv.save_evol(self.anly)                    # final_state / inter_vecs_* rows of the run log (:100-101)
         self.uks = self.Get_uks()
         if not self.sys_para.state_transfer:
-            self.Uf = self.engine.get_final_unitary()[self.seed]
+            self.Uf = self.anly.get_final_state(save=False)
         else:
             self.Uf = []
 
     def Get_uks(self):
-        return self.engine.get_uks()[self.seed]
+        """Physical pulse amplitudes maxA_k sin(base), (k, steps) (run_session.py:112-117): the controls the reported
+        loss / final_state / inter_vecs were evaluated on."""
+        return self.engine.get_uks(evaluated=True)[self.seed]
 
     def get_error(self, uks):
         """Loss, regularised loss, flattened gradient, unitary metric and grad_squared at controls `uks`
@@ -129,8 +145,7 @@ class run_session(object):
             self.grads = 0 * self.grads          # zero gradient terminates the scipy optimisation
         if not self.end:
             if self.iterations % self.conv.update_step == 0:
-                self.save_data()
-                self.display()
+                self.update_and_save()
             self.iterations += 1
         return np.float64(self.rl), np.asarray(self.grads, dtype=np.float64)
 

@@ -97,25 +97,3 @@ def test_builder_helpers_match_reference():
     assert gf.Bin(5, 6) == str(fx['bin_5_6']) and gf.Basis(7, 3, 3) == str(fx['basis_7_3_3'])
     assert gf.baseN(11, 3) == str(fx['baseN_11_3']) and gf.baseN(0, 5) == '0'
     assert gf.hamming_distance(0b101101) == 4
-
-
-def test_h5_run_log_add_and_append(tmp_path):
-    """Row f3: HDF5 run log semantics (datasets grow along axis 0 on append; add overwrites). Needs optional h5py."""
-    pytest.importorskip('h5py')
-    from quantum_optimal_control.helper_functions.data_management import H5File
-    path = str(tmp_path / 'log.h5')
-    with H5File(path) as hf:
-        hf.add('steps', data=500)
-        hf.add('H0', data=np.eye(2) * (1 + 2j))
-        hf.add('Hnames', data=['x', 'y'])
-        hf.append('error', np.array(0.5))
-        hf.append('error', np.array(0.25))
-        hf.append('uks', np.ones((2, 3)))
-        hf.append('uks', 2 * np.ones((2, 3)))
-        hf.add('steps', data=600)
-    import h5py
-    with h5py.File(path, 'r') as f:
-        assert int(f['steps'][()]) == 600
-        np.testing.assert_array_equal(f['error'][:], [0.5, 0.25])
-        assert f['uks'].shape == (2, 2, 3) and f['uks'][1, 0, 0] == 2.0
-        assert f['H0'][0, 0] == 1 + 2j and [s.decode() for s in f['Hnames'][:]] == ['x', 'y']
