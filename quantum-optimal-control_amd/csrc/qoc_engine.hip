@@ -318,18 +318,23 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     int path = cfg->path;
     const bool mfma_ok = qoc_mfma_supported(d);
     const bool st_ok = st_fused_supported(d);
-    const bool gemm_ok = qoc_gemm_supported(d);
+    const bool gemm_ok = qoc_gemm_supported(d, cfg->state_transfer ? qoc_all_antihermitian((const cplx*)Hs, n, k + 1) : true);
     // 48 < n <= 64 would run the register-resident kernels with spills (NT = 4): the tree-chunked GEMM path is 1.4-2.4x
     // faster there for every seed count and slice count measured (tools/path_sweep.py), so AUTO hands n > 48 to it
     const bool prefer_gemm = gemm_ok && n > 48;
+    // State transfer: the fused mat-vec kernels cost ~26 us per slice whatever n <= 64 and B <= 256 are (one workgroup per
+    // seed, latency-bound); the propagator route costs ~(1.4 + 0.17 B) us per slice at n <= 32 and ~(2.9 + 0.68 B) us at
+    // n <= 64 (tools/path_sweep.py), i.e. it wins for few seeds -- 7.5x on a single C3 trajectory.
+    const bool st_prefer_gemm = gemm_ok && cfg->state_transfer && (n <= 32 ? B <= 128 : B <= 32);
     if (path == QOC_PATH_AUTO)
-        path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (st_ok ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));
+        path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA
+               : ((st_ok && !st_prefer_gemm) ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));
     if (path == QOC_PATH_MFMA && !mfma_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 64, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_GEMM && !gemm_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: GEMM path needs unitary mode and m <= 32 (m=%d)", m));
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: GEMM path needs m <= 32 and, in state transfer, exactly anti-Hermitian generators (m=%d)", m));
     if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;

@@ -150,10 +150,10 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
 
 // A_t = (H0' + sum_k u_k H_k') / 2^s for every (seed, slice), padded N x N           tensorflow_state.py:30-33
 // Slices are padded to SP = NC*S per seed; a padded slice gets A = 0, i.e. K = I exactly.
-__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP) {
+__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq) {
     const size_t NN = (size_t)N * N;
     const size_t total = (size_t)d.B * SP * NN;
-    const double inv = 1.0 / (double)(1 << d.s);
+    const double inv = 1.0 / (double)(1 << sq);
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         const size_t item = o / NN, e = o - item * NN;
         const int b = (int)(item / SP), t = (int)(item - (size_t)b * SP);
@@ -182,9 +182,10 @@ __global__ void __launch_bounds__(256) k_gemm_ps_init(const cplx* __restrict__ A
         S[o] = v;
     }
 }
-// Y[b] = [U0 | Psi0] padded (N x (N+32)); Psibnd[b][0] = Psi0 padded; inter[b][0] = V
-__global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restrict__ Y, cplx* __restrict__ Psibnd, int N, int NC) {
-    const int ld = N + QOC_TW;
+// Y[b] = [U0 | Psi0] padded (N x (xw+32), xw = N, or 0 in state transfer: no X chain); Psibnd[b][0] = Psi0 padded;
+// inter[b][0] = V
+__global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restrict__ Y, cplx* __restrict__ Psibnd, int N, int NC, int xw) {
+    const int ld = xw + QOC_TW;
     const size_t per = (size_t)N * ld;
     const size_t total = (size_t)d.B * per;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
@@ -192,11 +193,11 @@ __global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restr
         const int row = (int)(e / ld), col = (int)(e - (size_t)row * ld);
         cplx v = cmake(0.0, 0.0);
         if (row < d.n) {
-            if (col < d.n) v = d.U0[row * d.n + col];
-            else if (col >= N && col - N < d.m) v = d.Psi0[row * d.m + (col - N)];
+            if (col < xw) { if (col < d.n) v = d.U0[row * d.n + col]; }
+            else if (col - xw < d.m) v = d.Psi0[row * d.m + (col - xw)];
         }
         Y[o] = v;
-        if (col >= N) Psibnd[(bb * NC) * (size_t)N * QOC_TW + (size_t)row * QOC_TW + (col - N)] = v;
+        if (col >= xw) Psibnd[(bb * NC) * (size_t)N * QOC_TW + (size_t)row * QOC_TW + (col - xw)] = v;
     }
     const size_t nm = (size_t)d.n * d.m;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * nm; o += (size_t)gridDim.x * blockDim.x) {
@@ -205,13 +206,13 @@ __global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restr
     }
 }
 // copy the thin block of Y (columns N..N+31) into Psibnd[b][c]
-__global__ void __launch_bounds__(256) k_gemm_take_bnd(QocDev d, const cplx* __restrict__ Y, cplx* __restrict__ Psibnd, int N, int NC, int c) {
-    const int ld = N + QOC_TW;
+__global__ void __launch_bounds__(256) k_gemm_take_bnd(QocDev d, const cplx* __restrict__ Y, cplx* __restrict__ Psibnd, int N, int NC, int c, int xw) {
+    const int ld = xw + QOC_TW;
     const size_t per = (size_t)N * QOC_TW;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * per; o += (size_t)gridDim.x * blockDim.x) {
         const size_t bb = o / per, e = o - bb * per;
         const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
-        Psibnd[(bb * NC + c) * per + e] = Y[bb * (size_t)N * ld + (size_t)row * ld + N + col];
+        Psibnd[(bb * NC + c) * per + e] = Y[bb * (size_t)N * ld + (size_t)row * ld + xw + col];
     }
 }
 // inter[b][t+1] (API layout) from interP[b][t] (padded thin), t < steps
@@ -308,7 +309,21 @@ struct QocGemm {
     double* partial = nullptr; // [B*steps][k][N/32]
 };
 
-static inline bool qoc_gemm_supported(const QocDev& d) { return !d.state_transfer && d.m <= QOC_TW && d.T >= 1; }
+// Unitary mode: any n.  State transfer: psi <- P(B_t) psi is the same chain with K_t = sum_{j<T} B_t^j/j! (no squaring);
+// the reference's backward step lambda <- P(-B_t) lambda (tensorflow_state.py:118-131) equals K_t^dagger lambda exactly
+// when every generator is anti-Hermitian (-i dt H with H Hermitian), which `antiherm` certifies at create time.
+static inline bool qoc_gemm_supported(const QocDev& d, bool antiherm) {
+    return d.m <= QOC_TW && d.T >= 1 && (!d.state_transfer || antiherm);
+}
+static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
+    for (int q = 0; q < count; ++q) {
+        const cplx* H = Hs + (size_t)q * n * n;
+        for (int a = 0; a < n; ++a)
+            for (int c = a; c < n; ++c)
+                if (H[a * n + c].x != -H[c * n + a].x || H[a * n + c].y != H[c * n + a].y) return false;
+    }
+    return true;
+}
 
 static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg) {
     const int N = ((d.n + 31) / 32) * 32;
@@ -391,7 +406,9 @@ static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; retu
 static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N;
     const size_t NN = (size_t)N * N, BS = (size_t)d.B * gm.SP;
-    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N, gm.SP);
+    const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
+    const int nsq = d.state_transfer ? 0 : d.s;
+    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N, gm.SP, nsq);
     // Taylor polynomial sum_{j<=T} A^j/j! (tensorflow_state.py:37-41) in Paterson-Stockmeyer form over A2 = A*A:
     // S = B_m ; S = B_i + A2*S with B_i = c_{2i} I + c_{2i+1} A  (T = 5: 3 products instead of 4); then s squarings.
     GemmArgs g;
@@ -399,17 +416,17 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     g.lda = g.ldb = g.ldc = g.lde = N; g.sA = g.sB = g.sC = g.sE = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.batch = (int)BS;
     double invf[24];
     { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; invf[j] = 1.0 / f; } }
-    const int mm = d.T >> 1;
-    const bool even = (d.T & 1) == 0;
-    const int horner = d.T >= 2 ? (even ? mm - 1 : mm) : 0;      // products after A2
-    const int products = horner + d.s;                           // buffer flips until the result
+    const int mm = deg >> 1;
+    const bool even = (deg & 1) == 0;
+    const int horner = deg >= 2 ? (even ? mm - 1 : mm) : 0;      // products after A2
+    const int products = horner + nsq;                           // buffer flips until the result
     cplx* cur = (products % 2 == 0) ? gm.K : gm.P;               // buffers alternate cur -> other on every product
     cplx* oth = (products % 2 == 0) ? gm.P : gm.K;
-    if (d.T >= 2) {
+    if (deg >= 2) {
         g.A = gm.A; g.Bm = gm.A; g.C = gm.A2; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
         qoc_gemm_launch(false, 0, g, s);                         // A2 = A*A
         if (even) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, gm.A2, cur, BS * NN, N,
-                                     invf[2 * mm - 2], invf[2 * mm - 1], invf[d.T]);
+                                     invf[2 * mm - 2], invf[2 * mm - 1], invf[deg]);
         else hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N,
                                 invf[2 * mm], invf[2 * mm + 1], 0.0);
         for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {    // S <- c_{2i} I + c_{2i+1} A + A2*S
@@ -418,9 +435,10 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
             cplx* t = cur; cur = oth; oth = t;
         }
     } else {
-        hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N, 1.0, 1.0, 0.0);
+        hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N, 1.0,
+                           deg >= 1 ? 1.0 : 0.0, 0.0);
     }
-    for (int sq = 0; sq < d.s; ++sq) {                       // M <- M M                    tensorflow_state.py:43-44
+    for (int sq = 0; sq < nsq; ++sq) {                       // M <- M M                    tensorflow_state.py:43-44
         g.A = cur; g.Bm = cur; g.C = oth; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
         qoc_gemm_launch(false, 0, g, s);
         cplx* t = cur; cur = oth; oth = t;
@@ -440,10 +458,10 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
 static inline const cplx* qoc_gemm_chunk_products(const QocGemm& gm) { return gm.L > 0 ? gm.tree + gm.tree_off[gm.L] : gm.K; }
 
 static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s) {
-    const int N = gm.N, ld = N + QOC_TW, S = gm.S, NC = gm.NC;
+    const int N = gm.N, xw = d.state_transfer ? 0 : N, ld = xw + QOC_TW, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
-    hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC);
+    hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
     // chunk boundaries: [X | Psi] <- P_c [X | Psi]   (X for final_state, Psi for the chunk starts)      :214-238
     GemmArgs g;
     memset(&g, 0, sizeof g);
@@ -454,10 +472,10 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         g.A = Pc + (size_t)c * NN; g.Bm = cur; g.C = oth;
         qoc_gemm_launch(false, 0, g, s);
         if (c + 1 < NC)
-            hipLaunchKernelGGL(k_gemm_take_bnd, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, oth, gm.Psibnd, N, NC, c + 1);
+            hipLaunchKernelGGL(k_gemm_take_bnd, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, oth, gm.Psibnd, N, NC, c + 1, xw);
         cplx* x = cur; cur = oth; oth = x;
     }
-    hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
+    if (!d.state_transfer) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
     // all chunks swept together: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}, one launch per j, batch = B*NC
     GemmArgs h;
     memset(&h, 0, sizeof h);

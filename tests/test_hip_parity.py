@@ -115,9 +115,11 @@ def test_mfma_path_parity(chunks, variant):
     eng.close()
 
 
+@pytest.mark.parametrize('path', [3, 4])
 @pytest.mark.parametrize('variant', ['c3_small', 'allreg_m2', 'n64_m1', 'n5_m2', 'm4_T1'])
-def test_fused_state_transfer_parity(variant):
-    """Register-resident state-transfer kernels (path 3) against the oracle."""
+def test_fused_state_transfer_parity(variant, path):
+    """State transfer against the oracle: register-resident mat-vec kernels (path 3) and the propagator route (path 4:
+    K_t = P(B_t) as a matrix, tree-chunked thin chains; needs anti-Hermitian generators)."""
     if variant == 'c3_small':
         c = cases.ALL_CASES['c3_small']()
     elif variant == 'allreg_m2':
@@ -138,8 +140,8 @@ def test_fused_state_transfer_parity(variant):
     sp = oracle_system(c)
     rng = np.random.default_rng(11)
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1]
-    eng = make_engine(sp, n_seeds=2, path=3)
-    assert eng.path == 3
+    eng = make_engine(sp, n_seeds=2, path=path)
+    assert eng.path == path
     eng.set_base(np.stack(bases))
     check_eval(eng, sp, bases)
     eng.close()
@@ -382,6 +384,14 @@ def edge_cases():
     c['U'] = [v / np.linalg.norm(v) for v in vs[5:8]]
     out.append(('st_m3_fused', c, 3))
     out.append(('st_n65_generic', cases.case_c3(n=65, k=2, steps=4, taylor=(4, 0)), 0))
+    out.append(('st_n65_forced_generic', cases.case_c3(n=65, k=2, steps=4, taylor=(4, 0)), 1))
+    # a non-Hermitian drift: lambda <- P(-B) lambda differs from K^dagger lambda, so AUTO must not take the propagator route
+    c = cases.case_state_small(); c['Taylor_terms'] = [6, 0]
+    c['H0'] = c['H0'] + 0.3 * rng.normal(size=(5, 5))
+    out.append(('st_nonhermitian_fused', c, 0))
+    c = cases.case_c3(n=65, k=2, steps=4, taylor=(4, 0))
+    c['H0'] = c['H0'] + 0.3 * rng.normal(size=(65, 65))
+    out.append(('st_nonhermitian_generic', c, 0))
     return out
 
 
@@ -394,7 +404,8 @@ def test_edge_cases_all_paths(name, c, path):
     sp = oracle_system(c)
     bases = [sp.base0, -1.5 * sp.base0 + 0.05]
     eng = make_engine(sp, n_seeds=2, path=path)
-    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'st_m5_generic': 1, 'st_n65_generic': 1}
+    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'st_m5_generic': 4, 'st_n65_generic': 4,
+              'st_nonhermitian_fused': 3, 'st_nonhermitian_generic': 1, 'state_small_auto': 4}
     if name in expect:
         assert eng.path == expect[name], (name, eng.path)
     eng.set_base(np.stack(bases))
@@ -407,8 +418,10 @@ def test_unsupported_path_requests_fail_loudly():
     sp = oracle_system(cases.case_c2(n=66, k=2, steps=3, m=2, taylor=(3, 1), seed=1))
     with pytest.raises(hip_engine.QocError, match='MFMA path needs'):
         make_engine(sp, path=2)
-    sp = oracle_system(cases.case_state_small())
-    with pytest.raises(hip_engine.QocError, match='GEMM path needs unitary'):
+    c = cases.case_state_small()
+    c['H0'] = c['H0'] + 0.1 * np.arange(25.0).reshape(5, 5)          # not Hermitian: the propagator route must refuse
+    sp = oracle_system(c)
+    with pytest.raises(hip_engine.QocError, match='anti-Hermitian generators'):
         make_engine(sp, path=4)
     with pytest.raises(hip_engine.QocError, match='unknown path'):
         make_engine(sp, path=9)
@@ -433,13 +446,15 @@ def test_grape_restarts_extension_returns_best_seed():
     assert uksB.shape == uks1.shape and UfB.shape == Uf1.shape
 
 
-def test_full_size_c3_state_transfer_against_oracle():
+@pytest.mark.parametrize('path,expect', [(0, 4), (3, 3)])
+def test_full_size_c3_state_transfer_against_oracle(path, expect):
     """BASELINE config C3 at full size (n=64, k=6, steps=1000, dwdt + forbidden regularisers): mat-vec chains are cheap
-    enough for the NumPy oracle, so this is a full comparison plus the size-independent properties."""
+    enough for the NumPy oracle, so this is a full comparison plus the size-independent properties.  AUTO takes the
+    propagator route for a couple of trajectories; the fused mat-vec kernels are what large restart batches run."""
     c = cases.case_c3()
     sp = oracle_system(c)
-    eng = make_engine(sp, n_seeds=2)
-    assert eng.path == 3
+    eng = make_engine(sp, n_seeds=2, path=path)
+    assert eng.path == expect
     bases = [sp.base0, 0.3 * sp.base0]
     eng.set_base(np.stack(bases))
     r = eng.evaluate()

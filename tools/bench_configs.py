@@ -40,9 +40,10 @@ if __name__ == '__main__':
     run('C2 x64', cases.case_c2(), 64, 20)
     c = cases.case_c2(); c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [30, 31]}
     run('C2 x64 + dwdt + forbidden', c, 64, 20)
-    run('C3 state transfer', cases.case_c3(), 1, 5)
+    run('C3 state transfer (propagator route)', cases.case_c3(), 1, 5)
+    run('C3 state transfer (fused mat-vec)', cases.case_c3(), 1, 5, path=3)
     run('C3 state transfer x64 seeds', cases.case_c3(), 64, 5)
-    run('n=64 unitary (generic path) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 3, path=1)
+    run('C3 state transfer x256 seeds', cases.case_c3(), 256, 5)
     run('n=64 unitary (GEMM path) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 5, path=4)
     run('n=64 unitary (MFMA NT=4) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 5, path=2)
     run('n=48 unitary (MFMA NT=3) x64', cases.case_c2(n=48, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 3)

@@ -39,3 +39,28 @@ if __name__ == '__main__':
                 a = ms_per_iter(c, seeds, 2)
                 b = ms_per_iter(c, seeds, 4)
                 print('%4d %6d %6d %10.3f %10.3f %s' % (n, steps, seeds, a, b, 'GEMM' if b < a else ''), flush=True)
+
+    print('state transfer: fused mat-vec kernels (path 3) vs propagator route (path 4)')
+    print('%4s %6s %6s %10s %10s' % ('n', 'steps', 'seeds', 'fused ms', 'gemm ms'))
+
+    def st_ms(c, n_seeds, path, iters=2):
+        sp = oracle_system(c)
+        eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms,
+                                   sp.scaling, state_transfer=True, reg_coeffs=sp.reg_coeffs, n_seeds=n_seeds, path=path)
+        rng = np.random.default_rng(0)
+        eng.set_base(rng.normal(0, 1 / np.sqrt(sp.steps), (n_seeds, sp.k, sp.steps)))
+        p = eng.adam_params(max_iterations=10 ** 9, conv_target=-1.0, min_grad=-1.0)
+        eng.iterate(p, 1); eng.sync()
+        t0 = time.perf_counter()
+        eng.iterate(p, iters); eng.sync()
+        el = (time.perf_counter() - t0) / iters * 1e3
+        eng.close()
+        return el
+
+    for n in (16, 32, 64):
+        for steps in (200, 1000):
+            for seeds in (1, 8, 32, 64, 128):
+                c = cases.case_c3(n=n, k=6, steps=steps, taylor=(10, 0))
+                a = st_ms(c, seeds, 3)
+                b = st_ms(c, seeds, 4)
+                print('%4d %6d %6d %10.3f %10.3f %s' % (n, steps, seeds, a, b, 'GEMM' if b < a else ''), flush=True)
