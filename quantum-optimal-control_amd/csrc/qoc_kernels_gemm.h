@@ -291,12 +291,136 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
     }
 }
 
+// ---- persistent thin chains (N <= 64, m <= 8) ---------------------------------------------------------------------
+// y <- op(K_j) y (+ E_j) for `len` consecutive matrices, one workgroup per chain, y in LDS.  Launch-per-step chains cost
+// ~5 us of launch latency per step; here a step costs one L2 read of K_j (prefetched one step ahead into registers) plus
+// N*N*m complex MACs on the VALU (fp64 FMA rate ~ MFMA rate on gfx950, and no padding of m to an MFMA tile).
+// Thread (i, q): row i of the result, columns LPR*e + q of op(K); LPR = 256/N lanes share a row (xor-shuffle reduction).
+struct ChainArgs {
+    const cplx* K; long long sKb, sKc, sKs;     // matrix of step j: K + b*sKb + c*sKc + j*sKs  (elements; sKs may be negative)
+    const cplx* X0; long long sXb, sXc;         // initial thin vectors (nullptr = zeros)
+    const cplx* E; long long sEb, sEc, sEs;     // optional addend per step (nullptr = none)
+    cplx* Out; long long sOb, sOc, sOs;         // optional output per step (nullptr = none)
+    cplx* Fin; long long sFb, sFc;              // optional final state
+    cplx* api; long long sAb;                   // optional inter_vecs output (API layout [tau][n][m]); tau = tau0 + c*tauc + j
+    int tau0, tauc, tau_max;                    // rows with tau > tau_max are not written
+    int CI;                                     // chains per seed (blockIdx.x = b*CI + c)
+    int len, m, n;
+    int store_initial;                          // also store y0 at Out - sOs
+};
+
+template <int N, int MV, bool CONJT>
+__global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
+    constexpr int LPR = 256 / N, EL = N / LPR;
+    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
+    const int tid = threadIdx.x, i = tid / LPR, q = tid % LPR;
+    const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
+    const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
+    const cplx* Ep = a.E ? a.E + b * a.sEb + c * a.sEc : nullptr;
+    cplx* Op = a.Out ? a.Out + b * a.sOb + c * a.sOc : nullptr;
+    cplx yrow[MV];
+#pragma unroll
+    for (int jv = 0; jv < MV; ++jv) yrow[jv] = cmake(0.0, 0.0);
+    if (q == 0) {
+        if (a.X0) {
+            const cplx* x = a.X0 + b * a.sXb + c * a.sXc + (size_t)i * QOC_TW;
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) yrow[jv] = x[jv];
+        }
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) y[0][i * MV + jv] = yrow[jv];
+        if (a.store_initial && Op) {
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) (Op - a.sOs)[(size_t)i * QOC_TW + jv] = yrow[jv];
+        }
+    }
+    auto load = [&](cplx* dst, const cplx* Kj) {
+#pragma unroll
+        for (int e = 0; e < EL; ++e) dst[e] = CONJT ? Kj[(size_t)(LPR * e + q) * N + i] : Kj[(size_t)i * N + LPR * e + q];
+    };
+    cplx kc[EL], kn[EL];
+    if (a.len > 0) load(kc, Kp);
+    __syncthreads();
+    int cur = 0;
+    for (int j = 0; j < a.len; ++j) {
+        if (j + 1 < a.len) load(kn, Kp + (long long)(j + 1) * a.sKs);
+        cplx acc[MV];
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
+#pragma unroll
+        for (int e = 0; e < EL; ++e) {
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) {
+                const cplx v = y[cur][(LPR * e + q) * MV + jv];
+                if (CONJT) cfma_conj(acc[jv], kc[e], v); else cfma(acc[jv], kc[e], v);
+            }
+        }
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) {
+#pragma unroll
+            for (int off = 1; off < LPR; off <<= 1) {
+                acc[jv].x += __shfl_xor(acc[jv].x, off, 64);
+                acc[jv].y += __shfl_xor(acc[jv].y, off, 64);
+            }
+        }
+        if (q == 0) {
+            if (Ep) {
+                const cplx* ej = Ep + (long long)j * a.sEs + (size_t)i * QOC_TW;
+#pragma unroll
+                for (int jv = 0; jv < MV; ++jv) acc[jv] = cadd(acc[jv], ej[jv]);
+            }
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) y[cur ^ 1][i * MV + jv] = acc[jv];
+            if (Op) {
+                cplx* oj = Op + (long long)j * a.sOs + (size_t)i * QOC_TW;
+#pragma unroll
+                for (int jv = 0; jv < MV; ++jv) oj[jv] = acc[jv];
+            }
+            if (a.api) {
+                const int tau = a.tau0 + c * a.tauc + j;
+                if (tau <= a.tau_max && i < a.n) {
+                    cplx* o = a.api + b * a.sAb + ((size_t)tau * a.n + i) * a.m;
+#pragma unroll
+                    for (int jv = 0; jv < MV; ++jv)
+                        if (jv < a.m) o[jv] = acc[jv];
+                }
+            }
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) yrow[jv] = acc[jv];
+        }
+#pragma unroll
+        for (int e = 0; e < EL; ++e) kc[e] = kn[e];
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (a.Fin && q == 0) {
+        cplx* f = a.Fin + b * a.sFb + c * a.sFc + (size_t)i * QOC_TW;
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) f[jv] = yrow[jv];
+    }
+}
+
+template <int N, bool CONJT>
+static inline void qoc_chain_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
+    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain<N, 1, CONJT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain<N, 2, CONJT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain<N, 4, CONJT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_chain<N, 8, CONJT>), dim3(blocks), dim3(256), 0, s, a);
+}
+static inline void qoc_chain_launch(int N, bool conjt, const ChainArgs& a, int blocks, hipStream_t s) {
+    if (a.len <= 0 && !a.Fin && !a.store_initial) return;
+    if (N == 32) { if (conjt) qoc_chain_launch_n<32, true>(a, blocks, s); else qoc_chain_launch_n<32, false>(a, blocks, s); }
+    else { if (conjt) qoc_chain_launch_n<64, true>(a, blocks, s); else qoc_chain_launch_n<64, false>(a, blocks, s); }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 // Time is cut into NC chunks of S = 2^L slices (padded with identity slices to SP = NC*S).  A pairwise product tree over
 // the K_t gives the chunk products at the batched-GEMM rate; the sequential part of each chain shrinks from `steps`
 // launches to NC (chunk boundaries) + S (all chunks swept in parallel).
 struct QocGemm {
     int N = 0, S = 1, L = 0, NC = 1, SP = 1;
+    bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
     cplx* HsP = nullptr;      // [k+1][N][N]
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
@@ -328,6 +452,7 @@ static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
 static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg) {
     const int N = ((d.n + 31) / 32) * 32;
     gm.N = N;
+    gm.persistent = N <= 64 && d.m <= 8;
     int L = 0;
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
     gm.L = L; gm.S = 1 << L;
@@ -362,6 +487,12 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     if (ok && need_src) ok = al((void**)&gm.SrcP, BSP * thin * sizeof(cplx));
     if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+    // the persistent chain kernels write only the first m (<= 8) of the 32 thin columns; the rest must read as zero
+    hipMemset(gm.interP, 0, BSP * thin * sizeof(cplx));
+    hipMemset(gm.LamP, 0, BSP * thin * sizeof(cplx));
+    hipMemset(gm.Psibnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx));
+    hipMemset(gm.Ebnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx));
+    hipMemset(gm.Aoff, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx));
     return 0;
 }
 
@@ -462,13 +593,23 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
     hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
+    if (gm.persistent && d.state_transfer) {
+        // chunk-start vectors Psibnd[c+1] = P_c Psibnd[c]: one persistent workgroup per seed
+        ChainArgs a;
+        memset(&a, 0, sizeof a);
+        a.K = Pc; a.sKb = (long long)NN * NC; a.sKs = (long long)NN;
+        a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC;
+        a.Out = gm.Psibnd + thin; a.sOb = (long long)thin * NC; a.sOs = (long long)thin;
+        a.CI = 1; a.len = NC - 1; a.m = d.m; a.n = d.n;
+        qoc_chain_launch(N, false, a, d.B, s);
+    }
     // chunk boundaries: [X | Psi] <- P_c [X | Psi]   (X for final_state, Psi for the chunk starts)      :214-238
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.lda = N; g.sA = (long long)NN * NC; g.ldb = g.ldc = ld; g.sB = g.sC = (long long)N * ld;
     g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = ld / 32; g.batch = d.B; g.alpha = 1.0;
     cplx *cur = gm.Y0, *oth = gm.Y1;
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < ((gm.persistent && d.state_transfer) ? 0 : NC); ++c) {
         g.A = Pc + (size_t)c * NN; g.Bm = cur; g.C = oth;
         qoc_gemm_launch(false, 0, g, s);
         if (c + 1 < NC)
@@ -476,6 +617,18 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         cplx* x = cur; cur = oth; oth = x;
     }
     if (!d.state_transfer) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
+    if (gm.persistent) {
+        // every chunk swept by its own persistent workgroup: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}
+        ChainArgs a;
+        memset(&a, 0, sizeof a);
+        a.K = gm.K; a.sKb = (long long)NN * gm.SP; a.sKc = (long long)NN * S; a.sKs = (long long)NN;
+        a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
+        a.Out = gm.interP; a.sOb = (long long)thin * gm.SP; a.sOc = (long long)thin * S; a.sOs = (long long)thin;
+        a.api = d.inter; a.sAb = (long long)(d.steps + 1) * d.n * d.m; a.tau0 = 1; a.tauc = S; a.tau_max = d.steps;
+        a.CI = NC; a.len = S; a.m = d.m; a.n = d.n;
+        qoc_chain_launch(N, false, a, d.B * NC, s);
+        return;
+    }
     // all chunks swept together: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}, one launch per j, batch = B*NC
     GemmArgs h;
     memset(&h, 0, sizeof h);
@@ -515,6 +668,35 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     const bool need_src = d.n_forb > 0 || d.has_speed;
     const cplx* Pc = qoc_gemm_chunk_products(gm);
     hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC);
+    if (gm.persistent) {
+        ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
+        memset(&sw, 0, sizeof sw);
+        sw.K = gm.K + (size_t)(S - 1) * NN; sw.sKb = (long long)NN * gm.SP; sw.sKc = (long long)NN * S; sw.sKs = -(long long)NN;
+        if (need_src) { sw.E = gm.SrcP + (size_t)(S - 1) * thin; sw.sEb = (long long)thin * gm.SP; sw.sEc = (long long)thin * S; sw.sEs = -(long long)thin; }
+        sw.CI = NC; sw.m = d.m; sw.n = d.n;
+        if (need_src && NC > 1) {                            // affine offsets a_c: every chunk run from a zero costate
+            ChainArgs a = sw;
+            a.len = S; a.Fin = gm.Aoff; a.sFb = (long long)thin * NC; a.sFc = (long long)thin;
+            qoc_chain_launch(N, true, a, d.B * NC, s);
+        }
+        {                                                    // chunk-end costates E_{c-1} = P_c^dagger E_c + a_c
+            ChainArgs a;
+            memset(&a, 0, sizeof a);
+            a.K = Pc + (size_t)(NC - 1) * NN; a.sKb = (long long)NN * NC; a.sKs = -(long long)NN;
+            a.X0 = gm.Ebnd + (size_t)(NC - 1) * thin; a.sXb = (long long)thin * NC;
+            if (need_src) { a.E = gm.Aoff + (size_t)(NC - 1) * thin; a.sEb = (long long)thin * NC; a.sEs = -(long long)thin; }
+            a.Out = gm.Ebnd + (long long)(NC - 2) * (long long)thin; a.sOb = (long long)thin * NC; a.sOs = -(long long)thin;
+            a.CI = 1; a.len = NC - 1; a.m = d.m; a.n = d.n;
+            qoc_chain_launch(N, true, a, d.B, s);
+        }
+        {
+            ChainArgs a = sw;
+            a.X0 = gm.Ebnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
+            a.Out = gm.LamP + (long long)(S - 2) * (long long)thin; a.sOb = (long long)thin * gm.SP; a.sOc = (long long)thin * S; a.sOs = -(long long)thin;
+            a.store_initial = 1; a.len = S - 1;
+            qoc_chain_launch(N, true, a, d.B * NC, s);
+        }
+    } else {
     if (need_src && NC > 1) {                                // affine offsets a_c: every chunk run from a zero costate
         hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)nullptr, N, S, NC);
         qoc_gemm_bwd_sweep(gm, d, s, true, gm.Aoff);
@@ -531,6 +713,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     }
     hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)gm.Ebnd, N, S, NC);
     qoc_gemm_bwd_sweep(gm, d, s, need_src, nullptr);
+    }
     // gradients: for each control one batched product H_k' Psi_t contracted with conj(Lambda_t)   tensorflow_state.py:61-63
     GemmArgs h;
     memset(&h, 0, sizeof h);
