@@ -165,7 +165,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
         hipLaunchKernelGGL(k_st_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
     }
-    hipLaunchKernelGGL(k_finish, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, ap);
+    hipLaunchKernelGGL(k_finish, dim3(d.B), dim3(d.k * d.steps >= 2048 ? 1024 : QOC_BLOCK), 0, e->stream, d, ap);
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
     return QOC_OK;

@@ -18,8 +18,9 @@ __device__ __forceinline__ void unit_phase(int f, int t, int N, double* c, doubl
     sincos(-2.0 * M_PI * (double)r / (double)N, s, c);
 }
 
-__global__ void __launch_bounds__(QOC_BLOCK) k_finish(QocDev d, QocAdamDev ap) {
-    __shared__ double red[8];
+// Launched with 1024 threads when a seed has >= 2048 (k, t) elements: the element loops are latency-bound
+__global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
+    __shared__ double red[17];
     const int b = blockIdx.x, steps = d.steps, ks = d.k * steps;
     const double* w = d.w + (size_t)b * ks;
     const double* dLdu = d.dLdu + (size_t)b * ks;

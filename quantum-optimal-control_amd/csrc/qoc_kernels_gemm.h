@@ -292,126 +292,163 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
 }
 
 // ---- persistent thin chains (N <= 64, m <= 8) ---------------------------------------------------------------------
-// y <- op(K_j) y (+ E_j) for `len` consecutive matrices, one workgroup per chain, y in LDS.  Launch-per-step chains cost
-// ~5 us of launch latency per step; here a step costs one L2 read of K_j (prefetched one step ahead into registers) plus
-// N*N*m complex MACs on the VALU (fp64 FMA rate ~ MFMA rate on gfx950, and no padding of m to an MFMA tile).
-// Thread (i, q): row i of the result, columns LPR*e + q of op(K); LPR = 256/N lanes share a row (xor-shuffle reduction).
+// y <- op(K_j) y + E_j for `len` consecutive matrices, one workgroup per chain, y in LDS.  Launch-per-step chains cost
+// ~5 us of launch latency per step; here a step costs N*N*m complex MACs on the VALU (fp64 FMA rate ~ MFMA rate on
+// gfx950, and no padding of m to an MFMA tile) with K_j fetched two steps ahead into registers.
+// The steady-state loop is one basic block (unconditional clamped prefetch, E always loaded -- from a zero buffer when
+// there is no addend --, all lanes of a row store the same value): with conditional loads or stores in the loop hipcc's
+// s_waitcnt placement has to assume the worst path and waits for the loads it has just issued.
 struct ChainArgs {
     const cplx* K; long long sKb, sKc, sKs;     // matrix of step j: K + b*sKb + c*sKc + j*sKs  (elements; sKs may be negative)
     const cplx* X0; long long sXb, sXc;         // initial thin vectors (nullptr = zeros)
-    const cplx* E; long long sEb, sEc, sEs;     // optional addend per step (nullptr = none)
-    cplx* Out; long long sOb, sOc, sOs;         // optional output per step (nullptr = none)
+    const cplx* E; long long sEb, sEc, sEs;     // addend per step (a zero buffer with zero strides when there is none)
+    cplx* Out; long long sOb, sOc, sOs;         // output per step (HAS_OUT)
     cplx* Fin; long long sFb, sFc;              // optional final state
-    cplx* api; long long sAb;                   // optional inter_vecs output (API layout [tau][n][m]); tau = tau0 + c*tauc + j
-    int tau0, tauc, tau_max;                    // rows with tau > tau_max are not written
     int CI;                                     // chains per seed (blockIdx.x = b*CI + c)
-    int len, m, n;
+    int len, m;
     int store_initial;                          // also store y0 at Out - sOs
 };
 
-template <int N, int MV, bool CONJT>
+// Thread mappings (both keep the 4 lanes of a quad on 64 contiguous bytes -- the texture-address unit serialises a quad
+// that touches 4 different cache lines, which made a transposed read of the forward mapping 2x slower per step):
+//   forward   y = K x    : thread (i, q) owns row i, columns LPR*e + q, LPR = 256/N lanes per row; xor-shuffle reduction
+//   CONJT     y = K^H x  : lane <-> column i (a wave reads whole rows of K), wave w owns rows (4e + w)*RPI + h; x[r] is a
+//                          broadcast LDS read; the 4 wave partials meet in LDS (one extra barrier per step)
+template <int N, int MV, bool CONJT, bool HAS_OUT>
 __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
-    constexpr int LPR = 256 / N, EL = N / LPR;
+    constexpr int LPR = 256 / N, EL = N / LPR, RPI = 64 / N;
     __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
-    const int tid = threadIdx.x, i = tid / LPR, q = tid % LPR;
+    __shared__ __attribute__((aligned(16))) cplx part[CONJT ? 4 * N * MV : 1];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int i = CONJT ? (lane % N) : tid / LPR;            // result row this thread reports
+    const int q = tid % LPR, h = lane / N;
     const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
     const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
-    const cplx* Ep = a.E ? a.E + b * a.sEb + c * a.sEc : nullptr;
-    cplx* Op = a.Out ? a.Out + b * a.sOb + c * a.sOc : nullptr;
+    const cplx* Ep = a.E + b * a.sEb + c * a.sEc + (size_t)i * QOC_TW;
+    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc + (size_t)i * QOC_TW : nullptr;
     cplx yrow[MV];
 #pragma unroll
     for (int jv = 0; jv < MV; ++jv) yrow[jv] = cmake(0.0, 0.0);
-    if (q == 0) {
-        if (a.X0) {
-            const cplx* x = a.X0 + b * a.sXb + c * a.sXc + (size_t)i * QOC_TW;
+    if (a.X0) {
+        const cplx* x = a.X0 + b * a.sXb + c * a.sXc + (size_t)i * QOC_TW;
 #pragma unroll
-            for (int jv = 0; jv < MV; ++jv) yrow[jv] = x[jv];
-        }
-#pragma unroll
-        for (int jv = 0; jv < MV; ++jv) y[0][i * MV + jv] = yrow[jv];
-        if (a.store_initial && Op) {
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) (Op - a.sOs)[(size_t)i * QOC_TW + jv] = yrow[jv];
-        }
+        for (int jv = 0; jv < MV; ++jv) yrow[jv] = x[jv];
     }
-    auto load = [&](cplx* dst, const cplx* Kj) {
 #pragma unroll
-        for (int e = 0; e < EL; ++e) dst[e] = CONJT ? Kj[(size_t)(LPR * e + q) * N + i] : Kj[(size_t)i * N + LPR * e + q];
+    for (int jv = 0; jv < MV; ++jv) y[0][i * MV + jv] = yrow[jv];
+    if (HAS_OUT && a.store_initial) {
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) (Op - a.sOs)[jv] = yrow[jv];
+    }
+    const int last = a.len - 1;
+    auto load = [&](cplx (&kd)[EL], cplx (&ed)[MV], int j) {
+        const int jc = min(j, last);
+        const cplx* Kj = Kp + (long long)jc * a.sKs;
+#pragma unroll
+        for (int e = 0; e < EL; ++e) kd[e] = CONJT ? Kj[(size_t)((4 * e + wv) * RPI + h) * N + i] : Kj[(size_t)i * N + LPR * e + q];
+        const cplx* ej = Ep + (long long)jc * a.sEs;
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) ed[jv] = ej[jv];
     };
-    cplx kc[EL], kn[EL];
-    if (a.len > 0) load(kc, Kp);
-    __syncthreads();
     int cur = 0;
-    for (int j = 0; j < a.len; ++j) {
-        if (j + 1 < a.len) load(kn, Kp + (long long)(j + 1) * a.sKs);
+    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[MV]) {
         cplx acc[MV];
 #pragma unroll
         for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
+        if (CONJT) {
 #pragma unroll
-        for (int e = 0; e < EL; ++e) {
+            for (int e = 0; e < EL; ++e) {
+                const int r = (4 * e + wv) * RPI + h;
+#pragma unroll
+                for (int jv = 0; jv < MV; ++jv) cfma_conj(acc[jv], ku[e], y[cur][r * MV + jv]);
+            }
 #pragma unroll
             for (int jv = 0; jv < MV; ++jv) {
-                const cplx v = y[cur][(LPR * e + q) * MV + jv];
-                if (CONJT) cfma_conj(acc[jv], kc[e], v); else cfma(acc[jv], kc[e], v);
+                if (RPI == 2) { acc[jv].x += __shfl_xor(acc[jv].x, 32, 64); acc[jv].y += __shfl_xor(acc[jv].y, 32, 64); }
+                part[(wv * N + i) * MV + jv] = acc[jv];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) {
+                cplx t = part[(0 * N + i) * MV + jv];
+                t = cadd(t, part[(1 * N + i) * MV + jv]);
+                t = cadd(t, part[(2 * N + i) * MV + jv]);
+                t = cadd(t, part[(3 * N + i) * MV + jv]);
+                acc[jv] = t;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EL; ++e) {
+#pragma unroll
+                for (int jv = 0; jv < MV; ++jv) cfma(acc[jv], ku[e], y[cur][(LPR * e + q) * MV + jv]);
+            }
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) {
+#pragma unroll
+                for (int off = 1; off < LPR; off <<= 1) {
+                    acc[jv].x += __shfl_xor(acc[jv].x, off, 64);
+                    acc[jv].y += __shfl_xor(acc[jv].y, off, 64);
+                }
             }
         }
 #pragma unroll
         for (int jv = 0; jv < MV; ++jv) {
-#pragma unroll
-            for (int off = 1; off < LPR; off <<= 1) {
-                acc[jv].x += __shfl_xor(acc[jv].x, off, 64);
-                acc[jv].y += __shfl_xor(acc[jv].y, off, 64);
-            }
+            acc[jv] = cadd(acc[jv], eu[jv]);
+            y[cur ^ 1][i * MV + jv] = acc[jv];
+            yrow[jv] = acc[jv];
         }
-        if (q == 0) {
-            if (Ep) {
-                const cplx* ej = Ep + (long long)j * a.sEs + (size_t)i * QOC_TW;
+        if (HAS_OUT) {
+            cplx* oj = Op + (long long)j * a.sOs;
 #pragma unroll
-                for (int jv = 0; jv < MV; ++jv) acc[jv] = cadd(acc[jv], ej[jv]);
-            }
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) y[cur ^ 1][i * MV + jv] = acc[jv];
-            if (Op) {
-                cplx* oj = Op + (long long)j * a.sOs + (size_t)i * QOC_TW;
-#pragma unroll
-                for (int jv = 0; jv < MV; ++jv) oj[jv] = acc[jv];
-            }
-            if (a.api) {
-                const int tau = a.tau0 + c * a.tauc + j;
-                if (tau <= a.tau_max && i < a.n) {
-                    cplx* o = a.api + b * a.sAb + ((size_t)tau * a.n + i) * a.m;
-#pragma unroll
-                    for (int jv = 0; jv < MV; ++jv)
-                        if (jv < a.m) o[jv] = acc[jv];
-                }
-            }
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) yrow[jv] = acc[jv];
+            for (int jv = 0; jv < MV; ++jv) oj[jv] = acc[jv];
         }
-#pragma unroll
-        for (int e = 0; e < EL; ++e) kc[e] = kn[e];
         __syncthreads();
         cur ^= 1;
+    };
+    if (a.len > 0) {
+        // three register stages used round-robin by a 3x unrolled loop (rotating them with copies would make every
+        // iteration wait for the newest load)
+        cplx k0[EL], k1[EL], k2[EL], e0[MV], e1[MV], e2[MV];
+        load(k0, e0, 0);
+        load(k1, e1, 1);
+        __syncthreads();
+        int j = 0;
+        for (; j + 3 <= a.len; j += 3) {
+            load(k2, e2, j + 2); step(j, k0, e0);
+            load(k0, e0, j + 3); step(j + 1, k1, e1);
+            load(k1, e1, j + 4); step(j + 2, k2, e2);
+        }
+        if (j < a.len) step(j, k0, e0);
+        if (j + 1 < a.len) step(j + 1, k1, e1);
+    } else {
+        __syncthreads();
     }
-    if (a.Fin && q == 0) {
+    if (a.Fin) {
         cplx* f = a.Fin + b * a.sFb + c * a.sFc + (size_t)i * QOC_TW;
 #pragma unroll
         for (int jv = 0; jv < MV; ++jv) f[jv] = yrow[jv];
     }
 }
 
-template <int N, bool CONJT>
+template <int N, bool CONJT, bool HAS_OUT>
 static inline void qoc_chain_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
     const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain<N, 1, CONJT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain<N, 2, CONJT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain<N, 4, CONJT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_chain<N, 8, CONJT>), dim3(blocks), dim3(256), 0, s, a);
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain<N, 1, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain<N, 2, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain<N, 4, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_chain<N, 8, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
 }
-static inline void qoc_chain_launch(int N, bool conjt, const ChainArgs& a, int blocks, hipStream_t s) {
+template <int N>
+static inline void qoc_chain_launch_c(bool conjt, const ChainArgs& a, int blocks, hipStream_t s) {
+    if (conjt) { if (a.Out) qoc_chain_launch_n<N, true, true>(a, blocks, s); else qoc_chain_launch_n<N, true, false>(a, blocks, s); }
+    else { if (a.Out) qoc_chain_launch_n<N, false, true>(a, blocks, s); else qoc_chain_launch_n<N, false, false>(a, blocks, s); }
+}
+// `zeros` = a zero thin buffer (N x 32) used as the addend when the chain has none
+static inline void qoc_chain_launch(int N, bool conjt, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
     if (a.len <= 0 && !a.Fin && !a.store_initial) return;
-    if (N == 32) { if (conjt) qoc_chain_launch_n<32, true>(a, blocks, s); else qoc_chain_launch_n<32, false>(a, blocks, s); }
-    else { if (conjt) qoc_chain_launch_n<64, true>(a, blocks, s); else qoc_chain_launch_n<64, false>(a, blocks, s); }
+    if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
+    if (N == 32) qoc_chain_launch_c<32>(conjt, a, blocks, s); else qoc_chain_launch_c<64>(conjt, a, blocks, s);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -429,6 +466,7 @@ struct QocGemm {
     cplx* interP = nullptr;   // [B][SP][N][32]   Psi_t
     cplx* LamP = nullptr;     // [B][SP][N][32]   Lambda_t
     cplx* SrcP = nullptr;     // [B][SP][N][32]   S_tau (state regularisers only)
+    cplx* zthin = nullptr;    // [N][32] zeros
     cplx *Psibnd = nullptr, *Ebnd = nullptr, *Aoff = nullptr;        // [B][NC][N][32] chunk-start Psi, chunk-end Lambda, affine offsets
     double* partial = nullptr; // [B*steps][k][N/32]
 };
@@ -483,11 +521,13 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
               al((void**)&gm.Psibnd, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
               al((void**)&gm.Ebnd, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
               al((void**)&gm.Aoff, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
+              al((void**)&gm.zthin, thin * sizeof(cplx)) &&
               al((void**)&gm.partial, (size_t)d.B * d.steps * d.k * (N / 32) * sizeof(double));
     if (ok && need_src) ok = al((void**)&gm.SrcP, BSP * thin * sizeof(cplx));
     if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     // the persistent chain kernels write only the first m (<= 8) of the 32 thin columns; the rest must read as zero
+    hipMemset(gm.zthin, 0, thin * sizeof(cplx));
     hipMemset(gm.interP, 0, BSP * thin * sizeof(cplx));
     hipMemset(gm.LamP, 0, BSP * thin * sizeof(cplx));
     hipMemset(gm.Psibnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx));
@@ -600,8 +640,8 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         a.K = Pc; a.sKb = (long long)NN * NC; a.sKs = (long long)NN;
         a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC;
         a.Out = gm.Psibnd + thin; a.sOb = (long long)thin * NC; a.sOs = (long long)thin;
-        a.CI = 1; a.len = NC - 1; a.m = d.m; a.n = d.n;
-        qoc_chain_launch(N, false, a, d.B, s);
+        a.CI = 1; a.len = NC - 1; a.m = d.m;
+        qoc_chain_launch(N, false, a, gm.zthin, d.B, s);
     }
     // chunk boundaries: [X | Psi] <- P_c [X | Psi]   (X for final_state, Psi for the chunk starts)      :214-238
     GemmArgs g;
@@ -624,9 +664,9 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         a.K = gm.K; a.sKb = (long long)NN * gm.SP; a.sKc = (long long)NN * S; a.sKs = (long long)NN;
         a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
         a.Out = gm.interP; a.sOb = (long long)thin * gm.SP; a.sOc = (long long)thin * S; a.sOs = (long long)thin;
-        a.api = d.inter; a.sAb = (long long)(d.steps + 1) * d.n * d.m; a.tau0 = 1; a.tauc = S; a.tau_max = d.steps;
-        a.CI = NC; a.len = S; a.m = d.m; a.n = d.n;
-        qoc_chain_launch(N, false, a, d.B * NC, s);
+        a.CI = NC; a.len = S; a.m = d.m;
+        qoc_chain_launch(N, false, a, gm.zthin, d.B * NC, s);
+        hipLaunchKernelGGL(k_gemm_unpad_inter, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.SP);
         return;
     }
     // all chunks swept together: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}, one launch per j, batch = B*NC
@@ -673,11 +713,11 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         memset(&sw, 0, sizeof sw);
         sw.K = gm.K + (size_t)(S - 1) * NN; sw.sKb = (long long)NN * gm.SP; sw.sKc = (long long)NN * S; sw.sKs = -(long long)NN;
         if (need_src) { sw.E = gm.SrcP + (size_t)(S - 1) * thin; sw.sEb = (long long)thin * gm.SP; sw.sEc = (long long)thin * S; sw.sEs = -(long long)thin; }
-        sw.CI = NC; sw.m = d.m; sw.n = d.n;
+        sw.CI = NC; sw.m = d.m;
         if (need_src && NC > 1) {                            // affine offsets a_c: every chunk run from a zero costate
             ChainArgs a = sw;
             a.len = S; a.Fin = gm.Aoff; a.sFb = (long long)thin * NC; a.sFc = (long long)thin;
-            qoc_chain_launch(N, true, a, d.B * NC, s);
+            qoc_chain_launch(N, true, a, gm.zthin, d.B * NC, s);
         }
         {                                                    // chunk-end costates E_{c-1} = P_c^dagger E_c + a_c
             ChainArgs a;
@@ -686,15 +726,15 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
             a.X0 = gm.Ebnd + (size_t)(NC - 1) * thin; a.sXb = (long long)thin * NC;
             if (need_src) { a.E = gm.Aoff + (size_t)(NC - 1) * thin; a.sEb = (long long)thin * NC; a.sEs = -(long long)thin; }
             a.Out = gm.Ebnd + (long long)(NC - 2) * (long long)thin; a.sOb = (long long)thin * NC; a.sOs = -(long long)thin;
-            a.CI = 1; a.len = NC - 1; a.m = d.m; a.n = d.n;
-            qoc_chain_launch(N, true, a, d.B, s);
+            a.CI = 1; a.len = NC - 1; a.m = d.m;
+            qoc_chain_launch(N, true, a, gm.zthin, d.B, s);
         }
         {
             ChainArgs a = sw;
             a.X0 = gm.Ebnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
             a.Out = gm.LamP + (long long)(S - 2) * (long long)thin; a.sOb = (long long)thin * gm.SP; a.sOc = (long long)thin * S; a.sOs = -(long long)thin;
             a.store_initial = 1; a.len = S - 1;
-            qoc_chain_launch(N, true, a, d.B * NC, s);
+            qoc_chain_launch(N, true, a, gm.zthin, d.B * NC, s);
         }
     } else {
     if (need_src && NC > 1) {                                // affine offsets a_c: every chunk run from a zero costate
