@@ -34,6 +34,7 @@ struct GemmArgs {
     const cplx* L; long long sL; int ldl;
     double* partial; int partial_stride;       // partial[(batch*partial_stride) + offset + tile_m]
     int partial_offset;
+    int ldp;                                   // EPI = 2: per-COLUMN dots, partial[batch*stride + offset + tile_m*ldp + col]
 };
 
 // SK wavefronts of a workgroup split the inner dimension of ONE tile (small-batch chain launches are latency-bound when
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
                     }
                     if (row == col) v.x += g.gamma;
                     g.C[(size_t)bt * g.sC + (size_t)row * g.ldc + col] = v;
-                } else {
+                } else if (EPI == 1) {
                     const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
                     part = fma(l.x, vre, part); part = fma(l.y, vim, part);      // Re(conj(l) * y)
                 }
@@ -145,6 +146,23 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
         if (lane == 0) g.partial[(size_t)bt * g.partial_stride + g.partial_offset + tm] = part;
+    }
+    if (EPI == 2) {                                            // Re sum_rows conj(L[row][col]) * (A*B)[row][col] for every column
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            double pc = 0.0;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + 16 * I + lk + 4 * r, col = c0 + 16 * J + lr;
+                    const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
+                    pc = fma(l.x, re[I][J][r], pc); pc = fma(l.y, im[I][J][r], pc);
+                }
+            pc += __shfl_xor(pc, 16, 64);
+            pc += __shfl_xor(pc, 32, 64);
+            if (lk == 0) g.partial[(size_t)bt * g.partial_stride + g.partial_offset + (size_t)tm * g.ldp + c0 + 16 * J + lr] = pc;
+        }
     }
 }
 
@@ -277,6 +295,30 @@ __global__ void __launch_bounds__(256) k_gemm_set_chunk_ends(QocDev d, cplx* __r
         LamP[(bc * S + (S - 1)) * per + e] = Ebnd ? Ebnd[o] : cmake(0.0, 0.0);
     }
 }
+// inter[b][t+1] (API layout) from the time-major wide layout W[b][row][t*MV + col]
+__global__ void __launch_bounds__(256) k_gemm_unpad_wide(QocDev d, const cplx* __restrict__ W, int N, int ldW, int MV) {
+    const size_t nm = (size_t)d.n * d.m;
+    const size_t total = (size_t)d.B * d.steps * nm;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bt = o / nm, e = o - bt * nm;
+        const size_t bb = bt / d.steps, t = bt - bb * d.steps;
+        const int row = (int)(e / d.m), col = (int)(e - (size_t)row * d.m);
+        d.inter[(bb * (size_t)(d.steps + 1) + t + 1) * nm + e] = W[(bb * N + row) * (size_t)ldW + t * MV + col];
+    }
+}
+// dLdu[b][k][t] = sum over row tiles and vector slots of the per-column dots (wide layout)
+__global__ void __launch_bounds__(256) k_gemm_grad_reduce_wide(QocDev d, const double* __restrict__ partial, int tiles_m, int ldW, int MV) {
+    const size_t total = (size_t)d.B * d.k * d.steps;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bk = o / d.steps;
+        const int t = (int)(o - bk * d.steps);
+        const double* p = partial + bk * tiles_m * (size_t)ldW + (size_t)t * MV;
+        double s = 0.0;
+        for (int i = 0; i < tiles_m; ++i)
+            for (int jv = 0; jv < MV; ++jv) s += p[(size_t)i * ldW + jv];
+        d.dLdu[o] = s;
+    }
+}
 // dLdu[b][k][t] = sum over row tiles of the partial dots
 __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double* __restrict__ partial, int tiles_m) {
     const size_t total = (size_t)d.B * d.steps * d.k;
@@ -291,6 +333,143 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
     }
 }
 
+// ---- fused per-slice exponential for N <= 64 ---------------------------------------------------------------------------
+// One workgroup per (seed, slice): A_t is assembled into LDS, the Paterson-Stockmeyer Taylor polynomial and the squarings
+// run as MFMA products whose operands are read from two LDS-resident matrices (row stride N+1 elements: conflict-free for
+// both the left-operand pattern, 16 rows x 1 column, and the right-operand pattern, 1 row x 16 columns), accumulators and
+// the per-wave block of A stay in registers, and only K_t is written to HBM.  The launch-per-product route streams three
+// B*SP*N*N buffers through HBM per product (7-11 products); this kernel writes one.
+// Wave w owns tile row I = w / (N/32) and the tile-column pair Jp = w % (N/32) (2 tiles of 16x16, sharing the left operand).
+struct ExpmCoef { double c[24]; };
+
+template <int N>
+__device__ __forceinline__ void lds_mm(const cplx* __restrict__ L, const cplx* __restrict__ R, int I, int Jp, int lane,
+                                       gd4 (&re)[2], gd4 (&im)[2]) {
+    constexpr int LD = N + 1;
+    gd4 t1[2], t2[2], t3[2];
+#pragma unroll
+    for (int J = 0; J < 2; ++J) { t1[J] = (gd4){0, 0, 0, 0}; t2[J] = (gd4){0, 0, 0, 0}; t3[J] = (gd4){0, 0, 0, 0}; }
+    const int lr = lane & 15, lk = lane >> 4;
+    const cplx* lp = L + (16 * I + lr) * LD + lk;
+    const cplx* rp = R + lk * LD + 32 * Jp + lr;
+#pragma unroll 4
+    for (int kk = 0; kk < N / 4; ++kk) {
+        const cplx a = lp[4 * kk];
+        const cplx b0 = rp[4 * kk * LD], b1 = rp[4 * kk * LD + 16];
+        const double as = a.x + a.y;
+        t1[0] = GMFMA(a.x, b0.x, t1[0]); t2[0] = GMFMA(a.y, b0.y, t2[0]); t3[0] = GMFMA(as, b0.x + b0.y, t3[0]);
+        t1[1] = GMFMA(a.x, b1.x, t1[1]); t2[1] = GMFMA(a.y, b1.y, t2[1]); t3[1] = GMFMA(as, b1.x + b1.y, t3[1]);
+    }
+#pragma unroll
+    for (int J = 0; J < 2; ++J) { re[J] = t1[J] - t2[J]; im[J] = t3[J] - t1[J] - t2[J]; }
+}
+
+template <int N>
+__global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Kout,
+                                                                               int SP, int deg, int nsq, ExpmCoef cf) {
+    constexpr int LD = N + 1, NT = (N / 16) * (N / 16) * 32, NN = N * N;
+    extern __shared__ __attribute__((aligned(16))) cplx ex_lds[];
+    cplx* X = ex_lds;                   // A, then S / M
+    cplx* Y = ex_lds + N * LD;          // A2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int I = wv / (N / 32), Jp = wv % (N / 32);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.x / SP, t = blockIdx.x - b * SP;
+    cplx* Kt = Kout + (size_t)blockIdx.x * NN;
+    // D-layout coordinates of this lane's 2 x 4 accumulator elements
+    auto drow = [&](int r) { return 16 * I + lk + 4 * r; };
+    auto dcol = [&](int J) { return 32 * Jp + 16 * J + lr; };
+    if (t >= d.steps) {                                           // padded slice: K = I exactly
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Kt[(size_t)drow(r) * N + dcol(J)] = cmake(drow(r) == dcol(J) ? 1.0 : 0.0, 0.0);
+        return;
+    }
+    // ---- A_t = (H0' + sum_k u_k H_k') / 2^s into X                                              tensorflow_state.py:30-33
+    const double inv = 1.0 / (double)(1 << nsq);
+    {
+        constexpr int PER = NN / NT;
+        cplx acc[PER];
+#pragma unroll
+        for (int x = 0; x < PER; ++x) acc[x] = cscale(HsP[tid + NT * x], inv);
+        for (int kk = 0; kk < d.k; ++kk) {
+            const double cu = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv;
+            const cplx* H = HsP + (size_t)(kk + 1) * NN;
+#pragma unroll
+            for (int x = 0; x < PER; ++x) {
+                const cplx hv = H[tid + NT * x];
+                acc[x].x = fma(cu, hv.x, acc[x].x); acc[x].y = fma(cu, hv.y, acc[x].y);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < PER; ++x) { const int e = tid + NT * x; X[(e / N) * LD + (e % N)] = acc[x]; }
+    }
+    __syncthreads();
+    cplx ablk[2][4];
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ablk[J][r] = X[drow(r) * LD + dcol(J)];
+    gd4 re[2], im[2];
+    auto put = [&](cplx* dst) {
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[drow(r) * LD + dcol(J)] = cmake(re[J][r], im[J][r]);
+    };
+    // re/im <- c0*I + c1*A + (re/im already holding a product, scaled by 1) : the Horner addend in D layout
+    auto add_b = [&](double c0, double c1) {
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                re[J][r] = fma(c1, ablk[J][r].x, re[J][r]) + (drow(r) == dcol(J) ? c0 : 0.0);
+                im[J][r] = fma(c1, ablk[J][r].y, im[J][r]);
+            }
+    };
+    const int mm = deg >> 1;
+    const bool even = (deg & 1) == 0;
+    if (deg >= 2) {
+        lds_mm<N>(X, X, I, Jp, lane, re, im);                     // A2 = A*A
+        __syncthreads();                                          // every wave is done reading A from X
+        put(Y);
+        if (even) {                                               // S = c_{2m-2} I + c_{2m-1} A + c_T A2
+#pragma unroll
+            for (int J = 0; J < 2; ++J) { re[J] = re[J] * cf.c[deg]; im[J] = im[J] * cf.c[deg]; }
+            add_b(cf.c[2 * mm - 2], cf.c[2 * mm - 1]);
+        } else {                                                  // S = c_{2m} I + c_{2m+1} A
+#pragma unroll
+            for (int J = 0; J < 2; ++J) { re[J] = (gd4){0, 0, 0, 0}; im[J] = (gd4){0, 0, 0, 0}; }
+            add_b(cf.c[2 * mm], cf.c[2 * mm + 1]);
+        }
+        put(X);
+        __syncthreads();
+        for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {     // S <- c_{2i} I + c_{2i+1} A + A2*S
+            lds_mm<N>(Y, X, I, Jp, lane, re, im);
+            add_b(cf.c[2 * i], cf.c[2 * i + 1]);
+            __syncthreads();
+            if (i > 0 || nsq > 0) { put(X); __syncthreads(); }
+        }
+    } else {
+#pragma unroll
+        for (int J = 0; J < 2; ++J) { re[J] = (gd4){0, 0, 0, 0}; im[J] = (gd4){0, 0, 0, 0}; }
+        add_b(1.0, deg >= 1 ? 1.0 : 0.0);
+        __syncthreads();
+        if (nsq > 0) { put(X); __syncthreads(); }
+    }
+    for (int sq = 0; sq < nsq; ++sq) {                            // M <- M M                       tensorflow_state.py:43-44
+        lds_mm<N>(X, X, I, Jp, lane, re, im);
+        __syncthreads();
+        if (sq + 1 < nsq) { put(X); __syncthreads(); }
+    }
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Kt[(size_t)drow(r) * N + dcol(J)] = cmake(re[J][r], im[J][r]);
+}
+
 // ---- persistent thin chains (N <= 64, m <= 8) ---------------------------------------------------------------------
 // y <- op(K_j) y + E_j for `len` consecutive matrices, one workgroup per chain, y in LDS.  Launch-per-step chains cost
 // ~5 us of launch latency per step; here a step costs N*N*m complex MACs on the VALU (fp64 FMA rate ~ MFMA rate on
@@ -302,7 +481,7 @@ struct ChainArgs {
     const cplx* K; long long sKb, sKc, sKs;     // matrix of step j: K + b*sKb + c*sKc + j*sKs  (elements; sKs may be negative)
     const cplx* X0; long long sXb, sXc;         // initial thin vectors (nullptr = zeros)
     const cplx* E; long long sEb, sEc, sEs;     // addend per step (a zero buffer with zero strides when there is none)
-    cplx* Out; long long sOb, sOc, sOs;         // output per step (HAS_OUT)
+    cplx* Out; long long sOb, sOc, sOs; int ldO; // output per step (HAS_OUT): Out + b*sOb + c*sOc + j*sOs + row*ldO + jv
     cplx* Fin; long long sFb, sFc;              // optional final state
     int CI;                                     // chains per seed (blockIdx.x = b*CI + c)
     int len, m;
@@ -326,7 +505,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
     const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
     const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
     const cplx* Ep = a.E + b * a.sEb + c * a.sEc + (size_t)i * QOC_TW;
-    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc + (size_t)i * QOC_TW : nullptr;
+    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc + (size_t)i * a.ldO : nullptr;
     cplx yrow[MV];
 #pragma unroll
     for (int jv = 0; jv < MV; ++jv) yrow[jv] = cmake(0.0, 0.0);
@@ -457,6 +636,7 @@ static inline void qoc_chain_launch(int N, bool conjt, ChainArgs a, const cplx* 
 // launches to NC (chunk boundaries) + S (all chunks swept in parallel).
 struct QocGemm {
     int N = 0, S = 1, L = 0, NC = 1, SP = 1;
+    int MV = 0, ldW = 0;      // persistent mode: vector slots (1/2/4/8) and row stride of the time-major wide buffers
     bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
     cplx* HsP = nullptr;      // [k+1][N][N]
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
@@ -491,11 +671,13 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     const int N = ((d.n + 31) / 32) * 32;
     gm.N = N;
     gm.persistent = N <= 64 && d.m <= 8;
+    gm.MV = d.m <= 1 ? 1 : (d.m <= 2 ? 2 : (d.m <= 4 ? 4 : 8));
     int L = 0;
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
     gm.L = L; gm.S = 1 << L;
     gm.NC = (d.steps + gm.S - 1) / gm.S;
     gm.SP = gm.NC * gm.S;
+    gm.ldW = ((gm.SP * gm.MV + 31) / 32) * 32;
     const size_t NN = (size_t)N * N, BSP = (size_t)d.B * gm.SP, thin = (size_t)N * QOC_TW;
     std::vector<cplx> hp((size_t)(d.k + 1) * NN);
     for (auto& v : hp) { v.x = 0; v.y = 0; }
@@ -522,7 +704,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
               al((void**)&gm.Ebnd, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
               al((void**)&gm.Aoff, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
               al((void**)&gm.zthin, thin * sizeof(cplx)) &&
-              al((void**)&gm.partial, (size_t)d.B * d.steps * d.k * (N / 32) * sizeof(double));
+              al((void**)&gm.partial, (size_t)d.B * d.k * (N / 32) * (gm.persistent ? (size_t)gm.ldW : (size_t)d.steps) * sizeof(double));
     if (ok && need_src) ok = al((void**)&gm.SrcP, BSP * thin * sizeof(cplx));
     if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
@@ -553,7 +735,12 @@ static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipSt
     if (tiles * 2 <= 2048 && (g.Kdim / 2) % 8 == 0) sk = 2;
     if (tiles * 4 <= 2048 && (g.Kdim / 4) % 8 == 0) sk = 4;
     if (tiles * 8 <= 2048 && (g.Kdim / 8) % 8 == 0) sk = 8;
-    if (epi == 1) {
+    if (epi == 2) {
+        if (sk == 8) qoc_gemm_launch_sk<false, 2, 8>(g, blocks, s);
+        else if (sk == 4) qoc_gemm_launch_sk<false, 2, 4>(g, blocks, s);
+        else if (sk == 2) qoc_gemm_launch_sk<false, 2, 2>(g, blocks, s);
+        else qoc_gemm_launch_sk<false, 2, 1>(g, blocks, s);
+    } else if (epi == 1) {
         if (sk == 8) qoc_gemm_launch_sk<false, 1, 8>(g, blocks, s);
         else if (sk == 4) qoc_gemm_launch_sk<false, 1, 4>(g, blocks, s);
         else if (sk == 2) qoc_gemm_launch_sk<false, 1, 2>(g, blocks, s);
@@ -573,12 +760,43 @@ static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipSt
 
 static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
 
+// pairwise product tree: T_l[i] = T_{l-1}[2i+1] * T_{l-1}[2i]  (later slice on the left), T_0 = K
+static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    const int N = gm.N;
+    const size_t NN = (size_t)N * N;
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.lda = g.ldb = g.ldc = N; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.alpha = 1.0;
+    const cplx* prev = gm.K;
+    for (int l = 1; l <= gm.L; ++l) {
+        cplx* out = gm.tree + gm.tree_off[l];
+        g.A = prev + NN; g.sA = 2 * (long long)NN; g.Bm = prev; g.sB = 2 * (long long)NN; g.C = out; g.sC = (long long)NN;
+        g.batch = (int)((size_t)d.B * (gm.SP >> l));
+        qoc_gemm_launch(false, 0, g, s);
+        prev = out;
+    }
+}
+
 // K_t for all (seed, slice): the dominant part of the path (bracketed by the profiling events of the engine)
 static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N;
     const size_t NN = (size_t)N * N, BS = (size_t)d.B * gm.SP;
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
+    if (N <= 64) {
+        ExpmCoef cf;
+        { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
+        const size_t lds = 2 * (size_t)N * (N + 1) * sizeof(cplx);
+        static bool lds_opt_in = false;                          // 133 KB of dynamic LDS at N = 64 (default limit: 64 KB)
+        if (!lds_opt_in) {
+            hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx));
+            lds_opt_in = true;
+        }
+        if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K, gm.SP, deg, nsq, cf);
+        else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K, gm.SP, deg, nsq, cf);
+        qoc_gemm_tree(gm, d, s);
+        return;
+    }
     hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N, gm.SP, nsq);
     // Taylor polynomial sum_{j<=T} A^j/j! (tensorflow_state.py:37-41) in Paterson-Stockmeyer form over A2 = A*A:
     // S = B_m ; S = B_i + A2*S with B_i = c_{2i} I + c_{2i+1} A  (T = 5: 3 products instead of 4); then s squarings.
@@ -615,15 +833,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         cplx* t = cur; cur = oth; oth = t;
     }
     (void)cur;                                               // == gm.K by construction
-    // pairwise product tree: T_l[i] = T_{l-1}[2i+1] * T_{l-1}[2i]  (later slice on the left), T_0 = K
-    const cplx* prev = gm.K;
-    for (int l = 1; l <= gm.L; ++l) {
-        cplx* out = gm.tree + gm.tree_off[l];
-        g.A = prev + NN; g.sA = 2 * (long long)NN; g.Bm = prev; g.sB = 2 * (long long)NN; g.C = out; g.sC = (long long)NN;
-        g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0; g.batch = (int)((size_t)d.B * (gm.SP >> l));
-        qoc_gemm_launch(false, 0, g, s);
-        prev = out;
-    }
+    qoc_gemm_tree(gm, d, s);
 }
 
 static inline const cplx* qoc_gemm_chunk_products(const QocGemm& gm) { return gm.L > 0 ? gm.tree + gm.tree_off[gm.L] : gm.K; }
@@ -639,7 +849,7 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         memset(&a, 0, sizeof a);
         a.K = Pc; a.sKb = (long long)NN * NC; a.sKs = (long long)NN;
         a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC;
-        a.Out = gm.Psibnd + thin; a.sOb = (long long)thin * NC; a.sOs = (long long)thin;
+        a.Out = gm.Psibnd + thin; a.sOb = (long long)thin * NC; a.sOs = (long long)thin; a.ldO = QOC_TW;
         a.CI = 1; a.len = NC - 1; a.m = d.m;
         qoc_chain_launch(N, false, a, gm.zthin, d.B, s);
     }
@@ -663,10 +873,10 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         memset(&a, 0, sizeof a);
         a.K = gm.K; a.sKb = (long long)NN * gm.SP; a.sKc = (long long)NN * S; a.sKs = (long long)NN;
         a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
-        a.Out = gm.interP; a.sOb = (long long)thin * gm.SP; a.sOc = (long long)thin * S; a.sOs = (long long)thin;
+        a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOc = (long long)S * gm.MV; a.sOs = gm.MV; a.ldO = gm.ldW;   // time-major wide layout
         a.CI = NC; a.len = S; a.m = d.m;
         qoc_chain_launch(N, false, a, gm.zthin, d.B * NC, s);
-        hipLaunchKernelGGL(k_gemm_unpad_inter, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.SP);
+        hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
         return;
     }
     // all chunks swept together: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}, one launch per j, batch = B*NC
@@ -725,14 +935,14 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
             a.K = Pc + (size_t)(NC - 1) * NN; a.sKb = (long long)NN * NC; a.sKs = -(long long)NN;
             a.X0 = gm.Ebnd + (size_t)(NC - 1) * thin; a.sXb = (long long)thin * NC;
             if (need_src) { a.E = gm.Aoff + (size_t)(NC - 1) * thin; a.sEb = (long long)thin * NC; a.sEs = -(long long)thin; }
-            a.Out = gm.Ebnd + (long long)(NC - 2) * (long long)thin; a.sOb = (long long)thin * NC; a.sOs = -(long long)thin;
+            a.Out = gm.Ebnd + (long long)(NC - 2) * (long long)thin; a.sOb = (long long)thin * NC; a.sOs = -(long long)thin; a.ldO = QOC_TW;
             a.CI = 1; a.len = NC - 1; a.m = d.m;
             qoc_chain_launch(N, true, a, gm.zthin, d.B, s);
         }
         {
             ChainArgs a = sw;
             a.X0 = gm.Ebnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
-            a.Out = gm.LamP + (long long)(S - 2) * (long long)thin; a.sOb = (long long)thin * gm.SP; a.sOc = (long long)thin * S; a.sOs = -(long long)thin;
+            a.Out = gm.LamP + (long long)(S - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOc = (long long)S * gm.MV; a.sOs = -gm.MV; a.ldO = gm.ldW;
             a.store_initial = 1; a.len = S - 1;
             qoc_chain_launch(N, true, a, gm.zthin, d.B * NC, s);
         }
@@ -753,6 +963,23 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     }
     hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)gm.Ebnd, N, S, NC);
     qoc_gemm_bwd_sweep(gm, d, s, need_src, nullptr);
+    }
+    if (gm.persistent) {
+        // gradients from the time-major wide layout: one product H_k' [Psi_0 ... Psi_{SP-1}] per control (batch = seeds),
+        // contracted column by column with conj(Lambda)                                          tensorflow_state.py:61-63
+        GemmArgs h;
+        memset(&h, 0, sizeof h);
+        const int tm = N / 32;
+        h.lda = N; h.sA = 0; h.ldb = h.ldl = gm.ldW; h.sB = h.sL = (long long)N * gm.ldW; h.Kdim = N;
+        h.tiles_m = tm; h.tiles_n = gm.ldW / 32; h.batch = d.B; h.Bm = gm.interP; h.L = gm.LamP;
+        h.partial = gm.partial; h.ldp = gm.ldW; h.partial_stride = d.k * tm * gm.ldW;
+        for (int kk = 0; kk < d.k; ++kk) {
+            h.A = gm.HsP + (size_t)(kk + 1) * NN;
+            h.partial_offset = kk * tm * gm.ldW;
+            qoc_gemm_launch(false, 2, h, s);
+        }
+        hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, tm, gm.ldW, gm.MV);
+        return;
     }
     // gradients: for each control one batched product H_k' Psi_t contracted with conj(Lambda_t)   tensorflow_state.py:61-63
     GemmArgs h;
