@@ -319,13 +319,15 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const bool mfma_ok = qoc_mfma_supported(d);
     const bool st_ok = st_fused_supported(d);
     const bool gemm_ok = qoc_gemm_supported(d, cfg->state_transfer ? qoc_all_antihermitian((const cplx*)Hs, n, k + 1) : true);
-    // 48 < n <= 64 would run the register-resident kernels with spills (NT = 4): the tree-chunked GEMM path is 1.4-2.4x
-    // faster there for every seed count and slice count measured (tools/path_sweep.py), so AUTO hands n > 48 to it
-    const bool prefer_gemm = gemm_ok && n > 48;
-    // State transfer: the fused mat-vec kernels cost ~26 us per slice whatever n <= 64 and B <= 256 are (one workgroup per
-    // seed, latency-bound); the propagator route costs ~(1.4 + 0.17 B) us per slice at n <= 32 and ~(2.9 + 0.68 B) us at
-    // n <= 64 (tools/path_sweep.py), i.e. it wins for few seeds -- 7.5x on a single C3 trajectory.
-    const bool st_prefer_gemm = gemm_ok && cfg->state_transfer && (n <= 32 ? B <= 128 : B <= 32);
+    // Measured with tools/path_sweep.py (profiles/r01_path_sweep.txt):
+    //  * unitary, n <= 32: the register-resident MFMA chain kernels win on throughput (1.8 vs 2.9 ms per iteration of 64
+    //    C2 seeds) and tie on single-trajectory latency; 32 < n <= 64: the GEMM path (fused LDS-resident exponential +
+    //    persistent thin chains) is 1.3-3.4x faster than the NT = 3/4 register-resident kernels for every seed count.
+    //  * state transfer: the fused mat-vec kernels cost ~26 us per slice whatever n <= 64 and B <= 256 are (one workgroup
+    //    per seed, latency-bound); the propagator route costs ~(0.2 + 0.05 B) us per slice at n <= 32 and ~(0.3 + 0.26 B)
+    //    us at n <= 64, so it wins for every batch at n <= 32 and up to ~100 seeds at n <= 64 (44x on one C3 trajectory).
+    const bool prefer_gemm = gemm_ok && n > 32;
+    const bool st_prefer_gemm = gemm_ok && cfg->state_transfer && (n <= 32 || B <= 96);
     if (path == QOC_PATH_AUTO)
         path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA
                : ((st_ok && !st_prefer_gemm) ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));

@@ -34,6 +34,7 @@ struct GemmArgs {
     const cplx* L; long long sL; int ldl;
     double* partial; int partial_stride;       // partial[(batch*partial_stride) + offset + tile_m]
     int partial_offset;
+    int inner; long long sA2, sB2, sC2;        // inner > 0: batch index bt -> (bt / inner, bt % inner); A, Bm, C offsets = hi*s?2 + lo*s?
     int ldp;                                   // EPI = 2: per-COLUMN dots, partial[batch*stride + offset + tile_m*ldp + col]
 };
 
@@ -48,8 +49,9 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
     const int bt = blockIdx.x / tiles, tile = blockIdx.x - bt * tiles;
     const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
     const int r0 = tm * 32, c0 = tn * 32;
-    const cplx* __restrict__ A = g.A + (size_t)bt * g.sA;
-    const cplx* __restrict__ Bm = g.Bm + (size_t)bt * g.sB;
+    const int bhi = g.inner > 0 ? bt / g.inner : 0, blo = g.inner > 0 ? bt - bhi * g.inner : bt;
+    const cplx* __restrict__ A = g.A + (size_t)bhi * g.sA2 + (size_t)blo * g.sA;
+    const cplx* __restrict__ Bm = g.Bm + (size_t)bhi * g.sB2 + (size_t)blo * g.sB;
     gd4 t1[2][2], t2[2][2], t3[2][2];
 #pragma unroll
     for (int I = 0; I < 2; ++I)
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
                         v.x = fma(g.beta, e.x, v.x); v.y = fma(g.beta, e.y, v.y);
                     }
                     if (row == col) v.x += g.gamma;
-                    g.C[(size_t)bt * g.sC + (size_t)row * g.ldc + col] = v;
+                    g.C[(size_t)bhi * g.sC2 + (size_t)blo * g.sC + (size_t)row * g.ldc + col] = v;
                 } else if (EPI == 1) {
                     const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
                     part = fma(l.x, vre, part); part = fma(l.y, vim, part);      // Re(conj(l) * y)
@@ -293,6 +295,14 @@ __global__ void __launch_bounds__(256) k_gemm_set_chunk_ends(QocDev d, cplx* __r
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * NC * per; o += (size_t)gridDim.x * blockDim.x) {
         const size_t bc = o / per, e = o - bc * per;
         LamP[(bc * S + (S - 1)) * per + e] = Ebnd ? Ebnd[o] : cmake(0.0, 0.0);
+    }
+}
+// dst[b] = src[b] for B matrices of NN elements (odd element of a product-tree level moves up unchanged)
+__global__ void __launch_bounds__(256) k_gemm_copy_mats(cplx* __restrict__ dst, long long sD, const cplx* __restrict__ src, long long sS, int B, int NN) {
+    const size_t total = (size_t)B * NN;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bb = o / NN, e = o - bb * NN;
+        dst[bb * sD + e] = src[bb * sS + e];
     }
 }
 // inter[b][t+1] (API layout) from the time-major wide layout W[b][row][t*MV + col]
@@ -646,6 +656,7 @@ struct QocGemm {
     cplx* interP = nullptr;   // [B][SP][N][32]   Psi_t
     cplx* LamP = nullptr;     // [B][SP][N][32]   Lambda_t
     cplx* SrcP = nullptr;     // [B][SP][N][32]   S_tau (state regularisers only)
+    cplx* root = nullptr;     // persistent unitary mode: product tree above the chunk products, down to one matrix per seed
     cplx* zthin = nullptr;    // [N][32] zeros
     cplx *Psibnd = nullptr, *Ebnd = nullptr, *Aoff = nullptr;        // [B][NC][N][32] chunk-start Psi, chunk-end Lambda, affine offsets
     double* partial = nullptr; // [B*steps][k][N/32]
@@ -694,8 +705,12 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     const bool need_src = d.n_forb > 0 || d.has_speed;
     size_t tree_elems = 0;
     for (int l = 1; l <= L; ++l) { gm.tree_off[l] = tree_elems; tree_elems += (size_t)d.B * (gm.SP >> l) * NN; }
-    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.A, BSP * NN * sizeof(cplx)) &&
-              al((void**)&gm.P, BSP * NN * sizeof(cplx)) && al((void**)&gm.A2, BSP * NN * sizeof(cplx)) &&
+    const bool fused = N <= 64;                                  // k_gemm_expm_fused needs no A / A2 / ping-pong buffers
+    size_t root_elems = 0;
+    for (int cnt = gm.NC; cnt > 1; cnt = (cnt + 1) / 2) root_elems += (size_t)d.B * ((cnt + 1) / 2) * NN;
+    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && (fused || al((void**)&gm.A, BSP * NN * sizeof(cplx))) &&
+              (fused || al((void**)&gm.P, BSP * NN * sizeof(cplx))) && (fused || al((void**)&gm.A2, BSP * NN * sizeof(cplx))) &&
+              al((void**)&gm.root, (gm.persistent && !d.state_transfer) ? root_elems * sizeof(cplx) : 16) &&
               al((void**)&gm.K, BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
               al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.Y1, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
@@ -843,7 +858,31 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
     hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
-    if (gm.persistent && d.state_transfer) {
+    if (gm.persistent && !d.state_transfer) {
+        // final_state = (P_{NC-1} ... P_0) U0: the product tree continues above the chunk products (log2(NC) launches)
+        GemmArgs r;
+        memset(&r, 0, sizeof r);
+        r.lda = r.ldb = r.ldc = N; r.Kdim = N; r.tiles_m = r.tiles_n = N / 32; r.alpha = 1.0;
+        const cplx* lvl = Pc;
+        cplx* out = gm.root;
+        for (int cnt = NC; cnt > 1; cnt = (cnt + 1) / 2) {
+            const int pairs = cnt / 2, nxt = (cnt + 1) / 2;
+            r.A = lvl + NN; r.Bm = lvl; r.C = out; r.sA = r.sB = 2 * (long long)NN; r.sC = (long long)NN;
+            r.inner = pairs; r.sA2 = r.sB2 = (long long)cnt * NN; r.sC2 = (long long)nxt * NN; r.batch = d.B * pairs;
+            qoc_gemm_launch(false, 0, r, s);
+            if (cnt & 1)
+                hipLaunchKernelGGL(k_gemm_copy_mats, dim3(gemm_grid((size_t)d.B * NN)), dim3(256), 0, s, out + (size_t)pairs * NN,
+                                   (long long)nxt * NN, lvl + (size_t)(cnt - 1) * NN, (long long)cnt * NN, d.B, (int)NN);
+            lvl = out;
+            out += (size_t)d.B * nxt * NN;
+        }
+        memset(&r, 0, sizeof r);
+        r.A = lvl; r.sA = (long long)NN; r.lda = N; r.Bm = gm.Y0; r.C = gm.Y1; r.ldb = r.ldc = ld; r.sB = r.sC = (long long)N * ld;
+        r.Kdim = N; r.tiles_m = N / 32; r.tiles_n = ld / 32; r.batch = d.B; r.alpha = 1.0;
+        qoc_gemm_launch(false, 0, r, s);
+        hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, gm.Y1, N);
+    }
+    if (gm.persistent) {
         // chunk-start vectors Psibnd[c+1] = P_c Psibnd[c]: one persistent workgroup per seed
         ChainArgs a;
         memset(&a, 0, sizeof a);
@@ -859,14 +898,14 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
     g.lda = N; g.sA = (long long)NN * NC; g.ldb = g.ldc = ld; g.sB = g.sC = (long long)N * ld;
     g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = ld / 32; g.batch = d.B; g.alpha = 1.0;
     cplx *cur = gm.Y0, *oth = gm.Y1;
-    for (int c = 0; c < ((gm.persistent && d.state_transfer) ? 0 : NC); ++c) {
+    for (int c = 0; c < (gm.persistent ? 0 : NC); ++c) {
         g.A = Pc + (size_t)c * NN; g.Bm = cur; g.C = oth;
         qoc_gemm_launch(false, 0, g, s);
         if (c + 1 < NC)
             hipLaunchKernelGGL(k_gemm_take_bnd, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, oth, gm.Psibnd, N, NC, c + 1, xw);
         cplx* x = cur; cur = oth; oth = x;
     }
-    if (!d.state_transfer) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
+    if (!d.state_transfer && !gm.persistent) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
     if (gm.persistent) {
         // every chunk swept by its own persistent workgroup: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}
         ChainArgs a;
