@@ -320,13 +320,14 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const bool st_ok = st_fused_supported(d);
     const bool gemm_ok = qoc_gemm_supported(d, cfg->state_transfer ? qoc_all_antihermitian((const cplx*)Hs, n, k + 1) : true);
     // Measured with tools/path_sweep.py (profiles/r01_path_sweep.txt):
-    //  * unitary, n <= 32: the register-resident MFMA chain kernels win on throughput (1.8 vs 2.9 ms per iteration of 64
-    //    C2 seeds) and tie on single-trajectory latency; 32 < n <= 64: the GEMM path (fused LDS-resident exponential +
-    //    persistent thin chains) is 1.3-3.4x faster than the NT = 3/4 register-resident kernels for every seed count.
+    //  * unitary, n <= 32: the register-resident MFMA chain kernels win on throughput (1.8 vs 2.3 ms per iteration of 64
+    //    C2 seeds), the GEMM path (fused LDS-resident exponential + product tree + persistent thin chains) on latency
+    //    (0.34 vs 0.66 ms for one C2 trajectory; crossover between 16 and 64 seeds); 32 < n <= 64: the GEMM path is
+    //    1.3-4x faster than the NT = 3/4 register-resident kernels for every seed count.
     //  * state transfer: the fused mat-vec kernels cost ~26 us per slice whatever n <= 64 and B <= 256 are (one workgroup
     //    per seed, latency-bound); the propagator route costs ~(0.2 + 0.05 B) us per slice at n <= 32 and ~(0.3 + 0.26 B)
     //    us at n <= 64, so it wins for every batch at n <= 32 and up to ~100 seeds at n <= 64 (44x on one C3 trajectory).
-    const bool prefer_gemm = gemm_ok && n > 32;
+    const bool prefer_gemm = gemm_ok && (n > 32 || (n > 16 && B <= 16 && m <= 8 && steps >= 100));
     const bool st_prefer_gemm = gemm_ok && cfg->state_transfer && (n <= 32 || B <= 96);
     if (path == QOC_PATH_AUTO)
         path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA

@@ -498,53 +498,91 @@ struct ChainArgs {
     int store_initial;                          // also store y0 at Out - sOs
 };
 
+// Butterfly over the LPR lanes that share a result row (forward chain mapping).  While more than SPL values are alive the
+// halves are exchanged (reduce-scatter: the lane with the bit set keeps the upper half), afterwards plain xor all-reduce.
+// Compile-time recursion keeps every register index static.
+template <int ALIVE, int OFF, int SPL, int MVT>
+__device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
+    if constexpr (OFF >= 1) {
+        if constexpr (ALIVE > SPL) {
+            constexpr int half = ALIVE / 2;
+            const bool up = (q & OFF) != 0;
+#pragma unroll
+            for (int x = 0; x < half; ++x) {
+                const cplx send = up ? acc[x] : acc[x + half];
+                const cplx keep = up ? acc[x + half] : acc[x];
+                acc[x].x = keep.x + __shfl_xor(send.x, OFF, 64);
+                acc[x].y = keep.y + __shfl_xor(send.y, OFF, 64);
+            }
+            chain_butterfly<half, OFF / 2, SPL, MVT>(acc, q);
+        } else {
+#pragma unroll
+            for (int x = 0; x < SPL; ++x) {
+                acc[x].x += __shfl_xor(acc[x].x, OFF, 64);
+                acc[x].y += __shfl_xor(acc[x].y, OFF, 64);
+            }
+            chain_butterfly<ALIVE, OFF / 2, SPL, MVT>(acc, q);
+        }
+    }
+}
+
 // Thread mappings (both keep the 4 lanes of a quad on 64 contiguous bytes -- the texture-address unit serialises a quad
 // that touches 4 different cache lines, which made a transposed read of the forward mapping 2x slower per step):
-//   forward   y = K x    : thread (i, q) owns row i, columns LPR*e + q, LPR = 256/N lanes per row; xor-shuffle reduction
+//   forward   y = K x    : thread (i, q) owns row i, columns LPR*e + q, LPR = 256/N lanes per row.  The row's MV partial sums
+//                          are combined by a butterfly REDUCE-SCATTER over the LPR lanes: lane q ends up with the finished
+//                          values of its own SPL = MV/NSL vector slots only (NSL = min(MV, LPR)), so addend loads, LDS writes
+//                          and output stores are split across the lanes of a row instead of being repeated by each.
 //   CONJT     y = K^H x  : lane <-> column i (a wave reads whole rows of K), wave w owns rows (4e + w)*RPI + h; x[r] is a
-//                          broadcast LDS read; the 4 wave partials meet in LDS (one extra barrier per step)
+//                          broadcast LDS read; the 4 wave partials meet in LDS (one extra barrier per step) and thread
+//                          (w, h, i) finishes the slots jv = sg + s*NF, sg = (w*RPI + h) % NF, NF = min(MV, 4*RPI).
 template <int N, int MV, bool CONJT, bool HAS_OUT>
 __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
     constexpr int LPR = 256 / N, EL = N / LPR, RPI = 64 / N;
+    constexpr int NSL = CONJT ? (MV < 4 * RPI ? MV : 4 * RPI) : (MV < LPR ? MV : LPR);   // lanes (threads) sharing a row's slots
+    constexpr int SPL = MV / NSL;                                                          // slots finished per thread
     __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
     __shared__ __attribute__((aligned(16))) cplx part[CONJT ? 4 * N * MV : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int i = CONJT ? (lane % N) : tid / LPR;            // result row this thread reports
     const int q = tid % LPR, h = lane / N;
+    // first vector slot this thread finishes; its slots are sg + s*NSL (CONJT) or sg*SPL + s (forward butterfly order)
+    const int sg = CONJT ? (wv * RPI + h) % NSL : q / (LPR / NSL);    // forward: the butterfly consumes the HIGH bits of q first
+    auto slot = [&](int s) { return CONJT ? sg + s * NSL : sg * SPL + s; };
     const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
     const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
     const cplx* Ep = a.E + b * a.sEb + c * a.sEc + (size_t)i * QOC_TW;
     cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc + (size_t)i * a.ldO : nullptr;
-    cplx yrow[MV];
+    cplx yfin[SPL];
 #pragma unroll
-    for (int jv = 0; jv < MV; ++jv) yrow[jv] = cmake(0.0, 0.0);
+    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
     if (a.X0) {
         const cplx* x = a.X0 + b * a.sXb + c * a.sXc + (size_t)i * QOC_TW;
 #pragma unroll
-        for (int jv = 0; jv < MV; ++jv) yrow[jv] = x[jv];
+        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[slot(sl)];
     }
 #pragma unroll
-    for (int jv = 0; jv < MV; ++jv) y[0][i * MV + jv] = yrow[jv];
+    for (int sl = 0; sl < SPL; ++sl) y[0][i * MV + slot(sl)] = yfin[sl];
     if (HAS_OUT && a.store_initial) {
 #pragma unroll
-        for (int jv = 0; jv < MV; ++jv) (Op - a.sOs)[jv] = yrow[jv];
+        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[slot(sl)] = yfin[sl];
     }
     const int last = a.len - 1;
-    auto load = [&](cplx (&kd)[EL], cplx (&ed)[MV], int j) {
+    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
         const int jc = min(j, last);
         const cplx* Kj = Kp + (long long)jc * a.sKs;
 #pragma unroll
         for (int e = 0; e < EL; ++e) kd[e] = CONJT ? Kj[(size_t)((4 * e + wv) * RPI + h) * N + i] : Kj[(size_t)i * N + LPR * e + q];
         const cplx* ej = Ep + (long long)jc * a.sEs;
 #pragma unroll
-        for (int jv = 0; jv < MV; ++jv) ed[jv] = ej[jv];
+        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[slot(sl)];
     };
     int cur = 0;
-    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[MV]) {
+    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
         cplx acc[MV];
 #pragma unroll
         for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
+        cplx fin[SPL];
         if (CONJT) {
 #pragma unroll
             for (int e = 0; e < EL; ++e) {
@@ -559,12 +597,13 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
             }
             __syncthreads();
 #pragma unroll
-            for (int jv = 0; jv < MV; ++jv) {
+            for (int sl = 0; sl < SPL; ++sl) {
+                const int jv = slot(sl);
                 cplx t = part[(0 * N + i) * MV + jv];
                 t = cadd(t, part[(1 * N + i) * MV + jv]);
                 t = cadd(t, part[(2 * N + i) * MV + jv]);
                 t = cadd(t, part[(3 * N + i) * MV + jv]);
-                acc[jv] = t;
+                fin[sl] = t;
             }
         } else {
 #pragma unroll
@@ -572,25 +611,20 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
 #pragma unroll
                 for (int jv = 0; jv < MV; ++jv) cfma(acc[jv], ku[e], y[cur][(LPR * e + q) * MV + jv]);
             }
+            chain_butterfly<MV, LPR / 2, SPL, MV>(acc, q);
 #pragma unroll
-            for (int jv = 0; jv < MV; ++jv) {
-#pragma unroll
-                for (int off = 1; off < LPR; off <<= 1) {
-                    acc[jv].x += __shfl_xor(acc[jv].x, off, 64);
-                    acc[jv].y += __shfl_xor(acc[jv].y, off, 64);
-                }
-            }
+            for (int sl = 0; sl < SPL; ++sl) fin[sl] = acc[sl];
         }
 #pragma unroll
-        for (int jv = 0; jv < MV; ++jv) {
-            acc[jv] = cadd(acc[jv], eu[jv]);
-            y[cur ^ 1][i * MV + jv] = acc[jv];
-            yrow[jv] = acc[jv];
+        for (int sl = 0; sl < SPL; ++sl) {
+            fin[sl] = cadd(fin[sl], eu[sl]);
+            y[cur ^ 1][i * MV + slot(sl)] = fin[sl];
+            yfin[sl] = fin[sl];
         }
         if (HAS_OUT) {
             cplx* oj = Op + (long long)j * a.sOs;
 #pragma unroll
-            for (int jv = 0; jv < MV; ++jv) oj[jv] = acc[jv];
+            for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = fin[sl];
         }
         __syncthreads();
         cur ^= 1;
@@ -598,7 +632,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
     if (a.len > 0) {
         // three register stages used round-robin by a 3x unrolled loop (rotating them with copies would make every
         // iteration wait for the newest load)
-        cplx k0[EL], k1[EL], k2[EL], e0[MV], e1[MV], e2[MV];
+        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
         load(k0, e0, 0);
         load(k1, e1, 1);
         __syncthreads();
@@ -616,7 +650,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
     if (a.Fin) {
         cplx* f = a.Fin + b * a.sFb + c * a.sFc + (size_t)i * QOC_TW;
 #pragma unroll
-        for (int jv = 0; jv < MV; ++jv) f[jv] = yrow[jv];
+        for (int sl = 0; sl < SPL; ++sl) f[slot(sl)] = yfin[sl];
     }
 }
 

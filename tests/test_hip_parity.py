@@ -270,12 +270,15 @@ def test_grape_lbfgs_driver_reduces_loss():
     assert l1 < 0.5 * l0
 
 
-def test_large_size_properties_c2():
-    """BASELINE config C2 at full size: size-independent properties instead of a (slow) oracle comparison."""
+@pytest.mark.parametrize('path,expect', [(0, 4), (2, 2)])
+def test_large_size_properties_c2(path, expect):
+    """BASELINE config C2 at full size: size-independent properties + an oracle comparison of one seed.  A couple of
+    trajectories take the latency route (AUTO -> GEMM path), large restart batches the register-resident MFMA kernels."""
     c = cases.case_c2()                                     # n=32, k=4, steps=500, m=8, (T,s)=(5,3)
     sp = oracle_system(c)
     bases = np.stack([sp.base0, 0.5 * sp.base0])
-    eng = make_engine(sp, n_seeds=2)
+    eng = make_engine(sp, n_seeds=2, path=path)
+    assert eng.path == expect
     eng.set_base(bases)
     r = eng.evaluate()
     Uf = eng.get_final_unitary()
