@@ -34,6 +34,9 @@ def run(name, c, n_seeds, iters, path=0):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'c3':           # profiling hook: C3 single trajectory only
+        run('C3 state transfer (propagator route)', cases.case_c3(), 1, 20)
+        sys.exit(0)
     run('C1 single qubit', cases.case_c1(), 1, 50)
     run('C1 single qubit x64 seeds', cases.case_c1(), 64, 50)
     run('C2 single trajectory (latency route)', cases.case_c2(), 1, 20)
