@@ -236,6 +236,19 @@ def main():
                 'traffic_unit': 'bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.txt)',
                 'avg_launch_ms': avg_ms, 'launches': pr['launches'], 'flops_per_launch': flops_per_launch,
                 'measured_mfma_f64_ceiling_TFLOPs': 48.2}
+    # ---- latency of ONE trajectory of the same workload (what a plain Grape() call runs), outside the timed region ----
+    single = None
+    if rank == 0:
+        e1 = hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], SLICES, TAYLOR[0], TAYLOR[1],
+                                  reg_coeffs={}, n_seeds=1, device=local_rank)
+        e1.set_base(seed_bases(0, 1))
+        e1.iterate(params, 3); e1.sync()
+        t1 = time.perf_counter()
+        e1.iterate(params, 50); e1.sync()
+        el1 = (time.perf_counter() - t1) / 50
+        single = {'value': 1.0 / el1, 'unit': 'GRAPE iterations/s', 'ms_per_iteration': el1 * 1e3, 'path': e1.path,
+                  'note': 'one control set (n_seeds=1, AUTO path) of the same C2 workload, 50 iterations; not part of `value`'}
+        e1.close()
     total_seeds = B * world
     value = total_seeds * args.steps / elapsed
     if rank == 0:
@@ -250,6 +263,7 @@ def main():
                        'stream_groups': G,
                        'parallelism': 'seed-sharded x%d, RCCL all-gather of final fidelities' % world},
             'per_seed_iterations_per_s': args.steps / elapsed,
+            'single_trajectory': single,
             'best_fidelity': float(np.max(fidelity)),
             'roofline': roof,
         }
