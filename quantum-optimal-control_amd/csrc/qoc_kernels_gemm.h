@@ -498,6 +498,24 @@ struct ChainArgs {
     int store_initial;                          // also store y0 at Out - sOs
 };
 
+// v from lane (l ^ OFF), OFF in {1, 2, 4}, as DPP moves on the VALU (quad_perm; xor 4 = row_half_mirror then quad_perm
+// [3,2,1,0]) instead of ds_bpermute round trips through the LDS crossbar: the chain step is a dependent sequence, and
+// three crossbar latencies per step were a tenth of it.
+template <int OFF>
+__device__ __forceinline__ double dpp_xor(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (OFF == 1) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
+    } else if constexpr (OFF == 2) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, true);
+    } else {
+        static_assert(OFF == 4, "dpp_xor: lane distance 1, 2 or 4");
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, true);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x1B, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x1B, 0xF, 0xF, true);
+    }
+    return __hiloint2double(hi, lo);
+}
+
 // Butterfly over the LPR lanes that share a result row (forward chain mapping).  While more than SPL values are alive the
 // halves are exchanged (reduce-scatter: the lane with the bit set keeps the upper half), afterwards plain xor all-reduce.
 // Compile-time recursion keeps every register index static.
@@ -511,15 +529,15 @@ __device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
             for (int x = 0; x < half; ++x) {
                 const cplx send = up ? acc[x] : acc[x + half];
                 const cplx keep = up ? acc[x + half] : acc[x];
-                acc[x].x = keep.x + __shfl_xor(send.x, OFF, 64);
-                acc[x].y = keep.y + __shfl_xor(send.y, OFF, 64);
+                acc[x].x = keep.x + dpp_xor<OFF>(send.x);
+                acc[x].y = keep.y + dpp_xor<OFF>(send.y);
             }
             chain_butterfly<half, OFF / 2, SPL, MVT>(acc, q);
         } else {
 #pragma unroll
             for (int x = 0; x < SPL; ++x) {
-                acc[x].x += __shfl_xor(acc[x].x, OFF, 64);
-                acc[x].y += __shfl_xor(acc[x].y, OFF, 64);
+                acc[x].x += dpp_xor<OFF>(acc[x].x);
+                acc[x].y += dpp_xor<OFF>(acc[x].y);
             }
             chain_butterfly<ALIVE, OFF / 2, SPL, MVT>(acc, q);
         }
@@ -533,7 +551,7 @@ __device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
 //                          values of its own SPL = MV/NSL vector slots only (NSL = min(MV, LPR)), so addend loads, LDS writes
 //                          and output stores are split across the lanes of a row instead of being repeated by each.
 //   CONJT     y = K^H x  : lane <-> column i (a wave reads whole rows of K), wave w owns rows (4e + w)*RPI + h; x[r] is a
-//                          broadcast LDS read; the 4 wave partials meet in LDS (one extra barrier per step) and thread
+//                          broadcast LDS read; the 4*RPI partials meet in LDS (one extra barrier per step) and thread
 //                          (w, h, i) finishes the slots jv = sg + s*NF, sg = (w*RPI + h) % NF, NF = min(MV, 4*RPI).
 template <int N, int MV, bool CONJT, bool HAS_OUT>
 __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
@@ -541,7 +559,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
     constexpr int NSL = CONJT ? (MV < 4 * RPI ? MV : 4 * RPI) : (MV < LPR ? MV : LPR);   // lanes (threads) sharing a row's slots
     constexpr int SPL = MV / NSL;                                                          // slots finished per thread
     __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
-    __shared__ __attribute__((aligned(16))) cplx part[CONJT ? 4 * N * MV : 1];
+    __shared__ __attribute__((aligned(16))) cplx part[CONJT ? 4 * RPI * N * MV : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int i = CONJT ? (lane % N) : tid / LPR;            // result row this thread reports
@@ -591,18 +609,14 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
                 for (int jv = 0; jv < MV; ++jv) cfma_conj(acc[jv], ku[e], y[cur][r * MV + jv]);
             }
 #pragma unroll
-            for (int jv = 0; jv < MV; ++jv) {
-                if (RPI == 2) { acc[jv].x += __shfl_xor(acc[jv].x, 32, 64); acc[jv].y += __shfl_xor(acc[jv].y, 32, 64); }
-                part[(wv * N + i) * MV + jv] = acc[jv];
-            }
+            for (int jv = 0; jv < MV; ++jv) part[((wv * RPI + h) * N + i) * MV + jv] = acc[jv];   // 4*RPI partial rows per column
             __syncthreads();
 #pragma unroll
             for (int sl = 0; sl < SPL; ++sl) {
                 const int jv = slot(sl);
-                cplx t = part[(0 * N + i) * MV + jv];
-                t = cadd(t, part[(1 * N + i) * MV + jv]);
-                t = cadd(t, part[(2 * N + i) * MV + jv]);
-                t = cadd(t, part[(3 * N + i) * MV + jv]);
+                cplx t = part[i * MV + jv];
+#pragma unroll
+                for (int w = 1; w < 4 * RPI; ++w) t = cadd(t, part[(w * N + i) * MV + jv]);
                 fin[sl] = t;
             }
         } else {
