@@ -318,26 +318,31 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     int path = cfg->path;
     const bool mfma_ok = qoc_mfma_supported(d);
     const bool st_ok = st_fused_supported(d);
-    const bool gemm_ok = qoc_gemm_supported(d, cfg->state_transfer ? qoc_all_antihermitian((const cplx*)Hs, n, k + 1) : true);
+    const bool antiherm = cfg->state_transfer ? qoc_all_antihermitian((const cplx*)Hs, n, k + 1) : true;
+    const bool gemm_ok = qoc_gemm_supported(d, antiherm);
     // Measured with tools/path_sweep.py (profiles/r01_path_sweep.txt):
     //  * unitary, n <= 32: the register-resident MFMA chain kernels win on throughput (1.8 vs 2.3 ms per iteration of 64
     //    C2 seeds), the GEMM path (fused LDS-resident exponential + product tree + persistent thin chains) on latency
     //    (0.34 vs 0.66 ms for one C2 trajectory; crossover between 16 and 64 seeds); 32 < n <= 64: the GEMM path is
     //    1.3-4x faster than the NT = 3/4 register-resident kernels for every seed count.
-    //  * state transfer: the fused mat-vec kernels cost ~26 us per slice whatever n <= 64 and B <= 256 are (one workgroup
-    //    per seed, latency-bound); the propagator route costs ~(0.2 + 0.05 B) us per slice at n <= 32 and ~(0.3 + 0.26 B)
-    //    us at n <= 64, so it wins for every batch at n <= 32 and up to ~100 seeds at n <= 64 (44x on one C3 trajectory).
+    //  * state transfer on the GEMM path: the propagator route (K_t = P(B_t) as matrices, time-parallel chunks; needs
+    //    anti-Hermitian generators) wins for few trajectories (one C3 trajectory: 0.55 ms vs 26 ms for the fused mat-vec
+    //    kernels); the direct route (Taylor mat-vec chains on pre-assembled generators, one workgroup per seed) wins for
+    //    batches.  ST_DIRECT_FROM is the measured crossover in seeds.
     const bool prefer_gemm = gemm_ok && (n > 32 || (n > 16 && B <= 16 && m <= 8 && steps >= 100));
-    const bool st_prefer_gemm = gemm_ok && cfg->state_transfer && (n <= 32 || B <= 96);
+    const int ST_DIRECT_FROM = n <= 32 ? 112 : 64;
+    const bool direct_ok = qoc_gemm_direct_supported(d);
+    bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));
+    if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
     if (path == QOC_PATH_AUTO)
-        path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA
-               : ((st_ok && !st_prefer_gemm) ? QOC_PATH_ST_FUSED : (gemm_ok ? QOC_PATH_GEMM : QOC_PATH_GENERIC));
+        path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
     if (path == QOC_PATH_MFMA && !mfma_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 64, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_GEMM && !gemm_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: GEMM path needs m <= 32 and, in state transfer, exactly anti-Hermitian generators (m=%d)", m));
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: GEMM path needs m <= 32 and, in state transfer, exactly anti-Hermitian generators or n <= 64, m <= 8 (m=%d)", m));
     if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
@@ -348,8 +353,9 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         e->chunks = e->mf.C;
     } else if (path == QOC_PATH_GEMM) {
         std::string msg;
-        rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, e->allocs, msg);
+        rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, gemm_direct, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
+        e->chunks = e->gm.NC;
     } else if (!cfg->state_transfer) {
         ALLOC(e->K, (size_t)B * steps * nn);
         int grid = B * steps;

@@ -496,6 +496,7 @@ struct ChainArgs {
     int CI;                                     // chains per seed (blockIdx.x = b*CI + c)
     int len, m;
     int store_initial;                          // also store y0 at Out - sOs
+    int nterms; double sign;                    // k_gemm_taylor_chain: y <- sum_{j<nterms} (sign*K)^j y / j!  (+ E)
 };
 
 // v from lane (l ^ OFF), OFF in {1, 2, 4}, as DPP moves on the VALU (quad_perm; xor 4 = row_half_mirror then quad_perm
@@ -515,6 +516,11 @@ __device__ __forceinline__ double dpp_xor(double v) {
     }
     return __hiloint2double(hi, lo);
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for the K/E prefetch of
+// two steps ahead (and the output stores) at every step of a chain; the chains exchange data through LDS alone, and hipcc
+// still places the vmcnt wait for each prefetched register stage before its first use.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Butterfly over the LPR lanes that share a result row (forward chain mapping).  While more than SPL values are alive the
 // halves are exchanged (reduce-scatter: the lane with the bit set keeps the upper half), afterwards plain xor all-reduce.
@@ -610,7 +616,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
             }
 #pragma unroll
             for (int jv = 0; jv < MV; ++jv) part[((wv * RPI + h) * N + i) * MV + jv] = acc[jv];   // 4*RPI partial rows per column
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int sl = 0; sl < SPL; ++sl) {
                 const int jv = slot(sl);
@@ -640,7 +646,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
 #pragma unroll
             for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = fin[sl];
         }
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     };
     if (a.len > 0) {
@@ -649,7 +655,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
         cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
         load(k0, e0, 0);
         load(k1, e1, 1);
-        __syncthreads();
+        lds_barrier();
         int j = 0;
         for (; j + 3 <= a.len; j += 3) {
             load(k2, e2, j + 2); step(j, k0, e0);
@@ -659,13 +665,125 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
         if (j < a.len) step(j, k0, e0);
         if (j + 1 < a.len) step(j + 1, k1, e1);
     } else {
-        __syncthreads();
+        lds_barrier();
     }
     if (a.Fin) {
         cplx* f = a.Fin + b * a.sFb + c * a.sFc + (size_t)i * QOC_TW;
 #pragma unroll
         for (int sl = 0; sl < SPL; ++sl) f[slot(sl)] = yfin[sl];
     }
+}
+
+// State transfer without propagators: psi <- sum_{j<T} (sign*B_t)^j psi / j! (+ E_t), one workgroup per seed walking all
+// slices (tensorflow_state.py:88-96 forward, :118-131 backward with sign = -1 -- no anti-Hermiticity assumed).  Same mapping
+// and prefetch structure as the forward k_gemm_chain; a step is T-1 dependent mat-vecs on the register-resident B_t (the
+// generator was assembled for all slices by k_gemm_assemble, so the chain streams 1 matrix per slice instead of k+1).
+template <int N, int MV>
+__global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a) {
+    constexpr int LPR = 256 / N, EL = N / LPR;
+    constexpr int NSL = MV < LPR ? MV : LPR;
+    constexpr int SPL = MV / NSL;
+    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
+    const int tid = threadIdx.x;
+    const int i = tid / LPR, q = tid % LPR;
+    const int sg = q / (LPR / NSL);
+    auto slot = [&](int sl) { return sg * SPL + sl; };
+    const int b = blockIdx.x;
+    const cplx* Kp = a.K + b * a.sKb;
+    const cplx* Ep = a.E + b * a.sEb + (size_t)i * QOC_TW;
+    cplx* Op = a.Out + b * a.sOb + (size_t)i * a.ldO;
+    cplx yfin[SPL];
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
+    if (a.X0) {
+        const cplx* x = a.X0 + b * a.sXb + (size_t)i * QOC_TW;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[slot(sl)];
+    }
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) y[0][i * MV + slot(sl)] = yfin[sl];
+    if (a.store_initial) {
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[slot(sl)] = yfin[sl];
+    }
+    const int last = a.len - 1;
+    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
+        const int jc = min(j, last);
+        const cplx* Kj = Kp + (long long)jc * a.sKs + (size_t)i * N + q;
+#pragma unroll
+        for (int e = 0; e < EL; ++e) kd[e] = Kj[LPR * e];
+        const cplx* ej = Ep + (long long)jc * a.sEs;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[slot(sl)];
+    };
+    int cur = 0;
+    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
+        cplx out[SPL];
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) out[sl] = yfin[sl];
+        double fact = 1.0;
+        for (int ii = 1; ii < a.nterms; ++ii) {
+            cplx acc[MV];
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
+#pragma unroll
+            for (int e = 0; e < EL; ++e) {
+#pragma unroll
+                for (int jv = 0; jv < MV; ++jv) cfma(acc[jv], ku[e], y[cur][(LPR * e + q) * MV + jv]);
+            }
+            chain_butterfly<MV, LPR / 2, SPL, MV>(acc, q);
+            fact *= (double)ii;
+            const double inv = 1.0 / fact;
+            const bool lastterm = ii + 1 == a.nterms;
+#pragma unroll
+            for (int sl = 0; sl < SPL; ++sl) {
+                const cplx w = cscale(acc[sl], a.sign);                       // psi_n = (sign*B) psi_n            :94 / :130
+                out[sl].x = fma(w.x, inv, out[sl].x); out[sl].y = fma(w.y, inv, out[sl].y);   // += psi_n / factorial   :95 / :131
+                // the last term is needed by nobody else: the buffer takes the new state (+ addend) instead
+                y[cur ^ 1][i * MV + slot(sl)] = lastterm ? cadd(out[sl], eu[sl]) : w;
+            }
+            lds_barrier();
+            cur ^= 1;
+        }
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cadd(out[sl], eu[sl]);
+        if (a.nterms <= 1) {                                                   // T = 1: psi unchanged (+ addend)
+#pragma unroll
+            for (int sl = 0; sl < SPL; ++sl) y[cur ^ 1][i * MV + slot(sl)] = yfin[sl];
+            lds_barrier();
+            cur ^= 1;
+        }
+        cplx* oj = Op + (long long)j * a.sOs;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = yfin[sl];
+    };
+    if (a.len > 0) {
+        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
+        load(k0, e0, 0);
+        load(k1, e1, 1);
+        lds_barrier();
+        int j = 0;
+        for (; j + 3 <= a.len; j += 3) {
+            load(k2, e2, j + 2); step(j, k0, e0);
+            load(k0, e0, j + 3); step(j + 1, k1, e1);
+            load(k1, e1, j + 4); step(j + 2, k2, e2);
+        }
+        if (j < a.len) step(j, k0, e0);
+        if (j + 1 < a.len) step(j + 1, k1, e1);
+    }
+}
+
+template <int N>
+static inline void qoc_taylor_chain_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
+    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(256), 0, s, a);
+}
+static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
+    if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
+    if (N == 32) qoc_taylor_chain_launch_n<32>(a, blocks, s); else qoc_taylor_chain_launch_n<64>(a, blocks, s);
 }
 
 template <int N, bool CONJT, bool HAS_OUT>
@@ -695,6 +813,7 @@ static inline void qoc_chain_launch(int N, bool conjt, ChainArgs a, const cplx* 
 struct QocGemm {
     int N = 0, S = 1, L = 0, NC = 1, SP = 1;
     int MV = 0, ldW = 0;      // persistent mode: vector slots (1/2/4/8) and row stride of the time-major wide buffers
+    bool direct = false;      // state transfer as Taylor mat-vec chains on the assembled generators (one chunk, no propagators)
     bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
     cplx* HsP = nullptr;      // [k+1][N][N]
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
@@ -713,8 +832,11 @@ struct QocGemm {
 // Unitary mode: any n.  State transfer: psi <- P(B_t) psi is the same chain with K_t = sum_{j<T} B_t^j/j! (no squaring);
 // the reference's backward step lambda <- P(-B_t) lambda (tensorflow_state.py:118-131) equals K_t^dagger lambda exactly
 // when every generator is anti-Hermitian (-i dt H with H Hermitian), which `antiherm` certifies at create time.
+// Any state-transfer problem with n <= 64, m <= 8 can instead run "direct" (k_gemm_taylor_chain: the reference's own
+// mat-vec recursion, forward and backward, on pre-assembled generators; no time parallelism, so it is the large-batch mode).
+static inline bool qoc_gemm_direct_supported(const QocDev& d) { return d.state_transfer && d.n <= 64 && d.m <= 8 && d.T >= 1; }
 static inline bool qoc_gemm_supported(const QocDev& d, bool antiherm) {
-    return d.m <= QOC_TW && d.T >= 1 && (!d.state_transfer || antiherm);
+    return d.m <= QOC_TW && d.T >= 1 && (!d.state_transfer || antiherm || qoc_gemm_direct_supported(d));
 }
 static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
     for (int q = 0; q < count; ++q) {
@@ -726,16 +848,18 @@ static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
     return true;
 }
 
-static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg) {
+static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, bool direct, std::vector<void*>& allocs, std::string& msg) {
     const int N = ((d.n + 31) / 32) * 32;
     gm.N = N;
     gm.persistent = N <= 64 && d.m <= 8;
     gm.MV = d.m <= 1 ? 1 : (d.m <= 2 ? 2 : (d.m <= 4 ? 4 : 8));
+    gm.direct = direct && d.state_transfer && gm.persistent;
     int L = 0;
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
     gm.L = L; gm.S = 1 << L;
     gm.NC = (d.steps + gm.S - 1) / gm.S;
     gm.SP = gm.NC * gm.S;
+    if (gm.direct) { gm.L = L = 0; gm.S = d.steps; gm.NC = 1; gm.SP = d.steps; }   // one chunk, no padding, no tree
     gm.ldW = ((gm.SP * gm.MV + 31) / 32) * 32;
     const size_t NN = (size_t)N * N, BSP = (size_t)d.B * gm.SP, thin = (size_t)N * QOC_TW;
     std::vector<cplx> hp((size_t)(d.k + 1) * NN);
@@ -753,13 +877,14 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     const bool need_src = d.n_forb > 0 || d.has_speed;
     size_t tree_elems = 0;
     for (int l = 1; l <= L; ++l) { gm.tree_off[l] = tree_elems; tree_elems += (size_t)d.B * (gm.SP >> l) * NN; }
-    const bool fused = N <= 64;                                  // k_gemm_expm_fused needs no A / A2 / ping-pong buffers
+    const bool fused = N <= 64 && !gm.direct;                    // k_gemm_expm_fused needs no A / A2 / ping-pong buffers
     size_t root_elems = 0;
     for (int cnt = gm.NC; cnt > 1; cnt = (cnt + 1) / 2) root_elems += (size_t)d.B * ((cnt + 1) / 2) * NN;
+    const bool poly = !fused && !gm.direct;                      // launch-per-product route: A2 and ping-pong buffers
     bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && (fused || al((void**)&gm.A, BSP * NN * sizeof(cplx))) &&
-              (fused || al((void**)&gm.P, BSP * NN * sizeof(cplx))) && (fused || al((void**)&gm.A2, BSP * NN * sizeof(cplx))) &&
+              (!poly || al((void**)&gm.P, BSP * NN * sizeof(cplx))) && (!poly || al((void**)&gm.A2, BSP * NN * sizeof(cplx))) &&
               al((void**)&gm.root, (gm.persistent && !d.state_transfer) ? root_elems * sizeof(cplx) : 16) &&
-              al((void**)&gm.K, BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
+              al((void**)&gm.K, gm.direct ? 16 : BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
               al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.Y1, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.interP, BSP * thin * sizeof(cplx)) && al((void**)&gm.LamP, BSP * thin * sizeof(cplx)) &&
@@ -846,6 +971,10 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const size_t NN = (size_t)N * N, BS = (size_t)d.B * gm.SP;
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
+    if (gm.direct) {                                             // the chains apply the Taylor series themselves
+        hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N, gm.SP, 0);
+        return;
+    }
     if (N <= 64) {
         ExpmCoef cf;
         { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
@@ -906,6 +1035,17 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
     hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
+    if (gm.direct) {
+        ChainArgs a;
+        memset(&a, 0, sizeof a);
+        a.K = gm.A; a.sKb = (long long)NN * gm.SP; a.sKs = (long long)NN;
+        a.X0 = gm.Psibnd; a.sXb = (long long)thin;
+        a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOs = gm.MV; a.ldO = gm.ldW;
+        a.CI = 1; a.len = d.steps; a.m = d.m; a.nterms = d.T; a.sign = 1.0;
+        qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s);
+        hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
+        return;
+    }
     if (gm.persistent && !d.state_transfer) {
         // final_state = (P_{NC-1} ... P_0) U0: the product tree continues above the chunk products (log2(NC) launches)
         GemmArgs r;
@@ -1005,7 +1145,16 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     const bool need_src = d.n_forb > 0 || d.has_speed;
     const cplx* Pc = qoc_gemm_chunk_products(gm);
     hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC);
-    if (gm.persistent) {
+    if (gm.direct) {                                         // lambda_{t-1} = P(-B_t) lambda_t + S_t   tensorflow_state.py:118-131
+        ChainArgs a;
+        memset(&a, 0, sizeof a);
+        a.K = gm.A + (size_t)(d.steps - 1) * NN; a.sKb = (long long)NN * gm.SP; a.sKs = -(long long)NN;
+        a.X0 = gm.Ebnd; a.sXb = (long long)thin;
+        if (need_src) { a.E = gm.SrcP + (size_t)(d.steps - 1) * thin; a.sEb = (long long)thin * gm.SP; a.sEs = -(long long)thin; }
+        a.Out = gm.LamP + (long long)(d.steps - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOs = -gm.MV; a.ldO = gm.ldW;
+        a.store_initial = 1; a.CI = 1; a.len = d.steps - 1; a.m = d.m; a.nterms = d.T; a.sign = -1.0;
+        qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s);
+    } else if (gm.persistent) {
         ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
         memset(&sw, 0, sizeof sw);
         sw.K = gm.K + (size_t)(S - 1) * NN; sw.sKb = (long long)NN * gm.SP; sw.sKc = (long long)NN * S; sw.sKs = -(long long)NN;

@@ -115,11 +115,12 @@ def test_mfma_path_parity(chunks, variant):
     eng.close()
 
 
-@pytest.mark.parametrize('path', [3, 4])
+@pytest.mark.parametrize('path,chunks', [(3, 0), (4, 2), (4, 1)], ids=['fused', 'propagator', 'direct'])
 @pytest.mark.parametrize('variant', ['c3_small', 'allreg_m2', 'n64_m1', 'n5_m2', 'm4_T1'])
-def test_fused_state_transfer_parity(variant, path):
-    """State transfer against the oracle: register-resident mat-vec kernels (path 3) and the propagator route (path 4:
-    K_t = P(B_t) as a matrix, tree-chunked thin chains; needs anti-Hermitian generators)."""
+def test_fused_state_transfer_parity(variant, path, chunks):
+    """State transfer against the oracle: register-resident mat-vec kernels (path 3), the propagator route of the GEMM path
+    (K_t = P(B_t) as a matrix, tree-chunked thin chains; needs anti-Hermitian generators) and its direct route (chunks = 1:
+    Taylor mat-vec chains on pre-assembled generators)."""
     if variant == 'c3_small':
         c = cases.ALL_CASES['c3_small']()
     elif variant == 'allreg_m2':
@@ -140,8 +141,8 @@ def test_fused_state_transfer_parity(variant, path):
     sp = oracle_system(c)
     rng = np.random.default_rng(11)
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1]
-    eng = make_engine(sp, n_seeds=2, path=path)
-    assert eng.path == path
+    eng = make_engine(sp, n_seeds=2, path=path, chunks=chunks)
+    assert eng.path == path and (chunks != 1 or eng.chunks == 1)
     eng.set_base(np.stack(bases))
     check_eval(eng, sp, bases)
     eng.close()
@@ -408,7 +409,7 @@ def test_edge_cases_all_paths(name, c, path):
     bases = [sp.base0, -1.5 * sp.base0 + 0.05]
     eng = make_engine(sp, n_seeds=2, path=path)
     expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'st_m5_generic': 4, 'st_n65_generic': 4,
-              'st_nonhermitian_fused': 3, 'st_nonhermitian_generic': 1, 'state_small_auto': 4}
+              'st_nonhermitian_fused': 4, 'st_nonhermitian_generic': 1, 'state_small_auto': 4}
     if name in expect:
         assert eng.path == expect[name], (name, eng.path)
     eng.set_base(np.stack(bases))
@@ -425,7 +426,7 @@ def test_unsupported_path_requests_fail_loudly():
     c['H0'] = c['H0'] + 0.1 * np.arange(25.0).reshape(5, 5)          # not Hermitian: the propagator route must refuse
     sp = oracle_system(c)
     with pytest.raises(hip_engine.QocError, match='anti-Hermitian generators'):
-        make_engine(sp, path=4)
+        make_engine(sp, path=4, chunks=2)
     with pytest.raises(hip_engine.QocError, match='unknown path'):
         make_engine(sp, path=9)
 
@@ -449,14 +450,14 @@ def test_grape_restarts_extension_returns_best_seed():
     assert uksB.shape == uks1.shape and UfB.shape == Uf1.shape
 
 
-@pytest.mark.parametrize('path,expect', [(0, 4), (3, 3)])
-def test_full_size_c3_state_transfer_against_oracle(path, expect):
+@pytest.mark.parametrize('path,chunks,expect', [(0, 0, 4), (4, 1, 4), (3, 0, 3)], ids=['auto_propagator', 'direct', 'fused'])
+def test_full_size_c3_state_transfer_against_oracle(path, chunks, expect):
     """BASELINE config C3 at full size (n=64, k=6, steps=1000, dwdt + forbidden regularisers): mat-vec chains are cheap
     enough for the NumPy oracle, so this is a full comparison plus the size-independent properties.  AUTO takes the
     propagator route for a couple of trajectories; the fused mat-vec kernels are what large restart batches run."""
     c = cases.case_c3()
     sp = oracle_system(c)
-    eng = make_engine(sp, n_seeds=2, path=path)
+    eng = make_engine(sp, n_seeds=2, path=path, chunks=chunks)
     assert eng.path == expect
     bases = [sp.base0, 0.3 * sp.base0]
     eng.set_base(np.stack(bases))
