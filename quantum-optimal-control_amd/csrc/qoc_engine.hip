@@ -330,7 +330,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    kernels); the direct route (Taylor mat-vec chains on pre-assembled generators, one workgroup per seed) wins for
     //    batches.  ST_DIRECT_FROM is the measured crossover in seeds.
     const bool prefer_gemm = gemm_ok && (n > 32 || (n > 16 && B <= 16 && m <= 8 && steps >= 100));
-    const int ST_DIRECT_FROM = n <= 32 ? 112 : 64;
+    const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
     bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));
     if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
