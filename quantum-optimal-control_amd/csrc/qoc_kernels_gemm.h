@@ -485,7 +485,7 @@ __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(Qo
 // ~5 us of launch latency per step; here a step costs N*N*m complex MACs on the VALU (fp64 FMA rate ~ MFMA rate on
 // gfx950, and no padding of m to an MFMA tile) with K_j fetched two steps ahead into registers.
 // The steady-state loop is one basic block (unconditional clamped prefetch, E always loaded -- from a zero buffer when
-// there is no addend --, all lanes of a row store the same value): with conditional loads or stores in the loop hipcc's
+// there is no addend --, every finished value has exactly one owner lane): with conditional loads or stores in the loop hipcc's
 // s_waitcnt placement has to assume the worst path and waits for the loads it has just issued.
 struct ChainArgs {
     const cplx* K; long long sKb, sKc, sKs;     // matrix of step j: K + b*sKb + c*sKc + j*sKs  (elements; sKs may be negative)
@@ -552,29 +552,23 @@ __device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
     }
 }
 
-// Thread mappings (both keep the 4 lanes of a quad on 64 contiguous bytes -- the texture-address unit serialises a quad
-// that touches 4 different cache lines, which made a transposed read of the forward mapping 2x slower per step):
-//   forward   y = K x    : thread (i, q) owns row i, columns LPR*e + q, LPR = 256/N lanes per row.  The row's MV partial sums
-//                          are combined by a butterfly REDUCE-SCATTER over the LPR lanes: lane q ends up with the finished
-//                          values of its own SPL = MV/NSL vector slots only (NSL = min(MV, LPR)), so addend loads, LDS writes
-//                          and output stores are split across the lanes of a row instead of being repeated by each.
-//   CONJT     y = K^H x  : lane <-> column i (a wave reads whole rows of K), wave w owns rows (4e + w)*RPI + h; x[r] is a
-//                          broadcast LDS read; the 4*RPI partials meet in LDS (one extra barrier per step) and thread
-//                          (w, h, i) finishes the slots jv = sg + s*NF, sg = (w*RPI + h) % NF, NF = min(MV, 4*RPI).
-template <int N, int MV, bool CONJT, bool HAS_OUT>
-__global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
-    constexpr int LPR = 256 / N, EL = N / LPR, RPI = 64 / N;
-    constexpr int NSL = CONJT ? (MV < 4 * RPI ? MV : 4 * RPI) : (MV < LPR ? MV : LPR);   // lanes (threads) sharing a row's slots
-    constexpr int SPL = MV / NSL;                                                          // slots finished per thread
+// y <- K_j^H y + E_j (backward chains).  Lane <-> column i of K, so that a wave reads whole rows (the 4 lanes of a quad must
+// stay on 64 contiguous bytes: the texture-address unit serialises a quad that touches 4 cache lines, and a transposed read
+// with a row-per-thread mapping was 2x slower per step); wave w owns rows (4e + w)*RPI + h, RPI = 64/N; x[r] is a broadcast
+// LDS read; the 4*RPI partial rows meet in LDS (one extra barrier per step) and thread (w, h, i) finishes -- adds the
+// source, writes LDS, stores -- the slots jv = sg + s*NSL, sg = (w*RPI + h) % NSL, NSL = min(MV, 4*RPI).
+template <int N, int MV, bool HAS_OUT>
+__global__ void __launch_bounds__(256) k_gemm_chain_adj(ChainArgs a) {
+    constexpr int EL = N * N / 256, RPI = 64 / N;
+    constexpr int NSL = MV < 4 * RPI ? MV : 4 * RPI;
+    constexpr int SPL = MV / NSL;
     __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
-    __shared__ __attribute__((aligned(16))) cplx part[CONJT ? 4 * RPI * N * MV : 1];
+    __shared__ __attribute__((aligned(16))) cplx part[4 * RPI * N * MV];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int i = CONJT ? (lane % N) : tid / LPR;            // result row this thread reports
-    const int q = tid % LPR, h = lane / N;
-    // first vector slot this thread finishes; its slots are sg + s*NSL (CONJT) or sg*SPL + s (forward butterfly order)
-    const int sg = CONJT ? (wv * RPI + h) % NSL : q / (LPR / NSL);    // forward: the butterfly consumes the HIGH bits of q first
-    auto slot = [&](int s) { return CONJT ? sg + s * NSL : sg * SPL + s; };
+    const int i = lane % N, h = lane / N;
+    const int sg = (wv * RPI + h) % NSL;
+    auto slot = [&](int s) { return sg + s * NSL; };
     const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
     const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
     const cplx* Ep = a.E + b * a.sEb + c * a.sEc + (size_t)i * QOC_TW;
@@ -598,7 +592,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
         const int jc = min(j, last);
         const cplx* Kj = Kp + (long long)jc * a.sKs;
 #pragma unroll
-        for (int e = 0; e < EL; ++e) kd[e] = CONJT ? Kj[(size_t)((4 * e + wv) * RPI + h) * N + i] : Kj[(size_t)i * N + LPR * e + q];
+        for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)((4 * e + wv) * RPI + h) * N + i];
         const cplx* ej = Ep + (long long)jc * a.sEs;
 #pragma unroll
         for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[slot(sl)];
@@ -608,45 +602,28 @@ __global__ void __launch_bounds__(256) k_gemm_chain(ChainArgs a) {
         cplx acc[MV];
 #pragma unroll
         for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
-        cplx fin[SPL];
-        if (CONJT) {
 #pragma unroll
-            for (int e = 0; e < EL; ++e) {
-                const int r = (4 * e + wv) * RPI + h;
+        for (int e = 0; e < EL; ++e) {
+            const int r = (4 * e + wv) * RPI + h;
 #pragma unroll
-                for (int jv = 0; jv < MV; ++jv) cfma_conj(acc[jv], ku[e], y[cur][r * MV + jv]);
-            }
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) part[((wv * RPI + h) * N + i) * MV + jv] = acc[jv];   // 4*RPI partial rows per column
-            lds_barrier();
-#pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) {
-                const int jv = slot(sl);
-                cplx t = part[i * MV + jv];
-#pragma unroll
-                for (int w = 1; w < 4 * RPI; ++w) t = cadd(t, part[(w * N + i) * MV + jv]);
-                fin[sl] = t;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < EL; ++e) {
-#pragma unroll
-                for (int jv = 0; jv < MV; ++jv) cfma(acc[jv], ku[e], y[cur][(LPR * e + q) * MV + jv]);
-            }
-            chain_butterfly<MV, LPR / 2, SPL, MV>(acc, q);
-#pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) fin[sl] = acc[sl];
+            for (int jv = 0; jv < MV; ++jv) cfma_conj(acc[jv], ku[e], y[cur][r * MV + jv]);
         }
 #pragma unroll
+        for (int jv = 0; jv < MV; ++jv) part[((wv * RPI + h) * N + i) * MV + jv] = acc[jv];   // 4*RPI partial rows per column
+        lds_barrier();
+#pragma unroll
         for (int sl = 0; sl < SPL; ++sl) {
-            fin[sl] = cadd(fin[sl], eu[sl]);
-            y[cur ^ 1][i * MV + slot(sl)] = fin[sl];
-            yfin[sl] = fin[sl];
+            const int jv = slot(sl);
+            cplx t = part[i * MV + jv];
+#pragma unroll
+            for (int w = 1; w < 4 * RPI; ++w) t = cadd(t, part[(w * N + i) * MV + jv]);
+            yfin[sl] = cadd(t, eu[sl]);
+            y[cur ^ 1][i * MV + jv] = yfin[sl];
         }
         if (HAS_OUT) {
             cplx* oj = Op + (long long)j * a.sOs;
 #pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = fin[sl];
+            for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = yfin[sl];
         }
         lds_barrier();
         cur ^= 1;
@@ -742,7 +719,7 @@ struct RowMap {
 template <int N, int MV> struct FwdMap { using type = BlockMap<N, MV>; };
 template <int MV> struct FwdMap<32, MV> { using type = RowMap<32, MV>; };
 
-// y <- K_j y + E_j, forward direction (the CONJT = false role of k_gemm_chain) with the mapping FwdMap picks for N
+// y <- K_j y + E_j (forward chains) with the mapping FwdMap picks for N; same pipeline as k_gemm_chain_adj
 template <int N, int MV, bool HAS_OUT>
 __global__ void __launch_bounds__(256) k_gemm_chain_fwd(ChainArgs a) {
     using BM = typename FwdMap<N, MV>::type;
@@ -928,13 +905,13 @@ static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros
     if (N == 32) qoc_taylor_chain_launch_n<32>(a, blocks, s); else qoc_taylor_chain_launch_n<64>(a, blocks, s);
 }
 
-template <int N, bool CONJT, bool HAS_OUT>
-static inline void qoc_chain_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
+template <int N, bool HAS_OUT>
+static inline void qoc_chain_adj_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
     const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain<N, 1, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain<N, 2, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain<N, 4, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_chain<N, 8, CONJT, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_adj<N, 1, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_adj<N, 2, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_adj<N, 4, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_chain_adj<N, 8, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
 }
 template <int N, bool HAS_OUT>
 static inline void qoc_chain_fwd_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
@@ -946,7 +923,7 @@ static inline void qoc_chain_fwd_launch_n(const ChainArgs& a, int blocks, hipStr
 }
 template <int N>
 static inline void qoc_chain_launch_c(bool conjt, const ChainArgs& a, int blocks, hipStream_t s) {
-    if (conjt) { if (a.Out) qoc_chain_launch_n<N, true, true>(a, blocks, s); else qoc_chain_launch_n<N, true, false>(a, blocks, s); }
+    if (conjt) { if (a.Out) qoc_chain_adj_launch_n<N, true>(a, blocks, s); else qoc_chain_adj_launch_n<N, false>(a, blocks, s); }
     else { if (a.Out) qoc_chain_fwd_launch_n<N, true>(a, blocks, s); else qoc_chain_fwd_launch_n<N, false>(a, blocks, s); }
 }
 // `zeros` = a zero thin buffer (N x 32) used as the addend when the chain has none
