@@ -355,6 +355,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, gemm_direct, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
+        qoc_gemm_lds_opt_in();
         e->chunks = e->gm.NC;
     } else if (!cfg->state_transfer) {
         ALLOC(e->K, (size_t)B * steps * nn);

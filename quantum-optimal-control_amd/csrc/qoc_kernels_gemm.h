@@ -1036,11 +1036,16 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
 template <bool CONJT, int EPI, int SK>
 static inline void qoc_gemm_launch_sk(const GemmArgs& g, unsigned blocks, hipStream_t s) {
     const size_t lds = SK > 1 ? (size_t)(SK - 1) * 2048 * sizeof(double) : 0;
-    if (SK > 2) {
-        static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k_zgemm32<CONJT, EPI, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-    }
     hipLaunchKernelGGL((k_zgemm32<CONJT, EPI, SK>), dim3(blocks), dim3(64 * SK), lds, s, g);
+}
+// Kernels that use more than 64 KB of dynamic LDS must opt in, per device: called from qoc_gemm_setup (one engine = one device)
+template <bool CONJT, int EPI>
+static inline void qoc_gemm_lds_opt_in_sk() {
+    hipFuncSetAttribute((const void*)k_zgemm32<CONJT, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2048 * (int)sizeof(double));
+}
+static inline void qoc_gemm_lds_opt_in() {
+    qoc_gemm_lds_opt_in_sk<false, 0>(); qoc_gemm_lds_opt_in_sk<false, 1>(); qoc_gemm_lds_opt_in_sk<false, 2>(); qoc_gemm_lds_opt_in_sk<true, 0>();
+    hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx));
 }
 // picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small
 static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
@@ -1106,11 +1111,6 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         ExpmCoef cf;
         { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
         const size_t lds = 2 * (size_t)N * (N + 1) * sizeof(cplx);
-        static bool lds_opt_in = false;                          // 133 KB of dynamic LDS at N = 64 (default limit: 64 KB)
-        if (!lds_opt_in) {
-            hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx));
-            lds_opt_in = true;
-        }
         if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K, gm.SP, deg, nsq, cf);
         else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K, gm.SP, deg, nsq, cf);
         qoc_gemm_tree(gm, d, s);
