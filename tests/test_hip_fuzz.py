@@ -1,0 +1,81 @@
+"""Randomised differential test: random small problems (mode, sizes, Taylor order, regularisers, seed count) evaluated
+by every engine path that accepts them, each compared with the NumPy oracle.  Seeds are fixed, so a failure reproduces.
+Sizes stay small enough for the oracle to take milliseconds; the structured full-size checks live in test_hip_parity.py."""
+import numpy as np
+import pytest
+
+from tests.golden import cases
+from tests.helpers import oracle_system
+from tests.test_hip_parity import check_eval, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def random_problem(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    st = bool(rng.integers(0, 2))
+    n = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 40, 47, 48, 63, 64, 65, 70]))
+    k = int(rng.integers(1, 4))
+    steps = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 31, 33, 64, 65, 100, 130]))
+    if n > 40:
+        steps = min(steps, 33)                                    # keep the oracle fast
+    T = int(rng.integers(1, 9))
+    s = 0 if st else int(rng.integers(0, 4))
+    if st:
+        m = int(rng.integers(1, min(n, 9) + 1))
+        c = cases.case_c3(n=max(n, 2), k=k, steps=steps, taylor=(T, 0), seed=seed)
+        n = max(n, 2)
+        vs = [rng.normal(size=n) + 1j * rng.normal(size=n) for _ in range(2 * m)]
+        c['states_concerned_list'] = [v / np.linalg.norm(v) for v in vs[:m]]
+        c['U'] = [v / np.linalg.norm(v) for v in vs[m:]]
+        c['reg_coeffs'] = {}
+    else:
+        m = int(rng.integers(1, min(n, 12) + 1))
+        c = cases.case_c2(n=n, k=k, steps=steps, m=m, taylor=(T, s), seed=seed)
+    c['total_time'] = float(rng.uniform(0.2, 0.8)) * steps / 20.0          # |A_t| <= ~0.5: low Taylor orders stay bounded
+    reg = {}
+    if rng.random() < 0.4:
+        reg['amplitude'] = float(rng.uniform(0.05, 0.5))
+    if rng.random() < 0.4:
+        reg['dwdt'] = float(rng.uniform(0.01, 0.2))
+        if rng.random() < 0.5:
+            reg['d2wdt2'] = float(rng.uniform(0.01, 0.1))
+    if rng.random() < 0.3:
+        reg['envelope'] = float(rng.uniform(0.05, 0.3))
+    if rng.random() < 0.4 and n >= 3:
+        f = rng.choice(n, size=min(2, n - 1), replace=False)
+        reg['forbidden_coeff_list'] = [float(x) for x in rng.uniform(1, 5, size=len(f))]
+        reg['states_forbidden_list'] = [int(x) for x in f]
+    if rng.random() < 0.3:
+        reg['speed_up'] = float(rng.uniform(0.1, 0.8))
+    c['reg_coeffs'] = reg
+    B = int(rng.choice([1, 2, 3]))
+    return c, B, rng
+
+
+@pytest.mark.parametrize('seed', range(128))
+def test_random_problem_all_paths(seed):
+    from quantum_optimal_control.core import hip_engine
+    c, B, rng = random_problem(seed)
+    sp = oracle_system(c)
+    import oracle.grape_oracle as go
+    if not np.isfinite(go.evaluate(sp, sp.base0)['unitary_scale']) or abs(go.evaluate(sp, sp.base0)['unitary_scale']) > 1e6:
+        pytest.skip('ill-conditioned draw: the truncated series blows up, relative parity is meaningless')
+    bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 * (i + 1) for i in range(B - 1)]
+    tried = 0
+    for path, chunks in ((0, 0), (1, 0), (2, 0), (2, 3), (3, 0), (4, 0), (4, 1), (4, 2)):
+        try:
+            eng = make_engine(sp, n_seeds=B, path=path, chunks=chunks)
+        except hip_engine.QocError:
+            continue                                               # this path does not take this problem
+        try:
+            eng.set_base(np.stack(bases))
+            check_eval(eng, sp, bases)
+            tried += 1
+        except AssertionError as exc:
+            raise AssertionError('seed %d path %d chunks %d (n=%d k=%d steps=%d m=%d T=%d s=%d st=%s regs=%s): %s' % (
+                seed, path, chunks, sp.n, sp.k, sp.steps, sp.m, sp.exp_terms, sp.scaling, sp.state_transfer,
+                sorted(sp.reg_coeffs), exc))
+        finally:
+            eng.close()
+    assert tried >= 2                                              # AUTO + generic at the very least
