@@ -34,7 +34,7 @@ struct GemmArgs {
     const cplx* L; long long sL; int ldl;
     double* partial; int partial_stride;       // partial[(batch*partial_stride) + offset + tile_m]
     int partial_offset;
-    int inner; long long sA2, sB2, sC2;        // inner > 0: batch index bt -> (bt / inner, bt % inner); A, Bm, C offsets = hi*s?2 + lo*s?
+    int inner; long long sA2, sB2, sC2, sL2;   // inner > 0: batch index bt -> (bt / inner, bt % inner); A, Bm, C, L offsets = hi*s?2 + lo*s?
     int ldp;                                   // EPI = 2: per-COLUMN dots, partial[batch*stride + offset + tile_m*ldp + col]
 };
 
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = r0 + 16 * I + lk + 4 * r, col = c0 + 16 * J + lr;
-                    const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
+                    const cplx l = g.L[(size_t)bhi * g.sL2 + (size_t)blo * g.sL + (size_t)row * g.ldl + col];
                     pc = fma(l.x, re[I][J][r], pc); pc = fma(l.y, im[I][J][r], pc);
                 }
             pc += __shfl_xor(pc, 16, 64);
@@ -441,7 +441,51 @@ __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(Qo
     };
     const int mm = deg >> 1;
     const bool even = (deg & 1) == 0;
-    if (deg >= 2) {
+    if (deg >= 6) {
+        // Paterson-Stockmeyer with cubes: P = B_0 + A3 (B_1 + A3 (B_2 + ...)), B_i = c_{3i} I + c_{3i+1} A + c_{3i+2} A2.
+        // Degree 9 (state transfer, T = 10): A2, A3 + 2 Horner products = 4 instead of 5 with squares; never more.
+        gd4 a2r[2], a2i[2];
+        lds_mm<N>(X, X, I, Jp, lane, re, im);                     // A2 = A*A
+        put(Y);
+#pragma unroll
+        for (int J = 0; J < 2; ++J) { a2r[J] = re[J]; a2i[J] = im[J]; }
+        __syncthreads();
+        lds_mm<N>(Y, X, I, Jp, lane, re, im);                     // A3 = A2*A
+        __syncthreads();                                          // every wave is done reading A (X) and A2 (Y)
+        put(Y);                                                   // Y = A3 from here on
+        auto coef = [&](int j) { return j <= deg ? cf.c[j] : 0.0; };
+        auto add_blk = [&](int i) {                               // re/im += B_i
+            const double c0 = coef(3 * i), c1 = coef(3 * i + 1), c2 = coef(3 * i + 2);
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    re[J][r] += fma(c2, a2r[J][r], c1 * ablk[J][r].x) + (drow(r) == dcol(J) ? c0 : 0.0);
+                    im[J][r] += fma(c2, a2i[J][r], c1 * ablk[J][r].y);
+                }
+        };
+        const int nb = deg / 3;
+        int first;
+        if (deg % 3 == 0) {                                       // top block is the scalar c_deg: fold c_deg*A3 into B_{nb-1}
+#pragma unroll
+            for (int J = 0; J < 2; ++J) { re[J] = re[J] * cf.c[deg]; im[J] = im[J] * cf.c[deg]; }
+            add_blk(nb - 1);
+            first = nb - 2;
+        } else {
+#pragma unroll
+            for (int J = 0; J < 2; ++J) { re[J] = (gd4){0, 0, 0, 0}; im[J] = (gd4){0, 0, 0, 0}; }
+            add_blk(nb);
+            first = nb - 1;
+        }
+        put(X);
+        __syncthreads();
+        for (int i = first; i >= 0; --i) {                        // S <- B_i + A3*S
+            lds_mm<N>(Y, X, I, Jp, lane, re, im);
+            add_blk(i);
+            __syncthreads();
+            if (i > 0 || nsq > 0) { put(X); __syncthreads(); }
+        }
+    } else if (deg >= 2) {
         lds_mm<N>(X, X, I, Jp, lane, re, im);                     // A2 = A*A
         __syncthreads();                                          // every wave is done reading A from X
         put(Y);
@@ -1333,14 +1377,14 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         GemmArgs h;
         memset(&h, 0, sizeof h);
         const int tm = N / 32;
-        h.lda = N; h.sA = 0; h.ldb = h.ldl = gm.ldW; h.sB = h.sL = (long long)N * gm.ldW; h.Kdim = N;
-        h.tiles_m = tm; h.tiles_n = gm.ldW / 32; h.batch = d.B; h.Bm = gm.interP; h.L = gm.LamP;
-        h.partial = gm.partial; h.ldp = gm.ldW; h.partial_stride = d.k * tm * gm.ldW;
-        for (int kk = 0; kk < d.k; ++kk) {
-            h.A = gm.HsP + (size_t)(kk + 1) * NN;
-            h.partial_offset = kk * tm * gm.ldW;
-            qoc_gemm_launch(false, 2, h, s);
-        }
+        h.lda = N; h.ldb = h.ldl = gm.ldW; h.Kdim = N;
+        h.tiles_m = tm; h.tiles_n = gm.ldW / 32; h.Bm = gm.interP; h.L = gm.LamP;
+        h.partial = gm.partial; h.ldp = gm.ldW; h.partial_stride = tm * gm.ldW;         // partial[b][k][tile_m][column]
+        // one launch for all (seed, control) pairs: batch index bt = b*k + kk -> A = H'_{kk+1}, Bm / L = buffers of seed b
+        h.A = gm.HsP + NN; h.inner = d.k; h.sA = (long long)NN; h.sA2 = 0;
+        h.sB = h.sL = 0; h.sB2 = h.sL2 = (long long)N * gm.ldW;
+        h.batch = d.B * d.k;
+        qoc_gemm_launch(false, 2, h, s);
         hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, tm, gm.ldW, gm.MV);
         return;
     }
