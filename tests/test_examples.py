@@ -1,0 +1,26 @@
+"""The example scripts run end to end on the GPU and reach a sensible fidelity in a short budget."""
+import contextlib
+import io
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'examples'))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_qubit_pi_pulse_example():
+    import qubit_pi_pulse
+    with contextlib.redirect_stdout(io.StringIO()):
+        f = qubit_pi_pulse.main(iterations=150, quiet=True)
+    assert f > 0.99
+
+
+def test_transmon_state_transfer_example():
+    import transmon_state_transfer
+    with contextlib.redirect_stdout(io.StringIO()):
+        f = transmon_state_transfer.main(iterations=200, restarts=4, quiet=True)
+    assert f > 0.9
