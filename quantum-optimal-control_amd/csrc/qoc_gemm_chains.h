@@ -1,0 +1,458 @@
+// qoc_gemm_chains.h -- persistent thin-chain kernels of the GEMM path (N <= 64, m <= 8): k_gemm_chain_fwd (y <- K y + E),
+// k_gemm_chain_adj (y <- K^H y + E) and k_gemm_taylor_chain (state-transfer Taylor recursion), with their lane mappings.
+// Reference semantics: core/tensorflow_state.py:214-242 (chains), :77-133 (matvecexp forward / custom gradient).
+#pragma once
+#include "qoc_gemm_tiles.h"
+
+// ---- persistent thin chains (N <= 64, m <= 8) ---------------------------------------------------------------------
+// y <- op(K_j) y + E_j for `len` consecutive matrices, one workgroup per chain, y in LDS.  Launch-per-step chains cost
+// ~5 us of launch latency per step; here a step costs N*N*m complex MACs on the VALU (fp64 FMA rate ~ MFMA rate on
+// gfx950, and no padding of m to an MFMA tile) with K_j fetched two steps ahead into registers.
+// The steady-state loop is one basic block (unconditional clamped prefetch, E always loaded -- from a zero buffer when
+// there is no addend --, every finished value has exactly one owner lane): with conditional loads or stores in the loop hipcc's
+// s_waitcnt placement has to assume the worst path and waits for the loads it has just issued.
+struct ChainArgs {
+    const cplx* K; long long sKb, sKc, sKs;     // matrix of step j: K + b*sKb + c*sKc + j*sKs  (elements; sKs may be negative)
+    const cplx* X0; long long sXb, sXc;         // initial thin vectors (nullptr = zeros)
+    const cplx* E; long long sEb, sEc, sEs;     // addend per step (a zero buffer with zero strides when there is none)
+    cplx* Out; long long sOb, sOc, sOs; int ldO; // output per step (HAS_OUT): Out + b*sOb + c*sOc + j*sOs + row*ldO + jv
+    cplx* Fin; long long sFb, sFc;              // optional final state
+    int CI;                                     // chains per seed (blockIdx.x = b*CI + c)
+    int len, m;
+    int store_initial;                          // also store y0 at Out - sOs
+    int nterms; double sign;                    // k_gemm_taylor_chain: y <- sum_{j<nterms} (sign*K)^j y / j!  (+ E)
+};
+
+// v from lane (l ^ OFF), OFF in {1, 2, 4, 8}, as DPP moves on the VALU (quad_perm; xor 4 = row_half_mirror then quad_perm
+// [3,2,1,0]; xor 8 = row_ror:8) instead of ds_bpermute round trips through the LDS crossbar: the chain step is a dependent sequence, and
+// three crossbar latencies per step were a tenth of it.
+template <int OFF>
+__device__ __forceinline__ double dpp_xor(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (OFF == 1) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
+    } else if constexpr (OFF == 2) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, true);
+    } else if constexpr (OFF == 4) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, true);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x1B, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x1B, 0xF, 0xF, true);
+    } else {
+        static_assert(OFF == 8, "dpp_xor: lane distance 1, 2, 4 or 8");
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, true);   // row_ror:8
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for the K/E prefetch of
+// two steps ahead (and the output stores) at every step of a chain; the chains exchange data through LDS alone, and hipcc
+// still places the vmcnt wait for each prefetched register stage before its first use.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Butterfly over the LPR lanes that share a result row (forward chain mapping).  While more than SPL values are alive the
+// halves are exchanged (reduce-scatter: the lane with the bit set keeps the upper half), afterwards plain xor all-reduce.
+// Compile-time recursion keeps every register index static.
+template <int ALIVE, int OFF, int SPL, int MVT>
+__device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
+    if constexpr (OFF >= 1) {
+        if constexpr (ALIVE > SPL) {
+            constexpr int half = ALIVE / 2;
+            const bool up = (q & OFF) != 0;
+#pragma unroll
+            for (int x = 0; x < half; ++x) {
+                const cplx send = up ? acc[x] : acc[x + half];
+                const cplx keep = up ? acc[x + half] : acc[x];
+                acc[x].x = keep.x + dpp_xor<OFF>(send.x);
+                acc[x].y = keep.y + dpp_xor<OFF>(send.y);
+            }
+            chain_butterfly<half, OFF / 2, SPL, MVT>(acc, q);
+        } else {
+#pragma unroll
+            for (int x = 0; x < SPL; ++x) {
+                acc[x].x += dpp_xor<OFF>(acc[x].x);
+                acc[x].y += dpp_xor<OFF>(acc[x].y);
+            }
+            chain_butterfly<ALIVE, OFF / 2, SPL, MVT>(acc, q);
+        }
+    }
+}
+
+// y <- K_j^H y + E_j (backward chains).  Lane <-> column i of K, so that a wave reads whole rows (the 4 lanes of a quad must
+// stay on 64 contiguous bytes: the texture-address unit serialises a quad that touches 4 cache lines, and a transposed read
+// with a row-per-thread mapping was 2x slower per step); wave w owns rows (4e + w)*RPI + h, RPI = 64/N; x[r] is a broadcast
+// LDS read; the 4*RPI partial rows meet in LDS (one extra barrier per step) and thread (w, h, i) finishes -- adds the
+// source, writes LDS, stores -- the slots jv = sg + s*NSL, sg = (w*RPI + h) % NSL, NSL = min(MV, 4*RPI).
+template <int N, int MV, bool HAS_OUT>
+__global__ void __launch_bounds__(256) k_gemm_chain_adj(ChainArgs a) {
+    constexpr int EL = N * N / 256, RPI = 64 / N;
+    constexpr int NSL = MV < 4 * RPI ? MV : 4 * RPI;
+    constexpr int SPL = MV / NSL;
+    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
+    __shared__ __attribute__((aligned(16))) cplx part[4 * RPI * N * MV];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int i = lane % N, h = lane / N;
+    const int sg = (wv * RPI + h) % NSL;
+    auto slot = [&](int s) { return sg + s * NSL; };
+    const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
+    const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
+    const cplx* Ep = a.E + b * a.sEb + c * a.sEc + (size_t)i * QOC_TW;
+    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc + (size_t)i * a.ldO : nullptr;
+    cplx yfin[SPL];
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
+    if (a.X0) {
+        const cplx* x = a.X0 + b * a.sXb + c * a.sXc + (size_t)i * QOC_TW;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[slot(sl)];
+    }
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) y[0][i * MV + slot(sl)] = yfin[sl];
+    if (HAS_OUT && a.store_initial) {
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[slot(sl)] = yfin[sl];
+    }
+    const int last = a.len - 1;
+    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
+        const int jc = min(j, last);
+        const cplx* Kj = Kp + (long long)jc * a.sKs;
+#pragma unroll
+        for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)((4 * e + wv) * RPI + h) * N + i];
+        const cplx* ej = Ep + (long long)jc * a.sEs;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[slot(sl)];
+    };
+    int cur = 0;
+    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
+        cplx acc[MV];
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
+#pragma unroll
+        for (int e = 0; e < EL; ++e) {
+            const int r = (4 * e + wv) * RPI + h;
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) cfma_conj(acc[jv], ku[e], y[cur][r * MV + jv]);
+        }
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) part[((wv * RPI + h) * N + i) * MV + jv] = acc[jv];   // 4*RPI partial rows per column
+        lds_barrier();
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) {
+            const int jv = slot(sl);
+            cplx t = part[i * MV + jv];
+#pragma unroll
+            for (int w = 1; w < 4 * RPI; ++w) t = cadd(t, part[(w * N + i) * MV + jv]);
+            yfin[sl] = cadd(t, eu[sl]);
+            y[cur ^ 1][i * MV + jv] = yfin[sl];
+        }
+        if (HAS_OUT) {
+            cplx* oj = Op + (long long)j * a.sOs;
+#pragma unroll
+            for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = yfin[sl];
+        }
+        lds_barrier();
+        cur ^= 1;
+    };
+    if (a.len > 0) {
+        // three register stages used round-robin by a 3x unrolled loop (rotating them with copies would make every
+        // iteration wait for the newest load)
+        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
+        load(k0, e0, 0);
+        load(k1, e1, 1);
+        lds_barrier();
+        int j = 0;
+        for (; j + 3 <= a.len; j += 3) {
+            load(k2, e2, j + 2); step(j, k0, e0);
+            load(k0, e0, j + 3); step(j + 1, k1, e1);
+            load(k1, e1, j + 4); step(j + 2, k2, e2);
+        }
+        if (j < a.len) step(j, k0, e0);
+        if (j + 1 < a.len) step(j + 1, k1, e1);
+    } else {
+        lds_barrier();
+    }
+    if (a.Fin) {
+        cplx* f = a.Fin + b * a.sFb + c * a.sFc + (size_t)i * QOC_TW;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) f[slot(sl)] = yfin[sl];
+    }
+}
+
+// ---- register-blocked forward mat-vec mapping (k_gemm_chain_fwd, k_gemm_taylor_chain) ---------------------------------
+// Thread (g, c) = (tid / 16, tid % 16) owns the R x R block rows R*g + rr, columns c + 16*cc of K (R = N/16): a 16-lane DPP
+// row reads 256 contiguous bytes per load, a thread reads only R entries of the vector per slot (the row-per-thread mapping
+// re-read 16 at N = 64: 64 KB of LDS traffic per mat-vec, which bound the step) and the R*MV partial sums are combined by a
+// reduce-scatter butterfly over the 16 lanes (DPP), after which lane c holds the finished values x = base + s, s < SPLB,
+// of its row group in (row, slot)-major order; addend, LDS write and output store are done by the owner of each value.
+template <int N, int MV>
+struct BlockMap {
+    static constexpr int R = N / 16, EL = R * R, V = R * MV;
+    static constexpr int NSLB = V < 16 ? V : 16, SPLB = V / NSLB;
+    int g, c, base;
+    __device__ __forceinline__ BlockMap(int tid) : g(tid >> 4), c(tid & 15), base(((tid & 15) / (16 / NSLB)) * SPLB) {}
+    __device__ __forceinline__ int row(int s) const { return R * g + (base + s) / MV; }
+    __device__ __forceinline__ int slot(int s) const { return (base + s) % MV; }
+    __device__ __forceinline__ void load(cplx (&kd)[EL], const cplx* Kj) const {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < R; ++cc) kd[rr * R + cc] = Kj[(size_t)(R * g + rr) * N + c + 16 * cc];
+    }
+    // acc[rr*MV + jv] = sum_cc K[rr][cc] * v[c + 16 cc][jv], then the 16-lane reduce-scatter: acc[0..SPLB) are this lane's values
+    __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
+#pragma unroll
+        for (int x = 0; x < V; ++x) acc[x] = cmake(0.0, 0.0);
+#pragma unroll
+        for (int cc = 0; cc < R; ++cc) {
+            cplx vv[MV];
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) vv[jv] = v[(c + 16 * cc) * MV + jv];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int jv = 0; jv < MV; ++jv) cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]);
+        }
+        chain_butterfly<V, 8, SPLB, V>(acc, c);
+    }
+};
+
+// Row-per-thread mapping with the same interface: thread (i, q) owns row i and the columns LPR*e + q.  Faster than the
+// blocked mapping at N = 32 (4 vector reads per slot either way, a 3-level butterfly instead of 4); measured per 1000-slice
+// direct iteration: N = 32: 4.65 (row) vs 4.81 ms (blocked); N = 64: 13.0 (row) vs 10.0 ms (blocked).
+template <int N, int MV>
+struct RowMap {
+    static constexpr int LPR = 256 / N, EL = N / LPR, V = MV;
+    static constexpr int NSLB = MV < LPR ? MV : LPR, SPLB = MV / NSLB;
+    int i, q, base;
+    __device__ __forceinline__ RowMap(int tid) : i(tid / LPR), q(tid % LPR), base(((tid % LPR) / (LPR / NSLB)) * SPLB) {}
+    __device__ __forceinline__ int row(int) const { return i; }
+    __device__ __forceinline__ int slot(int s) const { return base + s; }
+    __device__ __forceinline__ void load(cplx (&kd)[EL], const cplx* Kj) const {
+#pragma unroll
+        for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)i * N + LPR * e + q];
+    }
+    __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
+#pragma unroll
+        for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+            for (int jv = 0; jv < MV; ++jv) cfma(acc[jv], ku[e], v[(LPR * e + q) * MV + jv]);
+        chain_butterfly<MV, LPR / 2, SPLB, MV>(acc, q);
+    }
+};
+template <int N, int MV> struct FwdMap { using type = BlockMap<N, MV>; };
+template <int MV> struct FwdMap<32, MV> { using type = RowMap<32, MV>; };
+
+// y <- K_j y + E_j (forward chains) with the mapping FwdMap picks for N; same pipeline as k_gemm_chain_adj
+template <int N, int MV, bool HAS_OUT>
+__global__ void __launch_bounds__(256) k_gemm_chain_fwd(ChainArgs a) {
+    using BM = typename FwdMap<N, MV>::type;
+    constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
+    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
+    const BM bm(threadIdx.x);
+    const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
+    const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
+    const cplx* Ep = a.E + b * a.sEb + c * a.sEc;
+    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc : nullptr;
+    int thin_off[SPL], out_off[SPL], lds_off[SPL];
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) {
+        thin_off[sl] = bm.row(sl) * QOC_TW + bm.slot(sl);
+        out_off[sl] = bm.row(sl) * a.ldO + bm.slot(sl);
+        lds_off[sl] = bm.row(sl) * MV + bm.slot(sl);
+    }
+    cplx yfin[SPL];
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
+    if (a.X0) {
+        const cplx* x = a.X0 + b * a.sXb + c * a.sXc;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[thin_off[sl]];
+    }
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) y[0][lds_off[sl]] = yfin[sl];
+    if (HAS_OUT && a.store_initial) {
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[out_off[sl]] = yfin[sl];
+    }
+    const int last = a.len - 1;
+    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
+        const int jc = min(j, last);
+        bm.load(kd, Kp + (long long)jc * a.sKs);
+        const cplx* ej = Ep + (long long)jc * a.sEs;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[thin_off[sl]];
+    };
+    int cur = 0;
+    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
+        cplx acc[V];
+        bm.matvec(ku, y[cur], acc);
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) {
+            yfin[sl] = cadd(acc[sl], eu[sl]);
+            y[cur ^ 1][lds_off[sl]] = yfin[sl];
+        }
+        if (HAS_OUT) {
+            cplx* oj = Op + (long long)j * a.sOs;
+#pragma unroll
+            for (int sl = 0; sl < SPL; ++sl) oj[out_off[sl]] = yfin[sl];
+        }
+        lds_barrier();
+        cur ^= 1;
+    };
+    if (a.len > 0) {
+        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
+        load(k0, e0, 0);
+        load(k1, e1, 1);
+        lds_barrier();
+        int j = 0;
+        for (; j + 3 <= a.len; j += 3) {
+            load(k2, e2, j + 2); step(j, k0, e0);
+            load(k0, e0, j + 3); step(j + 1, k1, e1);
+            load(k1, e1, j + 4); step(j + 2, k2, e2);
+        }
+        if (j < a.len) step(j, k0, e0);
+        if (j + 1 < a.len) step(j + 1, k1, e1);
+    } else {
+        lds_barrier();
+    }
+    if (a.Fin) {
+        cplx* f = a.Fin + b * a.sFb + c * a.sFc;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) f[thin_off[sl]] = yfin[sl];
+    }
+}
+
+// State transfer without propagators: psi <- sum_{j<T} (sign*B_t)^j psi / j! (+ E_t), one workgroup per seed walking all
+// slices (tensorflow_state.py:88-96 forward, :118-131 backward with sign = -1 -- no anti-Hermiticity assumed).  Same mapping
+// and prefetch structure as k_gemm_chain_fwd; a step is T-1 dependent mat-vecs on the register-resident B_t (the
+// generator was assembled for all slices by k_gemm_assemble, so the chain streams 1 matrix per slice instead of k+1).
+template <int N, int MV>
+__global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a) {
+    using BM = typename FwdMap<N, MV>::type;
+    constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
+    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
+    const BM bm(threadIdx.x);
+    const int b = blockIdx.x;
+    const cplx* Kp = a.K + b * a.sKb;
+    const cplx* Ep = a.E + b * a.sEb;
+    cplx* Op = a.Out + b * a.sOb;
+    int thin_off[SPL], out_off[SPL], lds_off[SPL];
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) {
+        thin_off[sl] = bm.row(sl) * QOC_TW + bm.slot(sl);
+        out_off[sl] = bm.row(sl) * a.ldO + bm.slot(sl);
+        lds_off[sl] = bm.row(sl) * MV + bm.slot(sl);
+    }
+    cplx yfin[SPL];
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
+    if (a.X0) {
+        const cplx* x = a.X0 + b * a.sXb;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[thin_off[sl]];
+    }
+#pragma unroll
+    for (int sl = 0; sl < SPL; ++sl) y[0][lds_off[sl]] = yfin[sl];
+    if (a.store_initial) {
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[out_off[sl]] = yfin[sl];
+    }
+    const int last = a.len - 1;
+    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
+        const int jc = min(j, last);
+        bm.load(kd, Kp + (long long)jc * a.sKs);
+        const cplx* ej = Ep + (long long)jc * a.sEs;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[thin_off[sl]];
+    };
+    int cur = 0;
+    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
+        cplx out[SPL];
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) out[sl] = yfin[sl];
+        double fact = 1.0;
+        for (int ii = 1; ii < a.nterms; ++ii) {
+            cplx acc[V];
+            bm.matvec(ku, y[cur], acc);
+            fact *= (double)ii;
+            const double inv = 1.0 / fact;
+            const bool lastterm = ii + 1 == a.nterms;
+#pragma unroll
+            for (int sl = 0; sl < SPL; ++sl) {
+                const cplx w = cscale(acc[sl], a.sign);                       // psi_n = (sign*B) psi_n            :94 / :130
+                out[sl].x = fma(w.x, inv, out[sl].x); out[sl].y = fma(w.y, inv, out[sl].y);   // += psi_n / factorial   :95 / :131
+                // the last term is needed by nobody else: the buffer takes the new state (+ addend) instead
+                y[cur ^ 1][lds_off[sl]] = lastterm ? cadd(out[sl], eu[sl]) : w;
+            }
+            lds_barrier();
+            cur ^= 1;
+        }
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cadd(out[sl], eu[sl]);
+        if (a.nterms <= 1) {                                                   // T = 1: psi unchanged (+ addend)
+#pragma unroll
+            for (int sl = 0; sl < SPL; ++sl) y[cur ^ 1][lds_off[sl]] = yfin[sl];
+            lds_barrier();
+            cur ^= 1;
+        }
+        cplx* oj = Op + (long long)j * a.sOs;
+#pragma unroll
+        for (int sl = 0; sl < SPL; ++sl) oj[out_off[sl]] = yfin[sl];
+    };
+    if (a.len > 0) {
+        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
+        load(k0, e0, 0);
+        load(k1, e1, 1);
+        lds_barrier();
+        int j = 0;
+        for (; j + 3 <= a.len; j += 3) {
+            load(k2, e2, j + 2); step(j, k0, e0);
+            load(k0, e0, j + 3); step(j + 1, k1, e1);
+            load(k1, e1, j + 4); step(j + 2, k2, e2);
+        }
+        if (j < a.len) step(j, k0, e0);
+        if (j + 1 < a.len) step(j + 1, k1, e1);
+    }
+}
+
+template <int N>
+static inline void qoc_taylor_chain_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
+    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(256), 0, s, a);
+}
+static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
+    if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
+    if (N == 32) qoc_taylor_chain_launch_n<32>(a, blocks, s); else qoc_taylor_chain_launch_n<64>(a, blocks, s);
+}
+
+template <int N, bool HAS_OUT>
+static inline void qoc_chain_adj_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
+    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_adj<N, 1, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_adj<N, 2, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_adj<N, 4, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_chain_adj<N, 8, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+}
+template <int N, bool HAS_OUT>
+static inline void qoc_chain_fwd_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
+    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 1, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 2, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 4, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_chain_fwd<N, 8, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+}
+template <int N>
+static inline void qoc_chain_launch_c(bool conjt, const ChainArgs& a, int blocks, hipStream_t s) {
+    if (conjt) { if (a.Out) qoc_chain_adj_launch_n<N, true>(a, blocks, s); else qoc_chain_adj_launch_n<N, false>(a, blocks, s); }
+    else { if (a.Out) qoc_chain_fwd_launch_n<N, true>(a, blocks, s); else qoc_chain_fwd_launch_n<N, false>(a, blocks, s); }
+}
+// `zeros` = a zero thin buffer (N x 32) used as the addend when the chain has none
+static inline void qoc_chain_launch(int N, bool conjt, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
+    if (a.len <= 0 && !a.Fin && !a.store_initial) return;
+    if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
+    if (N == 32) qoc_chain_launch_c<32>(conjt, a, blocks, s); else qoc_chain_launch_c<64>(conjt, a, blocks, s);
+}

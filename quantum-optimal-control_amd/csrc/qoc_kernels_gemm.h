@@ -1,172 +1,23 @@
-// qoc_kernels_gemm.h -- "GEMM path": unitary mode for any n > 32 (and m <= 32), e.g. BASELINE config C5 (n = 512).
+// qoc_kernels_gemm.h -- "GEMM path" (QOC_PATH_GEMM): any n, m <= 32, unitary mode and state transfer.
 //
-// Matrices are zero-padded to N = 32*ceil(n/32) and stay in HBM/L2 as plain row-major complex128; every product is a
-// launch of k_zgemm32: ONE wavefront per 32x32 output tile, v_mfma_f64_16x16x4_f64 with the 3-multiplication complex
-// form (12 MFMAs per 4-deep k-slice, 12 independent accumulator chains), operand fragments loaded straight from
-// global memory in the MFMA A/B lane layouts (B rows are coalesced 256-byte segments; A is a 16-row x 64-byte gather
-// that L1/L2 absorb), no LDS and no barriers.  The host sequences the launches:
-//   * matrix exponentials: batched over ALL (seed, slice) pairs -- Horner form of the Taylor series + squarings;
-//   * forward chain: one launch per slice on the concatenation [X | Psi] (N x (N+32)), i.e. X_t = K_t X_{t-1} and
-//     Psi_t = K_t Psi_{t-1} together;
-//   * backward chain: one launch per slice, Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1} (epilogue adds the sources);
-//   * control gradients: for each control k ONE batched launch over all (seed, slice): the tile of H_k' Psi_t is
-//     contracted with conj(Lambda_t) in the epilogue (deterministic per-tile partial sums, reduced by k_gemm_grad_reduce).
-// Reference semantics: core/tensorflow_state.py:25-46, 49-65, 204-242.
+// Matrices are zero-padded to N = 32*ceil(n/32) and live in HBM/L2 as plain row-major complex128.  Time is cut into NC
+// chunks of S = 2^L ~ sqrt(steps) slices so that every chain has NC + S sequential steps instead of `steps`:
+//   * exponentials for all (seed, slice) pairs: k_gemm_expm_fused (N <= 64, qoc_gemm_expm.h) or batched k_zgemm32 launches
+//     (qoc_gemm_tiles.h) of the Paterson-Stockmeyer polynomial + squarings;
+//   * a pairwise product tree gives the chunk products (and, in unitary mode, final_state at the root);
+//   * forward / backward: chunk boundaries sequentially, then all chunks swept in parallel -- persistent VALU chain
+//     kernels (qoc_gemm_chains.h) for N <= 64, m <= 8, one batched k_zgemm32 launch per step otherwise;
+//   * control gradients: products H_k' [Psi_0 ... Psi_t ...] with a dot-product epilogue against conj(Lambda).
+// State transfer runs either through the same propagators (anti-Hermitian generators) or "direct" (k_gemm_taylor_chain).
+// This file: the small helper kernels and the host-side orchestration (QocGemm, qoc_gemm_setup/expm/forward/backward).
+// Reference semantics: core/tensorflow_state.py:25-46, 49-65, 77-133, 204-261.
 #pragma once
 #include <string>
 #include <vector>
 #include "qoc_common.h"
-
-typedef double gd4 __attribute__((ext_vector_type(4)));
-#define GMFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-#define QOC_TW 32          // thin (vector block) width
-
-struct GemmArgs {
-    const cplx* A; long long sA; int lda;      // left operand  (batch stride in elements; 0 = shared)
-    const cplx* Bm; long long sB; int ldb;     // right operand
-    cplx* C; long long sC; int ldc;            // output
-    const cplx* E; long long sE; int lde;      // optional addend (nullptr = none)
-    double alpha, beta, gamma;                 // C = alpha*op(A)*B + beta*E + gamma*I
-    int Kdim;                                  // inner dimension (multiple of 4)
-    int tiles_m, tiles_n;                      // output tiles per matrix
-    int batch;
-    // dot epilogue (EPI = 1): partial[batch][tile_m] = Re sum conj(L)*(A*B) over the tile
-    const cplx* L; long long sL; int ldl;
-    double* partial; int partial_stride;       // partial[(batch*partial_stride) + offset + tile_m]
-    int partial_offset;
-    int inner; long long sA2, sB2, sC2, sL2;   // inner > 0: batch index bt -> (bt / inner, bt % inner); A, Bm, C, L offsets = hi*s?2 + lo*s?
-    int ldp;                                   // EPI = 2: per-COLUMN dots, partial[batch*stride + offset + tile_m*ldp + col]
-};
-
-// SK wavefronts of a workgroup split the inner dimension of ONE tile (small-batch chain launches are latency-bound when
-// a single wave walks all of K); partial (re, im) tiles meet in LDS (16 KB per extra wave), wave 0 runs the epilogue.
-template <bool CONJT, int EPI, int SK>
-__global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) double sk_part[];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles = g.tiles_m * g.tiles_n;
-    const int bt = blockIdx.x / tiles, tile = blockIdx.x - bt * tiles;
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-    const int r0 = tm * 32, c0 = tn * 32;
-    const int bhi = g.inner > 0 ? bt / g.inner : 0, blo = g.inner > 0 ? bt - bhi * g.inner : bt;
-    const cplx* __restrict__ A = g.A + (size_t)bhi * g.sA2 + (size_t)blo * g.sA;
-    const cplx* __restrict__ Bm = g.Bm + (size_t)bhi * g.sB2 + (size_t)blo * g.sB;
-    gd4 t1[2][2], t2[2][2], t3[2][2];
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-        for (int J = 0; J < 2; ++J) { t1[I][J] = (gd4){0, 0, 0, 0}; t2[I][J] = (gd4){0, 0, 0, 0}; t3[I][J] = (gd4){0, 0, 0, 0}; }
-    const int lr = lane & 15, lk = lane >> 4;
-    const int kspan = g.Kdim / SK;
-    for (int k0 = wv * kspan; k0 < (wv + 1) * kspan; k0 += 8) {     // two k-slices per trip: 8 loads in flight
-        cplx a[2][2], b[2][2];
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const int kk = k0 + 4 * qq + lk;
-#pragma unroll
-            for (int I = 0; I < 2; ++I) {
-                if (CONJT) a[qq][I] = A[(size_t)kk * g.lda + r0 + 16 * I + lr];
-                else a[qq][I] = A[(size_t)(r0 + 16 * I + lr) * g.lda + kk];
-            }
-#pragma unroll
-            for (int J = 0; J < 2; ++J) b[qq][J] = Bm[(size_t)kk * g.ldb + c0 + 16 * J + lr];
-        }
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-            for (int I = 0; I < 2; ++I) {
-                const double ar = a[qq][I].x, ai = CONJT ? -a[qq][I].y : a[qq][I].y, as = ar + ai;
-#pragma unroll
-                for (int J = 0; J < 2; ++J) {
-                    const double br = b[qq][J].x, bi = b[qq][J].y;
-                    t1[I][J] = GMFMA(ar, br, t1[I][J]);
-                    t2[I][J] = GMFMA(ai, bi, t2[I][J]);
-                    t3[I][J] = GMFMA(as, br + bi, t3[I][J]);
-                }
-            }
-    }
-    // combine the 3-multiplication accumulators (linear, so partial K ranges simply add)
-    gd4 re[2][2], im[2][2];
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-        for (int J = 0; J < 2; ++J) { re[I][J] = t1[I][J] - t2[I][J]; im[I][J] = t3[I][J] - t1[I][J] - t2[I][J]; }
-    if (SK > 1) {
-        if (wv > 0) {
-            double* dst = sk_part + (size_t)(wv - 1) * 2048 + lane;             // [32 values][64 lanes]
-#pragma unroll
-            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                for (int J = 0; J < 2; ++J)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dst[(((I * 2 + J) * 4 + r) * 2 + 0) * 64] = re[I][J][r];
-                        dst[(((I * 2 + J) * 4 + r) * 2 + 1) * 64] = im[I][J][r];
-                    }
-        }
-        __syncthreads();
-        if (wv > 0) return;
-#pragma unroll
-        for (int w = 1; w < SK; ++w) {
-            const double* src = sk_part + (size_t)(w - 1) * 2048 + lane;
-#pragma unroll
-            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                for (int J = 0; J < 2; ++J)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        re[I][J][r] += src[(((I * 2 + J) * 4 + r) * 2 + 0) * 64];
-                        im[I][J][r] += src[(((I * 2 + J) * 4 + r) * 2 + 1) * 64];
-                    }
-        }
-    }
-    // D layout: register r of tile (I, J) <-> (row = r0 + 16I + (lane>>4) + 4r, col = c0 + 16J + (lane&15))
-    double part = 0.0;
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-        for (int J = 0; J < 2; ++J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + 16 * I + lk + 4 * r, col = c0 + 16 * J + lr;
-                const double vre = re[I][J][r], vim = im[I][J][r];
-                if (EPI == 0) {
-                    cplx v = cmake(g.alpha * vre, g.alpha * vim);
-                    if (g.E) {
-                        const cplx e = g.E[(size_t)bt * g.sE + (size_t)row * g.lde + col];
-                        v.x = fma(g.beta, e.x, v.x); v.y = fma(g.beta, e.y, v.y);
-                    }
-                    if (row == col) v.x += g.gamma;
-                    g.C[(size_t)bhi * g.sC2 + (size_t)blo * g.sC + (size_t)row * g.ldc + col] = v;
-                } else if (EPI == 1) {
-                    const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
-                    part = fma(l.x, vre, part); part = fma(l.y, vim, part);      // Re(conj(l) * y)
-                }
-            }
-    if (EPI == 1) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-        if (lane == 0) g.partial[(size_t)bt * g.partial_stride + g.partial_offset + tm] = part;
-    }
-    if (EPI == 2) {                                            // Re sum_rows conj(L[row][col]) * (A*B)[row][col] for every column
-#pragma unroll
-        for (int J = 0; J < 2; ++J) {
-            double pc = 0.0;
-#pragma unroll
-            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = r0 + 16 * I + lk + 4 * r, col = c0 + 16 * J + lr;
-                    const cplx l = g.L[(size_t)bhi * g.sL2 + (size_t)blo * g.sL + (size_t)row * g.ldl + col];
-                    pc = fma(l.x, re[I][J][r], pc); pc = fma(l.y, im[I][J][r], pc);
-                }
-            pc += __shfl_xor(pc, 16, 64);
-            pc += __shfl_xor(pc, 32, 64);
-            if (lk == 0) g.partial[(size_t)bt * g.partial_stride + g.partial_offset + (size_t)tm * g.ldp + c0 + 16 * J + lr] = pc;
-        }
-    }
-}
+#include "qoc_gemm_tiles.h"
+#include "qoc_gemm_expm.h"
+#include "qoc_gemm_chains.h"
 
 // A_t = (H0' + sum_k u_k H_k') / 2^s for every (seed, slice), padded N x N           tensorflow_state.py:30-33
 // Slices are padded to SP = NC*S per seed; a padded slice gets A = 0, i.e. K = I exactly.
@@ -341,640 +192,6 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
         for (int i = 0; i < tiles_m; ++i) s += p[i];
         d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = s;
     }
-}
-
-// ---- fused per-slice exponential for N <= 64 ---------------------------------------------------------------------------
-// One workgroup per (seed, slice): A_t is assembled into LDS, the Paterson-Stockmeyer Taylor polynomial and the squarings
-// run as MFMA products whose operands are read from two LDS-resident matrices (row stride N+1 elements: conflict-free for
-// both the left-operand pattern, 16 rows x 1 column, and the right-operand pattern, 1 row x 16 columns), accumulators and
-// the per-wave block of A stay in registers, and only K_t is written to HBM.  The launch-per-product route streams three
-// B*SP*N*N buffers through HBM per product (7-11 products); this kernel writes one.
-// Wave w owns tile row I = w / (N/32) and the tile-column pair Jp = w % (N/32) (2 tiles of 16x16, sharing the left operand).
-struct ExpmCoef { double c[24]; };
-
-template <int N>
-__device__ __forceinline__ void lds_mm(const cplx* __restrict__ L, const cplx* __restrict__ R, int I, int Jp, int lane,
-                                       gd4 (&re)[2], gd4 (&im)[2]) {
-    constexpr int LD = N + 1;
-    gd4 t1[2], t2[2], t3[2];
-#pragma unroll
-    for (int J = 0; J < 2; ++J) { t1[J] = (gd4){0, 0, 0, 0}; t2[J] = (gd4){0, 0, 0, 0}; t3[J] = (gd4){0, 0, 0, 0}; }
-    const int lr = lane & 15, lk = lane >> 4;
-    const cplx* lp = L + (16 * I + lr) * LD + lk;
-    const cplx* rp = R + lk * LD + 32 * Jp + lr;
-#pragma unroll 4
-    for (int kk = 0; kk < N / 4; ++kk) {
-        const cplx a = lp[4 * kk];
-        const cplx b0 = rp[4 * kk * LD], b1 = rp[4 * kk * LD + 16];
-        const double as = a.x + a.y;
-        t1[0] = GMFMA(a.x, b0.x, t1[0]); t2[0] = GMFMA(a.y, b0.y, t2[0]); t3[0] = GMFMA(as, b0.x + b0.y, t3[0]);
-        t1[1] = GMFMA(a.x, b1.x, t1[1]); t2[1] = GMFMA(a.y, b1.y, t2[1]); t3[1] = GMFMA(as, b1.x + b1.y, t3[1]);
-    }
-#pragma unroll
-    for (int J = 0; J < 2; ++J) { re[J] = t1[J] - t2[J]; im[J] = t3[J] - t1[J] - t2[J]; }
-}
-
-template <int N>
-__global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Kout,
-                                                                               int SP, int deg, int nsq, ExpmCoef cf) {
-    constexpr int LD = N + 1, NT = (N / 16) * (N / 16) * 32, NN = N * N;
-    extern __shared__ __attribute__((aligned(16))) cplx ex_lds[];
-    cplx* X = ex_lds;                   // A, then S / M
-    cplx* Y = ex_lds + N * LD;          // A2
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int I = wv / (N / 32), Jp = wv % (N / 32);
-    const int lr = lane & 15, lk = lane >> 4;
-    const int b = blockIdx.x / SP, t = blockIdx.x - b * SP;
-    cplx* Kt = Kout + (size_t)blockIdx.x * NN;
-    // D-layout coordinates of this lane's 2 x 4 accumulator elements
-    auto drow = [&](int r) { return 16 * I + lk + 4 * r; };
-    auto dcol = [&](int J) { return 32 * Jp + 16 * J + lr; };
-    if (t >= d.steps) {                                           // padded slice: K = I exactly
-#pragma unroll
-        for (int J = 0; J < 2; ++J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Kt[(size_t)drow(r) * N + dcol(J)] = cmake(drow(r) == dcol(J) ? 1.0 : 0.0, 0.0);
-        return;
-    }
-    // ---- A_t = (H0' + sum_k u_k H_k') / 2^s into X                                              tensorflow_state.py:30-33
-    const double inv = 1.0 / (double)(1 << nsq);
-    {
-        constexpr int PER = NN / NT;
-        cplx acc[PER];
-#pragma unroll
-        for (int x = 0; x < PER; ++x) acc[x] = cscale(HsP[tid + NT * x], inv);
-        for (int kk = 0; kk < d.k; ++kk) {
-            const double cu = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv;
-            const cplx* H = HsP + (size_t)(kk + 1) * NN;
-#pragma unroll
-            for (int x = 0; x < PER; ++x) {
-                const cplx hv = H[tid + NT * x];
-                acc[x].x = fma(cu, hv.x, acc[x].x); acc[x].y = fma(cu, hv.y, acc[x].y);
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < PER; ++x) { const int e = tid + NT * x; X[(e / N) * LD + (e % N)] = acc[x]; }
-    }
-    __syncthreads();
-    cplx ablk[2][4];
-#pragma unroll
-    for (int J = 0; J < 2; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ablk[J][r] = X[drow(r) * LD + dcol(J)];
-    gd4 re[2], im[2];
-    auto put = [&](cplx* dst) {
-#pragma unroll
-        for (int J = 0; J < 2; ++J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[drow(r) * LD + dcol(J)] = cmake(re[J][r], im[J][r]);
-    };
-    // re/im <- c0*I + c1*A + (re/im already holding a product, scaled by 1) : the Horner addend in D layout
-    auto add_b = [&](double c0, double c1) {
-#pragma unroll
-        for (int J = 0; J < 2; ++J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                re[J][r] = fma(c1, ablk[J][r].x, re[J][r]) + (drow(r) == dcol(J) ? c0 : 0.0);
-                im[J][r] = fma(c1, ablk[J][r].y, im[J][r]);
-            }
-    };
-    const int mm = deg >> 1;
-    const bool even = (deg & 1) == 0;
-    if (deg >= 6) {
-        // Paterson-Stockmeyer with cubes: P = B_0 + A3 (B_1 + A3 (B_2 + ...)), B_i = c_{3i} I + c_{3i+1} A + c_{3i+2} A2.
-        // Degree 9 (state transfer, T = 10): A2, A3 + 2 Horner products = 4 instead of 5 with squares; never more.
-        gd4 a2r[2], a2i[2];
-        lds_mm<N>(X, X, I, Jp, lane, re, im);                     // A2 = A*A
-        put(Y);
-#pragma unroll
-        for (int J = 0; J < 2; ++J) { a2r[J] = re[J]; a2i[J] = im[J]; }
-        __syncthreads();
-        lds_mm<N>(Y, X, I, Jp, lane, re, im);                     // A3 = A2*A
-        __syncthreads();                                          // every wave is done reading A (X) and A2 (Y)
-        put(Y);                                                   // Y = A3 from here on
-        auto coef = [&](int j) { return j <= deg ? cf.c[j] : 0.0; };
-        auto add_blk = [&](int i) {                               // re/im += B_i
-            const double c0 = coef(3 * i), c1 = coef(3 * i + 1), c2 = coef(3 * i + 2);
-#pragma unroll
-            for (int J = 0; J < 2; ++J)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    re[J][r] += fma(c2, a2r[J][r], c1 * ablk[J][r].x) + (drow(r) == dcol(J) ? c0 : 0.0);
-                    im[J][r] += fma(c2, a2i[J][r], c1 * ablk[J][r].y);
-                }
-        };
-        const int nb = deg / 3;
-        int first;
-        if (deg % 3 == 0) {                                       // top block is the scalar c_deg: fold c_deg*A3 into B_{nb-1}
-#pragma unroll
-            for (int J = 0; J < 2; ++J) { re[J] = re[J] * cf.c[deg]; im[J] = im[J] * cf.c[deg]; }
-            add_blk(nb - 1);
-            first = nb - 2;
-        } else {
-#pragma unroll
-            for (int J = 0; J < 2; ++J) { re[J] = (gd4){0, 0, 0, 0}; im[J] = (gd4){0, 0, 0, 0}; }
-            add_blk(nb);
-            first = nb - 1;
-        }
-        put(X);
-        __syncthreads();
-        for (int i = first; i >= 0; --i) {                        // S <- B_i + A3*S
-            lds_mm<N>(Y, X, I, Jp, lane, re, im);
-            add_blk(i);
-            __syncthreads();
-            if (i > 0 || nsq > 0) { put(X); __syncthreads(); }
-        }
-    } else if (deg >= 2) {
-        lds_mm<N>(X, X, I, Jp, lane, re, im);                     // A2 = A*A
-        __syncthreads();                                          // every wave is done reading A from X
-        put(Y);
-        if (even) {                                               // S = c_{2m-2} I + c_{2m-1} A + c_T A2
-#pragma unroll
-            for (int J = 0; J < 2; ++J) { re[J] = re[J] * cf.c[deg]; im[J] = im[J] * cf.c[deg]; }
-            add_b(cf.c[2 * mm - 2], cf.c[2 * mm - 1]);
-        } else {                                                  // S = c_{2m} I + c_{2m+1} A
-#pragma unroll
-            for (int J = 0; J < 2; ++J) { re[J] = (gd4){0, 0, 0, 0}; im[J] = (gd4){0, 0, 0, 0}; }
-            add_b(cf.c[2 * mm], cf.c[2 * mm + 1]);
-        }
-        put(X);
-        __syncthreads();
-        for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {     // S <- c_{2i} I + c_{2i+1} A + A2*S
-            lds_mm<N>(Y, X, I, Jp, lane, re, im);
-            add_b(cf.c[2 * i], cf.c[2 * i + 1]);
-            __syncthreads();
-            if (i > 0 || nsq > 0) { put(X); __syncthreads(); }
-        }
-    } else {
-#pragma unroll
-        for (int J = 0; J < 2; ++J) { re[J] = (gd4){0, 0, 0, 0}; im[J] = (gd4){0, 0, 0, 0}; }
-        add_b(1.0, deg >= 1 ? 1.0 : 0.0);
-        __syncthreads();
-        if (nsq > 0) { put(X); __syncthreads(); }
-    }
-    for (int sq = 0; sq < nsq; ++sq) {                            // M <- M M                       tensorflow_state.py:43-44
-        lds_mm<N>(X, X, I, Jp, lane, re, im);
-        __syncthreads();
-        if (sq + 1 < nsq) { put(X); __syncthreads(); }
-    }
-#pragma unroll
-    for (int J = 0; J < 2; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Kt[(size_t)drow(r) * N + dcol(J)] = cmake(re[J][r], im[J][r]);
-}
-
-// ---- persistent thin chains (N <= 64, m <= 8) ---------------------------------------------------------------------
-// y <- op(K_j) y + E_j for `len` consecutive matrices, one workgroup per chain, y in LDS.  Launch-per-step chains cost
-// ~5 us of launch latency per step; here a step costs N*N*m complex MACs on the VALU (fp64 FMA rate ~ MFMA rate on
-// gfx950, and no padding of m to an MFMA tile) with K_j fetched two steps ahead into registers.
-// The steady-state loop is one basic block (unconditional clamped prefetch, E always loaded -- from a zero buffer when
-// there is no addend --, every finished value has exactly one owner lane): with conditional loads or stores in the loop hipcc's
-// s_waitcnt placement has to assume the worst path and waits for the loads it has just issued.
-struct ChainArgs {
-    const cplx* K; long long sKb, sKc, sKs;     // matrix of step j: K + b*sKb + c*sKc + j*sKs  (elements; sKs may be negative)
-    const cplx* X0; long long sXb, sXc;         // initial thin vectors (nullptr = zeros)
-    const cplx* E; long long sEb, sEc, sEs;     // addend per step (a zero buffer with zero strides when there is none)
-    cplx* Out; long long sOb, sOc, sOs; int ldO; // output per step (HAS_OUT): Out + b*sOb + c*sOc + j*sOs + row*ldO + jv
-    cplx* Fin; long long sFb, sFc;              // optional final state
-    int CI;                                     // chains per seed (blockIdx.x = b*CI + c)
-    int len, m;
-    int store_initial;                          // also store y0 at Out - sOs
-    int nterms; double sign;                    // k_gemm_taylor_chain: y <- sum_{j<nterms} (sign*K)^j y / j!  (+ E)
-};
-
-// v from lane (l ^ OFF), OFF in {1, 2, 4, 8}, as DPP moves on the VALU (quad_perm; xor 4 = row_half_mirror then quad_perm
-// [3,2,1,0]; xor 8 = row_ror:8) instead of ds_bpermute round trips through the LDS crossbar: the chain step is a dependent sequence, and
-// three crossbar latencies per step were a tenth of it.
-template <int OFF>
-__device__ __forceinline__ double dpp_xor(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    if constexpr (OFF == 1) {
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
-    } else if constexpr (OFF == 2) {
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, true);
-    } else if constexpr (OFF == 4) {
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, true);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x1B, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x1B, 0xF, 0xF, true);
-    } else {
-        static_assert(OFF == 8, "dpp_xor: lane distance 1, 2, 4 or 8");
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, true);   // row_ror:8
-    }
-    return __hiloint2double(hi, lo);
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for the K/E prefetch of
-// two steps ahead (and the output stores) at every step of a chain; the chains exchange data through LDS alone, and hipcc
-// still places the vmcnt wait for each prefetched register stage before its first use.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Butterfly over the LPR lanes that share a result row (forward chain mapping).  While more than SPL values are alive the
-// halves are exchanged (reduce-scatter: the lane with the bit set keeps the upper half), afterwards plain xor all-reduce.
-// Compile-time recursion keeps every register index static.
-template <int ALIVE, int OFF, int SPL, int MVT>
-__device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
-    if constexpr (OFF >= 1) {
-        if constexpr (ALIVE > SPL) {
-            constexpr int half = ALIVE / 2;
-            const bool up = (q & OFF) != 0;
-#pragma unroll
-            for (int x = 0; x < half; ++x) {
-                const cplx send = up ? acc[x] : acc[x + half];
-                const cplx keep = up ? acc[x + half] : acc[x];
-                acc[x].x = keep.x + dpp_xor<OFF>(send.x);
-                acc[x].y = keep.y + dpp_xor<OFF>(send.y);
-            }
-            chain_butterfly<half, OFF / 2, SPL, MVT>(acc, q);
-        } else {
-#pragma unroll
-            for (int x = 0; x < SPL; ++x) {
-                acc[x].x += dpp_xor<OFF>(acc[x].x);
-                acc[x].y += dpp_xor<OFF>(acc[x].y);
-            }
-            chain_butterfly<ALIVE, OFF / 2, SPL, MVT>(acc, q);
-        }
-    }
-}
-
-// y <- K_j^H y + E_j (backward chains).  Lane <-> column i of K, so that a wave reads whole rows (the 4 lanes of a quad must
-// stay on 64 contiguous bytes: the texture-address unit serialises a quad that touches 4 cache lines, and a transposed read
-// with a row-per-thread mapping was 2x slower per step); wave w owns rows (4e + w)*RPI + h, RPI = 64/N; x[r] is a broadcast
-// LDS read; the 4*RPI partial rows meet in LDS (one extra barrier per step) and thread (w, h, i) finishes -- adds the
-// source, writes LDS, stores -- the slots jv = sg + s*NSL, sg = (w*RPI + h) % NSL, NSL = min(MV, 4*RPI).
-template <int N, int MV, bool HAS_OUT>
-__global__ void __launch_bounds__(256) k_gemm_chain_adj(ChainArgs a) {
-    constexpr int EL = N * N / 256, RPI = 64 / N;
-    constexpr int NSL = MV < 4 * RPI ? MV : 4 * RPI;
-    constexpr int SPL = MV / NSL;
-    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
-    __shared__ __attribute__((aligned(16))) cplx part[4 * RPI * N * MV];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int i = lane % N, h = lane / N;
-    const int sg = (wv * RPI + h) % NSL;
-    auto slot = [&](int s) { return sg + s * NSL; };
-    const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
-    const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
-    const cplx* Ep = a.E + b * a.sEb + c * a.sEc + (size_t)i * QOC_TW;
-    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc + (size_t)i * a.ldO : nullptr;
-    cplx yfin[SPL];
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
-    if (a.X0) {
-        const cplx* x = a.X0 + b * a.sXb + c * a.sXc + (size_t)i * QOC_TW;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[slot(sl)];
-    }
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) y[0][i * MV + slot(sl)] = yfin[sl];
-    if (HAS_OUT && a.store_initial) {
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[slot(sl)] = yfin[sl];
-    }
-    const int last = a.len - 1;
-    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
-        const int jc = min(j, last);
-        const cplx* Kj = Kp + (long long)jc * a.sKs;
-#pragma unroll
-        for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)((4 * e + wv) * RPI + h) * N + i];
-        const cplx* ej = Ep + (long long)jc * a.sEs;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[slot(sl)];
-    };
-    int cur = 0;
-    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
-        cplx acc[MV];
-#pragma unroll
-        for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
-#pragma unroll
-        for (int e = 0; e < EL; ++e) {
-            const int r = (4 * e + wv) * RPI + h;
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) cfma_conj(acc[jv], ku[e], y[cur][r * MV + jv]);
-        }
-#pragma unroll
-        for (int jv = 0; jv < MV; ++jv) part[((wv * RPI + h) * N + i) * MV + jv] = acc[jv];   // 4*RPI partial rows per column
-        lds_barrier();
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) {
-            const int jv = slot(sl);
-            cplx t = part[i * MV + jv];
-#pragma unroll
-            for (int w = 1; w < 4 * RPI; ++w) t = cadd(t, part[(w * N + i) * MV + jv]);
-            yfin[sl] = cadd(t, eu[sl]);
-            y[cur ^ 1][i * MV + jv] = yfin[sl];
-        }
-        if (HAS_OUT) {
-            cplx* oj = Op + (long long)j * a.sOs;
-#pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = yfin[sl];
-        }
-        lds_barrier();
-        cur ^= 1;
-    };
-    if (a.len > 0) {
-        // three register stages used round-robin by a 3x unrolled loop (rotating them with copies would make every
-        // iteration wait for the newest load)
-        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
-        load(k0, e0, 0);
-        load(k1, e1, 1);
-        lds_barrier();
-        int j = 0;
-        for (; j + 3 <= a.len; j += 3) {
-            load(k2, e2, j + 2); step(j, k0, e0);
-            load(k0, e0, j + 3); step(j + 1, k1, e1);
-            load(k1, e1, j + 4); step(j + 2, k2, e2);
-        }
-        if (j < a.len) step(j, k0, e0);
-        if (j + 1 < a.len) step(j + 1, k1, e1);
-    } else {
-        lds_barrier();
-    }
-    if (a.Fin) {
-        cplx* f = a.Fin + b * a.sFb + c * a.sFc + (size_t)i * QOC_TW;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) f[slot(sl)] = yfin[sl];
-    }
-}
-
-// ---- register-blocked forward mat-vec mapping (k_gemm_chain_fwd, k_gemm_taylor_chain) ---------------------------------
-// Thread (g, c) = (tid / 16, tid % 16) owns the R x R block rows R*g + rr, columns c + 16*cc of K (R = N/16): a 16-lane DPP
-// row reads 256 contiguous bytes per load, a thread reads only R entries of the vector per slot (the row-per-thread mapping
-// re-read 16 at N = 64: 64 KB of LDS traffic per mat-vec, which bound the step) and the R*MV partial sums are combined by a
-// reduce-scatter butterfly over the 16 lanes (DPP), after which lane c holds the finished values x = base + s, s < SPLB,
-// of its row group in (row, slot)-major order; addend, LDS write and output store are done by the owner of each value.
-template <int N, int MV>
-struct BlockMap {
-    static constexpr int R = N / 16, EL = R * R, V = R * MV;
-    static constexpr int NSLB = V < 16 ? V : 16, SPLB = V / NSLB;
-    int g, c, base;
-    __device__ __forceinline__ BlockMap(int tid) : g(tid >> 4), c(tid & 15), base(((tid & 15) / (16 / NSLB)) * SPLB) {}
-    __device__ __forceinline__ int row(int s) const { return R * g + (base + s) / MV; }
-    __device__ __forceinline__ int slot(int s) const { return (base + s) % MV; }
-    __device__ __forceinline__ void load(cplx (&kd)[EL], const cplx* Kj) const {
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < R; ++cc) kd[rr * R + cc] = Kj[(size_t)(R * g + rr) * N + c + 16 * cc];
-    }
-    // acc[rr*MV + jv] = sum_cc K[rr][cc] * v[c + 16 cc][jv], then the 16-lane reduce-scatter: acc[0..SPLB) are this lane's values
-    __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
-#pragma unroll
-        for (int x = 0; x < V; ++x) acc[x] = cmake(0.0, 0.0);
-#pragma unroll
-        for (int cc = 0; cc < R; ++cc) {
-            cplx vv[MV];
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) vv[jv] = v[(c + 16 * cc) * MV + jv];
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-                for (int jv = 0; jv < MV; ++jv) cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]);
-        }
-        chain_butterfly<V, 8, SPLB, V>(acc, c);
-    }
-};
-
-// Row-per-thread mapping with the same interface: thread (i, q) owns row i and the columns LPR*e + q.  Faster than the
-// blocked mapping at N = 32 (4 vector reads per slot either way, a 3-level butterfly instead of 4); measured per 1000-slice
-// direct iteration: N = 32: 4.65 (row) vs 4.81 ms (blocked); N = 64: 13.0 (row) vs 10.0 ms (blocked).
-template <int N, int MV>
-struct RowMap {
-    static constexpr int LPR = 256 / N, EL = N / LPR, V = MV;
-    static constexpr int NSLB = MV < LPR ? MV : LPR, SPLB = MV / NSLB;
-    int i, q, base;
-    __device__ __forceinline__ RowMap(int tid) : i(tid / LPR), q(tid % LPR), base(((tid % LPR) / (LPR / NSLB)) * SPLB) {}
-    __device__ __forceinline__ int row(int) const { return i; }
-    __device__ __forceinline__ int slot(int s) const { return base + s; }
-    __device__ __forceinline__ void load(cplx (&kd)[EL], const cplx* Kj) const {
-#pragma unroll
-        for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)i * N + LPR * e + q];
-    }
-    __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
-#pragma unroll
-        for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
-#pragma unroll
-        for (int e = 0; e < EL; ++e)
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) cfma(acc[jv], ku[e], v[(LPR * e + q) * MV + jv]);
-        chain_butterfly<MV, LPR / 2, SPLB, MV>(acc, q);
-    }
-};
-template <int N, int MV> struct FwdMap { using type = BlockMap<N, MV>; };
-template <int MV> struct FwdMap<32, MV> { using type = RowMap<32, MV>; };
-
-// y <- K_j y + E_j (forward chains) with the mapping FwdMap picks for N; same pipeline as k_gemm_chain_adj
-template <int N, int MV, bool HAS_OUT>
-__global__ void __launch_bounds__(256) k_gemm_chain_fwd(ChainArgs a) {
-    using BM = typename FwdMap<N, MV>::type;
-    constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
-    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
-    const BM bm(threadIdx.x);
-    const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
-    const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
-    const cplx* Ep = a.E + b * a.sEb + c * a.sEc;
-    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc : nullptr;
-    int thin_off[SPL], out_off[SPL], lds_off[SPL];
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) {
-        thin_off[sl] = bm.row(sl) * QOC_TW + bm.slot(sl);
-        out_off[sl] = bm.row(sl) * a.ldO + bm.slot(sl);
-        lds_off[sl] = bm.row(sl) * MV + bm.slot(sl);
-    }
-    cplx yfin[SPL];
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
-    if (a.X0) {
-        const cplx* x = a.X0 + b * a.sXb + c * a.sXc;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[thin_off[sl]];
-    }
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) y[0][lds_off[sl]] = yfin[sl];
-    if (HAS_OUT && a.store_initial) {
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[out_off[sl]] = yfin[sl];
-    }
-    const int last = a.len - 1;
-    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
-        const int jc = min(j, last);
-        bm.load(kd, Kp + (long long)jc * a.sKs);
-        const cplx* ej = Ep + (long long)jc * a.sEs;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[thin_off[sl]];
-    };
-    int cur = 0;
-    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
-        cplx acc[V];
-        bm.matvec(ku, y[cur], acc);
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) {
-            yfin[sl] = cadd(acc[sl], eu[sl]);
-            y[cur ^ 1][lds_off[sl]] = yfin[sl];
-        }
-        if (HAS_OUT) {
-            cplx* oj = Op + (long long)j * a.sOs;
-#pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) oj[out_off[sl]] = yfin[sl];
-        }
-        lds_barrier();
-        cur ^= 1;
-    };
-    if (a.len > 0) {
-        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
-        load(k0, e0, 0);
-        load(k1, e1, 1);
-        lds_barrier();
-        int j = 0;
-        for (; j + 3 <= a.len; j += 3) {
-            load(k2, e2, j + 2); step(j, k0, e0);
-            load(k0, e0, j + 3); step(j + 1, k1, e1);
-            load(k1, e1, j + 4); step(j + 2, k2, e2);
-        }
-        if (j < a.len) step(j, k0, e0);
-        if (j + 1 < a.len) step(j + 1, k1, e1);
-    } else {
-        lds_barrier();
-    }
-    if (a.Fin) {
-        cplx* f = a.Fin + b * a.sFb + c * a.sFc;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) f[thin_off[sl]] = yfin[sl];
-    }
-}
-
-// State transfer without propagators: psi <- sum_{j<T} (sign*B_t)^j psi / j! (+ E_t), one workgroup per seed walking all
-// slices (tensorflow_state.py:88-96 forward, :118-131 backward with sign = -1 -- no anti-Hermiticity assumed).  Same mapping
-// and prefetch structure as k_gemm_chain_fwd; a step is T-1 dependent mat-vecs on the register-resident B_t (the
-// generator was assembled for all slices by k_gemm_assemble, so the chain streams 1 matrix per slice instead of k+1).
-template <int N, int MV>
-__global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a) {
-    using BM = typename FwdMap<N, MV>::type;
-    constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
-    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
-    const BM bm(threadIdx.x);
-    const int b = blockIdx.x;
-    const cplx* Kp = a.K + b * a.sKb;
-    const cplx* Ep = a.E + b * a.sEb;
-    cplx* Op = a.Out + b * a.sOb;
-    int thin_off[SPL], out_off[SPL], lds_off[SPL];
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) {
-        thin_off[sl] = bm.row(sl) * QOC_TW + bm.slot(sl);
-        out_off[sl] = bm.row(sl) * a.ldO + bm.slot(sl);
-        lds_off[sl] = bm.row(sl) * MV + bm.slot(sl);
-    }
-    cplx yfin[SPL];
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
-    if (a.X0) {
-        const cplx* x = a.X0 + b * a.sXb;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[thin_off[sl]];
-    }
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) y[0][lds_off[sl]] = yfin[sl];
-    if (a.store_initial) {
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[out_off[sl]] = yfin[sl];
-    }
-    const int last = a.len - 1;
-    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
-        const int jc = min(j, last);
-        bm.load(kd, Kp + (long long)jc * a.sKs);
-        const cplx* ej = Ep + (long long)jc * a.sEs;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[thin_off[sl]];
-    };
-    int cur = 0;
-    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
-        cplx out[SPL];
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) out[sl] = yfin[sl];
-        double fact = 1.0;
-        for (int ii = 1; ii < a.nterms; ++ii) {
-            cplx acc[V];
-            bm.matvec(ku, y[cur], acc);
-            fact *= (double)ii;
-            const double inv = 1.0 / fact;
-            const bool lastterm = ii + 1 == a.nterms;
-#pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) {
-                const cplx w = cscale(acc[sl], a.sign);                       // psi_n = (sign*B) psi_n            :94 / :130
-                out[sl].x = fma(w.x, inv, out[sl].x); out[sl].y = fma(w.y, inv, out[sl].y);   // += psi_n / factorial   :95 / :131
-                // the last term is needed by nobody else: the buffer takes the new state (+ addend) instead
-                y[cur ^ 1][lds_off[sl]] = lastterm ? cadd(out[sl], eu[sl]) : w;
-            }
-            lds_barrier();
-            cur ^= 1;
-        }
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cadd(out[sl], eu[sl]);
-        if (a.nterms <= 1) {                                                   // T = 1: psi unchanged (+ addend)
-#pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) y[cur ^ 1][lds_off[sl]] = yfin[sl];
-            lds_barrier();
-            cur ^= 1;
-        }
-        cplx* oj = Op + (long long)j * a.sOs;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) oj[out_off[sl]] = yfin[sl];
-    };
-    if (a.len > 0) {
-        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
-        load(k0, e0, 0);
-        load(k1, e1, 1);
-        lds_barrier();
-        int j = 0;
-        for (; j + 3 <= a.len; j += 3) {
-            load(k2, e2, j + 2); step(j, k0, e0);
-            load(k0, e0, j + 3); step(j + 1, k1, e1);
-            load(k1, e1, j + 4); step(j + 2, k2, e2);
-        }
-        if (j < a.len) step(j, k0, e0);
-        if (j + 1 < a.len) step(j + 1, k1, e1);
-    }
-}
-
-template <int N>
-static inline void qoc_taylor_chain_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
-    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 1>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 2>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(256), 0, s, a);
-}
-static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
-    if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
-    if (N == 32) qoc_taylor_chain_launch_n<32>(a, blocks, s); else qoc_taylor_chain_launch_n<64>(a, blocks, s);
-}
-
-template <int N, bool HAS_OUT>
-static inline void qoc_chain_adj_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
-    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_adj<N, 1, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_adj<N, 2, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_adj<N, 4, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_chain_adj<N, 8, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-}
-template <int N, bool HAS_OUT>
-static inline void qoc_chain_fwd_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
-    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 1, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 2, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 4, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_chain_fwd<N, 8, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-}
-template <int N>
-static inline void qoc_chain_launch_c(bool conjt, const ChainArgs& a, int blocks, hipStream_t s) {
-    if (conjt) { if (a.Out) qoc_chain_adj_launch_n<N, true>(a, blocks, s); else qoc_chain_adj_launch_n<N, false>(a, blocks, s); }
-    else { if (a.Out) qoc_chain_fwd_launch_n<N, true>(a, blocks, s); else qoc_chain_fwd_launch_n<N, false>(a, blocks, s); }
-}
-// `zeros` = a zero thin buffer (N x 32) used as the addend when the chain has none
-static inline void qoc_chain_launch(int N, bool conjt, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
-    if (a.len <= 0 && !a.Fin && !a.store_initial) return;
-    if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
-    if (N == 32) qoc_chain_launch_c<32>(conjt, a, blocks, s); else qoc_chain_launch_c<64>(conjt, a, blocks, s);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
