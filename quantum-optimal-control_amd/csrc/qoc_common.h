@@ -53,6 +53,7 @@ struct QocDev {
     int* adam_t;         // [B]
     int* iters;          // [B]
     int* done;           // [B]
+    int skip_done;       // loop iterations only: kernels leave finished seeds untouched (their last evaluation stays readable)
     // per-evaluation intermediates
     double* w;           // [B][k][steps] sin(base)
     double* u;           // [B][k][steps] maxA*w

@@ -126,7 +126,8 @@ static int prof_collect(qoc_engine* e) {
 
 // ---- one evaluation (+ optional on-device stop rule / Adam), enqueued on the engine stream ------------------------
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
-    const QocDev& d = e->d;
+    QocDev d = e->d;
+    d.skip_done = ap.mode == 1 ? 1 : 0;      // qoc_eval / explicit steps always evaluate every seed
     const int total = d.B * d.k * d.steps;
     int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
     if (cgrid > 2048) cgrid = 2048;

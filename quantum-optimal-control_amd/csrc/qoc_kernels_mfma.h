@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk(
     const int lane = threadIdx.x & 63;
     const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
+    if (d.skip_done && d.done[b]) return;   // a finished seed keeps the results of its last evaluation (whole workgroup: no barrier yet)
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
     const double inv_scale = 1.0 / (double)(1 << d.s);
     const int dlt = (lane & 15) - (lane >> 4);     // identity: tile Ib == J, register r, lanes with dlt == 4r
@@ -312,6 +313,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
     const int n_sweep = d.B * mf.C;
     if (item < n_sweep) {
         const int b = item / mf.C, c = item - b * mf.C;
+        if (d.skip_done && d.done[b]) return;
         const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
         CTile Psi[NT];
 #pragma unroll
@@ -351,6 +353,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
     } else if (item < n_sweep + d.B * NT) {
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
+        if (d.skip_done && d.done[b]) return;
         CTile X[NT];
         colblock_load<NT>(mf.U0fD, J, lane, X);
         AFragT<NT> A;
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
     const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (item >= d.B * mf.C) return;
     const int b = item / mf.C, c = item - b * mf.C;
-    if (c == 0) return;                                               // a_0 is never used
+    if (c == 0 || (d.skip_done && d.done[b])) return;                                  // a_0 is never used; finished seeds are frozen
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
     CTile Z[NT];
 #pragma unroll
@@ -438,6 +441,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     const int item = blockIdx.x * 4 + wv;
     if (item >= d.B * CC) return;
     const int b = item / CC, c = item - b * CC;
+    if (d.skip_done && d.done[b]) return;
     const int t0 = single_chunk ? 0 : c * mf.L, t1 = single_chunk ? d.steps : min(t0 + mf.L, d.steps);
     const bool need_src = d.n_forb > 0 || d.has_speed;
     // terminal costate: -(2/m^2) z W (+ S_steps)
