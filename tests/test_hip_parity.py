@@ -499,3 +499,32 @@ def test_c4_512_seeds_on_one_gpu_match_small_batches():
         assert np.array_equal(small_base[i], big_base[sd])
         assert small_loss[i] == big_loss[sd]
     assert np.all(np.isfinite(big_loss)) and np.all(big_loss < 1.0 + 1e-9)
+
+
+def test_create_destroy_releases_device_memory():
+    """Every path frees what it allocated: free HBM after 20 create/evaluate/destroy cycles per path is back to the level
+    after the first cycle (the first one may leave the HIP runtime's own pools behind)."""
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    problems = [(oracle_system(cases.case_c2(n=32, k=2, steps=64, m=4, taylor=(5, 2), seed=3)), 2, 0),     # MFMA
+                (oracle_system(cases.case_c2(n=40, k=2, steps=64, m=4, taylor=(5, 2), seed=3)), 4, 0),     # GEMM persistent
+                (oracle_system(cases.case_c2(n=70, k=2, steps=16, m=4, taylor=(5, 2), seed=3)), 4, 0),     # GEMM launches
+                (oracle_system(cases.case_c3(n=24, k=2, steps=64, taylor=(6, 0))), 4, 1),                  # GEMM direct
+                (oracle_system(cases.case_c3(n=24, k=2, steps=64, taylor=(6, 0))), 3, 0),                  # fused mat-vec
+                (oracle_system(cases.case_c2(n=12, k=2, steps=16, m=3, taylor=(5, 2), seed=3)), 1, 0)]     # generic
+    for sp, path, chunks in problems:
+        baseline = None
+        for cycle in range(20):
+            eng = make_engine(sp, n_seeds=4, path=path, chunks=chunks)
+            eng.set_base(np.stack([sp.base0] * 4))
+            eng.evaluate()
+            eng.close()
+            if cycle == 0:
+                baseline = free_bytes()
+        assert free_bytes() >= baseline - (8 << 20), (path, chunks, baseline, free_bytes())
