@@ -223,8 +223,9 @@ struct QocGemm {
 // Any state-transfer problem with n <= 64, m <= 8 can instead run "direct" (k_gemm_taylor_chain: the reference's own
 // mat-vec recursion, forward and backward, on pre-assembled generators; no time parallelism, so it is the large-batch mode).
 static inline bool qoc_gemm_direct_supported(const QocDev& d) { return d.state_transfer && d.n <= 64 && d.m <= 8 && d.T >= 1; }
+// the polynomial coefficient tables (ExpmCoef, invf[]) hold 1/j! for j < 24
 static inline bool qoc_gemm_supported(const QocDev& d, bool antiherm) {
-    return d.m <= QOC_TW && d.T >= 1 && (!d.state_transfer || antiherm || qoc_gemm_direct_supported(d));
+    return d.m <= QOC_TW && d.T >= 1 && d.T <= 23 && (!d.state_transfer || antiherm || qoc_gemm_direct_supported(d));
 }
 static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
     for (int q = 0; q < count; ++q) {

@@ -377,6 +377,8 @@ def edge_cases():
     out.append(('gemm_m32', cases.case_c2(n=32, k=2, steps=4, m=32, taylor=(4, 1), seed=35), 0))
     out.append(('gemm_n65', cases.case_c2(n=65, k=2, steps=3, m=2, taylor=(3, 2), seed=36), 0))
     out.append(('gemm_k9', cases.case_c2(n=8, k=9, steps=4, m=3, taylor=(4, 1), seed=37), 0))
+    out.append(('gemm_T23', cases.case_c2(n=40, k=1, steps=3, m=2, taylor=(23, 0), seed=38), 0))
+    out.append(('generic_T30', cases.case_c2(n=40, k=1, steps=3, m=2, taylor=(30, 1), seed=39), 0))
     c = cases.case_state_small(); c['Taylor_terms'] = [9, 0]
     rng = np.random.default_rng(3)
     vs = [rng.normal(size=5) + 1j * rng.normal(size=5) for _ in range(10)]
@@ -408,7 +410,7 @@ def test_edge_cases_all_paths(name, c, path):
     sp = oracle_system(c)
     bases = [sp.base0, -1.5 * sp.base0 + 0.05]
     eng = make_engine(sp, n_seeds=2, path=path)
-    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'st_m5_generic': 4, 'st_n65_generic': 4,
+    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'gemm_T23': 4, 'generic_T30': 1, 'st_m5_generic': 4, 'st_n65_generic': 4,
               'st_nonhermitian_fused': 4, 'st_nonhermitian_generic': 1, 'state_small_auto': 4}
     if name in expect:
         assert eng.path == expect[name], (name, eng.path)
