@@ -57,6 +57,83 @@ __global__ void __launch_bounds__(256) k_fma(double* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+
+// accumulators pinned to AGPRs (inline asm, "+a"): does the SrcC/D register file matter for the issue interval?
+template <int NACC>
+__global__ void __launch_bounds__(256) k_rate_agpr(double* out, int iters) {
+    d4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// v_mfma_f64_4x4x4_4b_f64: 4 blocks of 4x4x4, one double accumulator per lane (512 flops per instruction)
+template <int NACC>
+__global__ void __launch_bounds__(256) k_rate_4x4(double* out, int iters) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// MFMA and independent VALU FMA chains in the same wave: NF v_fma_f64 per MFMA.  If the FMAs are free next to the MFMAs the
+// VALU can carry part of a product.
+template <int NF>
+__global__ void __launch_bounds__(256) k_rate_mixed(double* out, int iters) {
+    d4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double x[NF > 0 ? NF : 1];
+    for (int i = 0; i < NF; ++i) x[i] = threadIdx.x * 1e-3 + i;
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    const double fa = 1.0000001, fb = 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) x[f] = fma(x[f], fa, fb);
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int f = 0; f < NF; ++f) s += x[f];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// 16x16x4 and 4x4x4 MFMAs interleaved in one wave: N4 small ones per big one
+template <int N4>
+__global__ void __launch_bounds__(256) k_rate_both(double* out, int iters) {
+    d4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double sm[4 * (N4 > 0 ? N4 : 1)];
+    for (int i = 0; i < 4 * N4; ++i) sm[i] = 0.0;
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < N4; ++f) sm[i * N4 + f] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, sm[i * N4 + f], 0, 0, 0);
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 4 * N4; ++i) s += sm[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 int main() {
@@ -94,6 +171,19 @@ int main() {
     bench("mfma_f64 4acc 2waves/SIMD", [&] { hipLaunchKernelGGL(k_rate<4>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0, blocks * 2, 256);
     bench("mfma_f64 4acc 4waves/SIMD", [&] { hipLaunchKernelGGL(k_rate<4>, dim3(blocks * 4), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0, blocks * 4, 256);
     bench("mfma_f64 2acc 8waves/SIMD", [&] { hipLaunchKernelGGL(k_rate<2>, dim3(blocks * 8), dim3(256), 0, 0, dout, iters); }, 2 * 4 * 2048.0, blocks * 8, 256);
+    bench("mfma_f64 AGPR acc 4acc 1wave/SIMD", [&] { hipLaunchKernelGGL(k_rate_agpr<4>, dim3(blocks), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0, blocks, 256);
+    bench("mfma_f64 AGPR acc 4acc 2waves/SIMD", [&] { hipLaunchKernelGGL(k_rate_agpr<4>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0, blocks * 2, 256);
+    bench("mfma_f64 AGPR acc 4acc 4waves/SIMD", [&] { hipLaunchKernelGGL(k_rate_agpr<4>, dim3(blocks * 4), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0, blocks * 4, 256);
+    bench("mfma_f64_4x4x4 8acc 1wave/SIMD", [&] { hipLaunchKernelGGL(k_rate_4x4<8>, dim3(blocks), dim3(256), 0, 0, dout, iters); }, 8 * 4 * 512.0, blocks, 256);
+    bench("mfma_f64_4x4x4 8acc 4waves/SIMD", [&] { hipLaunchKernelGGL(k_rate_4x4<8>, dim3(blocks * 4), dim3(256), 0, 0, dout, iters); }, 8 * 4 * 512.0, blocks * 4, 256);
+    // mixed: flops counted = MFMA flops + FMA flops (2 per lane per FMA: 4 MFMA * NF FMAs * 256 threads * 2)
+    bench("mixed 4 MFMA + 4x4 FMA 2waves/SIMD", [&] { hipLaunchKernelGGL(k_rate_mixed<4>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0 + 4 * 4 * 256 * 2.0, blocks * 2, 256);
+    bench("mixed 4 MFMA + 4x8 FMA 2waves/SIMD", [&] { hipLaunchKernelGGL(k_rate_mixed<8>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0 + 4 * 8 * 256 * 2.0, blocks * 2, 256);
+    bench("mixed 4 MFMA + 4x16 FMA 2waves/SIMD", [&] { hipLaunchKernelGGL(k_rate_mixed<16>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0 + 4 * 16 * 256 * 2.0, blocks * 2, 256);
+    bench("mixed 4 MFMA + 4x16 FMA 4waves/SIMD", [&] { hipLaunchKernelGGL(k_rate_mixed<16>, dim3(blocks * 4), dim3(256), 0, 0, dout, iters); }, 4 * 4 * 2048.0 + 4 * 16 * 256 * 2.0, blocks * 4, 256);
+    bench("16x16x4 + 1x 4x4x4 interleaved 2w/SIMD", [&] { hipLaunchKernelGGL(k_rate_both<1>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * (2048.0 + 1 * 512.0), blocks * 2, 256);
+    bench("16x16x4 + 2x 4x4x4 interleaved 2w/SIMD", [&] { hipLaunchKernelGGL(k_rate_both<2>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * (2048.0 + 2 * 512.0), blocks * 2, 256);
+    bench("16x16x4 + 4x 4x4x4 interleaved 2w/SIMD", [&] { hipLaunchKernelGGL(k_rate_both<4>, dim3(blocks * 2), dim3(256), 0, 0, dout, iters); }, 4 * 4 * (2048.0 + 4 * 512.0), blocks * 2, 256);
     {   // in-kernel shader-clock cycles per MFMA (s_memtime ticks = shader cycles) and effective clock
         long long* dcyc; hipMalloc(&dcyc, sizeof(long long) * 2);
         hipEventRecord(e0);
