@@ -37,6 +37,38 @@ __global__ void __launch_bounds__(128) k_prod(double* out, int iters) {
     out[blockIdx.x * 128 + tid] = sum;
 }
 
+// variant of k_prod whose loads stay inside their k-block (no parking of 64 blocks in AGPRs)
+__global__ void __launch_bounds__(128) k_prod_fenced(double* out, int iters) {
+    __shared__ __attribute__((aligned(16))) cplx img[32 * LD];      // img[col * LD + row] = A[row][col]
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int o = tid; o < 32 * LD; o += 128) { img[o].x = 1e-3 * (o % 7); img[o].y = 1e-3 * (o % 5); }
+    __syncthreads();
+    double br[8], bi[8], bs[8];
+    for (int s = 0; s < 8; ++s) { br[s] = 1.0 + lane * 1e-6 + s; bi[s] = 0.5 - lane * 1e-6; bs[s] = br[s] + bi[s]; }
+    double t1[8], t2[8], t3[8];
+    for (int s = 0; s < 8; ++s) t1[s] = t2[s] = t3[s] = 0.0;
+    const int k = lane >> 4, i = lane & 3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) {
+                const cplx a = img[(4 * kb + k) * LD + 4 * ib + i];
+                t1[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, br[kb], t1[ib], 0, 0, 0);
+                t2[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, bi[kb], t2[ib], 0, 0, 0);
+                t3[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x + a.y, bs[kb], t3[ib], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");                      // loads of the next k-block may not be hoisted above this point
+        }
+        // feed the result back as the next right operand (keeps the chain honest)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { br[s] = (t1[s] - t2[s]) * 1e-3; bi[s] = (t3[s] - t1[s] - t2[s]) * 1e-3; bs[s] = br[s] + bi[s]; }
+    }
+    double sum = 0;
+    for (int s = 0; s < 8; ++s) sum += br[s] + bi[s];
+    out[blockIdx.x * 128 + tid] = sum;
+}
+
 // variant: one wave owns all 32 columns (two strip sets): 6 MFMAs per A-block load
 __global__ void __launch_bounds__(64) k_prod32(double* out, int iters) {
     __shared__ __attribute__((aligned(16))) cplx img[32 * LD];
@@ -153,6 +185,15 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double mfma = (double)blocks * 2 * iters * 192.0;
         printf("register A, %d wave(s)/SIMD: %.3f ms, %.1f executed TFLOP/s, %.1f cycles per MFMA\n", wps, ms, mfma * 512 / ms * 1e-9,
+               ms * 1e-3 * 2.37e9 / (mfma / (cus * 4.0)));
+    }
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        const int blocks = cus * 2 * wps;
+        hipLaunchKernelGGL(k_prod_fenced, dim3(blocks), dim3(128), 0, 0, dout, iters); hipDeviceSynchronize();
+        hipEventRecord(e0); hipLaunchKernelGGL(k_prod_fenced, dim3(blocks), dim3(128), 0, 0, dout, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double mfma = (double)blocks * 2 * iters * 192.0;
+        printf("fenced LDS blocks, %d wave(s)/SIMD: %.3f ms, %.1f executed TFLOP/s, %.1f cycles per MFMA\n", wps, ms, mfma * 512 / ms * 1e-9,
                ms * 1e-3 * 2.37e9 / (mfma / (cus * 4.0)));
     }
     cplx* dA; hipMalloc(&dA, 8 * 1024 * sizeof(cplx)); hipMemset(dA, 0, 8 * 1024 * sizeof(cplx));
