@@ -126,6 +126,7 @@ def main():
     ap.add_argument('--seeds-per-gpu', type=int, default=SEEDS_PER_GPU)
     ap.add_argument('--chunks', type=int, default=0)
     ap.add_argument('--path', type=int, default=0)
+    ap.add_argument('--variant', type=int, default=0, help='MFMA path: kernel of the exponentials (qoc_config.variant)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--groups', type=int, default=1, help='split the seeds of this GPU over G engines/streams')
     args = ap.parse_args()
@@ -160,7 +161,7 @@ def main():
     for g in range(G):
         e = hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], SLICES, TAYLOR[0], TAYLOR[1],
                                  reg_coeffs={}, n_seeds=gsh[g].count, device=local_rank, path=args.path,
-                                 chunks=args.chunks)
+                                 chunks=args.chunks, variant=args.variant)
         e.set_base(seed_bases(shard.first + gsh[g].first, gsh[g].count))
         engs.append(e)
     eng = engs[0]

@@ -61,7 +61,9 @@ typedef struct qoc_config {
     int32_t device;             /* HIP device ordinal */
     int32_t path;               /* QOC_PATH_* */
     int32_t chunks;             /* MFMA path: time chunks per seed (0 = auto) */
-    int32_t reserved[7];
+    int32_t variant;            /* MFMA path, kernel of the exponentials: 0 = auto, 1 = v_mfma_f64_16x16x4 (two waves per chunk),
+                                 * 2 = v_mfma_f64_4x4x4 two waves per chunk, 3 = v_mfma_f64_4x4x4 one wave per chunk */
+    int32_t reserved[6];
 } qoc_config;
 
 /* Adam loop hyper-parameters == Convergence (core/convergence.py:16-49). */

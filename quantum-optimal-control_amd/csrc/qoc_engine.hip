@@ -349,6 +349,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     e->chunks = 1;
     if (path == QOC_PATH_MFMA) {
         std::string msg;
+        e->mf.variant = cfg->variant;
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         e->chunks = e->mf.C;

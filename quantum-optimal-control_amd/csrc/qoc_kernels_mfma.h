@@ -61,6 +61,7 @@ struct QocMfma {
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
     size_t bwd_lds = 0;
     bool h_in_lds = true;
+    int variant = 0;              // qoc_config.variant: 0 auto, 1 16x16x4, 2 4x4x4 two waves, 3 4x4x4 one wave
     int skew_c = 0, skew_b = 0;   // element skews per chunk / per seed that break the power-of-two strides of K storage
 };
 
@@ -164,6 +165,37 @@ __device__ __forceinline__ void lds_get_afrag(const cplx* img, int lane, AFragT<
             const cplx v = img[(4 * q + (lane >> 4)) * QLDR + 16 * I + (lane & 15)];
             A.re[I][q] = v.x; A.im[I][q] = v.y;
         }
+}
+
+// The same product with v_mfma_f64_4x4x4_4b_f64 (17 cycles per 512 flops; the 16x16x4 shape issues every 103 cycles per 2048), left operand read block by block from the
+// transposed LDS image (lane 16k+4b+i reads M[4ib+i][4kb+k], the 4 block lanes b share the address), right operand and
+// result in the usual strip registers (a strip = 4 rows x 16 columns = one register of a CTile).
+template <int NT>
+__device__ __forceinline__ void mm_colblock4(const cplx* img, int lane, const CTile p[NT], CTile out[NT]) {
+    double a[QQS], b[QQS], c[QQS];
+#pragma unroll
+    for (int s = 0; s < QQS; ++s) { a[s] = 0.0; b[s] = 0.0; c[s] = 0.0; }
+    const cplx* base = img + (lane >> 4) * QLDR + (lane & 3);
+#pragma unroll
+    for (int kb = 0; kb < QQS; ++kb) {
+        const double br = p[kb >> 2].re[kb & 3], bi = p[kb >> 2].im[kb & 3], bs = br + bi;
+#pragma unroll
+        for (int ib = 0; ib < QQS; ++ib) {
+            const cplx v = base[4 * kb * QLDR + 4 * ib];
+            a[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[ib], 0, 0, 0);
+            b[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, b[ib], 0, 0, 0);
+            c[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, c[ib], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");     // keep the block loads of a k-block inside it: hoisted, hipcc parks all 64 in AGPRs (1.69 vs 1.04 ms)
+    }
+#pragma unroll
+    for (int s = 0; s < QQS; ++s) { out[s >> 2].re[s & 3] = a[s] - b[s]; out[s >> 2].im[s & 3] = c[s] - a[s] - b[s]; }
+}
+// one 16-column half (I = J) of the A-layout fragments, for the fragD(M^T) store
+template <int NT>
+__device__ __forceinline__ void lds_store_fragT_half(const cplx* img, cplx* __restrict__ F, int J, int lane) {
+#pragma unroll
+    for (int q = 0; q < QQS; ++q) F[(J * QQS + q) * 64 + lane] = img[(4 * q + (lane >> 4)) * QLDR + 16 * J + (lane & 15)];
 }
 
 // ---- kernel E: K_t = matexp for every t of one chunk + chunk product P_c ---------------------------------------
@@ -302,6 +334,284 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk(
     AFragT<NT> A;
     lds_get_afrag<NT>(img[flip], lane, A);
     afrag_store_half<NT>(mf.PfT + pitem * QFR, J, lane, A);
+}
+
+// Two-wave variant on the 4x4x4 instruction (qoc_config.variant = 2): k_mfma_expm_chunk with every product done by mm_colblock4.  No A-operand fragments exist any
+// more: A_t is assembled in strip layout only (half the Hamiltonian loads) and every left operand is an LDS image.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk4(QocDev d, QocMfma mf) {
+    __shared__ __attribute__((aligned(16))) cplx img[2][QNP * QLDR];
+    const int lane = threadIdx.x & 63;
+    const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
+    if (d.skip_done && d.done[b]) return;
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const double inv_scale = 1.0 / (double)(1 << d.s);
+    const int dlt = (lane & 15) - (lane >> 4);
+    int flip = 0;
+    CTile R[NT];
+    colblock_identity<NT>(J, lane, R);
+    for (int t = t0; t < t1; ++t) {
+        CTile P[NT];
+        colblock_load<NT>(mf.HfD, J, lane, P);
+#pragma unroll
+        for (int Ib = 0; Ib < NT; ++Ib) { P[Ib].re *= inv_scale; P[Ib].im *= inv_scale; }
+#pragma unroll 1
+        for (int kk = 0; kk < d.k; ++kk) {
+            const double ck = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale;
+            const cplx* __restrict__ HD = mf.HfD + (size_t)(kk + 1) * QFR;
+#pragma unroll
+            for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cplx h = HD[(J * QQS + 4 * Ib + r) * 64 + lane];
+                    P[Ib].re[r] = fma(ck, h.x, P[Ib].re[r]);
+                    P[Ib].im[r] = fma(ck, h.y, P[Ib].im[r]);
+                }
+        }
+        if (d.T >= 2) {
+            CTile AJ[NT];
+            for (int Ib = 0; Ib < NT; ++Ib) AJ[Ib] = P[Ib];
+            lds_put_colblock<NT>(img[flip], 16 * J, lane, AJ);
+            __syncthreads();
+            CTile A2J[NT];
+            mm_colblock4<NT>(img[flip], lane, AJ, A2J);
+            flip ^= 1;
+            lds_put_colblock<NT>(img[flip], 16 * J, lane, A2J);
+            __syncthreads();
+            const cplx* a2img = img[flip];                          // stays valid through the Horner steps (no put until then)
+            flip ^= 1;
+            const int mm = d.T >> 1;
+            int i;
+            if ((d.T & 1) == 0) {
+                const double c0 = mf.invfact[2 * mm - 2], c1 = mf.invfact[2 * mm - 1], cT = mf.invfact[d.T];
+#pragma unroll
+                for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
+                        P[Ib].re[r] = one + c1 * AJ[Ib].re[r] + cT * A2J[Ib].re[r];
+                        P[Ib].im[r] = c1 * AJ[Ib].im[r] + cT * A2J[Ib].im[r];
+                    }
+                i = mm - 2;
+            } else {
+                const double c0 = mf.invfact[2 * mm], c1 = mf.invfact[2 * mm + 1];
+#pragma unroll
+                for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
+                        P[Ib].re[r] = one + c1 * AJ[Ib].re[r];
+                        P[Ib].im[r] = c1 * AJ[Ib].im[r];
+                    }
+                i = mm - 1;
+            }
+            for (; i >= 0; --i) {
+                CTile acc[NT];
+                mm_colblock4<NT>(a2img, lane, P, acc);
+                const double c0 = mf.invfact[2 * i], c1 = mf.invfact[2 * i + 1];
+#pragma unroll
+                for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
+                        P[Ib].re[r] = one + c1 * AJ[Ib].re[r] + acc[Ib].re[r];
+                        P[Ib].im[r] = c1 * AJ[Ib].im[r] + acc[Ib].im[r];
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[Ib].re[r] += (Ib == J && dlt == 4 * r) ? 1.0 : 0.0;
+        }
+        // img[flip] is the buffer the A image lived in: every wave passed the barrier after reading it
+        for (int sq = 0; sq < d.s; ++sq) {
+            lds_put_colblock<NT>(img[flip], 16 * J, lane, P);
+            __syncthreads();
+            CTile acc[NT];
+            mm_colblock4<NT>(img[flip], lane, P, acc);
+            flip ^= 1;
+            for (int Ib = 0; Ib < NT; ++Ib) P[Ib] = acc[Ib];
+        }
+        const size_t item = kitem(mf, d.steps, b, t);
+        colblock_store<NT>(mf.KfD + item, J, lane, P);
+        lds_put_colblock<NT>(img[flip], 16 * J, lane, P);
+        __syncthreads();
+        lds_store_fragT_half<NT>(img[flip], mf.KfT + item, J, lane);
+        CTile acc[NT];
+        mm_colblock4<NT>(img[flip], lane, R, acc);
+        flip ^= 1;
+        for (int Ib = 0; Ib < NT; ++Ib) R[Ib] = acc[Ib];
+    }
+    const size_t pitem = (size_t)b * mf.C + c;
+    colblock_store<NT>(mf.PfD + pitem * QFR, J, lane, R);
+    lds_put_colblock<NT>(img[flip], 16 * J, lane, R);
+    __syncthreads();
+    lds_store_fragT_half<NT>(img[flip], mf.PfT + pitem * QFR, J, lane);
+}
+
+// DEFAULT for NT = 2 batches: one WAVE per (seed, chunk) owning all NT column blocks: every block load of the left operand
+// feeds 3*NT MFMAs instead of 3, re+im comes pre-summed from a second image (no VALU in the product loop), and there is no
+// workgroup barrier at all (a wave's LDS operations execute in order).  C2 x 64: 0.92 ms per launch = 72.6 TFLOP/s algorithmic.
+template <int NT>
+__device__ __forceinline__ void mm_full4(const cplx* img, const double* imgs, int lane, const CTile (&p)[NT][NT], CTile (&out)[NT][NT]) {
+    double a[NT][QQS], b[NT][QQS], c[NT][QQS];
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int s = 0; s < QQS; ++s) { a[J][s] = 0.0; b[J][s] = 0.0; c[J][s] = 0.0; }
+    const cplx* base = img + (lane >> 4) * QLDR + (lane & 3);
+    const double* bases = imgs + (lane >> 4) * QLDR + (lane & 3);
+#pragma unroll
+    for (int kb = 0; kb < QQS; ++kb) {
+        double br[NT], bi[NT], bs[NT];
+#pragma unroll
+        for (int J = 0; J < NT; ++J) { br[J] = p[J][kb >> 2].re[kb & 3]; bi[J] = p[J][kb >> 2].im[kb & 3]; bs[J] = br[J] + bi[J]; }
+#pragma unroll
+        for (int ib = 0; ib < QQS; ++ib) {
+            const cplx v = base[4 * kb * QLDR + 4 * ib];
+            const double vs = bases[4 * kb * QLDR + 4 * ib];      // re + im, summed once by the writer of the image
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                a[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br[J], a[J][ib], 0, 0, 0);
+                b[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi[J], b[J][ib], 0, 0, 0);
+                c[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, bs[J], c[J][ib], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int s = 0; s < QQS; ++s) { out[J][s >> 2].re[s & 3] = a[J][s] - b[J][s]; out[J][s >> 2].im[s & 3] = c[J][s] - a[J][s] - b[J][s]; }
+}
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int NT>
+__global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4w(QocDev d, QocMfma mf) {
+    __shared__ __attribute__((aligned(16))) cplx img[QNP * QLDR];
+    __shared__ __attribute__((aligned(16))) double imgs[QNP * QLDR];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
+    if (d.skip_done && d.done[b]) return;
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const double inv_scale = 1.0 / (double)(1 << d.s);
+    const int dlt = (lane & 15) - (lane >> 4);
+    CTile R[NT][NT];
+#pragma unroll
+    for (int J = 0; J < NT; ++J) colblock_identity<NT>(J, lane, R[J]);
+    auto put_all = [&](const CTile (&m)[NT][NT]) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            lds_put_colblock<NT>(img, 16 * J, lane, m[J]);
+#pragma unroll
+            for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    imgs[(16 * J + (lane & 15)) * QLDR + 16 * Ib + (lane >> 4) + 4 * r] = m[J][Ib].re[r] + m[J][Ib].im[r];
+        }
+        wave_lds_fence();
+    };
+    for (int t = t0; t < t1; ++t) {
+        CTile P[NT][NT];
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            colblock_load<NT>(mf.HfD, J, lane, P[J]);
+#pragma unroll
+            for (int Ib = 0; Ib < NT; ++Ib) { P[J][Ib].re *= inv_scale; P[J][Ib].im *= inv_scale; }
+        }
+#pragma unroll 1
+        for (int kk = 0; kk < d.k; ++kk) {
+            const double ck = d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale;
+            const cplx* __restrict__ HD = mf.HfD + (size_t)(kk + 1) * QFR;
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+#pragma unroll
+                for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx h = HD[(J * QQS + 4 * Ib + r) * 64 + lane];
+                        P[J][Ib].re[r] = fma(ck, h.x, P[J][Ib].re[r]);
+                        P[J][Ib].im[r] = fma(ck, h.y, P[J][Ib].im[r]);
+                    }
+        }
+        if (d.T >= 2) {
+            CTile AJ[NT][NT], A2J[NT][NT];
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                for (int Ib = 0; Ib < NT; ++Ib) AJ[J][Ib] = P[J][Ib];
+            put_all(AJ);
+            mm_full4<NT>(img, imgs, lane, AJ, A2J);
+            wave_lds_fence();
+            put_all(A2J);
+            const int mm = d.T >> 1;
+            int i;
+            double c0, c1, cT = 0.0;
+            if ((d.T & 1) == 0) { c0 = mf.invfact[2 * mm - 2]; c1 = mf.invfact[2 * mm - 1]; cT = mf.invfact[d.T]; i = mm - 2; }
+            else { c0 = mf.invfact[2 * mm]; c1 = mf.invfact[2 * mm + 1]; i = mm - 1; }
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+#pragma unroll
+                for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double one = (Ib == J && dlt == 4 * r) ? c0 : 0.0;
+                        P[J][Ib].re[r] = one + c1 * AJ[J][Ib].re[r] + cT * A2J[J][Ib].re[r];
+                        P[J][Ib].im[r] = c1 * AJ[J][Ib].im[r] + cT * A2J[J][Ib].im[r];
+                    }
+            for (; i >= 0; --i) {
+                CTile acc[NT][NT];
+                mm_full4<NT>(img, imgs, lane, P, acc);
+                const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+#pragma unroll
+                    for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double one = (Ib == J && dlt == 4 * r) ? d0 : 0.0;
+                            P[J][Ib].re[r] = one + d1 * AJ[J][Ib].re[r] + acc[J][Ib].re[r];
+                            P[J][Ib].im[r] = d1 * AJ[J][Ib].im[r] + acc[J][Ib].im[r];
+                        }
+            }
+            wave_lds_fence();
+        } else {
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+#pragma unroll
+                for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P[J][Ib].re[r] += (Ib == J && dlt == 4 * r) ? 1.0 : 0.0;
+        }
+        for (int sq = 0; sq < d.s; ++sq) {
+            put_all(P);
+            CTile acc[NT][NT];
+            mm_full4<NT>(img, imgs, lane, P, acc);
+            wave_lds_fence();
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                for (int Ib = 0; Ib < NT; ++Ib) P[J][Ib] = acc[J][Ib];
+        }
+        const size_t item = kitem(mf, d.steps, b, t);
+#pragma unroll
+        for (int J = 0; J < NT; ++J) colblock_store<NT>(mf.KfD + item, J, lane, P[J]);
+        put_all(P);
+#pragma unroll
+        for (int J = 0; J < NT; ++J) lds_store_fragT_half<NT>(img, mf.KfT + item, J, lane);
+        CTile acc[NT][NT];
+        mm_full4<NT>(img, imgs, lane, R, acc);
+        wave_lds_fence();
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+            for (int Ib = 0; Ib < NT; ++Ib) R[J][Ib] = acc[J][Ib];
+    }
+    const size_t pitem = (size_t)b * mf.C + c;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) colblock_store<NT>(mf.PfD + pitem * QFR, J, lane, R[J]);
+    put_all(R);
+#pragma unroll
+    for (int J = 0; J < NT; ++J) lds_store_fragT_half<NT>(img, mf.PfT + pitem * QFR, J, lane);
 }
 
 // ---- kernel F: thin forward sweep  Psi_t = K_t Psi_{t-1}  (inter vectors) + final unitary ------------------------
@@ -646,7 +956,13 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
 
 template <int NT>
 static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    hipLaunchKernelGGL(k_mfma_expm_chunk<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
+    // AUTO: NT = 2 with at least half of the 1024 SIMDs busy -> one wave per (seed, chunk) on v_mfma_f64_4x4x4 (0.92 vs 1.21 ms
+    // per launch at C2 x 64); NT = 1 and small launches keep the 16x16x4 kernel (C1: 0.072 vs 0.074 ms; one C2 trajectory:
+    // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
+    const int v = mf.variant > 0 ? mf.variant : ((NT == 2 && d.B * mf.C >= 512) ? 3 : 1);
+    if (v == 3 && NT <= 2) hipLaunchKernelGGL(k_mfma_expm_chunk4w<NT>, dim3(d.B * mf.C), dim3(64), 0, s, d, mf);
+    else if (v == 2 && NT <= 2) hipLaunchKernelGGL(k_mfma_expm_chunk4<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
+    else hipLaunchKernelGGL(k_mfma_expm_chunk<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
 }
 static inline void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.NT == 1) qoc_mfma_launch_all_expm<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_expm<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_expm<3>(mf, d, s); else qoc_mfma_launch_all_expm<4>(mf, d, s);

@@ -26,7 +26,7 @@ class QocConfig(C.Structure):
                 ('c_d2wdt2', C.c_double), ('c_speed_up', C.c_double), ('c_bandpass', C.c_double),
                 ('band_lo', C.c_int32), ('band_hi', C.c_int32), ('n_forbidden', C.c_int32),
                 ('forbid_dressed', C.c_int32), ('device', C.c_int32), ('path', C.c_int32), ('chunks', C.c_int32),
-                ('reserved', C.c_int32 * 7)]
+                ('variant', C.c_int32), ('reserved', C.c_int32 * 6)]
 
 
 class QocAdamParams(C.Structure):
@@ -137,7 +137,7 @@ class HipEngine(object):
     """Device-resident GRAPE problem: constants in HBM, n_seeds control sets, one HIP stream."""
 
     def __init__(self, Hs, U0, V, W, maxA, dt, total_time, steps, taylor_terms, scaling, state_transfer=False,
-                 reg_coeffs=None, one_minus_gauss=None, Vs=None, n_seeds=1, device=0, path=PATH_AUTO, chunks=0):
+                 reg_coeffs=None, one_minus_gauss=None, Vs=None, n_seeds=1, device=0, path=PATH_AUTO, chunks=0, variant=0):
         lib = load_library()
         self._lib = lib
         self._h = C.c_void_p()
@@ -167,7 +167,7 @@ class HipEngine(object):
         cfg.n_forbidden = 0 if fs is None else len(fs)
         use_vs = Vs is not None and cfg.n_forbidden > 0
         cfg.forbid_dressed = int(use_vs)
-        cfg.device, cfg.path, cfg.chunks = int(device), int(path), int(chunks)
+        cfg.device, cfg.path, cfg.chunks, cfg.variant = int(device), int(path), int(chunks), int(variant)
         omg = None
         if one_minus_gauss is not None:
             omg = np.ascontiguousarray(np.asarray(one_minus_gauss, dtype=np.float64))

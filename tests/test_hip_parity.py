@@ -23,12 +23,12 @@ FULL_REG = {'amplitude': 0.3, 'envelope': 0.2, 'dwdt': 0.1, 'd2wdt2': 0.05, 'for
             'states_forbidden_list': [3, 2], 'speed_up': 0.7, 'bandpass': 0.4, 'band': [0.5, 2.0]}
 
 
-def make_engine(sp, n_seeds=1, path=0, chunks=0):
+def make_engine(sp, n_seeds=1, path=0, chunks=0, variant=0):
     from quantum_optimal_control.core import hip_engine
     return hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms,
                                 sp.scaling, state_transfer=sp.state_transfer, reg_coeffs=sp.reg_coeffs,
                                 one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=n_seeds, path=path,
-                                chunks=chunks)
+                                chunks=chunks, variant=variant)
 
 
 def parity_cases():
@@ -84,6 +84,18 @@ def test_eval_parity(name, c, path):
 @pytest.mark.parametrize('chunks', [1, 3, 7, 40])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'U0_dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n57_k1_nt4'])
 def test_mfma_path_parity(chunks, variant):
+    _mfma_path_parity(chunks, variant, 0)
+
+
+@pytest.mark.parametrize('kernel', [1, 2, 3], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave'])
+@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed'])
+@pytest.mark.parametrize('chunks', [1, 7])
+def test_mfma_exponential_kernels(chunks, variant, kernel):
+    """The three kernels of the exponentials (qoc_config.variant) on the n <= 32 problems, whatever AUTO would pick."""
+    _mfma_path_parity(chunks, variant, kernel)
+
+
+def _mfma_path_parity(chunks, variant, kernel):
     """Register-resident MFMA path (n <= 32, unitary mode) for several time-chunk counts, incl. ragged last chunk."""
     if variant == 'plain':
         c = cases.case_c2(n=32, k=4, steps=40, m=8, taylor=(5, 3), seed=0)
@@ -108,7 +120,7 @@ def test_mfma_path_parity(chunks, variant):
     sp = oracle_system(c)
     rng = np.random.default_rng(5)
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2, 3 * sp.base0]
-    eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks)
+    eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
     assert eng.path == 2
     eng.set_base(np.stack(bases))
     check_eval(eng, sp, bases)
