@@ -8,7 +8,7 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line f
     per-seed fidelities are all-gathered once over RCCL after the last iteration (inside the timed region).
   * a "step" = one GRAPE iteration of every seed on the GPU (all inputs resident in HBM).
   * value = (seeds on all GPUs) * K / wall time, wall = max over ranks, barrier + device sync on both sides.
-  * roofline: dominant kernel (k_mfma_expm_chunk: matrix exponentials + chunk products) timed with hipEvents on the
+  * roofline: dominant kernel (k_mfma_expm_chunk4w: matrix exponentials + chunk products) timed with hipEvents on the
     engine's stream in a separate short pass; algorithmic FLOPs per launch from SURVEY.md 8d.
   * cpu_baseline: the CPU oracle (NumPy complex128 port of the reference's op sequence, ONE evaluation per
     iteration) timed on a bounded sample on this host -- a reported baseline, not the target.

@@ -954,12 +954,18 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     return 0;
 }
 
+// which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave)
+static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
+    if (mf.NT > 2) return 1;
+    return mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 3 : 1);
+}
+
 template <int NT>
 static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
     // AUTO: NT = 2 with at least half of the 1024 SIMDs busy -> one wave per (seed, chunk) on v_mfma_f64_4x4x4 (0.92 vs 1.21 ms
     // per launch at C2 x 64); NT = 1 and small launches keep the 16x16x4 kernel (C1: 0.072 vs 0.074 ms; one C2 trajectory:
     // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
-    const int v = mf.variant > 0 ? mf.variant : ((NT == 2 && d.B * mf.C >= 512) ? 3 : 1);
+    const int v = qoc_mfma_expm_variant(mf, d);
     if (v == 3 && NT <= 2) hipLaunchKernelGGL(k_mfma_expm_chunk4w<NT>, dim3(d.B * mf.C), dim3(64), 0, s, d, mf);
     else if (v == 2 && NT <= 2) hipLaunchKernelGGL(k_mfma_expm_chunk4<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_expm_chunk<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
