@@ -542,3 +542,18 @@ def test_create_destroy_releases_device_memory():
             if cycle == 0:
                 baseline = free_bytes()
         assert free_bytes() >= baseline - (8 << 20), (path, chunks, baseline, free_bytes())
+
+
+def test_gemm_path_n128_batched_launches():
+    """n = 128 (launch-per-product exponentials, product tree, launch-per-step chains) with 8 seeds: full comparison with
+    the oracle."""
+    c = cases.case_c2(n=128, k=2, steps=8, m=8, taylor=(5, 2), seed=41)
+    c['reg_coeffs'] = {'dwdt': 0.05, 'forbidden_coeff_list': [2.0], 'states_forbidden_list': [127]}
+    sp = oracle_system(c)
+    rng = np.random.default_rng(8)
+    bases = [sp.base0] + [1.5 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.05 * i for i in range(7)]
+    eng = make_engine(sp, n_seeds=len(bases))
+    assert eng.path == 4
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
