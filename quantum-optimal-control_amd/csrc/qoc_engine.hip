@@ -258,8 +258,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     int rc = QOC_OK;
     auto bail = [&](int code) { qoc_destroy(e); return code; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QOC_ERR_HIP, "hipStreamCreate failed"));
-    hipEventCreate(&e->t0);
-    hipEventCreate(&e->t1);
+    if (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess) return bail(fail(QOC_ERR_HIP, "hipEventCreate failed"));
 
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, ks = (size_t)k * steps;
     // U0*V on the host (tiny): start vector of the thin forward recursion
@@ -305,15 +304,16 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     ALLOC(d.loss, (size_t)B); ALLOC(d.reg_state, (size_t)B); ALLOC(d.reg_loss, (size_t)B);
     ALLOC(d.g2, (size_t)B); ALLOC(d.uscale, (size_t)B);
     if (d.has_band) ALLOC(d.band_ph, B * ks);
-    hipMemset(d.base, 0, B * ks * sizeof(double));
-    hipMemset(d.adam_m, 0, B * ks * sizeof(double));
-    hipMemset(d.adam_v, 0, B * ks * sizeof(double));
-    hipMemset(d.adam_t, 0, B * sizeof(int));
-    hipMemset(d.iters, 0, B * sizeof(int));
-    hipMemset(d.done, 0, B * sizeof(int));
-    hipMemset(d.su_resid, 0, B * sizeof(double));
-    hipMemset(d.uscale, 0, B * sizeof(double));
-    hipMemset(d.Xfinal, 0, (size_t)B * nn * sizeof(cplx));
+    if (hipMemset(d.base, 0, B * ks * sizeof(double)) != hipSuccess ||
+        hipMemset(d.adam_m, 0, B * ks * sizeof(double)) != hipSuccess ||
+        hipMemset(d.adam_v, 0, B * ks * sizeof(double)) != hipSuccess ||
+        hipMemset(d.adam_t, 0, B * sizeof(int)) != hipSuccess ||
+        hipMemset(d.iters, 0, B * sizeof(int)) != hipSuccess ||
+        hipMemset(d.done, 0, B * sizeof(int)) != hipSuccess ||
+        hipMemset(d.su_resid, 0, B * sizeof(double)) != hipSuccess ||
+        hipMemset(d.uscale, 0, B * sizeof(double)) != hipSuccess ||
+        hipMemset(d.Xfinal, 0, (size_t)B * nn * sizeof(cplx)) != hipSuccess)
+        return bail(fail(QOC_ERR_HIP, "qoc_create: clearing the state buffers failed"));
 
     // ---- path selection -----------------------------------------------------------------------------------------
     int path = cfg->path;
@@ -357,7 +357,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, gemm_direct, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
-        qoc_gemm_lds_opt_in();
+        if (!qoc_gemm_lds_opt_in()) return bail(fail(QOC_ERR_HIP, "qoc_create: cannot reserve LDS for the GEMM-path kernels"));
         e->chunks = e->gm.NC;
     } else if (!cfg->state_transfer) {
         ALLOC(e->K, (size_t)B * steps * nn);
@@ -445,15 +445,19 @@ int qoc_adam_step(qoc_handle e, const double* lr) {
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_adam_step: no evaluation since the last qoc_set_base");
     double* dlr = nullptr;
     HIP_TRY(hipMalloc((void**)&dlr, e->d.B * sizeof(double)));
-    hipMemcpy(dlr, lr, e->d.B * sizeof(double), hipMemcpyHostToDevice);
+    if (hipMemcpy(dlr, lr, e->d.B * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(dlr);
+        return fail(QOC_ERR_HIP, "qoc_adam_step: learning-rate upload failed");
+    }
     QocAdamDev ap;
     memset(&ap, 0, sizeof ap);
     ap.mode = 2;
     ap.lr = dlr;
     // the reference re-evaluates the gradient at the same parameters inside session.run([optimizer]) (run_session.py:69)
     int rc = enqueue_iteration(e, ap);
-    hipStreamSynchronize(e->stream);
+    const hipError_t se = hipStreamSynchronize(e->stream);          // dlr must outlive the kernels that read it
     hipFree(dlr);
+    if (rc == QOC_OK && se != hipSuccess) rc = fail(QOC_ERR_HIP, "qoc_adam_step: %s", hipGetErrorString(se));
     return rc;
 }
 

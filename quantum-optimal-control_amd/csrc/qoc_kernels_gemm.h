@@ -286,12 +286,13 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     // the persistent chain kernels write only the first m (<= 8) of the 32 thin columns; the rest must read as zero
-    hipMemset(gm.zthin, 0, thin * sizeof(cplx));
-    hipMemset(gm.interP, 0, BSP * thin * sizeof(cplx));
-    hipMemset(gm.LamP, 0, BSP * thin * sizeof(cplx));
-    hipMemset(gm.Psibnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx));
-    hipMemset(gm.Ebnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx));
-    hipMemset(gm.Aoff, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx));
+    bool zeroed = hipMemset(gm.zthin, 0, thin * sizeof(cplx)) == hipSuccess &&
+                  hipMemset(gm.interP, 0, BSP * thin * sizeof(cplx)) == hipSuccess &&
+                  hipMemset(gm.LamP, 0, BSP * thin * sizeof(cplx)) == hipSuccess &&
+                  hipMemset(gm.Psibnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess &&
+                  hipMemset(gm.Ebnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess &&
+                  hipMemset(gm.Aoff, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess;
+    if (!zeroed) { msg = "GEMM path: clearing the work buffers failed"; return -2; }
     return 0;
 }
 
@@ -302,12 +303,12 @@ static inline void qoc_gemm_launch_sk(const GemmArgs& g, unsigned blocks, hipStr
 }
 // Kernels that use more than 64 KB of dynamic LDS must opt in, per device: called from qoc_gemm_setup (one engine = one device)
 template <bool CONJT, int EPI>
-static inline void qoc_gemm_lds_opt_in_sk() {
-    hipFuncSetAttribute((const void*)k_zgemm32<CONJT, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2048 * (int)sizeof(double));
+static inline bool qoc_gemm_lds_opt_in_sk() {
+    return hipFuncSetAttribute((const void*)k_zgemm32<CONJT, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2048 * (int)sizeof(double)) == hipSuccess;
 }
-static inline void qoc_gemm_lds_opt_in() {
-    qoc_gemm_lds_opt_in_sk<false, 0>(); qoc_gemm_lds_opt_in_sk<false, 1>(); qoc_gemm_lds_opt_in_sk<false, 2>(); qoc_gemm_lds_opt_in_sk<true, 0>();
-    hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx));
+static inline bool qoc_gemm_lds_opt_in() {
+    return qoc_gemm_lds_opt_in_sk<false, 0>() && qoc_gemm_lds_opt_in_sk<false, 1>() && qoc_gemm_lds_opt_in_sk<false, 2>() && qoc_gemm_lds_opt_in_sk<true, 0>() &&
+           hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx)) == hipSuccess;
 }
 // picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small
 static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
