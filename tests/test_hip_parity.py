@@ -557,3 +557,24 @@ def test_gemm_path_n128_batched_launches():
     eng.set_base(np.stack(bases))
     check_eval(eng, sp, bases)
     eng.close()
+
+
+@pytest.mark.parametrize('name', ['small_auto', 'big_auto', 'guess', 'dressed', 'state_small', 'c3_small'])
+def test_grape_end_to_end_every_recipe(name):
+    """Grape() on every golden recipe (U0 != I, automatic Taylor orders of both heuristic branches, explicit initial guess
+    with default maxA, dressed basis with forbid_dressed, state transfer with and without regularisers): 12 Adam iterations
+    against the oracle's loop from the same NumPy RNG state."""
+    from quantum_optimal_control.main_grape.grape import Grape
+    c = cases.ALL_CASES[name]()
+    conv = {'rate': 0.02, 'update_step': 5, 'max_iterations': 12, 'conv_target': 1e-14, 'learning_rate_decay': 50}
+    np.random.seed(c['np_seed'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        uks, Uf = Grape(convergence=conv, method='Adam', **grape_kwargs(c))
+    sp = oracle_system(c)
+    ref = go.run_adam(sp, conv)
+    assert ref['iterations'] == 12
+    np.testing.assert_allclose(uks, ref['uks'], atol=1e-9 * max(1.0, np.max(np.abs(ref['uks']))))
+    if sp.state_transfer:
+        assert Uf == []
+    else:
+        np.testing.assert_allclose(Uf, ref['U_final'], atol=1e-9)
