@@ -895,7 +895,10 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     mf.NT = NT; mf.FR = FR;
     int C = chunks_req;
     if (C <= 0) {
-        C = (1024 + d.B - 1) / d.B;                  // ~2 waves per SIMD for the expm kernel (NT waves per chunk)
+        // NT = 2: the default exponential kernel is ONE wave of 444 VGPRs per (seed, chunk), i.e. at most one resident wave per
+        // SIMD: B*C must not exceed the 1024 SIMDs or a second, nearly empty round doubles the launch (48 seeds: C = 22 ->
+        // 1056 items, 24.0k it/s; C = 21 -> 1008 items, 39.6k it/s).  Other NT: ~2 waves per SIMD.
+        C = NT == 2 ? 1024 / d.B : (1024 + d.B - 1) / d.B;
         if (C > 32) C = 32;
     }
     if (C > d.steps) C = d.steps;
