@@ -79,7 +79,9 @@ class run_session(object):
         self.anly = Analysis(self.sys_para, self.engine, self.seed)
         self.save_data()
         self.display()
-        if self.iterations % max(1, int(self.conv.evol_save_step)) == 0:
+        if self.show_plots and self.conv.in_notebook():
+            self.conv.plot_summary(self.l, self.rl, self.anly, self.metric)       # redraws the live figure (and snapshots)
+        elif self.iterations % max(1, int(self.conv.evol_save_step)) == 0:
             self.conv.save_evol(self.anly)
 
     # ---- results ------------------------------------------------------------------------------------------------

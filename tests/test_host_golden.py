@@ -97,3 +97,43 @@ def test_builder_helpers_match_reference():
     assert gf.Bin(5, 6) == str(fx['bin_5_6']) and gf.Basis(7, 3, 3) == str(fx['basis_7_3_3'])
     assert gf.baseN(11, 3) == str(fx['baseN_11_3']) and gf.baseN(0, 5) == '0'
     assert gf.hamming_distance(0b101101) == 4
+
+
+def test_convergence_plot_summary_writes_the_reference_panels(tmp_path):
+    """Row f4 (UI): the summary figure of convergence.py:121-222 -- error curves, final operator (re / im), pulses, one
+    population panel per concerned state with the forbidden-level sum -- drawn from stub read-back, off-screen."""
+    pytest.importorskip('matplotlib')
+    from quantum_optimal_control.core.convergence import Convergence
+
+    class Sys(object):
+        pass
+
+    n, k, steps, m = 4, 2, 20, 2
+    sp = Sys()
+    sp.state_transfer, sp.use_inter_vecs, sp.dt, sp.steps, sp.ops_len = False, True, 0.1, steps, k
+    sp.ops_max_amp, sp.Hnames, sp.states_concerned_list = [1.0, 2.0], ['x', 'y'], [0, 1]
+    sp.draw_list, sp.draw_names, sp.dressed_info = [], [], None
+    sp.reg_coeffs = {'states_forbidden_list': [3], 'forbidden_coeff_list': [1.0]}
+    rng = np.random.default_rng(0)
+
+    class Anly(object):
+        def get_final_state(self):
+            return np.linalg.qr(rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n)))[0]
+
+        def get_inter_vecs(self):
+            p = rng.uniform(size=(m, n, steps + 1))
+            return list(p / p.sum(axis=1, keepdims=True))
+
+        def get_ops_weight(self):
+            return np.sin(rng.normal(size=(k, steps)))
+
+    conv = Convergence(sp, 'ns', {'max_iterations': 100})
+    for it in range(0, 30, 10):
+        conv.record(it, 0.5 / (1 + it), 0.6 / (1 + it))
+    out = tmp_path / 'summary.png'
+    fig = conv.plot_summary(0.02, 0.03, Anly(), unitary_metric=0.99999, filename=str(out))
+    assert out.exists() and out.stat().st_size > 10000
+    titles = [ax.get_title() for ax in fig.axes]
+    assert any(t.startswith('Error = 2.00e-02; Other errors = 1.00e-02') for t in titles)
+    assert 'operator: real' in titles and 'operator: imaginary' in titles and 'Optimized pulse' in titles
+    assert titles.count('Evolution') == m
