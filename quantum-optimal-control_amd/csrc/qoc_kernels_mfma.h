@@ -59,8 +59,8 @@ struct QocMfma {
     cplx* PfD = nullptr;      // [B][C] fragD(P_c)
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
-    size_t bwd_lds = 0;
-    bool h_in_lds = true;
+    size_t bwd_lds = 0, bwd_lds2 = 0;
+    bool h_in_lds = true, h_in_lds2 = true;
     int variant = 0;              // qoc_config.variant: 0 auto, 1 16x16x4, 2 4x4x4 two waves, 3 4x4x4 one wave
     int skew_c = 0, skew_b = 0;   // element skews per chunk / per seed that break the power-of-two strides of K storage
 };
@@ -868,6 +868,185 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     }
 }
 
+// ---- kernel B2 (NT = 2): the backward sweep with every (seed, chunk) item split over a PAIR of waves by row tile ----------
+// The one-wave-per-item kernel above runs one wave per SIMD and its dependent 16x16x4 MFMA chains issue every ~143 cycles;
+// here wave h of a pair owns the 16-row tile h of Lambda: it forms the Q tiles (h, 0..1) of the gradient contraction and row
+// tile h of K_t^dagger Lambda_t (half the MFMAs, half the K fragments), so 2 waves per SIMD are resident (~103-cycle issue)
+// and each chain is half as long.  The pair exchanges tiles through its transposed LDS images (the same image that feeds the
+// A operand of Q), double-buffered, one workgroup barrier per slice; all trip counts are uniform over the workgroup
+// (4 items = 8 waves share one LDS image of the control Hamiltonians): inactive steps only take part in the barriers.
+// Measured at C2 x 64: 259 vs 301 us per launch (prefetching the K fragments one slice ahead made it 283: not the bound).
+#define B2_LDP 17
+template <bool H_IN_LDS>
+__global__ void __launch_bounds__(512) k_mfma_backward2(QocDev d, QocMfma mf) {
+    constexpr int NT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wv & 1, pair = wv >> 1;
+    cplx* Hl = (cplx*)smem;                                                     // [k] fragD(H_k')
+    cplx* pads = (cplx*)(smem + (H_IN_LDS ? (size_t)d.k * QFR * sizeof(cplx) : 0));   // [8 waves][2 buffers][16 * B2_LDP]
+    double* gpart = (double*)(pads + 8 * 2 * 16 * B2_LDP);                     // [4 pairs][2 buffers][8]
+    if (H_IN_LDS) {
+        for (int o = threadIdx.x; o < d.k * QFR; o += blockDim.x) Hl[o] = mf.HfD[QFR + o];
+    }
+    const cplx* Hsrc = H_IN_LDS ? Hl : (mf.HfD + QFR);
+    cplx* mypad = pads + (size_t)wv * 2 * 16 * B2_LDP;
+    const cplx* otherpad = pads + (size_t)(wv ^ 1) * 2 * 16 * B2_LDP;
+    const int item = blockIdx.x * 4 + pair;
+    const bool item_ok = item < d.B * mf.C;
+    const int b = item_ok ? item / mf.C : 0, c = item_ok ? item - b * mf.C : 0;
+    const bool active = item_ok && !(d.skip_done && d.done[b]);
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const bool need_src = d.n_forb > 0 || d.has_speed;
+    const int lk = lane >> 4, lc = lane & 15;
+    // own tile of the costate, D layout: register r <-> (row 16h + lk + 4r, column lc)
+    d4 ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};
+    if (active) {
+        const cplx z = d.zfin[b];
+        const double c0 = -2.0 / ((double)d.m * (double)d.m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * h + lk + 4 * r;
+            cplx v = cmake(0.0, 0.0);
+            if (row < d.n && lc < d.m) {
+                v = cscale(cmul(z, d.W[row * d.m + lc]), c0);
+                if (need_src) v = cadd(v, source_at(d, b, d.steps, row, lc));
+            }
+            ore[r] = v.x; oim[r] = v.y;
+        }
+    }
+    int buf = 0;
+    auto put_own = [&](int bf) {                                                 // image[col][row16]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mypad[(bf * 16 + lc) * B2_LDP + lk + 4 * r] = cmake(ore[r], oim[r]);
+    };
+    auto get_other = [&](int bf, d4& xre, d4& xim) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const cplx v = otherpad[(bf * 16 + lc) * B2_LDP + lk + 4 * r]; xre[r] = v.x; xim[r] = v.y; }
+    };
+    // row tile h of M^dagger * Lambda with M given as fragD(M): 24 MFMAs
+    auto dagger_product = [&](const cplx* __restrict__ F, const d4& xre, const d4& xim) {
+        d4 a = {0, 0, 0, 0}, bq = {0, 0, 0, 0}, cq = {0, 0, 0, 0};
+        cplx fr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fr[q] = F[(h * QQS + q) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool own = (q >> 2) == h;
+            const double br = own ? ore[q & 3] : xre[q & 3], bi = own ? oim[q & 3] : xim[q & 3];
+            const double ar = fr[q].x, ai = -fr[q].y;
+            a = QMFMA(ar, br, a);
+            bq = QMFMA(ai, bi, bq);
+            cq = QMFMA(ar + ai, br + bi, cq);
+        }
+        ore = a - bq; oim = cq - a - bq;
+    };
+    put_own(0);
+    __syncthreads();
+    // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc + a_cc, uniform trip count ---------------------
+    for (int cc = mf.C - 1; cc >= 1; --cc) {
+        if (active && cc > c) {
+            d4 xre, xim;
+            get_other(buf, xre, xim);
+            dagger_product(mf.PfD + ((size_t)b * mf.C + cc) * QFR, xre, xim);
+            if (need_src) {
+                const cplx* off = mf.Aoff + ((size_t)b * mf.C + cc) * (QQS * 64);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const cplx v = off[(4 * h + r) * 64 + lane]; ore[r] += v.x; oim[r] += v.y; }
+            }
+        }
+        put_own(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
+    for (int i = 0; i < mf.L; ++i) {
+        const int t = t1 - 1 - i;
+        const bool live = active && t >= t0;
+        double g[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) g[kk] = 0.0;
+        if (live) {
+            // ---- Q tiles (h, 0..1) = conj(Lambda_t)[rows of tile h] Psi_t^T and the contraction with H_k' -----------------
+            double lr[4], li[4], pr[2][4], pi[2][4];
+            const cplx* psi = iv + (size_t)(t + 1) * d.n * d.m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lr[q] = 0.0; li[q] = 0.0;
+#pragma unroll
+                for (int Jp = 0; Jp < 2; ++Jp) { pr[Jp][q] = 0.0; pi[Jp][q] = 0.0; }
+                if (q < mf.mq) {
+                    const int j = 4 * q + lk;
+                    const cplx lv = mypad[(buf * 16 + j) * B2_LDP + lc];          // Lambda[16h + lc][j]
+                    lr[q] = lv.x; li[q] = lv.y;
+#pragma unroll
+                    for (int Jp = 0; Jp < 2; ++Jp) {
+                        const int row = 16 * Jp + lc;
+                        if (row < d.n && j < d.m) { const cplx pv = psi[row * d.m + j]; pr[Jp][q] = pv.x; pi[Jp][q] = pv.y; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int Jp = 0; Jp < 2; ++Jp) {
+                d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < mf.mq) {
+                        t1v = QMFMA(lr[q], pr[Jp][q], t1v);
+                        t2v = QMFMA(li[q], pi[Jp][q], t2v);
+                        t3v = QMFMA(lr[q] - li[q], pr[Jp][q] + pi[Jp][q], t3v);
+                    }
+                }
+                const d4 qr = t1v + t2v, qi = t3v - t1v + t2v;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    if (kk >= d.k) continue;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx hv = Hsrc[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
+                        acc = fma(hv.x, qr[r], acc);
+                        acc = fma(-hv.y, qi[r], acc);
+                    }
+                    g[kk] += acc;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if (kk >= d.k) continue;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) g[kk] += __shfl_down(g[kk], off, 64);
+            }
+            if (h == 1 && lane == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) gpart[(pair * 2 + buf) * 8 + kk] = g[kk];
+            }
+            // ---- Lambda_{t-1} = K_t^dagger Lambda_t (+ S_{t-1}) -----------------------------------------------------------
+            if (t > 0) {
+                d4 xre, xim;
+                get_other(buf, xre, xim);
+                dagger_product(mf.KfD + kitem(mf, d.steps, b, t), xre, xim);
+                if (need_src) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * h + lk + 4 * r;
+                        if (row < d.n && lc < d.m) { const cplx sv = source_at(d, b, t, row, lc); ore[r] += sv.x; oim[r] += sv.y; }
+                    }
+                }
+            }
+        }
+        put_own(buf ^ 1);
+        __syncthreads();
+        if (live && h == 0 && lane == 0) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (kk < d.k) d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = g[kk] + gpart[(pair * 2 + buf) * 8 + kk];
+        }
+        buf ^= 1;
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 
 static inline bool qoc_mfma_supported(const QocDev& d) {
@@ -944,6 +1123,15 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
     mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
     mf.bwd_lds = pads + (mf.h_in_lds ? hbytes : 0);
+    // row-split kernel (NT = 2): 8 waves x 2 image buffers x 16 x 17 cplx + the pair mailboxes of the gradient partials
+    const size_t pads2 = (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 8 * sizeof(double);
+    mf.h_in_lds2 = (hbytes + pads2) <= 160 * 1024;
+    mf.bwd_lds2 = pads2 + (mf.h_in_lds2 ? hbytes : 0);
+    if (NT == 2 && mf.h_in_lds2 &&
+        hipFuncSetAttribute((const void*)k_mfma_backward2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds2) != hipSuccess) {
+        msg = "MFMA path: cannot reserve LDS for the row-split backward kernel";
+        return -2;
+    }
     if (mf.h_in_lds) {
         const hipError_t e1 = hipFuncSetAttribute((const void*)k_mfma_backward<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
         const hipError_t e2 = hipFuncSetAttribute((const void*)k_mfma_backward<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
@@ -989,6 +1177,14 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     const int items = d.B * mf.C;
     if ((d.n_forb > 0 || d.has_speed) && mf.C > 1)
         hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    // NT = 2: each item split over a pair of waves (2 waves per SIMD for the batches AUTO sends here, 259 vs 301 us at C2 x 64).
+    // The choice must not depend on the batch size: its gradient sums associate differently from the one-wave kernel, and a
+    // seed has to evolve bit-identically whatever batch / GPU it is sharded into.  variant 1 keeps the one-wave kernel (A/B).
+    if (NT == 2 && mf.variant != 1) {
+        if (mf.h_in_lds2) hipLaunchKernelGGL((k_mfma_backward2<true>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_backward2<false>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
+        return;
+    }
     if (mf.h_in_lds)
         hipLaunchKernelGGL((k_mfma_backward<NT, true>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
     else
