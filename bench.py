@@ -10,8 +10,8 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line f
   * value = (seeds on all GPUs) * K / wall time, wall = max over ranks, barrier + device sync on both sides.
   * roofline: dominant kernel (k_mfma_expm_chunk4w: matrix exponentials + chunk products) timed with hipEvents on the
     engine's stream in a separate short pass; algorithmic FLOPs per launch from SURVEY.md 8d.
-  * cpu_baseline: the CPU oracle (NumPy complex128 port of the reference's op sequence, ONE evaluation per
-    iteration) timed on a bounded sample on this host -- a reported baseline, not the target.
+  * cpu_baseline: the compiled C restatement of the oracle (oracle/qoc_oracle.c, OpenMP, one seed per thread, ONE
+    evaluation per iteration) timed on a bounded sample on this host -- a reported baseline, not the target.
 """
 import argparse
 import json
@@ -236,7 +236,7 @@ def main():
                 'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
                 'traffic_unit': 'bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.txt)',
                 'avg_launch_ms': avg_ms, 'launches': pr['launches'], 'flops_per_launch': flops_per_launch,
-                'measured_mfma_f64_ceiling_TFLOPs': 48.2}
+                'measured_mfma_f64_ceilings_TFLOPs': {'v_mfma_f64_16x16x4': 48.2, 'v_mfma_f64_4x4x4_4b': 73.0}}
     # ---- latency of ONE trajectory of the same workload (what a plain Grape() call runs), outside the timed region ----
     single = None
     if rank == 0:
