@@ -32,9 +32,10 @@ extern "C" {
 
 #define QOC_PATH_AUTO 0
 #define QOC_PATH_GENERIC 1     /* any n: workgroup-cooperative complex-fp64 products from HBM/L2 */
-#define QOC_PATH_MFMA 2        /* n <= 64, unitary mode: register-resident v_mfma_f64_16x16x4 chain kernels (NP = 16/32/48/64) */
+#define QOC_PATH_MFMA 2        /* n <= 64, unitary mode: register-resident MFMA chain kernels (v_mfma_f64_4x4x4 / 16x16x4; AUTO for n <= 32 batches) */
 #define QOC_PATH_ST_FUSED 3    /* state transfer, n <= 64, m <= 4: register-resident generator, LDS vectors */
-#define QOC_PATH_GEMM 4        /* unitary mode, any n (m <= 32): tiled MFMA complex GEMM launches from HBM/L2 (n = 512) */
+#define QOC_PATH_GEMM 4        /* any n, m <= 32, both modes: fused LDS exponentials + product tree + persistent thin chains (n <= 64),
+                                * batched tiled MFMA GEMM launches above; state transfer by propagators or, with chunks = 1, directly */
 
 typedef struct qoc_engine* qoc_handle;
 
@@ -60,7 +61,8 @@ typedef struct qoc_config {
     int32_t forbid_dressed;     /* rotate inter_vecs by sort_ev(v_c)^dagger  regularization_functions.py:73-80 */
     int32_t device;             /* HIP device ordinal */
     int32_t path;               /* QOC_PATH_* */
-    int32_t chunks;             /* MFMA path: time chunks per seed (0 = auto) */
+    int32_t chunks;             /* MFMA path: time chunks per seed (0 = auto).  GEMM path, state transfer: 1 = direct route (Taylor
+                                 * mat-vec chains, any H), > 1 = propagator route (needs anti-Hermitian generators), 0 = auto */
     int32_t variant;            /* MFMA path, kernel of the exponentials: 0 = auto, 1 = v_mfma_f64_16x16x4 (two waves per chunk),
                                  * 2 = v_mfma_f64_4x4x4 two waves per chunk, 3 = v_mfma_f64_4x4x4 one wave per chunk */
     int32_t reserved[6];
@@ -146,7 +148,7 @@ int qoc_profile_read(qoc_handle h, const char** kernel_name, int64_t* launches, 
 int qoc_time_iterations(qoc_handle h, const qoc_adam_params* p, int32_t iters, double* elapsed_ms);
 
 /* ---- introspection ---------------------------------------------------------------------------------------------*/
-int qoc_path_in_use(qoc_handle h);        /* QOC_PATH_GENERIC or QOC_PATH_MFMA */
+int qoc_path_in_use(qoc_handle h);        /* the QOC_PATH_* the engine resolved AUTO to */
 int qoc_chunks_in_use(qoc_handle h);
 int qoc_device_count(void);
 int qoc_device_info(int32_t device, char* name, int32_t name_len, int32_t* compute_units, int64_t* hbm_bytes);
