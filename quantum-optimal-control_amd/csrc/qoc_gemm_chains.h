@@ -1,5 +1,6 @@
 // qoc_gemm_chains.h -- persistent thin-chain kernels of the GEMM path (N <= 64, m <= 8): k_gemm_chain_fwd (y <- K y + E),
-// k_gemm_chain_adj (y <- K^H y + E) and k_gemm_taylor_chain (state-transfer Taylor recursion), with their lane mappings.
+// (with CONJ on the transposed copies: y <- K^H y + E) and k_gemm_taylor_chain (state-transfer Taylor recursion), with their
+// lane mappings.
 // Reference semantics: core/tensorflow_state.py:214-242 (chains), :77-133 (matvecexp forward / custom gradient).
 #pragma once
 #include "qoc_gemm_tiles.h"
@@ -76,107 +77,6 @@ __device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
     }
 }
 
-// y <- K_j^H y + E_j (backward chains).  Lane <-> column i of K, so that a wave reads whole rows (the 4 lanes of a quad must
-// stay on 64 contiguous bytes: the texture-address unit serialises a quad that touches 4 cache lines, and a transposed read
-// with a row-per-thread mapping was 2x slower per step); wave w owns rows (4e + w)*RPI + h, RPI = 64/N; x[r] is a broadcast
-// LDS read; the 4*RPI partial rows meet in LDS (one extra barrier per step) and thread (w, h, i) finishes -- adds the
-// source, writes LDS, stores -- the slots jv = sg + s*NSL, sg = (w*RPI + h) % NSL, NSL = min(MV, 4*RPI).
-template <int N, int MV, bool HAS_OUT>
-__global__ void __launch_bounds__(256) k_gemm_chain_adj(ChainArgs a) {
-    constexpr int EL = N * N / 256, RPI = 64 / N;
-    constexpr int NSL = MV < 4 * RPI ? MV : 4 * RPI;
-    constexpr int SPL = MV / NSL;
-    __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
-    __shared__ __attribute__((aligned(16))) cplx part[4 * RPI * N * MV];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int i = lane % N, h = lane / N;
-    const int sg = (wv * RPI + h) % NSL;
-    auto slot = [&](int s) { return sg + s * NSL; };
-    const int b = blockIdx.x / a.CI, c = blockIdx.x - b * a.CI;
-    const cplx* Kp = a.K + b * a.sKb + c * a.sKc;
-    const cplx* Ep = a.E + b * a.sEb + c * a.sEc + (size_t)i * QOC_TW;
-    cplx* Op = HAS_OUT ? a.Out + b * a.sOb + c * a.sOc + (size_t)i * a.ldO : nullptr;
-    cplx yfin[SPL];
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) yfin[sl] = cmake(0.0, 0.0);
-    if (a.X0) {
-        const cplx* x = a.X0 + b * a.sXb + c * a.sXc + (size_t)i * QOC_TW;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) yfin[sl] = x[slot(sl)];
-    }
-#pragma unroll
-    for (int sl = 0; sl < SPL; ++sl) y[0][i * MV + slot(sl)] = yfin[sl];
-    if (HAS_OUT && a.store_initial) {
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) (Op - a.sOs)[slot(sl)] = yfin[sl];
-    }
-    const int last = a.len - 1;
-    auto load = [&](cplx (&kd)[EL], cplx (&ed)[SPL], int j) {
-        const int jc = min(j, last);
-        const cplx* Kj = Kp + (long long)jc * a.sKs;
-#pragma unroll
-        for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)((4 * e + wv) * RPI + h) * N + i];
-        const cplx* ej = Ep + (long long)jc * a.sEs;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[slot(sl)];
-    };
-    int cur = 0;
-    auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
-        cplx acc[MV];
-#pragma unroll
-        for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
-#pragma unroll
-        for (int e = 0; e < EL; ++e) {
-            const int r = (4 * e + wv) * RPI + h;
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) cfma_conj(acc[jv], ku[e], y[cur][r * MV + jv]);
-        }
-#pragma unroll
-        for (int jv = 0; jv < MV; ++jv) part[((wv * RPI + h) * N + i) * MV + jv] = acc[jv];   // 4*RPI partial rows per column
-        lds_barrier();
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) {
-            const int jv = slot(sl);
-            cplx t = part[i * MV + jv];
-#pragma unroll
-            for (int w = 1; w < 4 * RPI; ++w) t = cadd(t, part[(w * N + i) * MV + jv]);
-            yfin[sl] = cadd(t, eu[sl]);
-            y[cur ^ 1][i * MV + jv] = yfin[sl];
-        }
-        if (HAS_OUT) {
-            cplx* oj = Op + (long long)j * a.sOs;
-#pragma unroll
-            for (int sl = 0; sl < SPL; ++sl) oj[slot(sl)] = yfin[sl];
-        }
-        lds_barrier();
-        cur ^= 1;
-    };
-    if (a.len > 0) {
-        // three register stages used round-robin by a 3x unrolled loop (rotating them with copies would make every
-        // iteration wait for the newest load)
-        cplx k0[EL], k1[EL], k2[EL], e0[SPL], e1[SPL], e2[SPL];
-        load(k0, e0, 0);
-        load(k1, e1, 1);
-        lds_barrier();
-        int j = 0;
-        for (; j + 3 <= a.len; j += 3) {
-            load(k2, e2, j + 2); step(j, k0, e0);
-            load(k0, e0, j + 3); step(j + 1, k1, e1);
-            load(k1, e1, j + 4); step(j + 2, k2, e2);
-        }
-        if (j < a.len) step(j, k0, e0);
-        if (j + 1 < a.len) step(j + 1, k1, e1);
-    } else {
-        lds_barrier();
-    }
-    if (a.Fin) {
-        cplx* f = a.Fin + b * a.sFb + c * a.sFc + (size_t)i * QOC_TW;
-#pragma unroll
-        for (int sl = 0; sl < SPL; ++sl) f[slot(sl)] = yfin[sl];
-    }
-}
-
 // ---- register-blocked forward mat-vec mapping (k_gemm_chain_fwd, k_gemm_taylor_chain) ---------------------------------
 // Thread (g, c) = (tid / 16, tid % 16) owns the R x R block rows R*g + rr, columns c + 16*cc of K (R = N/16): a 16-lane DPP
 // row reads 256 contiguous bytes per load, a thread reads only R entries of the vector per slot (the row-per-thread mapping
@@ -198,6 +98,7 @@ struct BlockMap {
             for (int cc = 0; cc < R; ++cc) kd[rr * R + cc] = Kj[(size_t)(R * g + rr) * N + c + 16 * cc];
     }
     // acc[rr*MV + jv] = sum_cc K[rr][cc] * v[c + 16 cc][jv], then the 16-lane reduce-scatter: acc[0..SPLB) are this lane's values
+    template <bool CONJ>
     __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
 #pragma unroll
         for (int x = 0; x < V; ++x) acc[x] = cmake(0.0, 0.0);
@@ -209,7 +110,7 @@ struct BlockMap {
 #pragma unroll
             for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                for (int jv = 0; jv < MV; ++jv) cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]);
+                for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); else cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); }
         }
         chain_butterfly<V, 8, SPLB, V>(acc, c);
     }
@@ -230,21 +131,23 @@ struct RowMap {
 #pragma unroll
         for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)i * N + LPR * e + q];
     }
+    template <bool CONJ>
     __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
 #pragma unroll
         for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
 #pragma unroll
         for (int e = 0; e < EL; ++e)
 #pragma unroll
-            for (int jv = 0; jv < MV; ++jv) cfma(acc[jv], ku[e], v[(LPR * e + q) * MV + jv]);
+            for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[jv], ku[e], v[(LPR * e + q) * MV + jv]); else cfma(acc[jv], ku[e], v[(LPR * e + q) * MV + jv]); }
         chain_butterfly<MV, LPR / 2, SPLB, MV>(acc, q);
     }
 };
 template <int N, int MV> struct FwdMap { using type = BlockMap<N, MV>; };
 template <int MV> struct FwdMap<32, MV> { using type = RowMap<32, MV>; };
 
-// y <- K_j y + E_j (forward chains) with the mapping FwdMap picks for N; same pipeline as k_gemm_chain_adj
-template <int N, int MV, bool HAS_OUT>
+// y <- K_j y + E_j (CONJ: conj(K_j) y + E_j) with the mapping FwdMap picks for N.  Pipeline: K_j / E_j of the next two steps
+// are in flight in three register stages used round-robin by a 3x unrolled branch-free loop; y lives in LDS (double buffer)
+template <int N, int MV, bool CONJ, bool HAS_OUT>
 __global__ void __launch_bounds__(256) k_gemm_chain_fwd(ChainArgs a) {
     using BM = typename FwdMap<N, MV>::type;
     constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
@@ -286,7 +189,7 @@ __global__ void __launch_bounds__(256) k_gemm_chain_fwd(ChainArgs a) {
     int cur = 0;
     auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
         cplx acc[V];
-        bm.matvec(ku, y[cur], acc);
+        bm.template matvec<CONJ>(ku, y[cur], acc);
 #pragma unroll
         for (int sl = 0; sl < SPL; ++sl) {
             yfin[sl] = cadd(acc[sl], eu[sl]);
@@ -374,7 +277,7 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a) {
         double fact = 1.0;
         for (int ii = 1; ii < a.nterms; ++ii) {
             cplx acc[V];
-            bm.matvec(ku, y[cur], acc);
+            bm.template matvec<false>(ku, y[cur], acc);
             fact *= (double)ii;
             const double inv = 1.0 / fact;
             const bool lastterm = ii + 1 == a.nterms;
@@ -429,26 +332,20 @@ static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros
     if (N == 32) qoc_taylor_chain_launch_n<32>(a, blocks, s); else qoc_taylor_chain_launch_n<64>(a, blocks, s);
 }
 
-template <int N, bool HAS_OUT>
-static inline void qoc_chain_adj_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
-    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_adj<N, 1, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_adj<N, 2, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_adj<N, 4, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_chain_adj<N, 8, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-}
-template <int N, bool HAS_OUT>
+template <int N, bool CONJ, bool HAS_OUT>
 static inline void qoc_chain_fwd_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
     const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 1, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 2, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 4, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_chain_fwd<N, 8, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 1, CONJ, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 2, CONJ, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_chain_fwd<N, 4, CONJ, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_chain_fwd<N, 8, CONJ, HAS_OUT>), dim3(blocks), dim3(256), 0, s, a);
 }
+// conj = true: y <- conj(M_j) y, used with M_j = K_j^T for the backward chains (K_j^H = conj(K_j^T): the rows of the transposed
+// copy are read with the same coalesced pattern as the forward chains)
 template <int N>
-static inline void qoc_chain_launch_c(bool conjt, const ChainArgs& a, int blocks, hipStream_t s) {
-    if (conjt) { if (a.Out) qoc_chain_adj_launch_n<N, true>(a, blocks, s); else qoc_chain_adj_launch_n<N, false>(a, blocks, s); }
-    else { if (a.Out) qoc_chain_fwd_launch_n<N, true>(a, blocks, s); else qoc_chain_fwd_launch_n<N, false>(a, blocks, s); }
+static inline void qoc_chain_launch_c(bool conj, const ChainArgs& a, int blocks, hipStream_t s) {
+    if (conj) { if (a.Out) qoc_chain_fwd_launch_n<N, true, true>(a, blocks, s); else qoc_chain_fwd_launch_n<N, true, false>(a, blocks, s); }
+    else { if (a.Out) qoc_chain_fwd_launch_n<N, false, true>(a, blocks, s); else qoc_chain_fwd_launch_n<N, false, false>(a, blocks, s); }
 }
 // `zeros` = a zero thin buffer (N x 32) used as the addend when the chain has none
 static inline void qoc_chain_launch(int N, bool conjt, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {

@@ -36,7 +36,7 @@ __device__ __forceinline__ void lds_mm(const cplx* __restrict__ L, const cplx* _
 
 template <int N>
 __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Kout,
-                                                                               int SP, int deg, int nsq, ExpmCoef cf) {
+                                                                               cplx* __restrict__ KTout, int SP, int deg, int nsq, ExpmCoef cf) {
     constexpr int LD = N + 1, NT = (N / 16) * (N / 16) * 32, NN = N * N;
     extern __shared__ __attribute__((aligned(16))) cplx ex_lds[];
     cplx* X = ex_lds;                   // A, then S / M
@@ -47,6 +47,7 @@ __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(Qo
     const int lr = lane & 15, lk = lane >> 4;
     const int b = blockIdx.x / SP, t = blockIdx.x - b * SP;
     cplx* Kt = Kout + (size_t)blockIdx.x * NN;
+    cplx* KTt = KTout ? KTout + (size_t)blockIdx.x * NN : nullptr;     // K_t^T as well: the backward chains then read rows
     // D-layout coordinates of this lane's 2 x 4 accumulator elements
     auto drow = [&](int r) { return 16 * I + lk + 4 * r; };
     auto dcol = [&](int J) { return 32 * Jp + 16 * J + lr; };
@@ -54,7 +55,11 @@ __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(Qo
 #pragma unroll
         for (int J = 0; J < 2; ++J)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Kt[(size_t)drow(r) * N + dcol(J)] = cmake(drow(r) == dcol(J) ? 1.0 : 0.0, 0.0);
+            for (int r = 0; r < 4; ++r) {
+                const cplx one = cmake(drow(r) == dcol(J) ? 1.0 : 0.0, 0.0);
+                Kt[(size_t)drow(r) * N + dcol(J)] = one;
+                if (KTt) KTt[(size_t)dcol(J) * N + drow(r)] = one;
+            }
         return;
     }
     // ---- A_t = (H0' + sum_k u_k H_k') / 2^s into X                                              tensorflow_state.py:30-33
@@ -181,5 +186,8 @@ __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(Qo
 #pragma unroll
     for (int J = 0; J < 2; ++J)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Kt[(size_t)drow(r) * N + dcol(J)] = cmake(re[J][r], im[J][r]);
+        for (int r = 0; r < 4; ++r) {
+            Kt[(size_t)drow(r) * N + dcol(J)] = cmake(re[J][r], im[J][r]);
+            if (KTt) KTt[(size_t)dcol(J) * N + drow(r)] = cmake(re[J][r], im[J][r]);
+        }
 }

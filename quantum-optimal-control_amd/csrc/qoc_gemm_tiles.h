@@ -27,6 +27,7 @@ struct GemmArgs {
     double* partial; int partial_stride;       // partial[(batch*partial_stride) + offset + tile_m]
     int partial_offset;
     int inner; long long sA2, sB2, sC2, sL2;   // inner > 0: batch index bt -> (bt / inner, bt % inner); A, Bm, C, L offsets = hi*s?2 + lo*s?
+    cplx* CT; long long sCT; int ldct;         // EPI = 0, optional: also store the transpose, CT[batch][col][row]
     int ldp;                                   // EPI = 2: per-COLUMN dots, partial[batch*stride + offset + tile_m*ldp + col]
 };
 
@@ -131,6 +132,7 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
                     }
                     if (row == col) v.x += g.gamma;
                     g.C[(size_t)bhi * g.sC2 + (size_t)blo * g.sC + (size_t)row * g.ldc + col] = v;
+                    if (g.CT) g.CT[(size_t)bt * g.sCT + (size_t)col * g.ldct + row] = v;
                 } else if (EPI == 1) {
                     const cplx l = g.L[(size_t)bt * g.sL + (size_t)row * g.ldl + col];
                     part = fma(l.x, vre, part); part = fma(l.y, vim, part);      // Re(conj(l) * y)

@@ -211,6 +211,8 @@ struct QocGemm {
     cplx* interP = nullptr;   // [B][SP][N][32]   Psi_t
     cplx* LamP = nullptr;     // [B][SP][N][32]   Lambda_t
     cplx* SrcP = nullptr;     // [B][SP][N][32]   S_tau (state regularisers only)
+    cplx* KT = nullptr;       // persistent mode: K_t^T  [B*SP][N][N] (rows of K^H for the backward chains)
+    cplx* PcT = nullptr;      // persistent mode: P_c^T  [B][NC][N][N] (== KT when S = 1)
     cplx* root = nullptr;     // persistent unitary mode: product tree above the chunk products, down to one matrix per seed
     cplx* zthin = nullptr;    // [N][32] zeros
     cplx *Psibnd = nullptr, *Ebnd = nullptr, *Aoff = nullptr;        // [B][NC][N][32] chunk-start Psi, chunk-end Lambda, affine offsets
@@ -274,6 +276,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
               (!poly || al((void**)&gm.P, BSP * NN * sizeof(cplx))) && (!poly || al((void**)&gm.A2, BSP * NN * sizeof(cplx))) &&
               al((void**)&gm.root, (gm.persistent && !d.state_transfer) ? root_elems * sizeof(cplx) : 16) &&
               al((void**)&gm.K, gm.direct ? 16 : BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
+              al((void**)&gm.KT, (gm.persistent && !gm.direct) ? BSP * NN * sizeof(cplx) : 16) &&
+              al((void**)&gm.PcT, (gm.persistent && !gm.direct && L > 0) ? (size_t)d.B * gm.NC * NN * sizeof(cplx) : 16) &&
               al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.Y1, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
               al((void**)&gm.interP, BSP * thin * sizeof(cplx)) && al((void**)&gm.LamP, BSP * thin * sizeof(cplx)) &&
@@ -355,6 +359,8 @@ static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s) {
         cplx* out = gm.tree + gm.tree_off[l];
         g.A = prev + NN; g.sA = 2 * (long long)NN; g.Bm = prev; g.sB = 2 * (long long)NN; g.C = out; g.sC = (long long)NN;
         g.batch = (int)((size_t)d.B * (gm.SP >> l));
+        const bool want_t = gm.persistent && !gm.direct && l == gm.L;        // chunk products also transposed, for the backward boundary chain
+        g.CT = want_t ? gm.PcT : nullptr; g.sCT = (long long)NN; g.ldct = N;
         qoc_gemm_launch(false, 0, g, s);
         prev = out;
     }
@@ -374,8 +380,8 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         ExpmCoef cf;
         { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
         const size_t lds = 2 * (size_t)N * (N + 1) * sizeof(cplx);
-        if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K, gm.SP, deg, nsq, cf);
-        else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K, gm.SP, deg, nsq, cf);
+        if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
+        else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
         qoc_gemm_tree(gm, d, s);
         return;
     }
@@ -547,7 +553,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     } else if (gm.persistent) {
         ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
         memset(&sw, 0, sizeof sw);
-        sw.K = gm.K + (size_t)(S - 1) * NN; sw.sKb = (long long)NN * gm.SP; sw.sKc = (long long)NN * S; sw.sKs = -(long long)NN;
+        sw.K = gm.KT + (size_t)(S - 1) * NN; sw.sKb = (long long)NN * gm.SP; sw.sKc = (long long)NN * S; sw.sKs = -(long long)NN;   // conj(K^T) = K^H
         if (need_src) { sw.E = gm.SrcP + (size_t)(S - 1) * thin; sw.sEb = (long long)thin * gm.SP; sw.sEc = (long long)thin * S; sw.sEs = -(long long)thin; }
         sw.CI = NC; sw.m = d.m;
         if (need_src && NC > 1) {                            // affine offsets a_c: every chunk run from a zero costate
@@ -558,7 +564,8 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         {                                                    // chunk-end costates E_{c-1} = P_c^dagger E_c + a_c
             ChainArgs a;
             memset(&a, 0, sizeof a);
-            a.K = Pc + (size_t)(NC - 1) * NN; a.sKb = (long long)NN * NC; a.sKs = -(long long)NN;
+            const cplx* PcT = gm.L > 0 ? gm.PcT : gm.KT;
+            a.K = PcT + (size_t)(NC - 1) * NN; a.sKb = (long long)NN * NC; a.sKs = -(long long)NN;
             a.X0 = gm.Ebnd + (size_t)(NC - 1) * thin; a.sXb = (long long)thin * NC;
             if (need_src) { a.E = gm.Aoff + (size_t)(NC - 1) * thin; a.sEb = (long long)thin * NC; a.sEs = -(long long)thin; }
             a.Out = gm.Ebnd + (long long)(NC - 2) * (long long)thin; a.sOb = (long long)thin * NC; a.sOs = -(long long)thin; a.ldO = QOC_TW;
