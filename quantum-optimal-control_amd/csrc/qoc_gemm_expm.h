@@ -186,8 +186,15 @@ __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(Qo
 #pragma unroll
     for (int J = 0; J < 2; ++J)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Kt[(size_t)drow(r) * N + dcol(J)] = cmake(re[J][r], im[J][r]);
-            if (KTt) KTt[(size_t)dcol(J) * N + drow(r)] = cmake(re[J][r], im[J][r]);
-        }
+        for (int r = 0; r < 4; ++r) Kt[(size_t)drow(r) * N + dcol(J)] = cmake(re[J][r], im[J][r]);
+    if (KTt) {
+        // the transpose leaves through LDS so that its rows are written coalesced (a direct store scatters 16-byte pieces
+        // over 64 rows per instruction): X[row][col] <- K, then thread e reads X[e % N][e / N]
+        __syncthreads();
+        put(X);
+        __syncthreads();
+        constexpr int PER = NN / NT;
+#pragma unroll
+        for (int x = 0; x < PER; ++x) { const int e = tid + NT * x; KTt[e] = X[(e % N) * LD + (e / N)]; }
+    }
 }
