@@ -11,9 +11,10 @@ from quantum_optimal_control.core import hip_engine
 
 class HipState(object):
 
-    def __init__(self, sys_para, n_seeds=1, device=0, path=hip_engine.PATH_AUTO, chunks=0):
+    def __init__(self, sys_para, n_seeds=1, device=0, path=hip_engine.PATH_AUTO, chunks=0, first_seed=0):
         self.sys_para = sys_para
         self.n_seeds = n_seeds
+        self.first_seed = first_seed      # global index of this engine's first restart (seed-sharded runs)
         self.device = device
         self.path = path
         self.chunks = chunks
@@ -39,11 +40,15 @@ class HipState(object):
             one_minus_gauss=sp.one_minus_gauss if 'envelope' in rc else None, Vs=Vs,
             n_seeds=self.n_seeds, device=self.device, path=self.path, chunks=self.chunks)
         base = np.asarray(sp.ops_weight_base, dtype=np.float64)
-        if base.ndim == 2 and self.n_seeds > 1:
-            # seed 0 = the reference's own starting point; the rest are independent random restarts
+        if base.ndim == 2 and (self.n_seeds > 1 or self.first_seed > 0):
+            # global restart 0 = the reference's own starting point; restart g > 0 = the reproducible stream of index g,
+            # whatever rank / batch it lands in
             from quantum_optimal_control.parallel_seeds import restart_guesses
-            extra = restart_guesses(base.shape[0], base.shape[1], 1, self.n_seeds - 1)
-            base = np.concatenate([base[None], extra], axis=0)
+            if self.first_seed == 0:
+                extra = restart_guesses(base.shape[0], base.shape[1], 1, self.n_seeds - 1)
+                base = np.concatenate([base[None], extra], axis=0)
+            else:
+                base = restart_guesses(base.shape[0], base.shape[1], self.first_seed, self.n_seeds)
         elif base.ndim == 2:
             base = base[None]
         self.engine.set_base(base)

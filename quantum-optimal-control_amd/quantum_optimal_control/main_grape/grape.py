@@ -52,7 +52,7 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
           dressed_info=None, maxA=None, use_gpu=True, sparse_H=True, sparse_U=False, sparse_K=False, draw=None,
           initial_guess=None, show_plots=True, unitary_error=1e-4, method='Adam', state_transfer=False,
           no_scaling=False, freq_unit='GHz', file_name=None, save=True, data_path=None, Taylor_terms=None,
-          use_inter_vecs=True, restarts=1):
+          use_inter_vecs=True, restarts=1, _first_seed=0, _device=0, _return_session=False):
     """Reference signature (main_grape/grape.py:19) plus one optional extension: ``restarts=B`` optimises B control sets at
     once on the GPU -- the first is the reference's own initial guess (same NumPy RNG draw / ``initial_guess``), the others
     are independent N(0, 1/sqrt(steps)) restarts -- and returns the (uks, U_final) of the best final fidelity."""
@@ -89,7 +89,7 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
                                 maxAmp, draw, initial_guess, show_plots, unitary_error, state_transfer, no_scaling,
                                 reg_coeffs, save, file_path, Taylor_terms, use_gpu, use_inter_vecs, sparse_H, sparse_U,
                                 sparse_K)
-    tfs = HipState(sys_para, n_seeds=max(1, int(restarts)))   # constants -> HBM (was: TF graph construction)
+    tfs = HipState(sys_para, n_seeds=max(1, int(restarts)), device=_device, first_seed=_first_seed)   # constants -> HBM
     graph = tfs.build_graph()
     conv = Convergence(sys_para, time_unit, convergence)
     try:
@@ -99,6 +99,8 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
             with H5File(file_path) as hf:
                 hf.add('wall_clock_time', data=np.array(time.time() - grape_start_time))
             print("data saved at: " + str(file_path))
+        if _return_session:
+            return SS.uks, SS.Uf, float(SS.l)
         return SS.uks, SS.Uf
     except KeyboardInterrupt:
         if save:
@@ -109,3 +111,41 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
         return None
     finally:
         tfs.close()
+
+
+def GrapeSharded(*args, restarts=8, dist=None, **kwargs):
+    """`Grape(...)` with `restarts` control sets block-partitioned over the ranks of a torch.distributed process group
+    (one process per GPU; `dist` = the initialised `torch.distributed` module, or None for a single process).  Every rank
+    optimises its own restarts on its own GPU -- no data-path collective --, the best final losses are all-gathered once
+    (RCCL when the backend is "nccl"), and the winner's (uks, U_final) is broadcast, so every rank returns the same pair.
+    Global restart g starts from the same point whatever the number of ranks (restart 0 = the reference's own draw)."""
+    from quantum_optimal_control.parallel_seeds import SeedShard
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    shard = SeedShard(total_seeds=int(restarts), rank=rank, world=world)
+    if shard.count == 0:
+        raise ValueError('GrapeSharded: more ranks (%d) than restarts (%d)' % (world, restarts))
+    device = int(kwargs.pop('device', os.environ.get('LOCAL_RANK', 0) if dist is not None else 0))
+    if rank != 0:
+        kwargs['save'] = False                                       # only rank 0 may write the run log
+    out = Grape(*args, restarts=shard.count, _first_seed=shard.first, _device=device, _return_session=True, **kwargs)
+    if out is None:
+        return None
+    uks, Uf, loss = out
+    if dist is None or world == 1:
+        return uks, Uf
+    # one value per RANK (its best restart): gather, pick the winner, broadcast its pulse and unitary
+    import torch
+    dev = shard._device(dist)
+    mine = torch.tensor([loss], dtype=torch.float64, device=dev)
+    allv = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    best = int(np.argmin([float(v.item()) for v in allv]))
+    t = torch.from_numpy(np.ascontiguousarray(uks, dtype=np.float64)).to(dev)
+    dist.broadcast(t, src=best)
+    uks = t.cpu().numpy()
+    if not isinstance(Uf, list):
+        tu = torch.from_numpy(np.ascontiguousarray(Uf).view(np.float64).copy()).to(dev)
+        dist.broadcast(tu, src=best)
+        Uf = tu.cpu().numpy().view(np.complex128)
+    return uks, Uf

@@ -68,3 +68,17 @@ def test_restart_guesses_are_reproducible_and_independent_of_sharding():
     parts = np.concatenate([restart_guesses(3, 10, 0, 4), restart_guesses(3, 10, 4, 2)])
     np.testing.assert_array_equal(whole, parts)
     assert abs(np.std(whole) - 1 / np.sqrt(10)) < 0.1
+
+
+@pytest.mark.gpu
+def test_grape_sharded_two_ranks_one_gpu():
+    """GrapeSharded: 6 restarts over 2 ranks (gloo rendezvous, both on GPU 0) = the single-process Grape(restarts=6) result on
+    every rank (all-gather of the rank-best losses + broadcast of the winner)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29533',
+                        os.path.join(os.path.dirname(os.path.abspath(__file__)), 'sharded_script.py')],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and 'OK sharded rank 0' in r.stdout and 'OK sharded rank 1' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
