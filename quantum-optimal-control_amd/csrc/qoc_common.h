@@ -92,3 +92,28 @@ __device__ __forceinline__ double block_sum(double v, double* red /* >= QOC_BLOC
     for (int i = 0; i < nw; ++i) t += red[i];
     return t;
 }
+
+// v from lane (l ^ OFF), OFF in {1, 2, 4, 8}, as DPP moves on the VALU (quad_perm; xor 4 = row_half_mirror then quad_perm
+// [3,2,1,0]; xor 8 = row_ror:8) instead of ds_bpermute round trips through the LDS crossbar: the chain step is a dependent sequence, and
+// three crossbar latencies per step were a tenth of it.
+template <int OFF>
+__device__ __forceinline__ double dpp_xor(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (OFF == 1) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
+    } else if constexpr (OFF == 2) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, true);
+    } else if constexpr (OFF == 4) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, true);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x1B, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x1B, 0xF, 0xF, true);
+    } else {
+        static_assert(OFF == 8, "dpp_xor: lane distance 1, 2, 4 or 8");
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, true);   // row_ror:8
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for the K/E prefetch of
+// two steps ahead (and the output stores) at every step of a chain; the chains exchange data through LDS alone, and hipcc
+// still places the vmcnt wait for each prefetched register stage before its first use.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -59,7 +59,7 @@ struct QocMfma {
     cplx* PfD = nullptr;      // [B][C] fragD(P_c)
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
-    size_t bwd_lds = 0, bwd_lds2 = 0;
+    size_t bwd_lds = 0, bwd_lds2 = 0, bwd_lds3 = 0;
     bool h_in_lds = true, h_in_lds2 = true;
     int variant = 0;              // qoc_config.variant: 0 auto, 1 16x16x4, 2 4x4x4 two waves, 3 4x4x4 one wave
     int skew_c = 0, skew_b = 0;   // element skews per chunk / per seed that break the power-of-two strides of K storage
@@ -1047,6 +1047,190 @@ __global__ void __launch_bounds__(512) k_mfma_backward2(QocDev d, QocMfma mf) {
     }
 }
 
+// ---- kernel B3: k_mfma_backward2 with every per-slice latency taken off the dependent chain --------------------------
+// Same split (pair of waves per (seed, chunk), tile h of the costate each), same LDS exchange.  What changes:
+//  * the slice loop is branch-free (finished / out-of-range steps run on clamped addresses and only their store is
+//    masked), so hipcc keeps counted vmcnt waits, and the K_t^dagger fragment and Psi_t of the NEXT slice are fetched at the
+//    top of each step into a second register set (2x unrolled rotation): backward2 exposed two HBM round trips per slice
+//    (Psi before the Q tiles, K before the costate product: ~5 of its 7.5 us per slice);
+//  * the chunk-boundary recursion prefetches P_{cc-1} the same way and computes every step unconditionally (select);
+//  * the workgroup barrier orders LDS only (lds_barrier), so the prefetch stays in flight across it;
+//  * control gradients: 16-lane DPP butterflies, the 4 row partials of both waves go through LDS and lane kk of wave h = 0
+//    adds the 8 partials of control kk (was: six ds_bpermute levels per control).
+// Used for k <= 4 controls without state regularisers (no per-slice source term); anything else keeps backward2.
+template <int MQ>
+__global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
+    constexpr int NT = 2, KC = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wv & 1, pair = wv >> 1;
+    cplx* Hl = (cplx*)smem;                                                     // [KC] fragD(H_k'), zero beyond k
+    cplx* pads = Hl + (size_t)KC * QFR;                                         // [8 waves][2 buffers][16 * B2_LDP]
+    double* gpart = (double*)(pads + 8 * 2 * 16 * B2_LDP);                     // [4 pairs][2 buffers][2 waves][4 rows][KC]
+    for (int o = threadIdx.x; o < KC * QFR; o += blockDim.x) Hl[o] = o < d.k * QFR ? mf.HfD[QFR + o] : cmake(0.0, 0.0);
+    cplx* mypad = pads + (size_t)wv * 2 * 16 * B2_LDP;
+    const cplx* otherpad = pads + (size_t)(wv ^ 1) * 2 * 16 * B2_LDP;
+    const int item = blockIdx.x * 4 + pair;
+    const bool item_ok = item < d.B * mf.C;
+    const int b = item_ok ? item / mf.C : 0, c = item_ok ? item - b * mf.C : 0;
+    const bool active = item_ok && !(d.skip_done && d.done[b]);
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const int lk = lane >> 4, lc = lane & 15;
+    d4 ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};       // own tile of the costate, D layout: register r <-> (row 16h + lk + 4r, column lc)
+    {
+        const cplx z = d.zfin[b];
+        const double c0 = -2.0 / ((double)d.m * (double)d.m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * h + lk + 4 * r;
+            cplx v = cmake(0.0, 0.0);
+            if (row < d.n && lc < d.m) v = cscale(cmul(z, d.W[row * d.m + lc]), c0);
+            ore[r] = v.x; oim[r] = v.y;
+        }
+    }
+    struct Frag { cplx f[8]; };
+    struct PsiReg { double pr[2][MQ], pi[2][MQ]; };
+    auto put_own = [&](int bf) {                                                 // image[col][row16]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mypad[(bf * 16 + lc) * B2_LDP + lk + 4 * r] = cmake(ore[r], oim[r]);
+    };
+    auto get_other = [&](int bf, d4& xre, d4& xim) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const cplx v = otherpad[(bf * 16 + lc) * B2_LDP + lk + 4 * r]; xre[r] = v.x; xim[r] = v.y; }
+    };
+    auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fr.f[q] = F[(h * QQS + q) * 64 + lane];
+    };
+    // row tile h of M^dagger * Lambda from the fragD(M) fragment: 24 MFMAs; result in (nre, nim)
+    auto dagger_product = [&](const Frag& fr, const d4& xre, const d4& xim, d4& nre, d4& nim) {
+        d4 a = {0, 0, 0, 0}, bq = {0, 0, 0, 0}, cq = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool own = (q >> 2) == h;
+            const double br = own ? ore[q & 3] : xre[q & 3], bi = own ? oim[q & 3] : xim[q & 3];
+            const double ar = fr.f[q].x, ai = -fr.f[q].y;
+            a = QMFMA(ar, br, a);
+            bq = QMFMA(ai, bi, bq);
+            cq = QMFMA(ar + ai, br + bi, cq);
+        }
+        nre = a - bq; nim = cq - a - bq;
+    };
+    put_own(0);
+    lds_barrier();
+    int buf = 0;
+    // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc, uniform trip count, result kept only while cc > c ----
+    {
+        const cplx* Pb = mf.PfD + (size_t)b * mf.C * QFR;
+        Frag f0, f1;
+        auto bstep = [&](const Frag& fr, int cc) {
+            d4 xre, xim, nre, nim;
+            get_other(buf, xre, xim);
+            dagger_product(fr, xre, xim, nre, nim);
+            const bool keep = cc > c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ore[r] = keep ? nre[r] : ore[r]; oim[r] = keep ? nim[r] : oim[r]; }
+            put_own(buf ^ 1);
+            lds_barrier();
+            buf ^= 1;
+        };
+        if (mf.C > 1) load_frag(Pb + (size_t)(mf.C - 1) * QFR, f0);
+        int cc = mf.C - 1;
+        for (; cc >= 2; cc -= 2) {
+            load_frag(Pb + (size_t)(cc - 1) * QFR, f1); asm volatile("" ::: "memory"); bstep(f0, cc);
+            load_frag(Pb + (size_t)max(cc - 2, 1) * QFR, f0); asm volatile("" ::: "memory"); bstep(f1, cc - 1);
+        }
+        if (cc == 1) bstep(f0, 1);
+    }
+    // ---- slices of the chunk, last to first ------------------------------------------------------------------------------
+    const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
+    const int prow0 = min(lc, d.n - 1), prow1 = min(16 + lc, d.n - 1);
+    auto fetch = [&](Frag& fr, PsiReg& ps, int i) {                          // operands of step i (slice t = t1 - 1 - i), clamped
+        const int t = max(t1 - 1 - i, 0);
+        load_frag(mf.KfD + kitem(mf, d.steps, b, t), fr);
+        const cplx* psi = iv + (size_t)(t + 1) * d.n * d.m;
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            const int j = 4 * q + lk, jc = min(j, d.m - 1);
+            // out-of-range (row >= n, column >= m) entries read a clamped, finite element and need no mask: they only meet
+            // the zero columns of Lambda (j >= m) or the zero padding of H_k' (row >= n); a masked load would be made
+            // conditional by hipcc and waited for on the spot, draining the K prefetch with it
+            const cplx p0 = psi[prow0 * d.m + jc], p1 = psi[prow1 * d.m + jc];
+            ps.pr[0][q] = p0.x; ps.pi[0][q] = p0.y;
+            ps.pr[1][q] = p1.x; ps.pi[1][q] = p1.y;
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto step = [&](const Frag& fr, const PsiReg& ps, int i) {
+        const int t = t1 - 1 - i;
+        const bool live = active && t >= t0;
+        // ---- Q tiles (h, 0..1) = conj(Lambda_t)[rows of tile h] Psi_t^T and the contraction with H_k' ---------------------
+        double lr[MQ], li[MQ];
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            const cplx lv = mypad[(buf * 16 + 4 * q + lk) * B2_LDP + lc];       // Lambda[16h + lc][4q + lk]
+            lr[q] = lv.x; li[q] = lv.y;
+        }
+        double g[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) g[kk] = 0.0;
+#pragma unroll
+        for (int Jp = 0; Jp < 2; ++Jp) {
+            d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < MQ; ++q) {
+                t1v = QMFMA(lr[q], ps.pr[Jp][q], t1v);
+                t2v = QMFMA(li[q], ps.pi[Jp][q], t2v);
+                t3v = QMFMA(lr[q] - li[q], ps.pr[Jp][q] + ps.pi[Jp][q], t3v);
+            }
+            const d4 qr = t1v + t2v, qi = t3v - t1v + t2v;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cplx hv = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
+                    acc = fma(hv.x, qr[r], acc);
+                    acc = fma(-hv.y, qi[r], acc);
+                }
+                g[kk] += acc;
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {                                       // sum over the 16 lanes of a DPP row
+            g[kk] += dpp_xor<1>(g[kk]); g[kk] += dpp_xor<2>(g[kk]); g[kk] += dpp_xor<4>(g[kk]); g[kk] += dpp_xor<8>(g[kk]);
+        }
+        if (lc == 0) {
+            double* gp = gpart + ((((size_t)pair * 2 + buf) * 2 + h) * 4 + lk) * KC;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) gp[kk] = g[kk];
+        }
+        // ---- Lambda_{t-1} = K_t^dagger Lambda_t ------------------------------------------------------------------------------
+        d4 xre, xim, nre, nim;
+        get_other(buf, xre, xim);
+        dagger_product(fr, xre, xim, nre, nim);
+        ore = nre; oim = nim;
+        put_own(buf ^ 1);
+        lds_barrier();
+        if (live && h == 0 && lane < d.k) {
+            const double* gp = gpart + ((size_t)pair * 2 + buf) * 2 * 4 * KC + lane;
+            double sum = 0.0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) sum += gp[x * KC];
+            d.dLdu[((size_t)b * d.k + lane) * d.steps + t] = sum;
+        }
+        buf ^= 1;
+    };
+    Frag k0, k1;
+    PsiReg p0, p1;
+    fetch(k0, p0, 0);
+    for (int i = 0; i < mf.L; i += 2) {
+        fetch(k1, p1, i + 1); step(k0, p0, i);
+        fetch(k0, p0, i + 2); step(k1, p1, i + 1);
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 
 static inline bool qoc_mfma_supported(const QocDev& d) {
@@ -1132,6 +1316,13 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         msg = "MFMA path: cannot reserve LDS for the row-split backward kernel";
         return -2;
     }
+    // prefetching row-split kernel (NT = 2, k <= 4, no state regularisers): 4 control images + the pads + row partials
+    mf.bwd_lds3 = (size_t)4 * FR * sizeof(cplx) + (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 2 * 4 * 4 * sizeof(double);
+    if (NT == 2 && (hipFuncSetAttribute((const void*)k_mfma_backward3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)k_mfma_backward3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess)) {
+        msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
+        return -2;
+    }
     if (mf.h_in_lds) {
         const hipError_t e1 = hipFuncSetAttribute((const void*)k_mfma_backward<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
         const hipError_t e2 = hipFuncSetAttribute((const void*)k_mfma_backward<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
@@ -1181,6 +1372,11 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     // The choice must not depend on the batch size: its gradient sums associate differently from the one-wave kernel, and a
     // seed has to evolve bit-identically whatever batch / GPU it is sharded into.  variant 1 keeps the one-wave kernel (A/B).
     if (NT == 2 && mf.variant != 1) {
+        if (d.k <= 4 && !(d.n_forb > 0 || d.has_speed)) {
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_backward3<2>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds3, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_backward3<4>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds3, s, d, mf);
+            return;
+        }
         if (mf.h_in_lds2) hipLaunchKernelGGL((k_mfma_backward2<true>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
         else hipLaunchKernelGGL((k_mfma_backward2<false>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
         return;
