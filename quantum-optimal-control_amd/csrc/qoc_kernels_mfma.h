@@ -1069,53 +1069,62 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     cplx* pads = Hl + (size_t)KC * QFR;                                         // [8 waves][2 buffers][16 * B2_LDP]
     double* gpart = (double*)(pads + 8 * 2 * 16 * B2_LDP);                     // [4 pairs][2 buffers][2 waves][4 rows][KC]
     for (int o = threadIdx.x; o < KC * QFR; o += blockDim.x) Hl[o] = o < d.k * QFR ? mf.HfD[QFR + o] : cmake(0.0, 0.0);
+    // costate images of the pair: image[buffer][column j][row % 16] (row stride B2_LDP), rows 0..15 in pad_lo, 16..31 in pad_hi
     cplx* mypad = pads + (size_t)wv * 2 * 16 * B2_LDP;
-    const cplx* otherpad = pads + (size_t)(wv ^ 1) * 2 * 16 * B2_LDP;
+    const cplx* pad_lo = pads + (size_t)(2 * pair) * 2 * 16 * B2_LDP;
+    const cplx* pad_hi = pads + (size_t)(2 * pair + 1) * 2 * 16 * B2_LDP;
     const int item = blockIdx.x * 4 + pair;
     const bool item_ok = item < d.B * mf.C;
     const int b = item_ok ? item / mf.C : 0, c = item_ok ? item - b * mf.C : 0;
     const bool active = item_ok && !(d.skip_done && d.done[b]);
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
-    const int lk = lane >> 4, lc = lane & 15;
-    d4 ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};       // own tile of the costate, D layout: register r <-> (row 16h + lk + 4r, column lc)
+    const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
+    // own part of the costate as the D operand of v_mfma_f64_4x4x4 on the TRANSPOSED recursion
+    //   Lambda_{t-1}^T = Lambda_t^T conj(K_t):  register jb, lane 16 i + 4 blk + j  <->  Lambda[row 16h + 4 blk + j][column 4 jb + i],
+    // so that the right operand (4 k-rows x 16 columns of conj(K)) is a fragD register exactly as the 16x16x4 kernels store it,
+    // the left operand is a 4x4 block of Lambda^T read from the LDS image (broadcast over blk), and no output column is padding
+    // (a 16x16x4 tile spends half of its columns on m = 8): 24 MQ MFMAs of 17 cycles instead of 24 of ~100.
+    double ore[MQ], oim[MQ];
     {
         const cplx z = d.zfin[b];
         const double c0 = -2.0 / ((double)d.m * (double)d.m);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * h + lk + 4 * r;
+        for (int jb = 0; jb < MQ; ++jb) {
+            const int row = 16 * h + lc, col = 4 * jb + lk;
             cplx v = cmake(0.0, 0.0);
-            if (row < d.n && lc < d.m) v = cscale(cmul(z, d.W[row * d.m + lc]), c0);
-            ore[r] = v.x; oim[r] = v.y;
+            if (row < d.n && col < d.m) v = cscale(cmul(z, d.W[row * d.m + col]), c0);
+            ore[jb] = v.x; oim[jb] = v.y;
         }
     }
     struct Frag { cplx f[8]; };
     struct PsiReg { double pr[2][MQ], pi[2][MQ]; };
-    auto put_own = [&](int bf) {                                                 // image[col][row16]
+    auto put_own = [&](int bf) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mypad[(bf * 16 + lc) * B2_LDP + lk + 4 * r] = cmake(ore[r], oim[r]);
-    };
-    auto get_other = [&](int bf, d4& xre, d4& xim) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const cplx v = otherpad[(bf * 16 + lc) * B2_LDP + lk + 4 * r]; xre[r] = v.x; xim[r] = v.y; }
+        for (int jb = 0; jb < MQ; ++jb) mypad[(bf * 16 + 4 * jb + lk) * B2_LDP + lc] = cmake(ore[jb], oim[jb]);
     };
     auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) fr.f[q] = F[(h * QQS + q) * 64 + lane];
     };
-    // row tile h of M^dagger * Lambda from the fragD(M) fragment: 24 MFMAs; result in (nre, nim)
-    auto dagger_product = [&](const Frag& fr, const d4& xre, const d4& xim, d4& nre, d4& nim) {
-        d4 a = {0, 0, 0, 0}, bq = {0, 0, 0, 0}, cq = {0, 0, 0, 0};
+    // (ore, oim) <- rows of tile h of M^dagger Lambda, M given by its fragD fragment, Lambda by the image `bf` of the pair
+    auto dagger_product = [&](const Frag& fr, int bf, double (&nre)[MQ], double (&nim)[MQ]) {
+        double a[MQ], bq[MQ], cq[MQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool own = (q >> 2) == h;
-            const double br = own ? ore[q & 3] : xre[q & 3], bi = own ? oim[q & 3] : xim[q & 3];
-            const double ar = fr.f[q].x, ai = -fr.f[q].y;
-            a = QMFMA(ar, br, a);
-            bq = QMFMA(ai, bi, bq);
-            cq = QMFMA(ar + ai, br + bi, cq);
+        for (int jb = 0; jb < MQ; ++jb) { a[jb] = 0.0; bq[jb] = 0.0; cq[jb] = 0.0; }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const cplx* src = (kb < 4 ? pad_lo : pad_hi) + (size_t)bf * 16 * B2_LDP + 4 * (kb & 3) + lk;
+            const double br = fr.f[kb].x, bi = -fr.f[kb].y, bs = br + bi;
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) {
+                const cplx v = src[(4 * jb + li4) * B2_LDP];                  // Lambda[4 kb + lk][4 jb + li4]
+                a[jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[jb], 0, 0, 0);
+                bq[jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, bq[jb], 0, 0, 0);
+                cq[jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, cq[jb], 0, 0, 0);
+            }
         }
-        nre = a - bq; nim = cq - a - bq;
+#pragma unroll
+        for (int jb = 0; jb < MQ; ++jb) { nre[jb] = a[jb] - bq[jb]; nim[jb] = cq[jb] - a[jb] - bq[jb]; }
     };
     put_own(0);
     lds_barrier();
@@ -1125,12 +1134,11 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         const cplx* Pb = mf.PfD + (size_t)b * mf.C * QFR;
         Frag f0, f1;
         auto bstep = [&](const Frag& fr, int cc) {
-            d4 xre, xim, nre, nim;
-            get_other(buf, xre, xim);
-            dagger_product(fr, xre, xim, nre, nim);
+            double nre[MQ], nim[MQ];
+            dagger_product(fr, buf, nre, nim);
             const bool keep = cc > c;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ore[r] = keep ? nre[r] : ore[r]; oim[r] = keep ? nim[r] : oim[r]; }
+            for (int jb = 0; jb < MQ; ++jb) { ore[jb] = keep ? nre[jb] : ore[jb]; oim[jb] = keep ? nim[jb] : oim[jb]; }
             put_own(buf ^ 1);
             lds_barrier();
             buf ^= 1;
@@ -1207,10 +1215,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
             for (int kk = 0; kk < KC; ++kk) gp[kk] = g[kk];
         }
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t ------------------------------------------------------------------------------
-        d4 xre, xim, nre, nim;
-        get_other(buf, xre, xim);
-        dagger_product(fr, xre, xim, nre, nim);
-        ore = nre; oim = nim;
+        dagger_product(fr, buf, ore, oim);
         put_own(buf ^ 1);
         lds_barrier();
         if (live && h == 0 && lane < d.k) {
