@@ -55,7 +55,8 @@ struct QocMfma {
     cplx* HfT = nullptr;      // [k+1] fragD((-i dt H)^T)
     cplx* U0fD = nullptr;     // fragD(U0), zero padded
     cplx* KfD = nullptr;      // [B][steps] fragD(K_t)
-    cplx* KfT = nullptr;      // [B][steps] fragD(K_t^T)
+    cplx* KfT = nullptr;      // [B][steps] fragD(K_t^T); only when store_T (the 16x16x4 forward sweep reads it)
+    bool store_T = true;      // false: NT = 2 sweeps on the 4x4x4 kernels, which gather K^T operands from KfD
     cplx* PfD = nullptr;      // [B][C] fragD(P_c)
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk(
         __syncthreads();
         lds_get_afrag<NT>(img[flip], lane, A);
         flip ^= 1;
-        afrag_store_half<NT>(mf.KfT + item, J, lane, A);
+        if (mf.store_T) afrag_store_half<NT>(mf.KfT + item, J, lane, A);
         CTile acc[NT];
         mm_colblock<NT>(A, R, acc);
         for (int Ib = 0; Ib < NT; ++Ib) R[Ib] = acc[Ib];
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk4
         colblock_store<NT>(mf.KfD + item, J, lane, P);
         lds_put_colblock<NT>(img[flip], 16 * J, lane, P);
         __syncthreads();
-        lds_store_fragT_half<NT>(img[flip], mf.KfT + item, J, lane);
+        if (mf.store_T) lds_store_fragT_half<NT>(img[flip], mf.KfT + item, J, lane);
         CTile acc[NT];
         mm_colblock4<NT>(img[flip], lane, R, acc);
         flip ^= 1;
@@ -597,8 +598,10 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4w(QocDev d, QocMfma m
 #pragma unroll
         for (int J = 0; J < NT; ++J) colblock_store<NT>(mf.KfD + item, J, lane, P[J]);
         put_all(P);
+        if (mf.store_T) {
 #pragma unroll
-        for (int J = 0; J < NT; ++J) lds_store_fragT_half<NT>(img, mf.KfT + item, J, lane);
+            for (int J = 0; J < NT; ++J) lds_store_fragT_half<NT>(img, mf.KfT + item, J, lane);
+        }
         CTile acc[NT][NT];
         mm_full4<NT>(img, imgs, lane, R, acc);
         wave_lds_fence();
@@ -660,6 +663,131 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
                     if (row < d.n && col < d.m) out[row * d.m + col] = cmake(Psi[Ib].re[r], Psi[Ib].im[r]);
                 }
         }
+    } else if (item < n_sweep + d.B * NT) {
+        // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
+        const int w = item - n_sweep, b = w / NT, J = w - b * NT;
+        if (d.skip_done && d.done[b]) return;
+        CTile X[NT];
+        colblock_load<NT>(mf.U0fD, J, lane, X);
+        AFragT<NT> A;
+        for (int cc = 0; cc < mf.C; ++cc) {
+            afrag_load<NT, false>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, X, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) X[Ib] = acc[Ib];
+        }
+        cplx* Xf = d.Xfinal + (size_t)b * d.n * d.n;
+#pragma unroll
+        for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * Ib + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
+                if (row < d.n && col < d.n) Xf[row * d.n + col] = cmake(X[Ib].re[r], X[Ib].im[r]);
+            }
+    }
+}
+
+// ---- kernel F2: the thin forward sweep of NT = 2 on v_mfma_f64_4x4x4 ---------------------------------------------------
+// Transposed recursion Psi_t^T = Psi_{t-1}^T K_t^T: the right operand (4 k-rows x 16 columns of K^T) is a fragD register of
+// KfT as stored, the left operand a 4x4 block of Psi^T read from a wave-private LDS image (broadcast over the 4 blocks), the
+// result register (I, jb) holds Psi[row 16 I + lane % 16][column 4 jb + lane / 16]: no output column is padding (a 16x16x4
+// tile spends half of its columns on m = 8) -- 48 MQ MFMAs of 17 cycles per slice instead of 48 of ~100.  K_{t+1} is fetched
+// while slice t multiplies.  Final-unitary waves as in k_mfma_forward.
+#define F2_LDP 33
+template <int MQ>
+__global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
+    constexpr int NT = 2;
+    __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * F2_LDP];          // per wave: image[column j][row]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wv;
+    const int n_sweep = d.B * mf.C;
+    if (item < n_sweep) {
+        const int b = item / mf.C, c = item - b * mf.C;
+        if (d.skip_done && d.done[b]) return;
+        const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+        const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
+        cplx* img = f2_img[wv];
+        double pre[2][MQ], pim[2][MQ];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) {
+                const int row = 16 * I + lc, col = 4 * jb + lk;
+                cplx v = cmake(0.0, 0.0);
+                if (row < d.n && col < d.m) v = d.Psi0[row * d.m + col];
+                pre[I][jb] = v.x; pim[I][jb] = v.y;
+            }
+        cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
+        if (c == 0) {                                                   // inter[0] = V  (tensorflow_state.py:232-233)
+            for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
+        }
+        struct Frag { cplx f[2][8]; };
+        auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)    // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
+                    fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
+        };
+        // Psi <- M Psi with M^T given by its fragD fragment
+        auto product = [&](const Frag& fr) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) img[(4 * jb + lk) * F2_LDP + 16 * I + lc] = cmake(pre[I][jb], pim[I][jb]);
+            wave_lds_fence();
+            double a[2][MQ], bq[2][MQ], cq[2][MQ];
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) { a[I][jb] = 0.0; bq[I][jb] = 0.0; cq[I][jb] = 0.0; }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                cplx v[MQ];
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) v[jb] = img[(4 * jb + li4) * F2_LDP + 4 * kb + lk];   // Psi[4 kb + lk][4 jb + li4]
+#pragma unroll
+                for (int I = 0; I < 2; ++I) {
+                    const double br = fr.f[I][kb].x, bi = fr.f[I][kb].y, bs = br + bi;
+#pragma unroll
+                    for (int jb = 0; jb < MQ; ++jb) {
+                        a[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].x, br, a[I][jb], 0, 0, 0);
+                        bq[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].y, bi, bq[I][jb], 0, 0, 0);
+                        cq[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].x + v[jb].y, bs, cq[I][jb], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) { pre[I][jb] = a[I][jb] - bq[I][jb]; pim[I][jb] = cq[I][jb] - a[I][jb] - bq[I][jb]; }
+        };
+        Frag A, A1;
+        for (int cc = 0; cc < c; ++cc) {                                // chunk boundary from the chunk products
+            load_frag(mf.PfD + ((size_t)b * mf.C + cc) * QFR, A);
+            product(A);
+        }
+        auto step = [&](const Frag& fr, int t) {
+            product(fr);
+            cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) {
+                    const int row = 16 * I + lc, col = 4 * jb + lk;
+                    if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I][jb], pim[I][jb]);
+                }
+        };
+        const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);             // slices of one chunk are FR apart
+        const int len = t1 - t0;
+        load_frag(Kb, A);
+        int t = 0;
+        for (; t + 2 <= len; t += 2) {
+            load_frag(Kb + (size_t)(t + 1) * mf.FR, A1); asm volatile("" ::: "memory"); step(A, t0 + t);
+            load_frag(Kb + (size_t)min(t + 2, len - 1) * mf.FR, A); asm volatile("" ::: "memory"); step(A1, t0 + t + 1);
+        }
+        if (t < len) step(A, t0 + t);
     } else if (item < n_sweep + d.B * NT) {
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
@@ -1307,7 +1435,8 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     mf.skew_c = 5 * 16;                            // 1280 B per chunk
     mf.skew_b = 3 * 16;                            //  768 B per seed
     const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
-    if (!al(&mf.KfD, nk) || !al(&mf.KfT, nk) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
+    mf.store_T = !(NT == 2 && mf.variant != 1);
+    if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
     mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
@@ -1363,6 +1492,11 @@ static inline void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_
 static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const int items = d.B * mf.C + d.B * mf.NT;
     if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    else if (mf.NT == 2 && mf.variant != 1) {
+        // 4x4x4 sweep; like the backward choice this must not depend on the batch size (bit-identical seeds across shardings)
+        if (mf.mq <= 2) hipLaunchKernelGGL(k_mfma_forward2<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        else hipLaunchKernelGGL(k_mfma_forward2<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    }
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
