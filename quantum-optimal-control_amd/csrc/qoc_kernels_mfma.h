@@ -464,23 +464,36 @@ __device__ __forceinline__ void mm_full4(const cplx* img, const double* imgs, in
         for (int s = 0; s < QQS; ++s) { a[J][s] = 0.0; b[J][s] = 0.0; c[J][s] = 0.0; }
     const cplx* base = img + (lane >> 4) * QLDR + (lane & 3);
     const double* bases = imgs + (lane >> 4) * QLDR + (lane & 3);
+    // 4x4 blocks of the left operand in (kb, ib) order through a 3-slot register ring, fetched TWO block steps (12 MFMAs,
+    // ~200 cycles) ahead of their use: left to itself hipcc issues each ds_read one step ahead and the wave -- alone on
+    // its SIMD -- stalls on LDS latency before every group of MFMAs.  The compiler fence after each fetch pins the order.
+    constexpr int NS = QQS * QQS;
+    cplx vb[3]; double sb[3];
+    auto fetch = [&](int st, int slot) {
+        const int kb = st / QQS, ib = st % QQS;
+        vb[slot] = base[4 * kb * QLDR + 4 * ib];
+        sb[slot] = bases[4 * kb * QLDR + 4 * ib];             // re + im, summed once by the writer of the image
+    };
+    fetch(0, 0);
+    fetch(1, 1);
+    double br[NT], bi[NT], bs[NT];
 #pragma unroll
-    for (int kb = 0; kb < QQS; ++kb) {
-        double br[NT], bi[NT], bs[NT];
-#pragma unroll
-        for (int J = 0; J < NT; ++J) { br[J] = p[J][kb >> 2].re[kb & 3]; bi[J] = p[J][kb >> 2].im[kb & 3]; bs[J] = br[J] + bi[J]; }
-#pragma unroll
-        for (int ib = 0; ib < QQS; ++ib) {
-            const cplx v = base[4 * kb * QLDR + 4 * ib];
-            const double vs = bases[4 * kb * QLDR + 4 * ib];      // re + im, summed once by the writer of the image
-#pragma unroll
-            for (int J = 0; J < NT; ++J) {
-                a[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br[J], a[J][ib], 0, 0, 0);
-                b[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi[J], b[J][ib], 0, 0, 0);
-                c[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, bs[J], c[J][ib], 0, 0, 0);
-            }
-        }
+    for (int st = 0; st < NS; ++st) {
+        const int kb = st / QQS, ib = st % QQS;
+        if (st + 2 < NS) fetch(st + 2, (st + 2) % 3);
         asm volatile("" ::: "memory");
+        if (ib == 0) {
+#pragma unroll
+            for (int J = 0; J < NT; ++J) { br[J] = p[J][kb >> 2].re[kb & 3]; bi[J] = p[J][kb >> 2].im[kb & 3]; bs[J] = br[J] + bi[J]; }
+        }
+        const cplx v = vb[st % 3];
+        const double vs = sb[st % 3];
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            a[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br[J], a[J][ib], 0, 0, 0);
+            b[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi[J], b[J][ib], 0, 0, 0);
+            c[J][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, bs[J], c[J][ib], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int J = 0; J < NT; ++J)
