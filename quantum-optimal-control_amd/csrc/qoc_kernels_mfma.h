@@ -468,7 +468,7 @@ __device__ __forceinline__ void mm_full4(const cplx* img, const double* imgs, in
     // ~200 cycles) ahead of their use: left to itself hipcc issues each ds_read one step ahead and the wave -- alone on
     // its SIMD -- stalls on LDS latency before every group of MFMAs.  The compiler fence after each fetch pins the order.
     constexpr int NS = QQS * QQS;
-    cplx vb[3]; double sb[3];
+    cplx vb[3]; double sb[3];                                 // 5 slots (4 steps ahead) measured no better: 0.862 vs 0.855 ms
     auto fetch = [&](int st, int slot) {
         const int kb = st / QQS, ib = st % QQS;
         vb[slot] = base[4 * kb * QLDR + 4 * ib];
