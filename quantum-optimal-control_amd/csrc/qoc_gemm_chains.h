@@ -330,3 +330,109 @@ static inline void qoc_chain_launch(int N, bool conjt, ChainArgs a, const cplx* 
     if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
     if (N == 32) qoc_chain_launch_c<32>(conjt, a, blocks, s); else qoc_chain_launch_c<64>(conjt, a, blocks, s);
 }
+
+// ---- chunk-boundary vectors in log depth ----------------------------------------------------------------------------
+// The boundary chains (Psibnd[c+1] = P_c Psibnd[c], Ebnd[c-1] = P_c^H Ebnd[c]) were NC - 1 dependent steps in one workgroup
+// per seed.  The pairwise product tree above the chunk products already exists (unitary mode needs its root for
+// final_state); level r, node j is the product of the chunks [j 2^r, min((j+1) 2^r, NC)).  So every boundary vector is
+// <= 2 log2(NC) node applications away from the initial vector, independently of the others: one workgroup per (seed, chunk)
+// walks the binary decomposition of its prefix [0, c) (forward) or suffix [c+1, NC) (backward, conjugate transposes, far end
+// first).  Nodes are staged through a padded LDS image (both M x and M^H x read it conflict-free, so no transposed copies of
+// the upper tree levels are needed) and the next node is fetched into registers while the current one multiplies.
+struct ScanArgs {
+    const cplx* lvl[10]; long long sLb[10]; int cnt[10];   // level r: node array of seed b at lvl[r] + b*sLb[r], cnt[r] nodes
+    int levels;
+    const cplx* X0; long long sXb;                          // [N][QOC_TW] start vector of seed b
+    cplx* Out; long long sOb, sOc;                          // result of (b, c) at Out + b*sOb + c*sOc, [N][QOC_TW]
+    int NC, c0, nchains, suffix;                            // chunks c0 .. c0 + nchains - 1 per seed
+};
+
+template <int N>
+__global__ void __launch_bounds__(256) k_gemm_scan_nodes(ScanArgs a) {
+    constexpr int LD = N + 1, PER = N * N / 256, NO = N / 32;        // NO outputs (columns tid/N... ) per thread
+    extern __shared__ __attribute__((aligned(16))) cplx sc_lds[];
+    cplx* M = sc_lds;                       // [N][LD]
+    cplx* xv = sc_lds + N * LD;             // [2][N][8]
+    __shared__ int s_list[24];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / a.nchains, c = a.c0 + blockIdx.x % a.nchains;
+    if (tid == 0) {
+        int n = 0;
+        if (!a.suffix) {                                            // prefix [0, c): big blocks first = application order
+            int pos = 0;
+            for (int r = a.levels - 1; r >= 0; --r)
+                if (pos + (1 << r) <= c) { s_list[n++] = (r << 16) | (pos >> r); pos += 1 << r; }
+        } else {                                                    // suffix [c+1, NC): collected near end first, applied in reverse
+            int lo = c + 1;
+            while (lo < a.NC) {
+                int r = 0;
+                while (r + 1 < a.levels && (lo & ((1 << (r + 1)) - 1)) == 0 && (lo >> (r + 1)) < a.cnt[r + 1]) ++r;
+                s_list[n++] = (r << 16) | (lo >> r);
+                lo = min(lo + (1 << r), a.NC);
+            }
+        }
+        s_n = n;
+    }
+    const int row = tid % N, cg = tid / N;                           // outputs (row, cg + (256/N) * o), o < NO
+    {
+        const cplx* x0 = a.X0 + (size_t)b * a.sXb;
+        for (int e = tid; e < N * 8; e += 256) xv[e] = x0[(e >> 3) * QOC_TW + (e & 7)];
+    }
+    __syncthreads();
+    const int n = s_n;
+    auto node_ptr = [&](int i) {
+        const int code = s_list[a.suffix ? n - 1 - i : i], r = code >> 16, j = code & 0xffff;
+        return a.lvl[r] + (size_t)b * a.sLb[r] + (size_t)j * N * N;
+    };
+    cplx reg[PER];
+    if (n > 0) {
+        const cplx* p = node_ptr(0);
+#pragma unroll
+        for (int x = 0; x < PER; ++x) reg[x] = p[tid + 256 * x];
+    }
+    int cur = 0;
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int x = 0; x < PER; ++x) { const int e = tid + 256 * x; M[(e / N) * LD + (e % N)] = reg[x]; }
+        lds_barrier();
+        {
+            const cplx* p = node_ptr(min(i + 1, n - 1));             // clamped: the last step re-reads its own node
+#pragma unroll
+            for (int x = 0; x < PER; ++x) reg[x] = p[tid + 256 * x];
+        }
+        cplx acc[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = cmake(0.0, 0.0);
+        const cplx* xc = xv + cur * N * 8;
+        if (!a.suffix) {
+#pragma unroll 8
+            for (int k = 0; k < N; ++k) {
+                const cplx mv = M[row * LD + k];
+#pragma unroll
+                for (int o = 0; o < NO; ++o) cfma(acc[o], mv, xc[k * 8 + cg + (256 / N) * o]);
+            }
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < N; ++k) {
+                const cplx mv = M[k * LD + row];                      // (M^H x)[row] = sum_k conj(M[k][row]) x[k]
+#pragma unroll
+                for (int o = 0; o < NO; ++o) cfma_conj(acc[o], mv, xc[k * 8 + cg + (256 / N) * o]);
+            }
+        }
+        cplx* xn = xv + (cur ^ 1) * N * 8;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) xn[row * 8 + cg + (256 / N) * o] = acc[o];
+        lds_barrier();
+        cur ^= 1;
+    }
+    cplx* out = a.Out + (size_t)b * a.sOb + (size_t)c * a.sOc;
+    const cplx* xc = xv + cur * N * 8;
+    for (int e = tid; e < N * QOC_TW; e += 256) out[e] = (e & (QOC_TW - 1)) < 8 ? xc[(e / QOC_TW) * 8 + (e & (QOC_TW - 1))] : cmake(0.0, 0.0);
+}
+static inline size_t qoc_scan_lds(int N) { return ((size_t)N * (N + 1) + 2 * (size_t)N * 8) * sizeof(cplx); }
+static inline void qoc_scan_launch(int N, const ScanArgs& a, int B, hipStream_t s) {
+    if (a.nchains <= 0) return;
+    if (N == 32) hipLaunchKernelGGL(k_gemm_scan_nodes<32>, dim3(B * a.nchains), dim3(256), qoc_scan_lds(32), s, a);
+    else hipLaunchKernelGGL(k_gemm_scan_nodes<64>, dim3(B * a.nchains), dim3(256), qoc_scan_lds(64), s, a);
+}

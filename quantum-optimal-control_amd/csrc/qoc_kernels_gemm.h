@@ -214,6 +214,7 @@ struct QocGemm {
     cplx* KT = nullptr;       // persistent mode: K_t^T  [B*SP][N][N] (rows of K^H for the backward chains)
     cplx* PcT = nullptr;      // persistent mode: P_c^T  [B][NC][N][N] (== KT when S = 1)
     cplx* root = nullptr;     // persistent unitary mode: product tree above the chunk products, down to one matrix per seed
+    ScanArgs scan;            // its levels (filled by qoc_gemm_forward each iteration; pointers are stable)
     cplx* zthin = nullptr;    // [N][32] zeros
     cplx *Psibnd = nullptr, *Ebnd = nullptr, *Aoff = nullptr;        // [B][NC][N][32] chunk-start Psi, chunk-end Lambda, affine offsets
     double* partial = nullptr; // [B*steps][k][N/32]
@@ -312,7 +313,8 @@ static inline bool qoc_gemm_lds_opt_in_sk() {
 }
 static inline bool qoc_gemm_lds_opt_in() {
     return qoc_gemm_lds_opt_in_sk<false, 0>() && qoc_gemm_lds_opt_in_sk<false, 1>() && qoc_gemm_lds_opt_in_sk<false, 2>() && qoc_gemm_lds_opt_in_sk<true, 0>() &&
-           hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx)) == hipSuccess;
+           hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx)) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k_gemm_scan_nodes<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_scan_lds(64)) == hipSuccess;
 }
 // picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small
 static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
@@ -442,13 +444,28 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
         return;
     }
+    if (gm.persistent && d.state_transfer) {
+        // chunk-start vectors Psibnd[c+1] = P_c Psibnd[c]: one persistent workgroup per seed.  State transfer has no use for
+        // the upper product tree, and building it only for the scan costs more than the chain (C3: 0.58 vs 0.50 ms)
+        ChainArgs a;
+        memset(&a, 0, sizeof a);
+        a.K = Pc; a.sKb = (long long)NN * NC; a.sKs = (long long)NN;
+        a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC;
+        a.Out = gm.Psibnd + thin; a.sOb = (long long)thin * NC; a.sOs = (long long)thin; a.ldO = QOC_TW;
+        a.CI = 1; a.len = NC - 1; a.m = d.m;
+        qoc_chain_launch(N, false, a, gm.zthin, d.B, s);
+    }
     if (gm.persistent && !d.state_transfer) {
-        // final_state = (P_{NC-1} ... P_0) U0: the product tree continues above the chunk products (log2(NC) launches)
+        // the product tree continues above the chunk products (log2(NC) launches): its root gives final_state =
+        // (P_{NC-1} ... P_0) U0, its nodes give every chunk-boundary vector in log depth (k_gemm_scan_nodes)
         GemmArgs r;
         memset(&r, 0, sizeof r);
         r.lda = r.ldb = r.ldc = N; r.Kdim = N; r.tiles_m = r.tiles_n = N / 32; r.alpha = 1.0;
         const cplx* lvl = Pc;
         cplx* out = gm.root;
+        ScanArgs& sc = gm.scan;
+        memset(&sc, 0, sizeof sc);
+        sc.lvl[0] = Pc; sc.sLb[0] = (long long)NC * NN; sc.cnt[0] = NC; sc.levels = 1;
         for (int cnt = NC; cnt > 1; cnt = (cnt + 1) / 2) {
             const int pairs = cnt / 2, nxt = (cnt + 1) / 2;
             r.A = lvl + NN; r.Bm = lvl; r.C = out; r.sA = r.sB = 2 * (long long)NN; r.sC = (long long)NN;
@@ -457,24 +474,22 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
             if (cnt & 1)
                 hipLaunchKernelGGL(k_gemm_copy_mats, dim3(gemm_grid((size_t)d.B * NN)), dim3(256), 0, s, out + (size_t)pairs * NN,
                                    (long long)nxt * NN, lvl + (size_t)(cnt - 1) * NN, (long long)cnt * NN, d.B, (int)NN);
+            if (sc.levels < 10) { sc.lvl[sc.levels] = out; sc.sLb[sc.levels] = (long long)nxt * NN; sc.cnt[sc.levels] = nxt; ++sc.levels; }
             lvl = out;
             out += (size_t)d.B * nxt * NN;
         }
+        sc.NC = NC;
         memset(&r, 0, sizeof r);
         r.A = lvl; r.sA = (long long)NN; r.lda = N; r.Bm = gm.Y0; r.C = gm.Y1; r.ldb = r.ldc = ld; r.sB = r.sC = (long long)N * ld;
         r.Kdim = N; r.tiles_m = N / 32; r.tiles_n = ld / 32; r.batch = d.B; r.alpha = 1.0;
         qoc_gemm_launch(false, 0, r, s);
         hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, gm.Y1, N);
-    }
-    if (gm.persistent) {
-        // chunk-start vectors Psibnd[c+1] = P_c Psibnd[c]: one persistent workgroup per seed
-        ChainArgs a;
-        memset(&a, 0, sizeof a);
-        a.K = Pc; a.sKb = (long long)NN * NC; a.sKs = (long long)NN;
+        // chunk-start vectors Psibnd[c] = P_{c-1} ... P_0 Psi0, c = 1 .. NC-1: one workgroup per (seed, chunk), <= log2(NC) nodes
+        ScanArgs a = sc;
         a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC;
-        a.Out = gm.Psibnd + thin; a.sOb = (long long)thin * NC; a.sOs = (long long)thin; a.ldO = QOC_TW;
-        a.CI = 1; a.len = NC - 1; a.m = d.m;
-        qoc_chain_launch(N, false, a, gm.zthin, d.B, s);
+        a.Out = gm.Psibnd; a.sOb = (long long)thin * NC; a.sOc = (long long)thin;
+        a.c0 = 1; a.nchains = NC - 1; a.suffix = 0;
+        qoc_scan_launch(N, a, d.B, s);
     }
     // chunk boundaries: [X | Psi] <- P_c [X | Psi]   (X for final_state, Psi for the chunk starts)      :214-238
     GemmArgs g;
@@ -561,7 +576,13 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
             a.len = S; a.Fin = gm.Aoff; a.sFb = (long long)thin * NC; a.sFc = (long long)thin;
             qoc_chain_launch(N, true, a, gm.zthin, d.B * NC, s);
         }
-        {                                                    // chunk-end costates E_{c-1} = P_c^dagger E_c + a_c
+        if (!need_src && !d.state_transfer) {                // chunk-end costates E_c = P_{c+1}^H ... P_{NC-1}^H E_{NC-1}, log depth (unitary mode: the tree exists)
+            ScanArgs a = gm.scan;
+            a.X0 = gm.Ebnd + (size_t)(NC - 1) * thin; a.sXb = (long long)thin * NC;
+            a.Out = gm.Ebnd; a.sOb = (long long)thin * NC; a.sOc = (long long)thin;
+            a.c0 = 0; a.nchains = NC - 1; a.suffix = 1;
+            qoc_scan_launch(N, a, d.B, s);
+        } else {                                             // with sources the recursion is affine: E_{c-1} = P_c^dagger E_c + a_c, sequential
             ChainArgs a;
             memset(&a, 0, sizeof a);
             const cplx* PcT = gm.L > 0 ? gm.PcT : gm.KT;
