@@ -248,6 +248,9 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     gm.direct = direct && d.state_transfer && gm.persistent;
     int L = 0;
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
+    // unitary chains get their chunk boundaries in log depth (k_gemm_scan_nodes), so a latency-bound launch (few (seed, chunk)
+    // workgroups) prefers chunks half as long: C2 single trajectory 0.214 (S = 16) -> 0.198 ms (S = 8); 0.195 at S = 4
+    if (gm.persistent && !d.state_transfer && !direct && L > 1 && (size_t)d.B * ((d.steps + (1 << L) - 1) >> L) <= 64) --L;
     gm.L = L; gm.S = 1 << L;
     gm.NC = (d.steps + gm.S - 1) / gm.S;
     gm.SP = gm.NC * gm.S;
