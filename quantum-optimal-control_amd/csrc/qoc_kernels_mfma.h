@@ -1199,7 +1199,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward2(QocDev d, QocMfma mf) {
 //  * control gradients: 16-lane DPP butterflies, the 4 row partials of both waves go through LDS and lane kk of wave h = 0
 //    adds the 8 partials of control kk (was: six ds_bpermute levels per control).
 // Used for k <= 4 controls without state regularisers (no per-slice source term); anything else keeps backward2.
-template <int MQ>
+template <int MQ, bool SRC>
 __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     constexpr int NT = 2, KC = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1233,7 +1233,10 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         for (int jb = 0; jb < MQ; ++jb) {
             const int row = 16 * h + lc, col = 4 * jb + lk;
             cplx v = cmake(0.0, 0.0);
-            if (row < d.n && col < d.m) v = cscale(cmul(z, d.W[row * d.m + col]), c0);
+            if (row < d.n && col < d.m) {
+                v = cscale(cmul(z, d.W[row * d.m + col]), c0);
+                if (SRC) v = cadd(v, source_at(d, b, d.steps, row, col));
+            }
             ore[jb] = v.x; oim[jb] = v.y;
         }
     }
@@ -1276,7 +1279,17 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         Frag f0, f1;
         auto bstep = [&](const Frag& fr, int cc) {
             double nre[MQ], nim[MQ];
+            cplx off[MQ];
+            if (SRC) {                                               // E_{cc-1} = P_cc^dagger E_cc + a_cc; a_cc is a D-layout 16x16x4 column block
+                const cplx* ao = mf.Aoff + ((size_t)b * mf.C + cc) * (QQS * 64) + (4 * h + (lc >> 2)) * 64 + 16 * (lc & 3) + lk;
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) off[jb] = ao[4 * jb];
+            }
             dagger_product(fr, buf, nre, nim);
+            if (SRC) {
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) { nre[jb] += off[jb].x; nim[jb] += off[jb].y; }
+            }
             const bool keep = cc > c;
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) { ore[jb] = keep ? nre[jb] : ore[jb]; oim[jb] = keep ? nim[jb] : oim[jb]; }
@@ -1310,6 +1323,21 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
             ps.pr[1][q] = p1.x; ps.pi[1][q] = p1.y;
         }
         asm volatile("" ::: "memory");
+    };
+    // state-regulariser source S of slice t = t1 - 1 - i at this lane's costate entries.  Its loads are conditional (hipcc waits
+    // for them on the spot, draining vmcnt), so it is evaluated BEFORE the next operands are fetched: what is in flight then
+    // are this step's operands, which are needed now anyway.
+    double sre[MQ], sim[MQ];
+    auto source = [&](int i) {
+        if (!SRC) return;
+        const int t = t1 - 1 - i, tc = max(t, 1);
+#pragma unroll
+        for (int jb = 0; jb < MQ; ++jb) {
+            const int row = 16 * h + lc, col = 4 * jb + lk;
+            cplx sv = cmake(0.0, 0.0);
+            if (t > 0 && row < d.n && col < d.m) sv = source_at(d, b, tc, row, col);
+            sre[jb] = sv.x; sim[jb] = sv.y;
+        }
     };
     auto step = [&](const Frag& fr, const PsiReg& ps, int i) {
         const int t = t1 - 1 - i;
@@ -1357,6 +1385,10 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         }
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t ------------------------------------------------------------------------------
         dagger_product(fr, buf, ore, oim);
+        if (SRC) {
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) { ore[jb] += sre[jb]; oim[jb] += sim[jb]; }
+        }
         put_own(buf ^ 1);
         lds_barrier();
         if (live && h == 0 && lane < d.k) {
@@ -1372,8 +1404,8 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     PsiReg p0, p1;
     fetch(k0, p0, 0);
     for (int i = 0; i < mf.L; i += 2) {
-        fetch(k1, p1, i + 1); step(k0, p0, i);
-        fetch(k0, p0, i + 2); step(k1, p1, i + 1);
+        source(i);     fetch(k1, p1, i + 1); step(k0, p0, i);
+        source(i + 1); fetch(k0, p0, i + 2); step(k1, p1, i + 1);
     }
 }
 
@@ -1465,8 +1497,10 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     }
     // prefetching row-split kernel (NT = 2, k <= 4, no state regularisers): 4 control images + the pads + row partials
     mf.bwd_lds3 = (size_t)4 * FR * sizeof(cplx) + (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 2 * 4 * 4 * sizeof(double);
-    if (NT == 2 && (hipFuncSetAttribute((const void*)k_mfma_backward3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)k_mfma_backward3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess)) {
+    if (NT == 2 && (hipFuncSetAttribute((const void*)k_mfma_backward3<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)k_mfma_backward3<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)k_mfma_backward3<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)k_mfma_backward3<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess)) {
         msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
         return -2;
     }
@@ -1524,9 +1558,11 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     // The choice must not depend on the batch size: its gradient sums associate differently from the one-wave kernel, and a
     // seed has to evolve bit-identically whatever batch / GPU it is sharded into.  variant 1 keeps the one-wave kernel (A/B).
     if (NT == 2 && mf.variant != 1) {
-        if (d.k <= 4 && !(d.n_forb > 0 || d.has_speed)) {
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_backward3<2>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds3, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_backward3<4>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds3, s, d, mf);
+        if (d.k <= 4) {
+            const bool src = d.n_forb > 0 || d.has_speed;
+            const dim3 g3((items + 3) / 4), b3(512);
+            if (mf.mq <= 2) { if (src) hipLaunchKernelGGL((k_mfma_backward3<2, true>), g3, b3, mf.bwd_lds3, s, d, mf); else hipLaunchKernelGGL((k_mfma_backward3<2, false>), g3, b3, mf.bwd_lds3, s, d, mf); }
+            else { if (src) hipLaunchKernelGGL((k_mfma_backward3<4, true>), g3, b3, mf.bwd_lds3, s, d, mf); else hipLaunchKernelGGL((k_mfma_backward3<4, false>), g3, b3, mf.bwd_lds3, s, d, mf); }
             return;
         }
         if (mf.h_in_lds2) hipLaunchKernelGGL((k_mfma_backward2<true>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);

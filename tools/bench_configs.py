@@ -37,6 +37,10 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'c3':           # profiling hook: C3 single trajectory only
         run('C3 state transfer (propagator route)', cases.case_c3(), 1, 20)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'c2reg':        # profiling hook: regularised C2 x 64 only
+        c = cases.case_c2(); c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [30, 31]}
+        run('C2 x64 + dwdt + forbidden', c, 64, 20)
+        sys.exit(0)
     run('C1 single qubit', cases.case_c1(), 1, 50)
     run('C1 single qubit x64 seeds', cases.case_c1(), 64, 50)
     run('C2 single trajectory (latency route)', cases.case_c2(), 1, 20)
