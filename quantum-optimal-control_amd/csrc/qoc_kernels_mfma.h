@@ -1470,18 +1470,24 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         return true;
     };
     if (!up(&mf.HfD, hd) || !up(&mf.HfT, ht) || !up(&mf.U0fD, u0)) { msg = "MFMA path: constant upload failed"; return -3; }
-    auto al = [&](cplx** dst, size_t count) -> bool {
-        void* p = nullptr;
-        if (hipMalloc(&p, count * sizeof(cplx)) != hipSuccess) return false;
-        allocs.push_back(p);
-        *dst = (cplx*)p;
-        return true;
-    };
+    // the large buffers are carved out of ONE allocation (placement of separate hipMallocs after earlier engines of the process
+    // were freed was worth a factor 2 on the GEMM path)
+    std::vector<std::pair<cplx**, size_t>> wanted;
+    auto al = [&](cplx** dst, size_t count) -> bool { wanted.emplace_back(dst, (count * sizeof(cplx) + 4095) & ~(size_t)4095); return true; };
     mf.skew_c = 5 * 16;                            // 1280 B per chunk
     mf.skew_b = 3 * 16;                            //  768 B per seed
     const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
     mf.store_T = !(NT == 2 && mf.variant != 1);
     if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
+    {
+        size_t total = 0;
+        for (auto& w : wanted) total += w.second;
+        char* arena = nullptr;
+        if (hipMalloc((void**)&arena, total) != hipSuccess) { msg = "MFMA path: out of device memory"; return -3; }
+        allocs.push_back(arena);
+        size_t off = 0;
+        for (auto& w : wanted) { *w.first = (cplx*)(arena + off); off += w.second; }
+    }
     const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
     mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
