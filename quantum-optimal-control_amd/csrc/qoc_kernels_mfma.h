@@ -177,17 +177,23 @@ __device__ __forceinline__ void mm_colblock4(const cplx* img, int lane, const CT
 #pragma unroll
     for (int s = 0; s < QQS; ++s) { a[s] = 0.0; b[s] = 0.0; c[s] = 0.0; }
     const cplx* base = img + (lane >> 4) * QLDR + (lane & 3);
+    // blocks in (kb, ib) order through a 4-slot ring, three block steps (9 MFMAs) ahead -- see mm_full4
+    constexpr int NS = QQS * QQS, RING = 4;
+    cplx vb[RING];
+    auto fetch = [&](int st, int slot) { vb[slot] = base[4 * (st / QQS) * QLDR + 4 * (st % QQS)]; };
 #pragma unroll
-    for (int kb = 0; kb < QQS; ++kb) {
-        const double br = p[kb >> 2].re[kb & 3], bi = p[kb >> 2].im[kb & 3], bs = br + bi;
+    for (int st = 0; st < RING - 1; ++st) fetch(st, st);
+    double br = 0.0, bi = 0.0, bs = 0.0;
 #pragma unroll
-        for (int ib = 0; ib < QQS; ++ib) {
-            const cplx v = base[4 * kb * QLDR + 4 * ib];
-            a[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[ib], 0, 0, 0);
-            b[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, b[ib], 0, 0, 0);
-            c[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, c[ib], 0, 0, 0);
-        }
-        asm volatile("" ::: "memory");     // keep the block loads of a k-block inside it: hoisted, hipcc parks all 64 in AGPRs (1.69 vs 1.04 ms)
+    for (int st = 0; st < NS; ++st) {
+        const int kb = st / QQS, ib = st % QQS;
+        if (st + RING - 1 < NS) fetch(st + RING - 1, (st + RING - 1) % RING);
+        asm volatile("" ::: "memory");
+        if (ib == 0) { br = p[kb >> 2].re[kb & 3]; bi = p[kb >> 2].im[kb & 3]; bs = br + bi; }
+        const cplx v = vb[st % RING];
+        a[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[ib], 0, 0, 0);
+        b[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, b[ib], 0, 0, 0);
+        c[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, c[ib], 0, 0, 0);
     }
 #pragma unroll
     for (int s = 0; s < QQS; ++s) { out[s >> 2].re[s & 3] = a[s] - b[s]; out[s >> 2].im[s & 3] = c[s] - a[s] - b[s]; }
