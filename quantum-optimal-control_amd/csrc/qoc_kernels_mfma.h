@@ -1531,7 +1531,7 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
 
 // which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave)
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
-    if (mf.NT > 2) return 1;
+    if (mf.NT > 2) return mf.variant == 1 ? 1 : 2;      // n > 32: NT waves per item on 4x4x4 (n = 48 x 64: 4.3 vs 11.9 ms per launch)
     return mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 3 : 1);
 }
 
@@ -1542,7 +1542,7 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
     const int v = qoc_mfma_expm_variant(mf, d);
     if (v == 3 && NT <= 2) hipLaunchKernelGGL(k_mfma_expm_chunk4w<NT>, dim3(d.B * mf.C), dim3(64), 0, s, d, mf);
-    else if (v == 2 && NT <= 2) hipLaunchKernelGGL(k_mfma_expm_chunk4<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
+    else if (v == 2) hipLaunchKernelGGL(k_mfma_expm_chunk4<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_expm_chunk<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
 }
 static inline void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {

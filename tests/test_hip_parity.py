@@ -89,10 +89,10 @@ def test_mfma_path_parity(chunks, variant):
 
 
 @pytest.mark.parametrize('kernel', [1, 2, 3], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave'])
-@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed'])
+@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4'])
 @pytest.mark.parametrize('chunks', [1, 7])
 def test_mfma_exponential_kernels(chunks, variant, kernel):
-    """The three kernels of the exponentials (qoc_config.variant) on the n <= 32 problems, whatever AUTO would pick."""
+    """The three kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variant 3 = variant 2)."""
     _mfma_path_parity(chunks, variant, kernel)
 
 
