@@ -54,7 +54,7 @@ if __name__ == '__main__':
     run('C3 state transfer x256 seeds', cases.case_c3(), 256, 5)
     run('n=64 unitary (GEMM path) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 5, path=4)
     run('n=64 unitary (MFMA NT=4) x16', cases.case_c2(n=64, k=6, steps=200, m=8, taylor=(6, 3), seed=2), 16, 5, path=2)
-    run('n=48 unitary (GEMM path) x64', cases.case_c2(n=48, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 3)
+    run('n=48 unitary (GEMM path) x64', cases.case_c2(n=48, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 3, path=4)
     run('n=48 unitary (MFMA NT=3) x64', cases.case_c2(n=48, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 3, path=2)
     run('n=128 unitary (GEMM path) x4', cases.case_c2(n=128, k=6, steps=500, m=8, taylor=(5, 3), seed=2), 4, 3)
     run('C5 n=512 k=8 steps=2000 (GEMM path)', cases.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2), 1, 2)
