@@ -54,6 +54,7 @@ struct QocDev {
     int* iters;          // [B]
     int* done;           // [B]
     int skip_done;       // loop iterations only: kernels leave finished seeds untouched (their last evaluation stays readable)
+    int uscale_in_loss;  // unitary mode: k_loss also forms unitary_scale from Xfinal (MFMA path: saves a launch per iteration)
     // per-evaluation intermediates
     double* w;           // [B][k][steps] sin(base)
     double* u;           // [B][k][steps] maxA*w

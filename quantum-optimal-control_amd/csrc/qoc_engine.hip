@@ -128,6 +128,7 @@ static int prof_collect(qoc_engine* e) {
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     QocDev d = e->d;
     d.skip_done = ap.mode == 1 ? 1 : 0;      // qoc_eval / explicit steps always evaluate every seed
+    d.uscale_in_loss = e->path == QOC_PATH_MFMA ? 1 : 0;
     const int total = d.B * d.k * d.steps;
     int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
     if (cgrid > 2048) cgrid = 2048;

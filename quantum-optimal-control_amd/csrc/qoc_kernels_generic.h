@@ -220,6 +220,17 @@ __global__ void __launch_bounds__(QOC_BLOCK) k_loss(QocDev d) {
         d.reg_state[b] = reg_state;
         if (d.state_transfer) d.uscale[b] = nrm * nrm / mm;                      // tensorflow_state.py:335
     }
+    if (d.uscale_in_loss && !d.state_transfer) {              // unitary_scale = (1/n) sum_c |sum_a X[c][a]|^2   tensorflow_state.py:225
+        const cplx* X = d.Xfinal + (size_t)b * n * n;
+        double part = 0.0;
+        for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            cplx rs = cmake(0.0, 0.0);
+            for (int a = 0; a < n; ++a) rs = cadd(rs, X[c * n + a]);
+            part += rs.x * rs.x + rs.y * rs.y;
+        }
+        part = block_sum(part, red);
+        if (threadIdx.x == 0) d.uscale[b] = part / (double)n;
+    }
 }
 
 // S[tau][a][j] = d(state regularisers)/dPsi_tau   (G = d/dRe + i d/dIm)

@@ -1559,7 +1559,7 @@ static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStre
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
+    if (!d.uscale_in_loss) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
 }
 template <int NT>
 static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
