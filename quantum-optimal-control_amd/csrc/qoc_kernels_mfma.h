@@ -878,6 +878,98 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
     colblock_store<NT>(mf.Aoff + ((size_t)b * mf.C + c) * (QQS * 64), 0, lane, Z);
 }
 
+// ---- kernel B0': the affine offsets of NT = 2 on v_mfma_f64_4x4x4 ------------------------------------------------------
+// Same recursion as k_mfma_bwd_offsets (Z <- K_t^dagger Z + S_t from a zero costate, one wave per (seed, chunk >= 1)) in the
+// transposed form of k_mfma_forward2: Z^T <- Z^T conj(K_t), right operand = the fragD(K) registers as stored (contiguous loads),
+// left operand = 4x4 blocks of Z^T from a wave-private LDS image.  The source term has conditional loads (waited for on the
+// spot), so it is evaluated before the next K_t is fetched.  163 -> ~115 us per launch at the regularised C2 x 64.
+template <int MQ>
+__global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf) {
+    constexpr int NT = 2;
+    __shared__ __attribute__((aligned(16))) cplx o2_img[4][16 * F2_LDP];          // per wave: image[column j][row]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= d.B * mf.C) return;
+    const int b = item / mf.C, c = item - b * mf.C;
+    if (c == 0 || (d.skip_done && d.done[b])) return;                                  // a_0 is never used; finished seeds are frozen
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
+    cplx* img = o2_img[wv];
+    double zre[2][MQ], zim[2][MQ];                                                      // (I, jb): Z[16 I + lc][4 jb + lk]
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int jb = 0; jb < MQ; ++jb) { zre[I][jb] = 0.0; zim[I][jb] = 0.0; }
+    struct Frag { cplx f[2][8]; };
+    auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];        // K[4q + lk][16 I + lc]
+    };
+    double sre[2][MQ], sim[2][MQ];
+    auto source = [&](int t) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) {
+                const int row = 16 * I + lc, col = 4 * jb + lk;
+                cplx sv = cmake(0.0, 0.0);
+                if (row < d.n && col < d.m) sv = source_at(d, b, t, row, col);
+                sre[I][jb] = sv.x; sim[I][jb] = sv.y;
+            }
+    };
+    auto step = [&](const Frag& fr) {                                                  // Z <- K^dagger Z + S
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) img[(4 * jb + lk) * F2_LDP + 16 * I + lc] = cmake(zre[I][jb], zim[I][jb]);
+        wave_lds_fence();
+        double a[2][MQ], bq[2][MQ], cq[2][MQ];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) { a[I][jb] = 0.0; bq[I][jb] = 0.0; cq[I][jb] = 0.0; }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            cplx v[MQ];
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) v[jb] = img[(4 * jb + li4) * F2_LDP + 4 * kb + lk];   // Z[4 kb + lk][4 jb + li4]
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const double br = fr.f[I][kb].x, bi = -fr.f[I][kb].y, bs = br + bi;
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) {
+                    a[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].x, br, a[I][jb], 0, 0, 0);
+                    bq[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].y, bi, bq[I][jb], 0, 0, 0);
+                    cq[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].x + v[jb].y, bs, cq[I][jb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) { zre[I][jb] = a[I][jb] - bq[I][jb] + sre[I][jb]; zim[I][jb] = cq[I][jb] - a[I][jb] - bq[I][jb] + sim[I][jb]; }
+    };
+    const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);                 // slices of one chunk are FR apart
+    const int len = t1 - t0;
+    Frag A, A1;
+    load_frag(Kb + (size_t)(len - 1) * mf.FR, A);
+    int i = 0;                                                           // step i handles slice t = t1 - 1 - i
+    for (; i + 2 <= len; i += 2) {
+        source(t1 - 1 - i);     load_frag(Kb + (size_t)(len - 2 - i) * mf.FR, A1); asm volatile("" ::: "memory"); step(A);
+        source(t1 - 2 - i);     load_frag(Kb + (size_t)max(len - 3 - i, 0) * mf.FR, A); asm volatile("" ::: "memory"); step(A1);
+    }
+    if (i < len) { source(t1 - 1 - i); step(A); }
+    cplx* out = mf.Aoff + ((size_t)b * mf.C + c) * (QQS * 64);             // D-layout 16x16x4 column block 0
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)                                     // all 16 columns: the 16x16x4 backward kernels read the whole block
+            out[(4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * jb + lk] = jb < MQ ? cmake(zre[I][jb < MQ ? jb : 0], zim[I][jb < MQ ? jb : 0]) : cmake(0.0, 0.0);
+}
+
 // ---- kernel B: thin backward sweep  Lambda_{t-1} = K_t^dagger Lambda_t  + control gradients ----------------------
 // dL/du_{k,t} = Re sum_ab H_k'[a][b] Q_t[a][b],  Q_t = conj(Lambda_t) Psi_t^T  (rank-m outer product on the MFMA),
 // which equals Re <Lambda_t, H_k' Psi_t> of the reference's matexp_op_grad (tensorflow_state.py:61-63).
@@ -1564,8 +1656,14 @@ static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStre
 template <int NT>
 static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const int items = d.B * mf.C;
-    if ((d.n_forb > 0 || d.has_speed) && mf.C > 1)
-        hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    if ((d.n_forb > 0 || d.has_speed) && mf.C > 1) {
+        if (NT == 2 && mf.variant != 1) {
+            if (mf.mq <= 2) hipLaunchKernelGGL(k_mfma_bwd_offsets2<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+            else hipLaunchKernelGGL(k_mfma_bwd_offsets2<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        } else {
+            hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        }
+    }
     // NT = 2: each item split over a pair of waves (2 waves per SIMD for the batches AUTO sends here, 259 vs 301 us at C2 x 64).
     // The choice must not depend on the batch size: its gradient sums associate differently from the one-wave kernel, and a
     // seed has to evolve bit-identically whatever batch / GPU it is sharded into.  variant 1 keeps the one-wave kernel (A/B).
