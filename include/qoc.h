@@ -63,8 +63,10 @@ typedef struct qoc_config {
     int32_t path;               /* QOC_PATH_* */
     int32_t chunks;             /* MFMA path: time chunks per seed (0 = auto).  GEMM path, state transfer: 1 = direct route (Taylor
                                  * mat-vec chains, any H), > 1 = propagator route (needs anti-Hermitian generators), 0 = auto */
-    int32_t variant;            /* MFMA path, kernel of the exponentials: 0 = auto, 1 = v_mfma_f64_16x16x4 (two waves per chunk),
-                                 * 2 = v_mfma_f64_4x4x4 two waves per chunk, 3 = v_mfma_f64_4x4x4 one wave per chunk */
+    int32_t variant;            /* MFMA path, kernel family: 0 = auto, 1 = v_mfma_f64_16x16x4 everywhere (exponentials by one wave per
+                                 * 16-column block of a chunk, one-wave sweeps), 2 = v_mfma_f64_4x4x4 exponentials by one wave per
+                                 * 16-column block, 3 = v_mfma_f64_4x4x4 exponentials by one wave per chunk (n <= 32; n > 32: same
+                                 * as 2); 2 and 3 (and auto) run the n <= 32 sweeps on v_mfma_f64_4x4x4 as well */
     int32_t reserved[6];
 } qoc_config;
 
