@@ -1339,7 +1339,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         }
     }
     struct Frag { cplx f[8]; };
-    struct PsiReg { double pr[2][MQ], pi[2][MQ]; };
+    struct PsiReg { double pr[2][MQ], pi[2][MQ]; cplx own[MQ]; cplx zt; };   // own / zt: inputs of the source term (SRC only)
     auto put_own = [&](int bf) {
 #pragma unroll
         for (int jb = 0; jb < MQ; ++jb) mypad[(bf * 16 + 4 * jb + lk) * B2_LDP + lc] = cmake(ore[jb], oim[jb]);
@@ -1419,15 +1419,41 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
             const cplx p0 = psi[prow0 * d.m + jc], p1 = psi[prow1 * d.m + jc];
             ps.pr[0][q] = p0.x; ps.pi[0][q] = p0.y;
             ps.pr[1][q] = p1.x; ps.pi[1][q] = p1.y;
+            if (SRC) ps.own[q] = (psi - (size_t)d.n * d.m)[(h ? prow1 : prow0) * d.m + jc];    // Psi_t at this lane's costate entries
         }
+        if (SRC) ps.zt = *(d.has_speed ? d.ztau + (size_t)b * (d.steps + 1) + t : d.zfin + b);
         asm volatile("" ::: "memory");
     };
-    // state-regulariser source S of slice t = t1 - 1 - i at this lane's costate entries.  Its loads are conditional (hipcc waits
-    // for them on the spot, draining vmcnt), so it is evaluated BEFORE the next operands are fetched: what is in flight then
-    // are this step's operands, which are needed now anyway.
+    // Source S_t of the state regularisers at this lane's costate entries (row 16h + lc, column 4 jb + lk).  Undressed forbidden
+    // levels and speed_up need only Psi_t at those same entries and one scalar per slice, which fetch() brings in with the other
+    // operands (unconditional loads, no wait on the spot).  A dressed forbidden level needs a whole column of Psi_t and falls
+    // back to source_at(): its loads are conditional (hipcc waits for them on the spot, draining vmcnt), so that call sits BEFORE
+    // the next operands are fetched -- what is in flight then are this step's operands, which are needed now anyway.
+    const bool fast_src = !d.forbid_dressed;
+    cplx wown[MQ];
+    const double speed_coef = (SRC && d.has_speed) ? -d.a_speed * d.su_resid[b] * 2.0 / ((double)d.m * (double)d.m) : 0.0;
+    if (SRC) {
+#pragma unroll
+        for (int jb = 0; jb < MQ; ++jb) wown[jb] = d.W[min(16 * h + lc, d.n - 1) * d.m + min(4 * jb + lk, d.m - 1)];
+    }
+    auto source_fast = [&](const PsiReg& ps, int i, double (&fre)[MQ], double (&fim)[MQ]) {
+        const int t = t1 - 1 - i, row = 16 * h + lc;
+#pragma unroll
+        for (int jb = 0; jb < MQ; ++jb) {
+            const cplx phi = ps.own[jb];
+            const double pop = phi.x * phi.x + phi.y * phi.y;
+            double w = 0.0;
+            for (int f = 0; f < d.n_forb; ++f) w += (row == d.forb_state[f]) ? 2.0 * d.forb_a[f] * pop : 0.0;
+            cplx sv = cscale(phi, w);
+            const cplx zw = cscale(cmul(ps.zt, wown[jb]), speed_coef);
+            sv.x += d.has_speed ? zw.x : 0.0; sv.y += d.has_speed ? zw.y : 0.0;
+            const bool ok = t > 0 && row < d.n && 4 * jb + lk < d.m;
+            fre[jb] = ok ? sv.x : 0.0; fim[jb] = ok ? sv.y : 0.0;
+        }
+    };
     double sre[MQ], sim[MQ];
     auto source = [&](int i) {
-        if (!SRC) return;
+        if (!SRC || fast_src) return;
         const int t = t1 - 1 - i, tc = max(t, 1);
 #pragma unroll
         for (int jb = 0; jb < MQ; ++jb) {
@@ -1484,6 +1510,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t ------------------------------------------------------------------------------
         dagger_product(fr, buf, ore, oim);
         if (SRC) {
+            if (fast_src) source_fast(ps, i, sre, sim);
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) { ore[jb] += sre[jb]; oim[jb] += sim[jb]; }
         }
