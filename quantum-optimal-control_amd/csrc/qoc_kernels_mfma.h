@@ -60,6 +60,8 @@ struct QocMfma {
     cplx* PfD = nullptr;      // [B][C] fragD(P_c)
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
+    cplx* LamD = nullptr;     // NT > 2: [B][steps][16 NT rows][16 columns] costates for the slice-parallel gradient kernel
+    size_t grad_lds = 0;
     size_t bwd_lds = 0, bwd_lds2 = 0, bwd_lds3 = 0;
     bool h_in_lds = true, h_in_lds2 = true;
     int variant = 0;              // qoc_config.variant: 0 auto, 1 16x16x4, 2 4x4x4 two waves, 3 4x4x4 one wave
@@ -974,7 +976,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
 // dL/du_{k,t} = Re sum_ab H_k'[a][b] Q_t[a][b],  Q_t = conj(Lambda_t) Psi_t^T  (rank-m outer product on the MFMA),
 // which equals Re <Lambda_t, H_k' Psi_t> of the reference's matexp_op_grad (tensorflow_state.py:61-63).
 // 4 waves per workgroup; LDS: fragD image of the k control Hamiltonians (shared) + one transposition pad per wave.
-template <int NT, bool H_IN_LDS>
+template <int NT, bool H_IN_LDS, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int single_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -1028,6 +1030,15 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     }
     const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
     for (int t = t1 - 1; t >= t0; --t) {
+        if constexpr (SPLIT) {
+            // costates only: Lambda_t goes to LamD[b][t][row][16 columns] and k_mfma_grad forms the gradients slice-parallel
+            cplx* lam_out = mf.LamD + ((size_t)b * d.steps + t) * (16 * NT * 16);
+#pragma unroll
+            for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lam_out[(16 * Ib + (lane >> 4) + 4 * r) * 16 + (lane & 15)] = cmake(Lam[Ib].re[r], Lam[Ib].im[r]);
+        } else {
         // ---- Q = conj(Lambda_t) Psi_t^T, 3-multiplication form:  Qr = T1 + T2, Qi = T3 - T1 + T2 with
         //      T1 = Lr Pr, T2 = Li Pi, T3 = (Lr - Li)(Pr + Pi) ------------------------------------------------------
         lds_put_colblock<NT>(pad, 0, lane, Lam);                             // wave-private image: pad[j][row]
@@ -1085,6 +1096,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0) d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = v;
+        }
         }
         if (t == 0) break;
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t (+ S_{t-1}) ---------------------------------------------------------
@@ -1283,6 +1295,95 @@ __global__ void __launch_bounds__(512) k_mfma_backward2(QocDev d, QocMfma mf) {
                 if (kk < d.k) d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = g[kk] + gpart[(pair * 2 + buf) * 8 + kk];
         }
         buf ^= 1;
+    }
+}
+
+// ---- kernel G: control gradients of all slices in parallel (n > 32) ---------------------------------------------------
+// For NT = 3/4 the fragD images of the control Hamiltonians (36 / 64 KB each) no longer fit in LDS next to the transposition
+// pads of the sweep, and a sweep that reads them from L2 at every slice is bound by that stream (2.0 of 6.9 ms at n = 48 x 64).
+// The sweep (k_mfma_backward<NT, false, true>) therefore only propagates the costates and stores Lambda_t; this kernel, with
+// nothing but the images of up to 4 controls in LDS, forms Q = conj(Lambda_t) Psi_t^T and dL/du_{k,t} = Re sum_ab H_k'[a,b] Q[a,b]
+// for every (seed, slice) independently: one wave per slice, the next slice's operands fetched while this one multiplies.
+template <int NT, int MQ>
+__global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
+    constexpr int KG = NT >= 4 ? 2 : 4;                                         // control images per pass: 2 x 64 KB or 4 x 36 KB of LDS
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Hl = (cplx*)smem;                                                     // [<= KG] fragD(H_k')
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lk = lane >> 4, lc = lane & 15;
+    const int total = d.B * d.steps, stride = gridDim.x * 4;
+    struct Ops { double lr[NT][MQ], li[NT][MQ], pr[NT][MQ], pi[NT][MQ]; };
+    auto fetch = [&](Ops& o, int s) {
+        s = min(s, total - 1);
+        const int b = s / d.steps, t = s - b * d.steps;
+        const cplx* lam = mf.LamD + (size_t)s * (16 * NT * 16);
+        const cplx* psi = d.inter + ((size_t)b * (d.steps + 1) + t + 1) * d.n * d.m;
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int q = 0; q < MQ; ++q) {
+                const int j = 4 * q + lk;
+                const cplx lv = lam[(16 * I + lc) * 16 + j];
+                // rows >= n / columns >= m: clamped, finite, unmasked (they meet zero columns of Lambda / zero padding of H')
+                const cplx pv = psi[min(16 * I + lc, d.n - 1) * d.m + min(j, d.m - 1)];
+                o.lr[I][q] = lv.x; o.li[I][q] = lv.y; o.pr[I][q] = pv.x; o.pi[I][q] = pv.y;
+            }
+        asm volatile("" ::: "memory");
+    };
+    for (int k0 = 0; k0 < d.k; k0 += KG) {                                   // controls in groups of <= KG images
+        const int kn = min(KG, d.k - k0);
+        __syncthreads();
+        for (int o = threadIdx.x; o < kn * QFR; o += blockDim.x) Hl[o] = mf.HfD[(size_t)(1 + k0) * QFR + o];
+        __syncthreads();
+        auto contract = [&](const Ops& o, int s) {
+            if (s >= total) return;
+            const int b = s / d.steps, t = s - b * d.steps;
+            if (d.skip_done && d.done[b]) return;
+            double g[KG];
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) g[kk] = 0.0;
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int Jp = 0; Jp < NT; ++Jp) {
+                    d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < MQ; ++q) {
+                        t1v = QMFMA(o.lr[I][q], o.pr[Jp][q], t1v);
+                        t2v = QMFMA(o.li[I][q], o.pi[Jp][q], t2v);
+                        t3v = QMFMA(o.lr[I][q] - o.li[I][q], o.pr[Jp][q] + o.pi[Jp][q], t3v);
+                    }
+                    const d4 qr = t1v + t2v, qi = t3v - t1v + t2v;
+#pragma unroll
+                    for (int kk = 0; kk < KG; ++kk) {
+                        if (kk >= kn) continue;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const cplx h = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * I + r) * 64 + lane];
+                            acc = fma(h.x, qr[r], acc);
+                            acc = fma(-h.y, qi[r], acc);
+                        }
+                        g[kk] += acc;
+                    }
+                }
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+                if (kk >= kn) continue;
+                double v = g[kk];
+                v += dpp_xor<1>(v); v += dpp_xor<2>(v); v += dpp_xor<4>(v); v += dpp_xor<8>(v);
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (lane == 0) d.dLdu[((size_t)b * d.k + k0 + kk) * d.steps + t] = v;
+            }
+        };
+        Ops o0, o1;
+        int s = blockIdx.x * 4 + wv;
+        fetch(o0, s);
+        for (; s < total; s += 2 * stride) {
+            fetch(o1, s + stride); contract(o0, s);
+            fetch(o0, s + 2 * stride); contract(o1, s + stride);
+        }
     }
 }
 
@@ -1603,6 +1704,9 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     mf.skew_b = 3 * 16;                            //  768 B per seed
     const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
     mf.store_T = !(NT == 2 && mf.variant != 1);
+    const bool split_grad = NT > 2 && mf.variant != 1;
+    if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
+    { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
     if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     {
         size_t total = 0;
@@ -1634,6 +1738,11 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
                     hipFuncSetAttribute((const void*)k_mfma_backward3<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess)) {
         msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
         return -2;
+    }
+    if (split_grad) {
+        const void* gk = NT == 3 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<3, 2> : (const void*)k_mfma_grad<3, 4>)
+                                 : (mf.mq <= 2 ? (const void*)k_mfma_grad<4, 2> : (const void*)k_mfma_grad<4, 4>);
+        if (hipFuncSetAttribute(gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.grad_lds) != hipSuccess) { msg = "MFMA path: cannot reserve LDS for the gradient kernel"; return -2; }
     }
     if (mf.h_in_lds) {
         const hipError_t e1 = hipFuncSetAttribute((const void*)k_mfma_backward<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
@@ -1704,6 +1813,16 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
         }
         if (mf.h_in_lds2) hipLaunchKernelGGL((k_mfma_backward2<true>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
         else hipLaunchKernelGGL((k_mfma_backward2<false>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
+        return;
+    }
+    if (NT > 2 && mf.variant != 1) {
+        // n > 32: the sweep only propagates the costates, the gradients are formed slice-parallel with the control images in LDS
+        hipLaunchKernelGGL((k_mfma_backward<NT, false, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 0);   // no pad, no images
+        const int slices = d.B * d.steps;
+        int gg = (slices + 3) / 4; if (gg > 1024) gg = 1024;
+        constexpr int GN = NT > 2 ? NT : 3;                                  // (never launched for NT <= 2)
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<GN, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_grad<GN, 4>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
         return;
     }
     if (mf.h_in_lds)
