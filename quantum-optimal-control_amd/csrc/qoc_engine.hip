@@ -325,15 +325,12 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // Measured with tools/path_sweep.py (profiles/r01_path_sweep.txt):
     //  * unitary, n <= 32: the register-resident MFMA chain kernels win on throughput (1.8 vs 2.3 ms per iteration of 64
     //    C2 seeds), the GEMM path (fused LDS-resident exponential + product tree + persistent thin chains) on latency
-    //    (0.20 vs 0.57 ms for one C2 trajectory; crossover between 16 and 64 seeds); 32 < n <= 48 (NT = 3, exponentials by
-    //    three waves per item on v_mfma_f64_4x4x4): the MFMA path wins from 16 seeds on (2.39 vs 2.71 ms at 16, 6.86 vs 9.88 ms
-    //    at 64 seeds of n = 48; the GEMM path pads to N = 64), loses below (1.62 vs 1.50 ms at 8); 48 < n <= 64: the GEMM
-    //    path wins for every seed count (10.2 vs 13.4 ms at 64 seeds).
-    //  * state transfer on the GEMM path: the propagator route (K_t = P(B_t) as matrices, time-parallel chunks; needs
-    //    anti-Hermitian generators) wins for few trajectories (one C3 trajectory: 0.55 ms vs 26 ms for the fused mat-vec
-    //    kernels); the direct route (Taylor mat-vec chains on pre-assembled generators, one workgroup per seed) wins for
-    //    batches.  ST_DIRECT_FROM is the measured crossover in seeds.
-    const bool prefer_gemm = gemm_ok && (n > 48 || (n > 32 && B < 16) || (n > 16 && n <= 32 && B <= 16 && m <= 8 && steps >= 100));
+    //    (0.20 vs 0.57 ms for one C2 trajectory; crossover between 16 and 64 seeds); 32 < n <= 48 (NT = 3: exponentials by
+    //    three waves per item on v_mfma_f64_4x4x4, costate sweep + slice-parallel gradient kernel): the MFMA path wins from 8 seeds
+    //    on (1.11 vs 1.50 ms at 8, 1.70 vs 2.72 at 16, 5.27 vs 9.88 ms at 64 seeds of n = 48; the GEMM path pads to N = 64), ties at
+    //    4 (1.00 vs 0.95) and loses below (0.96 vs 0.62 ms at 2); 48 < n <= 64: the GEMM path wins for every seed count
+    //    (10.1 vs 11.3 ms at 64 seeds).
+    const bool prefer_gemm = gemm_ok && (n > 48 || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 16 && m <= 8 && steps >= 100));
     const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
     bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));
