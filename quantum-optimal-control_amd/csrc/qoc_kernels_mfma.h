@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
 // transposed form of k_mfma_forward2: Z^T <- Z^T conj(K_t), right operand = the fragD(K) registers as stored (contiguous loads),
 // left operand = 4x4 blocks of Z^T from a wave-private LDS image.  The source term has conditional loads (waited for on the
 // spot), so it is evaluated before the next K_t is fetched.  163 -> ~115 us per launch at the regularised C2 x 64.
-template <int MQ>
+template <int MQ, bool FULL>
 __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf) {
     constexpr int NT = 2;
     __shared__ __attribute__((aligned(16))) cplx o2_img[4][16 * F2_LDP];          // per wave: image[column j][row]
@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
     const int item = blockIdx.x * 4 + wv;
     if (item >= d.B * mf.C) return;
     const int b = item / mf.C, c = item - b * mf.C;
-    if (c == 0 || (d.skip_done && d.done[b])) return;                                  // a_0 is never used; finished seeds are frozen
+    if ((!FULL && c == 0) || (d.skip_done && d.done[b])) return;                       // a_0 is never used; finished seeds are frozen
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
     const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
     cplx* img = o2_img[wv];
@@ -922,6 +922,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
                 sre[I][jb] = sv.x; sim[I][jb] = sv.y;
             }
     };
+    const bool need_src = d.n_forb > 0 || d.has_speed;
     auto step = [&](const Frag& fr) {                                                  // Z <- K^dagger Z + S
 #pragma unroll
         for (int I = 0; I < 2; ++I)
@@ -957,13 +958,60 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
     const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);                 // slices of one chunk are FR apart
     const int len = t1 - t0;
     Frag A, A1;
+    auto zero_src = [&]() {
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) { sre[I][jb] = 0.0; sim[I][jb] = 0.0; }
+    };
+    if (FULL) {
+        // FULL: the costate sweep itself (k > 4 controls: the gradients are formed by k_mfma_grad from the stored Lambda_t).
+        // Terminal costate -(2/m^2) z W (+ S_steps), then E_{cc-1} = P_cc^dagger E_cc + a_cc down to the end of this chunk.
+        const cplx z = d.zfin[b];
+        const double c0 = -2.0 / ((double)d.m * (double)d.m);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) {
+                const int row = 16 * I + lc, col = 4 * jb + lk;
+                cplx v = cmake(0.0, 0.0);
+                if (row < d.n && col < d.m) {
+                    v = cscale(cmul(z, d.W[row * d.m + col]), c0);
+                    if (need_src) v = cadd(v, source_at(d, b, d.steps, row, col));
+                }
+                zre[I][jb] = v.x; zim[I][jb] = v.y;
+            }
+        for (int cc = mf.C - 1; cc > c; --cc) {
+            if (need_src) {
+                const cplx* ao = mf.Aoff + ((size_t)b * mf.C + cc) * (QQS * 64) + 16 * (lc & 3) + lk;
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int jb = 0; jb < MQ; ++jb) { const cplx o = ao[(4 * I + (lc >> 2)) * 64 + 4 * jb]; sre[I][jb] = o.x; sim[I][jb] = o.y; }
+            } else {
+                zero_src();
+            }
+            load_frag(mf.PfD + ((size_t)b * mf.C + cc) * QFR, A);
+            step(A);
+        }
+    }
+    auto store_lam = [&](int t) {                                        // LamD[b][t][row][16 columns]
+        if (!FULL) return;
+        cplx* lo = mf.LamD + ((size_t)b * d.steps + t) * (16 * NT * 16);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) lo[(16 * I + lc) * 16 + 4 * jb + lk] = cmake(zre[I][jb], zim[I][jb]);
+    };
+    auto src_or_zero = [&](int t) { if (need_src && t > 0) source(max(t, 1)); else zero_src(); };
     load_frag(Kb + (size_t)(len - 1) * mf.FR, A);
     int i = 0;                                                           // step i handles slice t = t1 - 1 - i
     for (; i + 2 <= len; i += 2) {
-        source(t1 - 1 - i);     load_frag(Kb + (size_t)(len - 2 - i) * mf.FR, A1); asm volatile("" ::: "memory"); step(A);
-        source(t1 - 2 - i);     load_frag(Kb + (size_t)max(len - 3 - i, 0) * mf.FR, A); asm volatile("" ::: "memory"); step(A1);
+        src_or_zero(t1 - 1 - i); load_frag(Kb + (size_t)(len - 2 - i) * mf.FR, A1); asm volatile("" ::: "memory"); store_lam(t1 - 1 - i); step(A);
+        src_or_zero(t1 - 2 - i); load_frag(Kb + (size_t)max(len - 3 - i, 0) * mf.FR, A); asm volatile("" ::: "memory"); store_lam(t1 - 2 - i); step(A1);
     }
-    if (i < len) { source(t1 - 1 - i); step(A); }
+    if (i < len) { src_or_zero(t1 - 1 - i); store_lam(t1 - 1 - i); step(A); }
+    if (FULL) return;
     cplx* out = mf.Aoff + ((size_t)b * mf.C + c) * (QQS * 64);             // D-layout 16x16x4 column block 0
 #pragma unroll
     for (int I = 0; I < 2; ++I)
@@ -1704,7 +1752,7 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     mf.skew_b = 3 * 16;                            //  768 B per seed
     const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
     mf.store_T = !(NT == 2 && mf.variant != 1);
-    const bool split_grad = NT > 2 && mf.variant != 1;
+    const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k = 5 still fits backward2's LDS (1.45 vs 1.49 ms)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
     if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
@@ -1740,7 +1788,8 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         return -2;
     }
     if (split_grad) {
-        const void* gk = NT == 3 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<3, 2> : (const void*)k_mfma_grad<3, 4>)
+        const void* gk = NT == 2 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<2, 2> : (const void*)k_mfma_grad<2, 4>)
+                       : NT == 3 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<3, 2> : (const void*)k_mfma_grad<3, 4>)
                                  : (mf.mq <= 2 ? (const void*)k_mfma_grad<4, 2> : (const void*)k_mfma_grad<4, 4>);
         if (hipFuncSetAttribute(gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.grad_lds) != hipSuccess) { msg = "MFMA path: cannot reserve LDS for the gradient kernel"; return -2; }
     }
@@ -1794,8 +1843,8 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     const int items = d.B * mf.C;
     if ((d.n_forb > 0 || d.has_speed) && mf.C > 1) {
         if (NT == 2 && mf.variant != 1) {
-            if (mf.mq <= 2) hipLaunchKernelGGL(k_mfma_bwd_offsets2<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-            else hipLaunchKernelGGL(k_mfma_bwd_offsets2<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, false>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, false>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
         } else {
             hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
         }
@@ -1809,6 +1858,17 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
             const dim3 g3((items + 3) / 4), b3(512);
             if (mf.mq <= 2) { if (src) hipLaunchKernelGGL((k_mfma_backward3<2, true>), g3, b3, mf.bwd_lds3, s, d, mf); else hipLaunchKernelGGL((k_mfma_backward3<2, false>), g3, b3, mf.bwd_lds3, s, d, mf); }
             else { if (src) hipLaunchKernelGGL((k_mfma_backward3<4, true>), g3, b3, mf.bwd_lds3, s, d, mf); else hipLaunchKernelGGL((k_mfma_backward3<4, false>), g3, b3, mf.bwd_lds3, s, d, mf); }
+            return;
+        }
+        if (mf.LamD) {
+            // k >= 6: the control images fit in LDS next to no sweep's pads; costate sweep + slice-parallel gradient kernel (4 images
+            // per pass) instead of the row-split 16x16x4 sweep reading them from L2 (C2 x 64 with k = 8: 1.55 vs 1.71 ms per iteration)
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+            const int slices = d.B * d.steps;
+            int gg = (slices + 3) / 4; if (gg > 2048) gg = 2048;
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<2, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_grad<2, 4>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
             return;
         }
         if (mf.h_in_lds2) hipLaunchKernelGGL((k_mfma_backward2<true>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
