@@ -82,7 +82,7 @@ def test_eval_parity(name, c, path):
 
 
 @pytest.mark.parametrize('chunks', [1, 3, 7, 40])
-@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'U0_dressed', 'n30_m13_k2', 'n24_m16_k6', 'n32_m4_k3', 'n40_nt3',
+@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'U0_dressed', 'n30_m13_k2', 'n24_m16_k6', 'n28_k7_sources', 'n32_m4_k3', 'n40_nt3',
                                      'n48_k4_sources_nt3', 'n64_nt4', 'n57_k1_nt4'])
 def test_mfma_path_parity(chunks, variant):
     _mfma_path_parity(chunks, variant, 0)
@@ -110,6 +110,9 @@ def _mfma_path_parity(chunks, variant, kernel):
         c = cases.case_c2(n=30, k=2, steps=26, m=13, taylor=(5, 2), seed=21)
     elif variant == 'n24_m16_k6':        # k > 4: the row-split 16x16x4 backward kernel behind the 4x4x4 forward sweep
         c = cases.case_c2(n=24, k=6, steps=18, m=16, taylor=(6, 1), seed=22)
+    elif variant == 'n28_k7_sources':    # k >= 6 with state regularisers: affine offsets, costate sweep, gradient kernel in two passes
+        c = cases.case_c2(n=28, k=7, steps=29, m=5, taylor=(5, 2), seed=24)
+        c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [3.0, 2.0], 'states_forbidden_list': [27, 20], 'speed_up': 0.4}
     elif variant == 'n32_m4_k3':         # one column block used out of two
         c = cases.case_c2(n=32, k=3, steps=33, m=4, taylor=(4, 2), seed=23)
     elif variant == 'n40_nt3':
