@@ -715,10 +715,10 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
 // tile spends half of its columns on m = 8) -- 48 MQ MFMAs of 17 cycles per slice instead of 48 of ~100.  K_{t+1} is fetched
 // while slice t multiplies.  Final-unitary waves as in k_mfma_forward.
 #define F2_LDP 33
-template <int MQ>
+template <int NT, int MQ>
 __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
-    constexpr int NT = 2;
-    __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * F2_LDP];          // per wave: image[column j][row]
+    constexpr int LDP = 16 * NT + 1;
+    __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blockIdx.x * 4 + wv;
@@ -729,9 +729,9 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
         const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
         const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
         cplx* img = f2_img[wv];
-        double pre[2][MQ], pim[2][MQ];
+        double pre[NT][MQ], pim[NT][MQ];
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < NT; ++I)
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) {
                 const int row = 16 * I + lc, col = 4 * jb + lk;
@@ -743,33 +743,33 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
         if (c == 0) {                                                   // inter[0] = V  (tensorflow_state.py:232-233)
             for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
         }
-        struct Frag { cplx f[2][8]; };
+        struct Frag { cplx f[NT][QQS]; };
         auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
 #pragma unroll
-            for (int I = 0; I < 2; ++I)
+            for (int I = 0; I < NT; ++I)
 #pragma unroll
-                for (int q = 0; q < 8; ++q)    // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
+                for (int q = 0; q < QQS; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
                     fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
         };
         // Psi <- M Psi with M^T given by its fragD fragment
         auto product = [&](const Frag& fr) {
 #pragma unroll
-            for (int I = 0; I < 2; ++I)
+            for (int I = 0; I < NT; ++I)
 #pragma unroll
-                for (int jb = 0; jb < MQ; ++jb) img[(4 * jb + lk) * F2_LDP + 16 * I + lc] = cmake(pre[I][jb], pim[I][jb]);
+                for (int jb = 0; jb < MQ; ++jb) img[(4 * jb + lk) * LDP + 16 * I + lc] = cmake(pre[I][jb], pim[I][jb]);
             wave_lds_fence();
-            double a[2][MQ], bq[2][MQ], cq[2][MQ];
+            double a[NT][MQ], bq[NT][MQ], cq[NT][MQ];
 #pragma unroll
-            for (int I = 0; I < 2; ++I)
+            for (int I = 0; I < NT; ++I)
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) { a[I][jb] = 0.0; bq[I][jb] = 0.0; cq[I][jb] = 0.0; }
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
+            for (int kb = 0; kb < QQS; ++kb) {
                 cplx v[MQ];
 #pragma unroll
-                for (int jb = 0; jb < MQ; ++jb) v[jb] = img[(4 * jb + li4) * F2_LDP + 4 * kb + lk];   // Psi[4 kb + lk][4 jb + li4]
+                for (int jb = 0; jb < MQ; ++jb) v[jb] = img[(4 * jb + li4) * LDP + 4 * kb + lk];   // Psi[4 kb + lk][4 jb + li4]
 #pragma unroll
-                for (int I = 0; I < 2; ++I) {
+                for (int I = 0; I < NT; ++I) {
                     const double br = fr.f[I][kb].x, bi = fr.f[I][kb].y, bs = br + bi;
 #pragma unroll
                     for (int jb = 0; jb < MQ; ++jb) {
@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
                 }
             }
 #pragma unroll
-            for (int I = 0; I < 2; ++I)
+            for (int I = 0; I < NT; ++I)
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) { pre[I][jb] = a[I][jb] - bq[I][jb]; pim[I][jb] = cq[I][jb] - a[I][jb] - bq[I][jb]; }
         };
@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
             product(fr);
             cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
 #pragma unroll
-            for (int I = 0; I < 2; ++I)
+            for (int I = 0; I < NT; ++I)
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) {
                     const int row = 16 * I + lc, col = 4 * jb + lk;
@@ -1751,7 +1751,7 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     mf.skew_c = 5 * 16;                            // 1280 B per chunk
     mf.skew_b = 3 * 16;                            //  768 B per seed
     const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
-    mf.store_T = !(NT == 2 && mf.variant != 1);
+    mf.store_T = !((NT == 2 || NT == 3) && mf.variant != 1);     // the 4x4x4 forward sweep gathers K^T operands from fragD(K)
     const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k = 5 still fits backward2's LDS (1.45 vs 1.49 ms)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
@@ -1830,8 +1830,12 @@ static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStre
     if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 2 && mf.variant != 1) {
         // 4x4x4 sweep; like the backward choice this must not depend on the batch size (bit-identical seeds across shardings)
-        if (mf.mq <= 2) hipLaunchKernelGGL(k_mfma_forward2<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-        else hipLaunchKernelGGL(k_mfma_forward2<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_forward2<2, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    }
+    else if (mf.NT == 3 && mf.variant != 1) {
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_forward2<3, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     }
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
