@@ -1,0 +1,215 @@
+// qoc_mfma_forward.h -- MFMA path: thin forward sweeps Psi_t = K_t Psi_{t-1} (inter vectors), final unitary, unitary_scale.
+// Reference semantics: core/tensorflow_state.py:204-242.
+#pragma once
+#include "qoc_mfma_frag.h"
+
+// ---- kernel F: thin forward sweep  Psi_t = K_t Psi_{t-1}  (inter vectors) + final unitary ------------------------
+// grid.x = B*C sweep waves + B*2 final-unitary waves, 4 waves per workgroup, no LDS, no barriers.
+template <int NT>
+__global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_sweep = d.B * mf.C;
+    if (item < n_sweep) {
+        const int b = item / mf.C, c = item - b * mf.C;
+        if (d.skip_done && d.done[b]) return;
+        const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+        CTile Psi[NT];
+#pragma unroll
+        for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
+                cplx v = cmake(0.0, 0.0);
+                if (row < d.n && col < d.m) v = d.Psi0[row * d.m + col];
+                Psi[Ib].re[r] = v.x; Psi[Ib].im[r] = v.y;
+            }
+        cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
+        if (c == 0) {                                                   // inter[0] = V  (tensorflow_state.py:232-233)
+            for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
+        }
+        AFragT<NT> A;
+        for (int cc = 0; cc < c; ++cc) {                                // chunk boundary from the chunk products
+            afrag_load<NT, false>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, Psi, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) Psi[Ib] = acc[Ib];
+        }
+        for (int t = t0; t < t1; ++t) {
+            afrag_load<NT, false>(mf.KfT + kitem(mf, d.steps, b, t), lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, Psi, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) Psi[Ib] = acc[Ib];
+            cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
+#pragma unroll
+            for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * Ib + (lane >> 4) + 4 * r, col = lane & 15;
+                    if (row < d.n && col < d.m) out[row * d.m + col] = cmake(Psi[Ib].re[r], Psi[Ib].im[r]);
+                }
+        }
+    } else if (item < n_sweep + d.B * NT) {
+        // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
+        const int w = item - n_sweep, b = w / NT, J = w - b * NT;
+        if (d.skip_done && d.done[b]) return;
+        CTile X[NT];
+        colblock_load<NT>(mf.U0fD, J, lane, X);
+        AFragT<NT> A;
+        for (int cc = 0; cc < mf.C; ++cc) {
+            afrag_load<NT, false>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, X, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) X[Ib] = acc[Ib];
+        }
+        cplx* Xf = d.Xfinal + (size_t)b * d.n * d.n;
+#pragma unroll
+        for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * Ib + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
+                if (row < d.n && col < d.n) Xf[row * d.n + col] = cmake(X[Ib].re[r], X[Ib].im[r]);
+            }
+    }
+}
+
+// ---- kernel F2: the thin forward sweep of NT = 2 on v_mfma_f64_4x4x4 ---------------------------------------------------
+// Transposed recursion Psi_t^T = Psi_{t-1}^T K_t^T: the right operand (4 k-rows x 16 columns of K^T) is a fragD register of
+// KfT as stored, the left operand a 4x4 block of Psi^T read from a wave-private LDS image (broadcast over the 4 blocks), the
+// result register (I, jb) holds Psi[row 16 I + lane % 16][column 4 jb + lane / 16]: no output column is padding (a 16x16x4
+// tile spends half of its columns on m = 8) -- 48 MQ MFMAs of 17 cycles per slice instead of 48 of ~100.  K_{t+1} is fetched
+// while slice t multiplies.  Final-unitary waves as in k_mfma_forward.
+#define F2_LDP 33
+template <int NT, int MQ>
+__global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
+    constexpr int LDP = 16 * NT + 1;
+    __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wv;
+    const int n_sweep = d.B * mf.C;
+    if (item < n_sweep) {
+        const int b = item / mf.C, c = item - b * mf.C;
+        if (d.skip_done && d.done[b]) return;
+        const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+        const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
+        cplx* img = f2_img[wv];
+        double pre[NT][MQ], pim[NT][MQ];
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) {
+                const int row = 16 * I + lc, col = 4 * jb + lk;
+                cplx v = cmake(0.0, 0.0);
+                if (row < d.n && col < d.m) v = d.Psi0[row * d.m + col];
+                pre[I][jb] = v.x; pim[I][jb] = v.y;
+            }
+        cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
+        if (c == 0) {                                                   // inter[0] = V  (tensorflow_state.py:232-233)
+            for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
+        }
+        struct Frag { cplx f[NT][QQS]; };
+        auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int q = 0; q < QQS; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
+                    fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
+        };
+        // Psi <- M Psi with M^T given by its fragD fragment
+        auto product = [&](const Frag& fr) {
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) img[(4 * jb + lk) * LDP + 16 * I + lc] = cmake(pre[I][jb], pim[I][jb]);
+            wave_lds_fence();
+            double a[NT][MQ], bq[NT][MQ], cq[NT][MQ];
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) { a[I][jb] = 0.0; bq[I][jb] = 0.0; cq[I][jb] = 0.0; }
+#pragma unroll
+            for (int kb = 0; kb < QQS; ++kb) {
+                cplx v[MQ];
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) v[jb] = img[(4 * jb + li4) * LDP + 4 * kb + lk];   // Psi[4 kb + lk][4 jb + li4]
+#pragma unroll
+                for (int I = 0; I < NT; ++I) {
+                    const double br = fr.f[I][kb].x, bi = fr.f[I][kb].y, bs = br + bi;
+#pragma unroll
+                    for (int jb = 0; jb < MQ; ++jb) {
+                        a[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].x, br, a[I][jb], 0, 0, 0);
+                        bq[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].y, bi, bq[I][jb], 0, 0, 0);
+                        cq[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[jb].x + v[jb].y, bs, cq[I][jb], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) { pre[I][jb] = a[I][jb] - bq[I][jb]; pim[I][jb] = cq[I][jb] - a[I][jb] - bq[I][jb]; }
+        };
+        Frag A, A1;
+        for (int cc = 0; cc < c; ++cc) {                                // chunk boundary from the chunk products
+            load_frag(mf.PfD + ((size_t)b * mf.C + cc) * QFR, A);
+            product(A);
+        }
+        auto step = [&](const Frag& fr, int t) {
+            product(fr);
+            cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) {
+                    const int row = 16 * I + lc, col = 4 * jb + lk;
+                    if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I][jb], pim[I][jb]);
+                }
+        };
+        const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);             // slices of one chunk are FR apart
+        const int len = t1 - t0;
+        load_frag(Kb, A);
+        int t = 0;
+        for (; t + 2 <= len; t += 2) {
+            load_frag(Kb + (size_t)(t + 1) * mf.FR, A1); asm volatile("" ::: "memory"); step(A, t0 + t);
+            load_frag(Kb + (size_t)min(t + 2, len - 1) * mf.FR, A); asm volatile("" ::: "memory"); step(A1, t0 + t + 1);
+        }
+        if (t < len) step(A, t0 + t);
+    } else if (item < n_sweep + d.B * NT) {
+        // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
+        const int w = item - n_sweep, b = w / NT, J = w - b * NT;
+        if (d.skip_done && d.done[b]) return;
+        CTile X[NT];
+        colblock_load<NT>(mf.U0fD, J, lane, X);
+        AFragT<NT> A;
+        for (int cc = 0; cc < mf.C; ++cc) {
+            afrag_load<NT, false>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            CTile acc[NT];
+            mm_colblock<NT>(A, X, acc);
+            for (int Ib = 0; Ib < NT; ++Ib) X[Ib] = acc[Ib];
+        }
+        cplx* Xf = d.Xfinal + (size_t)b * d.n * d.n;
+#pragma unroll
+        for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * Ib + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
+                if (row < d.n && col < d.n) Xf[row * d.n + col] = cmake(X[Ib].re[r], X[Ib].im[r]);
+            }
+    }
+}
+
+// unitary_scale = (1/n) sum_c |sum_a X[c][a]|^2                      tensorflow_state.py:225
+__global__ void __launch_bounds__(64) k_mfma_uscale(QocDev d) {
+    const int b = blockIdx.x, n = d.n, lane = threadIdx.x;
+    const cplx* X = d.Xfinal + (size_t)b * n * n;
+    double part = 0.0;
+    for (int c = lane; c < n; c += 64) {
+        cplx rs = cmake(0.0, 0.0);
+        for (int a = 0; a < n; ++a) rs = cadd(rs, X[c * n + a]);
+        part += rs.x * rs.x + rs.y * rs.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) d.uscale[b] = part / (double)n;
+}
+
