@@ -161,3 +161,115 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
         }
     }
 }
+
+// ---- k_zgemm_wg: plain products (EPI 0, no CONJT) of large matrices on v_mfma_f64_4x4x4 --------------------------------
+// The 16x16x4 instruction of k_zgemm32 issues every ~103 cycles per SIMD (48 TFLOP/s); the 4x4x4 form reaches 73, but a 32x32
+// tile per wave fed from L1/L2 needs ~12 TB/s of operand traffic at that rate (measured: 2x SLOWER).  Here a workgroup of 4
+// waves owns a 64x128 tile of C (wave tile 32x64: 8 row blocks x 4 column strips = 96 accumulators in AGPRs) and shares the
+// operands through LDS: per 16-deep k-chunk the workgroup stages A (64 x 16) and B (16 x 128) together with their re+im sums
+// (a v_add_f64 inside the product loop costs as much as half an MFMA) -- fetched into registers while the previous chunk
+// multiplies, written to LDS between two LDS-only barriers.  In the loop a wave reads its 4x4 blocks of A (broadcast over the
+// four block lanes) through a 3-slot ring two steps ahead and the 4-row strips of B of the next k-block while this one
+// multiplies; __builtin_amdgcn_sched_barrier pins that order (left alone hipcc sinks the reads next to their use).
+#define ZW_LDA 20          // k-chunk of 16 + 4: the 16 (row, k) addresses of a block read fall into distinct banks
+struct ZwB { cplx v[4]; double s[4]; };
+__global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char zw_lds[];
+    cplx* Ai = (cplx*)zw_lds;                        // [64][ZW_LDA]
+    cplx* Bi = Ai + 64 * ZW_LDA;                     // [16][128]
+    double* As = (double*)(Bi + 16 * 128);           // [64][ZW_LDA]
+    double* Bs = As + 64 * ZW_LDA;                   // [16][128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tm2 = g.tiles_m >> 1, tn2 = g.tiles_n >> 2, tiles = tm2 * tn2;
+    const int bt = blockIdx.x / tiles, tile = blockIdx.x - bt * tiles;
+    const int tm = tile / tn2, tn = tile - tm * tn2;
+    const int r0 = tm * 64, c0 = tn * 128;
+    const int bhi = g.inner > 0 ? bt / g.inner : 0, blo = g.inner > 0 ? bt - bhi * g.inner : bt;
+    const cplx* __restrict__ A = g.A + (size_t)bhi * g.sA2 + (size_t)blo * g.sA;
+    const cplx* __restrict__ Bm = g.Bm + (size_t)bhi * g.sB2 + (size_t)blo * g.sB;
+    const int lr = lane & 15, lk = lane >> 4, li4 = lane & 3;
+    const int r0w = 32 * (wv & 1), c0w = 64 * (wv >> 1);
+    // staging roles, lane-contiguous in global memory AND in LDS (a first mapping with 4 / 8 consecutive elements per thread
+    // put every ds_write on 4 bank groups): element e of a thread is flat index e*256 + tid of the chunk,
+    // A chunk 64 rows x 16 k -> (row = idx / 16, k = idx % 16), B chunk 16 k x 128 columns -> (k = idx / 128, column = idx % 128)
+    const cplx* Ag = A + (size_t)(r0 + (tid >> 4)) * g.lda + (tid & 15);          // + e * 16 rows
+    const cplx* Bg = Bm + (size_t)(tid >> 7) * g.ldb + c0 + (tid & 127);          // + e * 2 k-rows
+    double t1[8][4], t2[8][4], t3[8][4];
+#pragma unroll
+    for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+        for (int J = 0; J < 4; ++J) { t1[ib][J] = 0.0; t2[ib][J] = 0.0; t3[ib][J] = 0.0; }
+    const int nch = g.Kdim >> 4;
+    cplx sa[4], sb[8];
+    auto stage_fetch = [&](int ch) {
+        ch = min(ch, nch - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sa[e] = Ag[(size_t)(16 * e) * g.lda + 16 * ch];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sb[e] = Bg[(size_t)(16 * ch + 2 * e) * g.ldb];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int o = (16 * e + (tid >> 4)) * ZW_LDA + (tid & 15); Ai[o] = sa[e]; As[o] = sa[e].x + sa[e].y; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int o = (2 * e + (tid >> 7)) * 128 + (tid & 127); Bi[o] = sb[e]; Bs[o] = sb[e].x + sb[e].y; }
+    };
+    const cplx* arow = Ai + (r0w + li4) * ZW_LDA + lk;          // + (4 ib) * ZW_LDA + 4 kb
+    const double* asrow = As + (r0w + li4) * ZW_LDA + lk;
+    const cplx* bcol = Bi + lk * 128 + c0w + lr;                // + (4 kb) * 128 + 16 J
+    const double* bscol = Bs + lk * 128 + c0w + lr;
+    auto load_b = [&](ZwB& b, int kb) {
+#pragma unroll
+        for (int J = 0; J < 4; ++J) { b.v[J] = bcol[(4 * kb) * 128 + 16 * J]; b.s[J] = bscol[(4 * kb) * 128 + 16 * J]; }
+    };
+    stage_fetch(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        stage_store();
+        lds_barrier();
+        stage_fetch(ch + 1);                                    // in flight while this chunk multiplies
+        // 32 block steps (kb, ib) of the chunk; A blocks through a 3-slot ring two steps ahead, B strips one k-block ahead
+        cplx av[3]; double as[3];
+        auto load_a = [&](int st, int slot) { const int kb = st >> 3, ib = st & 7; av[slot] = arow[(4 * ib) * ZW_LDA + 4 * kb]; as[slot] = asrow[(4 * ib) * ZW_LDA + 4 * kb]; };
+        ZwB b0, b1;
+        load_b(b0, 0);
+        load_a(0, 0);
+        load_a(1, 1);
+#pragma unroll
+        for (int st = 0; st < 32; ++st) {
+            const int kb = st >> 3, ib = st & 7;
+            if (st + 2 < 32) load_a(st + 2, (st + 2) % 3);
+            if (ib == 0 && kb + 1 < 4) load_b((kb & 1) ? b0 : b1, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const ZwB& b = (kb & 1) ? b1 : b0;
+            const cplx a = av[st % 3];
+            const double asum = as[st % 3];
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                t1[ib][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, b.v[J].x, t1[ib][J], 0, 0, 0);
+                t2[ib][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, b.v[J].y, t2[ib][J], 0, 0, 0);
+                t3[ib][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(asum, b.s[J], t3[ib][J], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();                                          // every wave is done reading this chunk's images
+    }
+    // D strip (ib, J): lane 16 i + c16 <-> (row = r0 + r0w + 4 ib + i, col = c0 + c0w + 16 J + c16)
+#pragma unroll
+    for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+        for (int J = 0; J < 4; ++J) {
+            const int row = r0 + r0w + 4 * ib + lk, col = c0 + c0w + 16 * J + lr;
+            const double vre = t1[ib][J] - t2[ib][J], vim = t3[ib][J] - t1[ib][J] - t2[ib][J];
+            cplx v = cmake(g.alpha * vre, g.alpha * vim);
+            if (g.E) {
+                const cplx e = g.E[(size_t)bt * g.sE + (size_t)row * g.lde + col];
+                v.x = fma(g.beta, e.x, v.x); v.y = fma(g.beta, e.y, v.y);
+            }
+            if (row == col) v.x += g.gamma;
+            g.C[(size_t)bhi * g.sC2 + (size_t)blo * g.sC + (size_t)row * g.ldc + col] = v;
+            if (g.CT) g.CT[(size_t)bt * g.sCT + (size_t)col * g.ldct + row] = v;
+        }
+}
+static inline size_t qoc_zgemm_wg_lds() { return (size_t)(64 * ZW_LDA + 16 * 128) * (sizeof(cplx) + sizeof(double)); }
