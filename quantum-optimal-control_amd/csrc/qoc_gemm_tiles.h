@@ -182,7 +182,11 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tm2 = g.tiles_m >> 1, tn2 = g.tiles_n >> 2, tiles = tm2 * tn2;
-    const int bt = blockIdx.x / tiles, tile = blockIdx.x - bt * tiles;
+    // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD x a CONTIGUOUS range of tiles, so that the
+    // workgroups sharing an A row panel / a B matrix meet in one L2 (measured neutral at C5: the kernel is not L2-bound)
+    const unsigned nb = gridDim.x;
+    const unsigned lid = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int bt = lid / tiles, tile = lid - bt * tiles;
     const int tm = tile / tn2, tn = tile - tm * tn2;
     const int r0 = tm * 64, c0 = tn * 128;
     const int bhi = g.inner > 0 ? bt / g.inner : 0, blo = g.inner > 0 ? bt - bhi * g.inner : bt;
