@@ -171,14 +171,15 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
 // multiplies, written to LDS between two LDS-only barriers.  In the loop a wave reads its 4x4 blocks of A (broadcast over the
 // four block lanes) through a 3-slot ring two steps ahead and the 4-row strips of B of the next k-block while this one
 // multiplies; __builtin_amdgcn_sched_barrier pins that order (left alone hipcc sinks the reads next to their use).
-#define ZW_LDA 20          // k-chunk of 16 + 4: the 16 (row, k) addresses of a block read fall into distinct banks
+#define ZW_KC 16           // depth of a k-chunk (32, filling the 160 KB of LDS, was slower: C5 281 vs 271 ms)
+#define ZW_LDA (ZW_KC + 4) // + 4: the 16 (row, k) addresses of a block read fall into distinct banks
 struct ZwB { cplx v[4]; double s[4]; };
 __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char zw_lds[];
     cplx* Ai = (cplx*)zw_lds;                        // [64][ZW_LDA]
-    cplx* Bi = Ai + 64 * ZW_LDA;                     // [16][128]
-    double* As = (double*)(Bi + 16 * 128);           // [64][ZW_LDA]
-    double* Bs = As + 64 * ZW_LDA;                   // [16][128]
+    cplx* Bi = Ai + 64 * ZW_LDA;                     // [ZW_KC][128]
+    double* As = (double*)(Bi + ZW_KC * 128);        // [64][ZW_LDA]
+    double* Bs = As + 64 * ZW_LDA;                   // [ZW_KC][128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tm2 = g.tiles_m >> 1, tn2 = g.tiles_n >> 2, tiles = tm2 * tn2;
@@ -196,29 +197,30 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
     const int r0w = 32 * (wv & 1), c0w = 64 * (wv >> 1);
     // staging roles, lane-contiguous in global memory AND in LDS (a first mapping with 4 / 8 consecutive elements per thread
     // put every ds_write on 4 bank groups): element e of a thread is flat index e*256 + tid of the chunk,
-    // A chunk 64 rows x 16 k -> (row = idx / 16, k = idx % 16), B chunk 16 k x 128 columns -> (k = idx / 128, column = idx % 128)
-    const cplx* Ag = A + (size_t)(r0 + (tid >> 4)) * g.lda + (tid & 15);          // + e * 16 rows
+    // A chunk 64 rows x KC k -> (row = idx / KC, k = idx % KC), B chunk KC k x 128 columns -> (k = idx / 128, column = idx % 128)
+    constexpr int KC = ZW_KC, NSA = 64 * KC / 256, NSB = KC * 128 / 256, RPE = 256 / KC;   // elements per thread, A rows per e
+    const cplx* Ag = A + (size_t)(r0 + tid / KC) * g.lda + (tid % KC);            // + e * RPE rows
     const cplx* Bg = Bm + (size_t)(tid >> 7) * g.ldb + c0 + (tid & 127);          // + e * 2 k-rows
     double t1[8][4], t2[8][4], t3[8][4];
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
         for (int J = 0; J < 4; ++J) { t1[ib][J] = 0.0; t2[ib][J] = 0.0; t3[ib][J] = 0.0; }
-    const int nch = g.Kdim >> 4;
-    cplx sa[4], sb[8];
+    const int nch = g.Kdim / KC;
+    cplx sa[NSA], sb[NSB];
     auto stage_fetch = [&](int ch) {
         ch = min(ch, nch - 1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sa[e] = Ag[(size_t)(16 * e) * g.lda + 16 * ch];
+        for (int e = 0; e < NSA; ++e) sa[e] = Ag[(size_t)(RPE * e) * g.lda + KC * ch];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sb[e] = Bg[(size_t)(16 * ch + 2 * e) * g.ldb];
+        for (int e = 0; e < NSB; ++e) sb[e] = Bg[(size_t)(KC * ch + 2 * e) * g.ldb];
         __builtin_amdgcn_sched_barrier(0);
     };
     auto stage_store = [&]() {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const int o = (16 * e + (tid >> 4)) * ZW_LDA + (tid & 15); Ai[o] = sa[e]; As[o] = sa[e].x + sa[e].y; }
+        for (int e = 0; e < NSA; ++e) { const int o = (RPE * e + tid / KC) * ZW_LDA + (tid % KC); Ai[o] = sa[e]; As[o] = sa[e].x + sa[e].y; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int o = (2 * e + (tid >> 7)) * 128 + (tid & 127); Bi[o] = sb[e]; Bs[o] = sb[e].x + sb[e].y; }
+        for (int e = 0; e < NSB; ++e) { const int o = (2 * e + (tid >> 7)) * 128 + (tid & 127); Bi[o] = sb[e]; Bs[o] = sb[e].x + sb[e].y; }
     };
     const cplx* arow = Ai + (r0w + li4) * ZW_LDA + lk;          // + (4 ib) * ZW_LDA + 4 kb
     const double* asrow = As + (r0w + li4) * ZW_LDA + lk;
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
         stage_store();
         lds_barrier();
         stage_fetch(ch + 1);                                    // in flight while this chunk multiplies
-        // 32 block steps (kb, ib) of the chunk; A blocks through a 3-slot ring two steps ahead, B strips one k-block ahead
+        // KC/4 x 8 block steps (kb, ib) of the chunk; A blocks through a 3-slot ring two steps ahead, B strips one k-block ahead
         cplx av[3]; double as[3];
         auto load_a = [&](int st, int slot) { const int kb = st >> 3, ib = st & 7; av[slot] = arow[(4 * ib) * ZW_LDA + 4 * kb]; as[slot] = asrow[(4 * ib) * ZW_LDA + 4 * kb]; };
         ZwB b0, b1;
@@ -241,10 +243,10 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
         load_a(0, 0);
         load_a(1, 1);
 #pragma unroll
-        for (int st = 0; st < 32; ++st) {
+        for (int st = 0; st < 2 * KC; ++st) {
             const int kb = st >> 3, ib = st & 7;
-            if (st + 2 < 32) load_a(st + 2, (st + 2) % 3);
-            if (ib == 0 && kb + 1 < 4) load_b((kb & 1) ? b0 : b1, kb + 1);
+            if (st + 2 < 2 * KC) load_a(st + 2, (st + 2) % 3);
+            if (ib == 0 && kb + 1 < KC / 4) load_b((kb & 1) ? b0 : b1, kb + 1);
             __builtin_amdgcn_sched_barrier(0);
             const ZwB& b = (kb & 1) ? b1 : b0;
             const cplx a = av[st % 3];
@@ -276,4 +278,4 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
             if (g.CT) g.CT[(size_t)bt * g.sCT + (size_t)col * g.ldct + row] = v;
         }
 }
-static inline size_t qoc_zgemm_wg_lds() { return (size_t)(64 * ZW_LDA + 16 * 128) * (sizeof(cplx) + sizeof(double)); }
+static inline size_t qoc_zgemm_wg_lds() { return (size_t)(64 * ZW_LDA + ZW_KC * 128) * (sizeof(cplx) + sizeof(double)); }
