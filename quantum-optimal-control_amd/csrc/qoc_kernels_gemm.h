@@ -351,7 +351,7 @@ static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipSt
         else if (sk == 4) qoc_gemm_launch_sk<true, 0, 4>(g, blocks, s);
         else if (sk == 2) qoc_gemm_launch_sk<true, 0, 2>(g, blocks, s);
         else qoc_gemm_launch_sk<true, 0, 1>(g, blocks, s);
-    } else if (sk == 1 && (g.tiles_m & 1) == 0 && (g.tiles_n & 3) == 0 && (g.Kdim % ZW_KC) == 0 && g.Kdim >= 256 && tiles >= 8 * 1024) {
+    } else if (sk == 1 && (g.tiles_m & 1) == 0 && (g.tiles_n & 3) == 0 && (g.Kdim % ZW_KC) == 0 && g.Kdim >= 128 && tiles >= 8 * 1024) {
         // large plain products: workgroup tiles of 64 x 128 on the 4x4x4 MFMA form
         hipLaunchKernelGGL(k_zgemm_wg, dim3((unsigned)(tiles / 8)), dim3(256), qoc_zgemm_wg_lds(), s, g);
     } else {
