@@ -569,6 +569,20 @@ def test_gemm_path_n128_batched_launches():
     eng.close()
 
 
+def test_gemm_path_n128_workgroup_tiled_products():
+    """n = 128 with 8 seeds x 64 slices = 512 products per launch: enough 32x32 tiles (8192) for the exponentials and the first
+    tree level to run on k_zgemm_wg (64x128 workgroup tiles, v_mfma_f64_4x4x4); full comparison with the oracle."""
+    c = cases.case_c2(n=128, k=2, steps=64, m=8, taylor=(5, 2), seed=43)
+    sp = oracle_system(c)
+    rng = np.random.default_rng(9)
+    bases = [sp.base0] + [1.5 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.05 * i for i in range(7)]
+    eng = make_engine(sp, n_seeds=len(bases))
+    assert eng.path == 4
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
+
+
 @pytest.mark.parametrize('name', ['small_auto', 'big_auto', 'guess', 'dressed', 'state_small', 'c3_small'])
 def test_grape_end_to_end_every_recipe(name):
     """Grape() on every golden recipe (U0 != I, automatic Taylor orders of both heuristic branches, explicit initial guess
