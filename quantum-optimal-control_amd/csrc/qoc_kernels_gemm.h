@@ -292,7 +292,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         size_t total = 0;
         for (auto& w : wanted) total += w.second;
         char* arena = nullptr;
-        ok = ok && hipMalloc((void**)&arena, total) == hipSuccess;
+        ok = ok && hipMalloc((void**)&arena, qoc_arena_bytes(total)) == hipSuccess;
         if (ok) {
             allocs.push_back(arena);
             size_t off = 0;

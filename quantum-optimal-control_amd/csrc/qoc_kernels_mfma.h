@@ -109,7 +109,7 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
         size_t total = 0;
         for (auto& w : wanted) total += w.second;
         char* arena = nullptr;
-        if (hipMalloc((void**)&arena, total) != hipSuccess) { msg = "MFMA path: out of device memory"; return -3; }
+        if (hipMalloc((void**)&arena, qoc_arena_bytes(total)) != hipSuccess) { msg = "MFMA path: out of device memory"; return -3; }
         allocs.push_back(arena);
         size_t off = 0;
         for (auto& w : wanted) { *w.first = (cplx*)(arena + off); off += w.second; }
