@@ -48,6 +48,8 @@ struct qoc_engine {
     int chunks;
     hipStream_t stream;
     std::vector<void*> allocs;
+    char* arena_cur = nullptr;      // bump allocator over the chunks in `allocs` (dev_alloc)
+    size_t arena_left = 0;
     // generic path
     cplx* K = nullptr;          // [B][steps][n][n]
     cplx* expm_scratch = nullptr;
@@ -68,12 +70,21 @@ struct qoc_engine {
 
 template <typename T>
 static int dev_alloc(qoc_engine* e, T** p, size_t count) {
-    void* q = nullptr;
+    // bump allocation out of 64 MB-granular chunks (qoc_arena_bytes: where many small recycled blocks land decides the speed)
     if (count == 0) count = 1;
-    hipError_t err = hipMalloc(&q, count * sizeof(T));
-    if (err != hipSuccess) return fail(QOC_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(err));
-    e->allocs.push_back(q);
-    *p = (T*)q;
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (bytes > e->arena_left) {
+        void* q = nullptr;
+        const size_t chunk = qoc_arena_bytes(bytes);
+        hipError_t err = hipMalloc(&q, chunk);
+        if (err != hipSuccess) return fail(QOC_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", chunk, hipGetErrorString(err));
+        e->allocs.push_back(q);
+        e->arena_cur = (char*)q;
+        e->arena_left = chunk;
+    }
+    *p = (T*)e->arena_cur;
+    e->arena_cur += bytes;
+    e->arena_left -= bytes;
     return QOC_OK;
 }
 
