@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
     const int item = blockIdx.x * 4 + wv;
     const int n_sweep = d.B * mf.C;
     if (item < n_sweep) {
-        const int b = item / mf.C, c = item - b * mf.C;
+        const int c = item / d.B, b = item - c * d.B;      // chunk-major: the waves of a workgroup walk 4 different seeds
         if (d.skip_done && d.done[b]) return;
         const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
         const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
