@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     const cplx* pad_hi = pads + (size_t)(2 * pair + 1) * 2 * 16 * B2_LDP;
     const int item = blockIdx.x * 4 + pair;
     const bool item_ok = item < d.B * mf.C;
-    const int b = item_ok ? item / mf.C : 0, c = item_ok ? item - b * mf.C : 0;
+    const int c = item_ok ? item / d.B : 0, b = item_ok ? item - c * d.B : 0;   // chunk-major, as in k_mfma_forward2
     const bool active = item_ok && !(d.skip_done && d.done[b]);
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
     const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
