@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
 // Same recursion as k_mfma_bwd_offsets (Z <- K_t^dagger Z + S_t from a zero costate, one wave per (seed, chunk >= 1)) in the
 // transposed form of k_mfma_forward2: Z^T <- Z^T conj(K_t), right operand = the fragD(K) registers as stored (contiguous loads),
 // left operand = 4x4 blocks of Z^T from a wave-private LDS image.  The source term has conditional loads (waited for on the
-// spot), so it is evaluated before the next K_t is fetched.  163 -> ~115 us per launch at the regularised C2 x 64.
+// spot), so it is evaluated before the next K_t is fetched.  163 -> 124 us per launch at the regularised C2 x 64.  FULL = true: the same
+// sweep from the terminal costate through the chunk boundaries, storing Lambda_t for k_mfma_grad (k >= 6 controls).
 template <int MQ, bool FULL>
 __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf) {
     constexpr int NT = 2;
