@@ -82,3 +82,22 @@ def test_grape_sharded_two_ranks_one_gpu():
                         os.path.join(os.path.dirname(os.path.abspath(__file__)), 'sharded_script.py')],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and 'OK sharded rank 0' in r.stdout and 'OK sharded rank 1' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_prints_one_aggregate_line():
+    """The driver's multi-GPU invocation of bench.py (torch.distributed.run, one rank per GPU) with the test hook that puts both
+    ranks on GPU 0 over gloo: rank 0 prints exactly one JSON line whose value aggregates the seeds of both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', QOC_BENCH_BACKEND='gloo', QOC_BENCH_SAME_DEVICE='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29547', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--seeds-per-gpu', '8', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1500:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['total_seeds'] == 16 and j['steps'] == 3 and j['value'] > 0 and j['scaling'] == 'weak'
