@@ -146,6 +146,8 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk(
 template <int NT>
 __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk4(QocDev d, QocMfma mf) {
     __shared__ __attribute__((aligned(16))) cplx img[2][QNP * QLDR];
+    constexpr bool SUMS = NT == 3;     // NT = 4: 2 x 64 x 65 x 24 B do not fit the 160 KB; NT = 2: the extra 17 KB cost a workgroup per CU (1.28 vs 0.95 ms)
+    __shared__ __attribute__((aligned(16))) double imgs[2][SUMS ? QNP * QLDR : 1];   // re + im of the image, summed once by its writer (a v_add_f64 per block in the product loop costs ~7 cycles of MFMA issue)
     const int lane = threadIdx.x & 63;
     const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
@@ -177,14 +179,15 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk4
         if (d.T >= 2) {
             CTile AJ[NT];
             for (int Ib = 0; Ib < NT; ++Ib) AJ[Ib] = P[Ib];
-            lds_put_colblock<NT>(img[flip], 16 * J, lane, AJ);
+            lds_put_colblock_sum<NT, SUMS>(img[flip], imgs[flip], 16 * J, lane, AJ);
             __syncthreads();
             CTile A2J[NT];
-            mm_colblock4<NT>(img[flip], lane, AJ, A2J);
+            mm_colblock4<NT, SUMS>(img[flip], imgs[flip], lane, AJ, A2J);
             flip ^= 1;
-            lds_put_colblock<NT>(img[flip], 16 * J, lane, A2J);
+            lds_put_colblock_sum<NT, SUMS>(img[flip], imgs[flip], 16 * J, lane, A2J);
             __syncthreads();
             const cplx* a2img = img[flip];                          // stays valid through the Horner steps (no put until then)
+            const double* a2imgs = imgs[flip];
             flip ^= 1;
             const int mm = d.T >> 1;
             int i;
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk4
             }
             for (; i >= 0; --i) {
                 CTile acc[NT];
-                mm_colblock4<NT>(a2img, lane, P, acc);
+                mm_colblock4<NT, SUMS>(a2img, a2imgs, lane, P, acc);
                 const double c0 = mf.invfact[2 * i], c1 = mf.invfact[2 * i + 1];
 #pragma unroll
                 for (int Ib = 0; Ib < NT; ++Ib)
@@ -232,26 +235,26 @@ __global__ void __launch_bounds__(64 * NT, (NT <= 2 ? 2 : 1)) k_mfma_expm_chunk4
         }
         // img[flip] is the buffer the A image lived in: every wave passed the barrier after reading it
         for (int sq = 0; sq < d.s; ++sq) {
-            lds_put_colblock<NT>(img[flip], 16 * J, lane, P);
+            lds_put_colblock_sum<NT, SUMS>(img[flip], imgs[flip], 16 * J, lane, P);
             __syncthreads();
             CTile acc[NT];
-            mm_colblock4<NT>(img[flip], lane, P, acc);
+            mm_colblock4<NT, SUMS>(img[flip], imgs[flip], lane, P, acc);
             flip ^= 1;
             for (int Ib = 0; Ib < NT; ++Ib) P[Ib] = acc[Ib];
         }
         const size_t item = kitem(mf, d.steps, b, t);
         colblock_store<NT>(mf.KfD + item, J, lane, P);
-        lds_put_colblock<NT>(img[flip], 16 * J, lane, P);
+        lds_put_colblock_sum<NT, SUMS>(img[flip], imgs[flip], 16 * J, lane, P);
         __syncthreads();
         if (mf.store_T) lds_store_fragT_half<NT>(img[flip], mf.KfT + item, J, lane);
         CTile acc[NT];
-        mm_colblock4<NT>(img[flip], lane, R, acc);
+        mm_colblock4<NT, SUMS>(img[flip], imgs[flip], lane, R, acc);
         flip ^= 1;
         for (int Ib = 0; Ib < NT; ++Ib) R[Ib] = acc[Ib];
     }
     const size_t pitem = (size_t)b * mf.C + c;
     colblock_store<NT>(mf.PfD + pitem * QFR, J, lane, R);
-    lds_put_colblock<NT>(img[flip], 16 * J, lane, R);
+    lds_put_colblock_sum<NT, SUMS>(img[flip], imgs[flip], 16 * J, lane, R);
     __syncthreads();
     lds_store_fragT_half<NT>(img[flip], mf.PfT + pitem * QFR, J, lane);
 }

@@ -136,6 +136,18 @@ __device__ __forceinline__ void lds_put_colblock(cplx* img, int Jcol0, int lane,
             img[(Jcol0 + (lane & 15)) * QLDR + 16 * Ib + (lane >> 4) + 4 * r] = cmake(p[Ib].re[r], p[Ib].im[r]);
 }
 // Read the A-layout fragments of the full 32x32 matrix held in the transposed image.
+// the same image plus its re + im sums (left operand of the 3-multiplication products on v_mfma_f64_4x4x4)
+template <int NT, bool SUMS>
+__device__ __forceinline__ void lds_put_colblock_sum(cplx* img, double* imgs, int Jcol0, int lane, const CTile p[NT]) {
+#pragma unroll
+    for (int Ib = 0; Ib < NT; ++Ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (Jcol0 + (lane & 15)) * QLDR + 16 * Ib + (lane >> 4) + 4 * r;
+            img[o] = cmake(p[Ib].re[r], p[Ib].im[r]);
+            if (SUMS) imgs[o] = p[Ib].re[r] + p[Ib].im[r];
+        }
+}
 template <int NT>
 __device__ __forceinline__ void lds_get_afrag(const cplx* img, int lane, AFragT<NT>& A) {
 #pragma unroll
@@ -150,16 +162,17 @@ __device__ __forceinline__ void lds_get_afrag(const cplx* img, int lane, AFragT<
 // The same product with v_mfma_f64_4x4x4_4b_f64 (17 cycles per 512 flops; the 16x16x4 shape issues every 103 cycles per 2048), left operand read block by block from the
 // transposed LDS image (lane 16k+4b+i reads M[4ib+i][4kb+k], the 4 block lanes b share the address), right operand and
 // result in the usual strip registers (a strip = 4 rows x 16 columns = one register of a CTile).
-template <int NT>
-__device__ __forceinline__ void mm_colblock4(const cplx* img, int lane, const CTile p[NT], CTile out[NT]) {
+template <int NT, bool SUMS>
+__device__ __forceinline__ void mm_colblock4(const cplx* img, const double* imgs, int lane, const CTile p[NT], CTile out[NT]) {
     double a[QQS], b[QQS], c[QQS];
 #pragma unroll
     for (int s = 0; s < QQS; ++s) { a[s] = 0.0; b[s] = 0.0; c[s] = 0.0; }
     const cplx* base = img + (lane >> 4) * QLDR + (lane & 3);
     // blocks in (kb, ib) order through a 4-slot ring, three block steps (9 MFMAs) ahead -- see mm_full4
     constexpr int NS = QQS * QQS, RING = 4;
-    cplx vb[RING];
-    auto fetch = [&](int st, int slot) { vb[slot] = base[4 * (st / QQS) * QLDR + 4 * (st % QQS)]; };
+    const double* bases = imgs + (lane >> 4) * QLDR + (lane & 3);
+    cplx vb[RING]; double sb[RING];
+    auto fetch = [&](int st, int slot) { const int o = 4 * (st / QQS) * QLDR + 4 * (st % QQS); vb[slot] = base[o]; sb[slot] = SUMS ? bases[o] : 0.0; };
 #pragma unroll
     for (int st = 0; st < RING - 1; ++st) fetch(st, st);
     double br = 0.0, bi = 0.0, bs = 0.0;
@@ -172,7 +185,7 @@ __device__ __forceinline__ void mm_colblock4(const cplx* img, int lane, const CT
         const cplx v = vb[st % RING];
         a[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[ib], 0, 0, 0);
         b[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, b[ib], 0, 0, 0);
-        c[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, c[ib], 0, 0, 0);
+        c[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(SUMS ? sb[st % RING] : v.x + v.y, bs, c[ib], 0, 0, 0);
     }
 #pragma unroll
     for (int s = 0; s < QQS; ++s) { out[s >> 2].re[s & 3] = a[s] - b[s]; out[s >> 2].im[s & 3] = c[s] - a[s] - b[s]; }
