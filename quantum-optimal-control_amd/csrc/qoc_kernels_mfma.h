@@ -101,7 +101,7 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     mf.skew_b = 3 * 16;                            //  768 B per seed
     const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
     mf.store_T = !((NT == 2 || NT == 3) && mf.variant != 1);     // the 4x4x4 forward sweep gathers K^T operands from fragD(K)
-    const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k = 5 still fits backward2's LDS (1.45 vs 1.49 ms)
+    const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k <= 5: backward3 (5 images still fit next to its pads)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
     if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
@@ -118,21 +118,16 @@ static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, c
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
     mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
     mf.bwd_lds = pads + (mf.h_in_lds ? hbytes : 0);
-    // row-split kernel (NT = 2): 8 waves x 2 image buffers x 16 x 17 cplx + the pair mailboxes of the gradient partials
-    const size_t pads2 = (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 8 * sizeof(double);
-    mf.h_in_lds2 = (hbytes + pads2) <= 160 * 1024;
-    mf.bwd_lds2 = pads2 + (mf.h_in_lds2 ? hbytes : 0);
-    if (NT == 2 && mf.h_in_lds2 &&
-        hipFuncSetAttribute((const void*)k_mfma_backward2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds2) != hipSuccess) {
-        msg = "MFMA path: cannot reserve LDS for the row-split backward kernel";
-        return -2;
+    // prefetching row-split kernel (NT = 2, k <= 5): 4 or 5 control images + the pads + row partials
+    {
+        const int kc = d.k == 5 ? 5 : 4;
+        mf.bwd_lds3 = (size_t)kc * FR * sizeof(cplx) + (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 2 * 4 * kc * sizeof(double);
     }
-    // prefetching row-split kernel (NT = 2, k <= 4, no state regularisers): 4 control images + the pads + row partials
-    mf.bwd_lds3 = (size_t)4 * FR * sizeof(cplx) + (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 2 * 4 * 4 * sizeof(double);
-    if (NT == 2 && (hipFuncSetAttribute((const void*)k_mfma_backward3<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)k_mfma_backward3<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)k_mfma_backward3<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
-                    hipFuncSetAttribute((const void*)k_mfma_backward3<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess)) {
+    const void* b3k = d.k == 5 ? (mf.mq <= 2 ? ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<2, true, 5> : (const void*)k_mfma_backward3<2, false, 5>)
+                                             : ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<4, true, 5> : (const void*)k_mfma_backward3<4, false, 5>))
+                               : (mf.mq <= 2 ? ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<2, true, 4> : (const void*)k_mfma_backward3<2, false, 4>)
+                                             : ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<4, true, 4> : (const void*)k_mfma_backward3<4, false, 4>));
+    if (NT == 2 && hipFuncSetAttribute(b3k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
         return -2;
     }
@@ -202,18 +197,21 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
             hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
         }
     }
-    // NT = 2: each item split over a pair of waves (2 waves per SIMD for the batches AUTO sends here, 259 vs 301 us at C2 x 64).
-    // The choice must not depend on the batch size: its gradient sums associate differently from the one-wave kernel, and a
-    // seed has to evolve bit-identically whatever batch / GPU it is sharded into.  variant 1 keeps the one-wave kernel (A/B).
+    // NT = 2: k <= 5 -> k_mfma_backward3 (pair of waves per item, control images in LDS); k >= 6 -> costate sweep + k_mfma_grad.
+    // The choice must not depend on the batch size: the gradient sums associate differently between the kernels, and a seed has
+    // to evolve bit-identically whatever batch / GPU it is sharded into.  variant 1 keeps the one-wave 16x16x4 kernel (A/B).
     if (NT == 2 && mf.variant != 1) {
-        if (d.k <= 4) {
+        if (d.k <= 5) {
             const bool src = d.n_forb > 0 || d.has_speed;
             const dim3 g3((items + 3) / 4), b3(512);
-            if (mf.mq <= 2) { if (src) hipLaunchKernelGGL((k_mfma_backward3<2, true>), g3, b3, mf.bwd_lds3, s, d, mf); else hipLaunchKernelGGL((k_mfma_backward3<2, false>), g3, b3, mf.bwd_lds3, s, d, mf); }
-            else { if (src) hipLaunchKernelGGL((k_mfma_backward3<4, true>), g3, b3, mf.bwd_lds3, s, d, mf); else hipLaunchKernelGGL((k_mfma_backward3<4, false>), g3, b3, mf.bwd_lds3, s, d, mf); }
+#define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
+                               else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
+            if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
+            else { if (src) QOC_B3(4, true); else QOC_B3(4, false); }
+#undef QOC_B3
             return;
         }
-        if (mf.LamD) {
+        {
             // k >= 6: the control images fit in LDS next to no sweep's pads; costate sweep + slice-parallel gradient kernel (4 images
             // per pass) instead of the row-split 16x16x4 sweep reading them from L2 (C2 x 64 with k = 8: 1.55 vs 1.71 ms per iteration)
             if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
@@ -222,10 +220,7 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
             int gg = (slices + 3) / 4; if (gg > 2048) gg = 2048;
             if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<2, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
             else hipLaunchKernelGGL((k_mfma_grad<2, 4>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
-            return;
         }
-        if (mf.h_in_lds2) hipLaunchKernelGGL((k_mfma_backward2<true>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
-        else hipLaunchKernelGGL((k_mfma_backward2<false>), dim3((items + 3) / 4), dim3(512), mf.bwd_lds2, s, d, mf);
         return;
     }
     if (NT > 2 && mf.variant != 1) {

@@ -324,184 +324,7 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     }
 }
 
-// ---- kernel B2 (NT = 2): the backward sweep with every (seed, chunk) item split over a PAIR of waves by row tile ----------
-// The one-wave-per-item kernel above runs one wave per SIMD and its dependent 16x16x4 MFMA chains issue every ~143 cycles;
-// here wave h of a pair owns the 16-row tile h of Lambda: it forms the Q tiles (h, 0..1) of the gradient contraction and row
-// tile h of K_t^dagger Lambda_t (half the MFMAs, half the K fragments), so 2 waves per SIMD are resident (~103-cycle issue)
-// and each chain is half as long.  The pair exchanges tiles through its transposed LDS images (the same image that feeds the
-// A operand of Q), double-buffered, one workgroup barrier per slice; all trip counts are uniform over the workgroup
-// (4 items = 8 waves share one LDS image of the control Hamiltonians): inactive steps only take part in the barriers.
-// Measured at C2 x 64: 259 vs 301 us per launch (prefetching the K fragments one slice ahead made it 283: not the bound).
-#define B2_LDP 17
-template <bool H_IN_LDS>
-__global__ void __launch_bounds__(512) k_mfma_backward2(QocDev d, QocMfma mf) {
-    constexpr int NT = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = wv & 1, pair = wv >> 1;
-    cplx* Hl = (cplx*)smem;                                                     // [k] fragD(H_k')
-    cplx* pads = (cplx*)(smem + (H_IN_LDS ? (size_t)d.k * QFR * sizeof(cplx) : 0));   // [8 waves][2 buffers][16 * B2_LDP]
-    double* gpart = (double*)(pads + 8 * 2 * 16 * B2_LDP);                     // [4 pairs][2 buffers][8]
-    if (H_IN_LDS) {
-        for (int o = threadIdx.x; o < d.k * QFR; o += blockDim.x) Hl[o] = mf.HfD[QFR + o];
-    }
-    const cplx* Hsrc = H_IN_LDS ? Hl : (mf.HfD + QFR);
-    cplx* mypad = pads + (size_t)wv * 2 * 16 * B2_LDP;
-    const cplx* otherpad = pads + (size_t)(wv ^ 1) * 2 * 16 * B2_LDP;
-    const int item = blockIdx.x * 4 + pair;
-    const bool item_ok = item < d.B * mf.C;
-    const int b = item_ok ? item / mf.C : 0, c = item_ok ? item - b * mf.C : 0;
-    const bool active = item_ok && !(d.skip_done && d.done[b]);
-    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
-    const bool need_src = d.n_forb > 0 || d.has_speed;
-    const int lk = lane >> 4, lc = lane & 15;
-    // own tile of the costate, D layout: register r <-> (row 16h + lk + 4r, column lc)
-    d4 ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};
-    if (active) {
-        const cplx z = d.zfin[b];
-        const double c0 = -2.0 / ((double)d.m * (double)d.m);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * h + lk + 4 * r;
-            cplx v = cmake(0.0, 0.0);
-            if (row < d.n && lc < d.m) {
-                v = cscale(cmul(z, d.W[row * d.m + lc]), c0);
-                if (need_src) v = cadd(v, source_at(d, b, d.steps, row, lc));
-            }
-            ore[r] = v.x; oim[r] = v.y;
-        }
-    }
-    int buf = 0;
-    auto put_own = [&](int bf) {                                                 // image[col][row16]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mypad[(bf * 16 + lc) * B2_LDP + lk + 4 * r] = cmake(ore[r], oim[r]);
-    };
-    auto get_other = [&](int bf, d4& xre, d4& xim) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const cplx v = otherpad[(bf * 16 + lc) * B2_LDP + lk + 4 * r]; xre[r] = v.x; xim[r] = v.y; }
-    };
-    // row tile h of M^dagger * Lambda with M given as fragD(M): 24 MFMAs
-    auto dagger_product = [&](const cplx* __restrict__ F, const d4& xre, const d4& xim) {
-        d4 a = {0, 0, 0, 0}, bq = {0, 0, 0, 0}, cq = {0, 0, 0, 0};
-        cplx fr[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) fr[q] = F[(h * QQS + q) * 64 + lane];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool own = (q >> 2) == h;
-            const double br = own ? ore[q & 3] : xre[q & 3], bi = own ? oim[q & 3] : xim[q & 3];
-            const double ar = fr[q].x, ai = -fr[q].y;
-            a = QMFMA(ar, br, a);
-            bq = QMFMA(ai, bi, bq);
-            cq = QMFMA(ar + ai, br + bi, cq);
-        }
-        ore = a - bq; oim = cq - a - bq;
-    };
-    put_own(0);
-    __syncthreads();
-    // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc + a_cc, uniform trip count ---------------------
-    for (int cc = mf.C - 1; cc >= 1; --cc) {
-        if (active && cc > c) {
-            d4 xre, xim;
-            get_other(buf, xre, xim);
-            dagger_product(mf.PfD + ((size_t)b * mf.C + cc) * QFR, xre, xim);
-            if (need_src) {
-                const cplx* off = mf.Aoff + ((size_t)b * mf.C + cc) * (QQS * 64);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const cplx v = off[(4 * h + r) * 64 + lane]; ore[r] += v.x; oim[r] += v.y; }
-            }
-        }
-        put_own(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-    const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
-    for (int i = 0; i < mf.L; ++i) {
-        const int t = t1 - 1 - i;
-        const bool live = active && t >= t0;
-        double g[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) g[kk] = 0.0;
-        if (live) {
-            // ---- Q tiles (h, 0..1) = conj(Lambda_t)[rows of tile h] Psi_t^T and the contraction with H_k' -----------------
-            double lr[4], li[4], pr[2][4], pi[2][4];
-            const cplx* psi = iv + (size_t)(t + 1) * d.n * d.m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                lr[q] = 0.0; li[q] = 0.0;
-#pragma unroll
-                for (int Jp = 0; Jp < 2; ++Jp) { pr[Jp][q] = 0.0; pi[Jp][q] = 0.0; }
-                if (q < mf.mq) {
-                    const int j = 4 * q + lk;
-                    const cplx lv = mypad[(buf * 16 + j) * B2_LDP + lc];          // Lambda[16h + lc][j]
-                    lr[q] = lv.x; li[q] = lv.y;
-#pragma unroll
-                    for (int Jp = 0; Jp < 2; ++Jp) {
-                        const int row = 16 * Jp + lc;
-                        if (row < d.n && j < d.m) { const cplx pv = psi[row * d.m + j]; pr[Jp][q] = pv.x; pi[Jp][q] = pv.y; }
-                    }
-                }
-            }
-#pragma unroll
-            for (int Jp = 0; Jp < 2; ++Jp) {
-                d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q < mf.mq) {
-                        t1v = QMFMA(lr[q], pr[Jp][q], t1v);
-                        t2v = QMFMA(li[q], pi[Jp][q], t2v);
-                        t3v = QMFMA(lr[q] - li[q], pr[Jp][q] + pi[Jp][q], t3v);
-                    }
-                }
-                const d4 qr = t1v + t2v, qi = t3v - t1v + t2v;
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    if (kk >= d.k) continue;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const cplx hv = Hsrc[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
-                        acc = fma(hv.x, qr[r], acc);
-                        acc = fma(-hv.y, qi[r], acc);
-                    }
-                    g[kk] += acc;
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                if (kk >= d.k) continue;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) g[kk] += __shfl_down(g[kk], off, 64);
-            }
-            if (h == 1 && lane == 0) {
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) gpart[(pair * 2 + buf) * 8 + kk] = g[kk];
-            }
-            // ---- Lambda_{t-1} = K_t^dagger Lambda_t (+ S_{t-1}) -----------------------------------------------------------
-            if (t > 0) {
-                d4 xre, xim;
-                get_other(buf, xre, xim);
-                dagger_product(mf.KfD + kitem(mf, d.steps, b, t), xre, xim);
-                if (need_src) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * h + lk + 4 * r;
-                        if (row < d.n && lc < d.m) { const cplx sv = source_at(d, b, t, row, lc); ore[r] += sv.x; oim[r] += sv.y; }
-                    }
-                }
-            }
-        }
-        put_own(buf ^ 1);
-        __syncthreads();
-        if (live && h == 0 && lane == 0) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                if (kk < d.k) d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = g[kk] + gpart[(pair * 2 + buf) * 8 + kk];
-        }
-        buf ^= 1;
-    }
-}
+#define B2_LDP 17          // row stride of the 16-row costate images of k_mfma_backward3
 
 // ---- kernel G: control gradients of all slices in parallel (n > 32) ---------------------------------------------------
 // For NT = 3/4 the fragD images of the control Hamiltonians (36 / 64 KB each) no longer fit in LDS next to the transposition
@@ -592,20 +415,22 @@ __global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
     }
 }
 
-// ---- kernel B3: k_mfma_backward2 with every per-slice latency taken off the dependent chain --------------------------
-// Same split (pair of waves per (seed, chunk), tile h of the costate each), same LDS exchange.  What changes:
+// ---- kernel B3: the row-split backward sweep of NT = 2 with every per-slice latency taken off the dependent chain ---------
+// A pair of waves per (seed, chunk) item, one 16-row tile of the costate each, exchanged through double-buffered LDS images
+// (8 waves = 4 items per workgroup share one LDS image of the control Hamiltonians).  Against its predecessor (k_mfma_backward2:
+// same split on 16x16x4, branchy loop, __syncthreads; removed):
 //  * the slice loop is branch-free (finished / out-of-range steps run on clamped addresses and only their store is
 //    masked), so hipcc keeps counted vmcnt waits, and the K_t^dagger fragment and Psi_t of the NEXT slice are fetched at the
-//    top of each step into a second register set (2x unrolled rotation): backward2 exposed two HBM round trips per slice
+//    top of each step into a second register set (2x unrolled rotation): the predecessor exposed two HBM round trips per slice
 //    (Psi before the Q tiles, K before the costate product: ~5 of its 7.5 us per slice);
 //  * the chunk-boundary recursion prefetches P_{cc-1} the same way and computes every step unconditionally (select);
 //  * the workgroup barrier orders LDS only (lds_barrier), so the prefetch stays in flight across it;
 //  * control gradients: 16-lane DPP butterflies, the 4 row partials of both waves go through LDS and lane kk of wave h = 0
 //    adds the 8 partials of control kk (was: six ds_bpermute levels per control).
 // Used for k <= 4 controls without state regularisers (no per-slice source term); anything else keeps backward2.
-template <int MQ, bool SRC>
+template <int MQ, bool SRC, int KC = 4>
 __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
-    constexpr int NT = 2, KC = 4;
+    constexpr int NT = 2;                                                       // KC = control images in LDS: 4, or 5 (k = 5 still fits the 160 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -39,8 +39,8 @@ struct QocMfma {
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
     cplx* LamD = nullptr;     // NT > 2: [B][steps][16 NT rows][16 columns] costates for the slice-parallel gradient kernel
     size_t grad_lds = 0;
-    size_t bwd_lds = 0, bwd_lds2 = 0, bwd_lds3 = 0;
-    bool h_in_lds = true, h_in_lds2 = true;
+    size_t bwd_lds = 0, bwd_lds3 = 0;
+    bool h_in_lds = true;
     int variant = 0;              // qoc_config.variant: 0 auto, 1 16x16x4, 2 4x4x4 two waves, 3 4x4x4 one wave
     int skew_c = 0, skew_b = 0;   // element skews per chunk / per seed that break the power-of-two strides of K storage
 };

@@ -82,7 +82,7 @@ def test_eval_parity(name, c, path):
 
 
 @pytest.mark.parametrize('chunks', [1, 3, 7, 40])
-@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'U0_dressed', 'n30_m13_k2', 'n24_m16_k6', 'n28_k7_sources', 'n32_m4_k3', 'n40_nt3',
+@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'U0_dressed', 'n30_m13_k2', 'n24_m16_k6', 'n28_k7_sources', 'n26_k5_sources', 'n32_m4_k3', 'n40_nt3',
                                      'n48_k4_sources_nt3', 'n64_nt4', 'n57_k1_nt4'])
 def test_mfma_path_parity(chunks, variant):
     _mfma_path_parity(chunks, variant, 0)
@@ -113,6 +113,9 @@ def _mfma_path_parity(chunks, variant, kernel):
     elif variant == 'n28_k7_sources':    # k >= 6 with state regularisers: affine offsets, costate sweep, gradient kernel in two passes
         c = cases.case_c2(n=28, k=7, steps=29, m=5, taylor=(5, 2), seed=24)
         c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [3.0, 2.0], 'states_forbidden_list': [27, 20], 'speed_up': 0.4}
+    elif variant == 'n26_k5_sources':    # k = 5: five control images next to the pads of the prefetching backward sweep
+        c = cases.case_c2(n=26, k=5, steps=31, m=7, taylor=(5, 2), seed=25)
+        c['reg_coeffs'] = {'forbidden_coeff_list': [3.0], 'states_forbidden_list': [25], 'speed_up': 0.3}
     elif variant == 'n32_m4_k3':         # one column block used out of two
         c = cases.case_c2(n=32, k=3, steps=33, m=4, taylor=(4, 2), seed=23)
     elif variant == 'n40_nt3':
