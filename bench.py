@@ -5,17 +5,25 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line f
   * workload (BASELINE.json configs[1] / SURVEY.md 8d "C2"): n=32, k=4, time slices=500, m=8, (T,s)=(5,3), fp64
     complex, synthetic Hamiltonians from numpy.random.default_rng(0); SEEDS_PER_GPU independent random-restart control
     sets per GPU (config 4: 512 seeds / 8 GPUs = 64 per GPU) -> weak scaling, no data-path collective; the final
-    per-seed fidelities are all-gathered once over RCCL after the last iteration (inside the timed region).
+    per-seed fidelities are all-gathered once over RCCL (C ABI, qoc_comm_all_gather_scalar: device to device on the
+    engine's stream) after the last iteration, inside the timed region.
+  * launch: one process per GPU.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks come from
+    RANK / LOCAL_RANK / WORLD_SIZE; a plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts the N ranks itself.
+    No torch in the process: the RCCL id travels through parallel_seeds.rendezvous (a file on the node).
   * a "step" = one GRAPE iteration of every seed on the GPU (all inputs resident in HBM).
   * value = (seeds on all GPUs) * K / wall time, wall = max over ranks, barrier + device sync on both sides.
-  * roofline: dominant kernel (k_mfma_expm_chunk4w: matrix exponentials + chunk products) timed with hipEvents on the
-    engine's stream in a separate short pass; algorithmic FLOPs per launch from SURVEY.md 8d.
+  * roofline: dominant kernel (the MFMA-path exponential kernel: matrix exponentials + chunk products) timed with hipEvents
+    on the engine's stream in a separate pass.  `achieved` / `frac` count the MFMA work the kernel EXECUTES (Paterson-Stockmeyer
+    product count x 3 real products per complex product); the SURVEY.md 8d algorithmic count (plain Taylor, 4 real products)
+    is reported beside it as `achieved_algorithmic` / `frac_algorithmic`.
   * cpu_baseline: the compiled C restatement of the oracle (oracle/qoc_oracle.c, OpenMP, one seed per thread, ONE
     evaluation per iteration) timed on a bounded sample on this host -- a reported baseline, not the target.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,11 +37,12 @@ import numpy as np  # noqa: E402
 N, K_OPS, SLICES, M, TAYLOR = 32, 4, 500, 8, (5, 3)
 SEEDS_PER_GPU = 64
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X public fp64 matrix (= vector) peak; MI355X_MICROARCH.md lists no fp64 row
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
 
 
 def build_problem():
-    from tests.golden import cases
-    c = cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0)
+    from quantum_optimal_control.helper_functions import synthetic_systems
+    c = synthetic_systems.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0)
     H0, Hops, U = c['H0'], c['Hops'], c['U']
     dt = c['total_time'] / SLICES
     Hs = np.stack([-1j * dt * H0] + [-1j * dt * h for h in Hops])
@@ -47,13 +56,33 @@ def seed_bases(first, count):
                      for i in range(count)])
 
 
+def executed_products_per_slice(T, s):
+    """Complex n x n products per time slice as the MFMA-path exponential kernels execute them (qoc_mfma_expm.h): A^2, the
+    Horner steps of the Paterson-Stockmeyer form over A^2, s squarings, one running chunk product.  (T, s) = (5, 3): 7."""
+    poly = 0
+    if T >= 2:
+        mm = T >> 1
+        poly = 1 + (mm - 1 if T % 2 == 0 else mm)
+    return poly + s + 1
+
+
+def oracle_problem():
+    """The same C2 inputs through the CPU oracle's pre-processing (cpu_baseline leg only)."""
+    from oracle import grape_oracle as go
+    from quantum_optimal_control.helper_functions import synthetic_systems
+    c = synthetic_systems.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0)
+    np.random.seed(c['np_seed'])
+    return go.OracleSystem(c['H0'], c['Hops'], c['U'], c['total_time'], c['steps'], c['states_concerned_list'],
+                           U0=c['U0'], reg_coeffs=c['reg_coeffs'], dressed_info=None, maxA=c['maxA'],
+                           initial_guess=c['initial_guess'], state_transfer=c['state_transfer'],
+                           Taylor_terms=c['Taylor_terms'])
+
+
 def cpu_baseline(budget_s=15.0):
     """CPU oracle timed on a bounded sample of the same workload: whole iterations (evaluate + Adam) of one seed per
     thread, all host threads busy (seeds are the parallel axis on the CPU too).  Compiled C port (oracle/qoc_oracle.c)
     when its .so is present, else the NumPy oracle on one thread."""
-    from tests.helpers import oracle_system
-    from tests.golden import cases
-    sp = oracle_system(cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0))
+    sp = oracle_problem()
     try:
         from oracle import c_port
         threads = c_port.max_threads()
@@ -75,9 +104,9 @@ def cpu_baseline(budget_s=15.0):
     from oracle import grape_oracle as go
     try:
         import threadpoolctl
-        ctx = threadpoolctl.threadpool_limits(limits=1)
+        threadpoolctl.threadpool_limits(limits=1)
     except Exception:
-        ctx = None
+        pass
     base = seed_bases(0, 1)[0]
     opt = go.Adam(base.shape)
     go.evaluate(sp, base)
@@ -101,9 +130,7 @@ def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
     emulated node for node in torch-CPU (oracle/tf_graph_emulation.py).  Not TensorFlow (absent)."""
     import torch
     from oracle import tf_graph_emulation as tfe
-    from tests.helpers import oracle_system
-    from tests.golden import cases
-    sp = oracle_system(cases.case_c2(n=N, k=K_OPS, steps=SLICES, m=M, taylor=TAYLOR, seed=0))
+    sp = oracle_problem()
     torch.set_num_threads(min(16, torch.get_num_threads()))        # 2n x 2n = 64 x 64 matmuls: more threads only thrash
     base = seed_bases(0, 1)[0]
     tfe.evaluate_graph(sp, base, dtype=torch.float32)               # warm-up
@@ -118,39 +145,81 @@ def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
                                       '%.1f s; 2 evaluations per reference iteration; torch-CPU emulation of the TF graph' % (evals, el)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, and wait."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+class _GlooTransport(object):
+    """Test hook (QOC_BENCH_BACKEND=gloo): torch.distributed on host tensors, so that N ranks can share ONE GPU (RCCL refuses
+    two ranks on one device).  Exercises the N-rank code path of this file on a 1-GPU box; never used by the driver."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        self.dist, self.world, self.rank = dist, world, rank
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_reduce_max(self, values):
+        import torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.numpy()
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--seeds-per-gpu', type=int, default=SEEDS_PER_GPU)
     ap.add_argument('--chunks', type=int, default=0)
     ap.add_argument('--path', type=int, default=0)
     ap.add_argument('--variant', type=int, default=0, help='MFMA path: kernel of the exponentials (qoc_config.variant)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-single', action='store_true', help='skip the one-trajectory latency measurement')
     ap.add_argument('--groups', type=int, default=1, help='split the seeds of this GPU over G engines/streams')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # test hook: QOC_BENCH_BACKEND=gloo + QOC_BENCH_SAME_DEVICE=1 runs N ranks on ONE GPU to exercise this code path
-        backend = os.environ.get('QOC_BENCH_BACKEND', 'nccl')
-        if os.environ.get('QOC_BENCH_SAME_DEVICE') == '1':
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
+    from quantum_optimal_control import parallel_seeds
     from quantum_optimal_control.core import hip_engine
     from quantum_optimal_control.parallel_seeds import SeedShard
+
+    rank, local_rank, world = parallel_seeds.launch_env()
+    if world != max(1, args.gpus):
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    backend = os.environ.get('QOC_BENCH_BACKEND', 'rccl')
+    if os.environ.get('QOC_BENCH_SAME_DEVICE') == '1':      # test hook: N ranks on ONE GPU (with the gloo transport)
+        local_rank = 0
+    comm = gloo = None
+    if world > 1:
+        if backend == 'gloo':
+            gloo = _GlooTransport(rank, world)
+        else:
+            comm = parallel_seeds.open_comm(rank=rank, world=world, device=local_rank)
+    transport = comm if comm is not None else gloo
 
     c, Hs, U0, V, W, dt = build_problem()
     B = args.seeds_per_gpu
@@ -168,91 +237,93 @@ def main():
     params = eng.adam_params(rate=0.01, learning_rate_decay=2500, conv_target=1e-8, min_grad=1e-25,
                              max_iterations=10 ** 9, poll_every=10 ** 9)
 
-    class _Multi(object):
-        def iterate(self, p, n):
-            for _ in range(n):
-                for e in engs:
-                    e.iterate(p, 1)
-
-        def sync(self):
+    def iterate(n):
+        for _ in range(n):
             for e in engs:
-                e.sync()
+                e.iterate(params, 1)
 
-        def scalars(self):
-            parts = [e.scalars() for e in engs]
-            return {k: np.concatenate([q[k] for q in parts]) for k in parts[0]}
-
-    multi = _Multi()
+    def sync():
+        for e in engs:
+            e.sync()
 
     def barrier():
-        multi.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        sync()
+        if transport is not None:
+            transport.barrier()
 
-    multi.iterate(params, args.warmup)
+    iterate(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    multi.iterate(params, args.steps)
-    multi.sync()
-    sc = multi.scalars()
-    fidelity = shard.all_gather(1.0 - sc['loss'], dist)          # RCCL all-gather of the final fidelities
-    if dist is not None:
-        import torch
-        torch.cuda.synchronize()
+    iterate(args.steps)
+    if comm is not None and G == 1:
+        # RCCL all-gather of the final per-seed losses straight from the engine's device array, on the engine's stream
+        loss_all = shard.all_gather_engine_scalar(eng, hip_engine.SCALAR_LOSS, comm)
+    else:
+        sync()
+        loss_local = np.concatenate([e.scalars()['loss'] for e in engs])
+        loss_all = shard.all_gather(loss_local, dist=None if gloo is None else gloo.dist, comm=comm)
+    sync()
     elapsed = time.perf_counter() - t0
     barrier()
+    fidelity = 1.0 - loss_all
+    assert fidelity.shape[0] == B * world, 'all-gather returned %d fidelities for %d seeds' % (fidelity.shape[0], B * world)
+    parts = [e.scalars() for e in engs]
+    sc = {k: np.concatenate([q[k] for q in parts]) for k in parts[0]}
     assert int(np.sum(sc['done'])) == 0 and np.all(sc['iterations'] == args.warmup + args.steps), \
         'a seed stopped early: timed work would be incomplete'
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    assert np.array_equal(fidelity[shard.first:shard.first + shard.count], 1.0 - sc['loss']), 'gathered row != local losses'
+    if transport is not None:
+        elapsed = float(transport.all_reduce_max([elapsed])[0])
 
     # ---- roofline of the dominant kernel, hipEvents on the engine stream (separate pass, rank 0) -----------------
     roof = None
     if rank == 0:
         eng.profile_enable(True)
-        eng.iterate(params, min(10, args.steps))
+        eng.iterate(params, min(50, args.steps))
         pr = eng.profile_read()
         eng.profile_enable(False)
         T, s = TAYLOR
-        flops_per_launch = gsh[0].count * SLICES * ((T - 1 + s) + 1) * 8.0 * N ** 3   # expm GEMMs + chain GEMM, SURVEY 8d
+        seeds0 = gsh[0].count
+        flops_alg = seeds0 * SLICES * ((T - 1 + s) + 1) * 8.0 * N ** 3      # plain Taylor + chain product, 4 real products
+        n_prod = executed_products_per_slice(T, s)
+        flops_exec = seeds0 * SLICES * n_prod * 6.0 * N ** 3                 # what the kernel issues: 3 real products per complex product
         avg_ms = pr['total_ms'] / max(1, pr['launches'])
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        ach_exec = flops_exec / (avg_ms * 1e-3) / 1e12
+        ach_alg = flops_alg / (avg_ms * 1e-3) / 1e12
         # HBM traffic of the dominant kernel: PMC counters need rocprofv3, so the value comes from the committed PMC pass of
-        # this same command (profiles/r01_pmc_traffic.json) when the workload matches; null otherwise
+        # this same command (profiles/r02_pmc_traffic.json) when the workload matches; null otherwise
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            pm = json.load(open(PMC_TRAFFIC_FILE))
             w = pm['workload']
-            if (w['seeds_per_gpu'], w['chunks'], pm['kernel']) == (gsh[0].count, eng.chunks, pr['kernel']):
+            if (w['seeds_per_gpu'], w['chunks'], pm['kernel']) == (seeds0, eng.chunks, pr['kernel']):
                 traffic = pm['hbm_bytes_per_launch']
         except Exception:
             traffic = None
-        roof = {'bound': 'mfma', 'kernel': pr['kernel'], 'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
-                'traffic_unit': 'bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.txt)',
-                'avg_launch_ms': avg_ms, 'launches': pr['launches'], 'flops_per_launch': flops_per_launch,
+        roof = {'bound': 'mfma', 'kernel': pr['kernel'], 'achieved': ach_exec, 'peak': FP64_MATRIX_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': ach_exec / FP64_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
+                'traffic_unit': 'bytes/launch (rocprofv3 PMC pass of this command, profiles/r02_pmc_traffic.txt)',
+                'avg_launch_ms': avg_ms, 'launches': pr['launches'],
+                'flops_per_launch': flops_exec, 'products_per_slice_executed': n_prod,
+                'counting': 'achieved/frac = EXECUTED MFMA flops (%d Paterson-Stockmeyer products per slice x 6 n^3: 3 real '
+                            'products per complex product); *_algorithmic = SURVEY 8d count (%d plain-Taylor products x 8 n^3)'
+                            % (n_prod, (T - 1 + s) + 1),
+                'achieved_algorithmic': ach_alg, 'frac_algorithmic': ach_alg / FP64_MATRIX_PEAK_TFLOPS,
+                'flops_per_launch_algorithmic': flops_alg,
                 'measured_mfma_f64_ceilings_TFLOPs': {'v_mfma_f64_16x16x4': 48.2, 'v_mfma_f64_4x4x4_4b': 73.0},
-                # `achieved` counts the ALGORITHMIC flops (4 real products per complex product, plain Taylor); the
-                # kernel issues 3 real MFMA products per complex product (Karatsuba form) = 3/4 of that on the matrix pipe
-                'executed_mfma_TFLOPs': 0.75 * achieved,
-                'executed_frac_of_measured_4x4x4_ceiling': 0.75 * achieved / 73.0}
+                'frac_of_measured_4x4x4_ceiling': ach_exec / 73.0}
     # ---- latency of ONE trajectory of the same workload (what a plain Grape() call runs), outside the timed region ----
     single = None
-    if rank == 0:
+    if rank == 0 and not args.no_single:
         e1 = hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], SLICES, TAYLOR[0], TAYLOR[1],
                                   reg_coeffs={}, n_seeds=1, device=local_rank)
         e1.set_base(seed_bases(0, 1))
-        e1.iterate(params, 3); e1.sync()
+        e1.iterate(params, 10); e1.sync()
         t1 = time.perf_counter()
-        e1.iterate(params, 50); e1.sync()
-        el1 = (time.perf_counter() - t1) / 50
+        e1.iterate(params, 200); e1.sync()
+        el1 = (time.perf_counter() - t1) / 200
         single = {'value': 1.0 / el1, 'unit': 'GRAPE iterations/s', 'ms_per_iteration': el1 * 1e3, 'path': e1.path,
-                  'note': 'one control set (n_seeds=1, AUTO path) of the same C2 workload, 50 iterations; not part of `value`'}
+                  'note': 'one control set (n_seeds=1, AUTO path) of the same C2 workload, 200 iterations; not part of `value`'}
         e1.close()
     total_seeds = B * world
     value = total_seeds * args.steps / elapsed
@@ -265,7 +336,8 @@ def main():
             'config': {'workload': 'C2 3-transmon-size unitary gate: n=32 k=4 steps=500 m=8 Taylor(T,s)=(5,3), '
                                    '%d independent control seeds per GPU (aggregate over seeds), reg_coeffs={}' % B,
                        'seeds_per_gpu': B, 'total_seeds': total_seeds, 'path': eng.path, 'chunks': eng.chunks,
-                       'stream_groups': G,
+                       'stream_groups': G, 'ranks_seen': world, 'fidelities_gathered': int(fidelity.shape[0]),
+                       'transport': ('rccl (%s)' % comm.library) if comm is not None else ('gloo (test hook)' if gloo is not None else 'single process'),
                        'parallelism': 'seed-sharded x%d, RCCL all-gather of final fidelities' % world},
             'per_seed_iterations_per_s': args.steps / elapsed,
             'single_trajectory': single,
@@ -278,12 +350,12 @@ def main():
                 out['cpu_baseline_reference_ops'] = cpu_baseline_reference_ops()
             except Exception as exc:                         # torch missing etc.: the primary baseline stands
                 out['cpu_baseline_reference_ops'] = {'error': repr(exc)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     for e in engs:
         e.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if transport is not None:
+        transport.barrier()
+        transport.close()
 
 
 if __name__ == '__main__':

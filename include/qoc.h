@@ -89,7 +89,7 @@ typedef struct qoc_adam_params {
  *   W    [n][m] complex        : target vectors as columns, U_target*V in unitary mode (tensorflow_state.py:158-166)
  *   maxA [k]                   : ops_max_amp                  (tensorflow_state.py:178)
  *   one_minus_gauss [k][steps] : envelope constant            (tensorflow_state.py:146-147); may be NULL if !has_envelope
- *   forbidden_states [n_forbidden], forbidden_coeffs [n_forbidden] (regularization_functions.py:81)
+ *   forbidden_states [n_forbidden], forbidden_coeffs [n_forbidden] (regularization_functions.py:81); any length
  *   Vs   [n][n] complex        : sort_ev(v_c, dressed_id), NULL unless forbid_dressed
  */
 int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const double* V, const double* W,
@@ -148,6 +148,31 @@ int qoc_profile_enable(qoc_handle h, int32_t on);
 int qoc_profile_read(qoc_handle h, const char** kernel_name, int64_t* launches, double* total_ms);
 /* Elapsed milliseconds (hipEvents on the engine stream) around `iters` iterations, after a sync. */
 int qoc_time_iterations(qoc_handle h, const qoc_adam_params* p, int32_t iters, double* elapsed_ms);
+
+/* ---- multi-GPU: seed-parallel sharding, one process per GPU (the reference is single-device,
+ * main_grape/grape.py:106-109, and optimises ONE control set per call, core/system_parameters.py:272-284) -------------
+ * Restarts are independent, so the data path has no collective.  The only exchange is an all-gather of per-seed scalars
+ * (final fidelities) over RCCL/xGMI and an optional broadcast of the winner's pulse.  librccl is opened at run time
+ * (dlopen, from the ROCm tree of this library's HIP runtime; QOC_RCCL_LIBRARY overrides), so single-GPU use needs no RCCL.
+ * The 128-byte id is created on rank 0 and handed to the other ranks by the launcher (any side channel; the Python host
+ * uses a file rendezvous, quantum_optimal_control/parallel_seeds.py). */
+typedef struct qoc_comm* qoc_comm_handle;
+#define QOC_COMM_ID_BYTES 128
+int qoc_comm_unique_id(void* id128);
+int qoc_comm_create(const void* id128, int32_t world, int32_t rank, int32_t device, qoc_comm_handle* out);
+int qoc_comm_destroy(qoc_comm_handle c);
+int qoc_comm_world(qoc_comm_handle c);
+int qoc_comm_rank(qoc_comm_handle c);
+const char* qoc_comm_library(void);        /* path of the librccl in use ("" before the first communicator) */
+/* All-gather of one per-seed scalar array of the engine, device to device on the ENGINE's stream (ordered behind the
+ * iterations already enqueued, no host synchronisation before the collective).  which: 0 loss, 1 reg_loss,
+ * 2 grad_squared, 3 unitary_scale.  width >= n_seeds on every rank (rows are zero padded).  out: [world][width] (host). */
+int qoc_comm_all_gather_scalar(qoc_comm_handle c, qoc_handle h, int32_t which, int32_t width, double* out);
+/* Host-buffer collectives on the communicator's own stream: recv is [world][count]. */
+int qoc_comm_all_gather_f64(qoc_comm_handle c, const double* send, int32_t count, double* recv);
+int qoc_comm_all_reduce_max_f64(qoc_comm_handle c, double* inout, int32_t count);
+int qoc_comm_broadcast_f64(qoc_comm_handle c, double* buf, int64_t count, int32_t root);
+int qoc_comm_barrier(qoc_comm_handle c);
 
 /* ---- introspection ---------------------------------------------------------------------------------------------*/
 int qoc_path_in_use(qoc_handle h);        /* the QOC_PATH_* the engine resolved AUTO to */

@@ -22,7 +22,6 @@ __device__ __forceinline__ void cfma_conj(cplx& acc, cplx a, cplx b) {
     acc.y = fma(a.x, b.y, acc.y); acc.y = fma(-a.y, b.x, acc.y);
 }
 
-#define QOC_MAX_FORBIDDEN 16
 #define QOC_BLOCK 256
 
 // Everything a kernel needs, passed by value (kernarg segment -> SGPRs).
@@ -35,8 +34,8 @@ struct QocDev {
     double a_amp, a_env, a_dwdt, a_d2wdt2, a_speed, a_band;
     int band_lo, band_hi;
     int n_forb, forbid_dressed;
-    int forb_state[QOC_MAX_FORBIDDEN];
-    double forb_a[QOC_MAX_FORBIDDEN];
+    const int* forb_state;    // [n_forb] device arrays: the reference accepts lists of any length (regularization_functions.py:81)
+    const double* forb_a;     // [n_forb] coefficient / steps
     // constants in HBM
     const cplx* Hs;      // [k+1][n][n]
     const cplx* U0;      // [n][n]

@@ -59,6 +59,7 @@ struct qoc_engine {
     QocMfma mf;
     QocGemm gm;
     bool evaluated = false;
+    double* step_lr = nullptr;  // [B] per-seed learning rates of qoc_adam_step
     // profiling of the dominant kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -227,8 +228,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     if (cfg->taylor_terms < 1 || cfg->scaling < 0 || cfg->scaling > 30)
         return fail(QOC_ERR_INVALID, "qoc_create: bad taylor_terms/scaling (%d, %d)", cfg->taylor_terms, cfg->scaling);
     if (!cfg->state_transfer && !U0) return fail(QOC_ERR_INVALID, "qoc_create: U0 required in unitary mode");
-    if (cfg->n_forbidden < 0 || cfg->n_forbidden > QOC_MAX_FORBIDDEN)
-        return fail(QOC_ERR_INVALID, "qoc_create: n_forbidden must be in [0, %d]", QOC_MAX_FORBIDDEN);
+    if (cfg->n_forbidden < 0) return fail(QOC_ERR_INVALID, "qoc_create: n_forbidden must be >= 0");
     if (cfg->n_forbidden > 0 && (!forbidden_states || !forbidden_coeffs))
         return fail(QOC_ERR_INVALID, "qoc_create: forbidden lists missing");
     if (cfg->forbid_dressed && cfg->n_forbidden > 0 && !Vs)
@@ -263,10 +263,6 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     d.has_band = cfg->has_bandpass; d.a_band = cfg->c_bandpass * inv_steps;
     d.band_lo = cfg->band_lo; d.band_hi = cfg->band_hi;
     d.n_forb = cfg->n_forbidden; d.forbid_dressed = cfg->forbid_dressed && cfg->n_forbidden > 0;
-    for (int f = 0; f < cfg->n_forbidden; ++f) {
-        d.forb_state[f] = forbidden_states[f];
-        d.forb_a[f] = forbidden_coeffs[f] * inv_steps;
-    }
     int rc = QOC_OK;
     auto bail = [&](int code) { qoc_destroy(e); return code; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QOC_ERR_HIP, "hipStreamCreate failed"));
@@ -304,6 +300,12 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     if (d.forbid_dressed && (rc = dev_upload(e, &d.Vs, (const cplx*)Vs, nn))) return bail(rc);
     if ((rc = dev_upload(e, &d.maxA, maxA, (size_t)k))) return bail(rc);
     if (one_minus_gauss && (rc = dev_upload(e, &d.omg, one_minus_gauss, ks))) return bail(rc);
+    if (cfg->n_forbidden > 0) {
+        std::vector<double> fa(cfg->n_forbidden);
+        for (int f = 0; f < cfg->n_forbidden; ++f) fa[f] = forbidden_coeffs[f] * inv_steps;
+        if ((rc = dev_upload(e, &d.forb_state, (const int*)forbidden_states, (size_t)cfg->n_forbidden))) return bail(rc);
+        if ((rc = dev_upload(e, &d.forb_a, (const double*)fa.data(), (size_t)cfg->n_forbidden))) return bail(rc);
+    }
 
 #define ALLOC(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     ALLOC(d.base, B * ks); ALLOC(d.adam_m, B * ks); ALLOC(d.adam_v, B * ks);
@@ -316,6 +318,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     ALLOC(d.loss, (size_t)B); ALLOC(d.reg_state, (size_t)B); ALLOC(d.reg_loss, (size_t)B);
     ALLOC(d.g2, (size_t)B); ALLOC(d.uscale, (size_t)B);
     if (d.has_band) ALLOC(d.band_ph, B * ks);
+    ALLOC(e->step_lr, (size_t)B);
     if (hipMemset(d.base, 0, B * ks * sizeof(double)) != hipSuccess ||
         hipMemset(d.adam_m, 0, B * ks * sizeof(double)) != hipSuccess ||
         hipMemset(d.adam_v, 0, B * ks * sizeof(double)) != hipSuccess ||
@@ -381,7 +384,10 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         ALLOC(e->seed_scratch, (size_t)B * (nn + 3 * nm));
     }
 #undef ALLOC
-    HIP_TRY(hipDeviceSynchronize());
+    {
+        const hipError_t se = hipDeviceSynchronize();
+        if (se != hipSuccess) return bail(fail(QOC_ERR_HIP, "qoc_create: %s", hipGetErrorString(se)));
+    }
     *out = e;
     return QOC_OK;
 }
@@ -406,13 +412,15 @@ int qoc_set_base(qoc_handle e, const double* base) {
     if (!base) return fail(QOC_ERR_INVALID, "qoc_set_base: null base");
     const QocDev& d = e->d;
     const size_t cnt = (size_t)d.B * d.k * d.steps;
+    // everything on the engine stream (it is non-blocking: the legacy null stream orders nothing against it), then one sync so
+    // that the caller may reuse `base` and the next qoc_iterate sees the cleared optimiser state
+    HIP_TRY(hipMemcpyAsync(d.base, base, cnt * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(d.adam_m, 0, cnt * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(d.adam_v, 0, cnt * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(d.adam_t, 0, d.B * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(d.iters, 0, d.B * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(d.done, 0, d.B * sizeof(int), e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(d.base, base, cnt * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(d.adam_m, 0, cnt * sizeof(double)));
-    HIP_TRY(hipMemset(d.adam_v, 0, cnt * sizeof(double)));
-    HIP_TRY(hipMemset(d.adam_t, 0, d.B * sizeof(int)));
-    HIP_TRY(hipMemset(d.iters, 0, d.B * sizeof(int)));
-    HIP_TRY(hipMemset(d.done, 0, d.B * sizeof(int)));
     e->evaluated = false;
     return QOC_OK;
 }
@@ -454,22 +462,16 @@ int qoc_adam_step(qoc_handle e, const double* lr) {
     CHECK_H(e);
     if (!lr) return fail(QOC_ERR_INVALID, "qoc_adam_step: null lr");
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_adam_step: no evaluation since the last qoc_set_base");
-    double* dlr = nullptr;
-    HIP_TRY(hipMalloc((void**)&dlr, e->d.B * sizeof(double)));
-    if (hipMemcpy(dlr, lr, e->d.B * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-        hipFree(dlr);
-        return fail(QOC_ERR_HIP, "qoc_adam_step: learning-rate upload failed");
-    }
+    // per-seed learning rates live in the engine's arena (no allocation per step); the copy is ordered on the engine stream
+    HIP_TRY(hipMemcpyAsync(e->step_lr, lr, e->d.B * sizeof(double), hipMemcpyHostToDevice, e->stream));
     QocAdamDev ap;
     memset(&ap, 0, sizeof ap);
     ap.mode = 2;
-    ap.lr = dlr;
+    ap.lr = e->step_lr;
     // the reference re-evaluates the gradient at the same parameters inside session.run([optimizer]) (run_session.py:69)
-    int rc = enqueue_iteration(e, ap);
-    const hipError_t se = hipStreamSynchronize(e->stream);          // dlr must outlive the kernels that read it
-    hipFree(dlr);
-    if (rc == QOC_OK && se != hipSuccess) rc = fail(QOC_ERR_HIP, "qoc_adam_step: %s", hipGetErrorString(se));
-    return rc;
+    TRY(enqueue_iteration(e, ap));
+    HIP_TRY(hipStreamSynchronize(e->stream));                       // `lr` (pageable host memory) may be reused by the caller
+    return QOC_OK;
 }
 
 int qoc_iterate(qoc_handle e, const qoc_adam_params* p, int32_t iters) {
@@ -591,3 +593,5 @@ int qoc_path_in_use(qoc_handle e) { return e ? e->path : QOC_ERR_INVALID; }
 int qoc_chunks_in_use(qoc_handle e) { return e ? e->chunks : QOC_ERR_INVALID; }
 
 }  // extern "C"
+
+#include "qoc_comm.h"

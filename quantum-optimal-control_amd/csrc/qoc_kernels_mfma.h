@@ -25,12 +25,11 @@
 //
 // Reference semantics: core/tensorflow_state.py:25-46 (matexp), :204-242 (chain, inter vectors), :49-65 (gradient).
 //
-// Files: qoc_mfma_frag.h (layouts, helpers), qoc_mfma_expm.h, qoc_mfma_forward.h, qoc_mfma_backward.h (kernels); host side below.
+// Files: qoc_mfma_frag.h (layouts, helpers); kernels in qoc_mfma_expm.h / qoc_mfma_forward.h / qoc_mfma_backward.h, each compiled in its
+// own translation unit (qoc_mfma_expm.hip, qoc_mfma_forward.hip, qoc_mfma_backward.hip: the three compile in parallel) behind the
+// host entry points declared below.
 #pragma once
 #include "qoc_mfma_frag.h"
-#include "qoc_mfma_expm.h"
-#include "qoc_mfma_forward.h"
-#include "qoc_mfma_backward.h"
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 
@@ -52,193 +51,15 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
         }
 }
 
-static inline int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
-                                 std::vector<void*>& allocs, std::string& msg) {
-    const int NT = d.n <= 16 ? 1 : (d.n <= 32 ? 2 : (d.n <= 48 ? 3 : 4));
-    const int FR = 256 * NT * NT;
-    mf.NT = NT; mf.FR = FR;
-    int C = chunks_req;
-    if (C <= 0) {
-        // NT = 2: the default exponential kernel is ONE wave of 444 VGPRs per (seed, chunk), i.e. at most one resident wave per
-        // SIMD: B*C must not exceed the 1024 SIMDs or a second, nearly empty round doubles the launch (48 seeds: C = 22 ->
-        // 1056 items, 24.0k it/s; C = 21 -> 1008 items, 39.6k it/s).  Other NT: ~2 waves per SIMD.
-        C = NT == 2 ? 1024 / d.B : (1024 + d.B - 1) / d.B;
-        if (C > 32) C = 32;
-    }
-    if (C > d.steps) C = d.steps;
-    if (C > QOC_MAXC) C = QOC_MAXC;
-    if (C < 1) C = 1;
-    int L = (d.steps + C - 1) / C;
-    C = (d.steps + L - 1) / L;                       // no empty chunks
-    mf.C = C; mf.L = L;
-    mf.mq = (d.m + 3) / 4;
-    {
-        double f = 1.0;
-        for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; mf.invfact[j] = 1.0 / f; }
-    }
-    std::vector<cplx> hd((size_t)(d.k + 1) * FR), ht((size_t)(d.k + 1) * FR), u0(FR);
-    for (int kk = 0; kk <= d.k; ++kk) {
-        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, false, hd.data() + (size_t)kk * FR, NT);
-        qoc_to_fragD(Hs_host + (size_t)kk * d.n * d.n, d.n, true, ht.data() + (size_t)kk * FR, NT);
-    }
-    std::vector<cplx> u0h((size_t)d.n * d.n);
-    if (hipMemcpy(u0h.data(), d.U0, u0h.size() * sizeof(cplx), hipMemcpyDeviceToHost) != hipSuccess) { msg = "U0 readback failed"; return -2; }
-    qoc_to_fragD(u0h.data(), d.n, false, u0.data(), NT);
-    auto up = [&](cplx** dst, const std::vector<cplx>& src) -> bool {
-        void* p = nullptr;
-        if (hipMalloc(&p, src.size() * sizeof(cplx)) != hipSuccess) return false;
-        allocs.push_back(p);
-        if (hipMemcpy(p, src.data(), src.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) return false;
-        *dst = (cplx*)p;
-        return true;
-    };
-    if (!up(&mf.HfD, hd) || !up(&mf.HfT, ht) || !up(&mf.U0fD, u0)) { msg = "MFMA path: constant upload failed"; return -3; }
-    // the large buffers are carved out of ONE allocation (placement of separate hipMallocs after earlier engines of the process
-    // were freed was worth a factor 2 on the GEMM path)
-    std::vector<std::pair<cplx**, size_t>> wanted;
-    auto al = [&](cplx** dst, size_t count) -> bool { wanted.emplace_back(dst, (count * sizeof(cplx) + 4095) & ~(size_t)4095); return true; };
-    mf.skew_c = 5 * 16;                            // 1280 B per chunk
-    mf.skew_b = 3 * 16;                            //  768 B per seed
-    const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
-    mf.store_T = !((NT == 2 || NT == 3) && mf.variant != 1);     // the 4x4x4 forward sweep gathers K^T operands from fragD(K)
-    const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k <= 5: backward3 (5 images still fit next to its pads)
-    if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
-    { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
-    if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
-    {
-        size_t total = 0;
-        for (auto& w : wanted) total += w.second;
-        char* arena = nullptr;
-        if (hipMalloc((void**)&arena, qoc_arena_bytes(total)) != hipSuccess) { msg = "MFMA path: out of device memory"; return -3; }
-        allocs.push_back(arena);
-        size_t off = 0;
-        for (auto& w : wanted) { *w.first = (cplx*)(arena + off); off += w.second; }
-    }
-    const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
-    const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
-    mf.h_in_lds = (hbytes + pads) <= 160 * 1024;
-    mf.bwd_lds = pads + (mf.h_in_lds ? hbytes : 0);
-    // prefetching row-split kernel (NT = 2, k <= 5): 4 or 5 control images + the pads + row partials
-    {
-        const int kc = d.k == 5 ? 5 : 4;
-        mf.bwd_lds3 = (size_t)kc * FR * sizeof(cplx) + (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 2 * 4 * kc * sizeof(double);
-    }
-    const void* b3k = d.k == 5 ? (mf.mq <= 2 ? ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<2, true, 5> : (const void*)k_mfma_backward3<2, false, 5>)
-                                             : ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<4, true, 5> : (const void*)k_mfma_backward3<4, false, 5>))
-                               : (mf.mq <= 2 ? ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<2, true, 4> : (const void*)k_mfma_backward3<2, false, 4>)
-                                             : ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<4, true, 4> : (const void*)k_mfma_backward3<4, false, 4>));
-    if (NT == 2 && hipFuncSetAttribute(b3k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
-        msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
-        return -2;
-    }
-    if (split_grad) {
-        const void* gk = NT == 2 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<2, 2> : (const void*)k_mfma_grad<2, 4>)
-                       : NT == 3 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<3, 2> : (const void*)k_mfma_grad<3, 4>)
-                                 : (mf.mq <= 2 ? (const void*)k_mfma_grad<4, 2> : (const void*)k_mfma_grad<4, 4>);
-        if (hipFuncSetAttribute(gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.grad_lds) != hipSuccess) { msg = "MFMA path: cannot reserve LDS for the gradient kernel"; return -2; }
-    }
-    if (mf.h_in_lds) {
-        const hipError_t e1 = hipFuncSetAttribute((const void*)k_mfma_backward<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
-        const hipError_t e2 = hipFuncSetAttribute((const void*)k_mfma_backward<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
-        const hipError_t e3 = hipFuncSetAttribute((const void*)k_mfma_backward<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
-        const hipError_t e4 = hipFuncSetAttribute((const void*)k_mfma_backward<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds);
-        if ((NT == 1 ? e1 : (NT == 2 ? e2 : (NT == 3 ? e3 : e4))) != hipSuccess) {
-            msg = "MFMA path: cannot reserve LDS for the backward kernel";
-            return -2;
-        }
-    }
-    return 0;
-}
-
 // which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave)
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     if (mf.NT > 2) return mf.variant == 1 ? 1 : 2;      // n > 32: NT waves per item on 4x4x4 (n = 48 x 64: 4.3 vs 11.9 ms per launch)
     return mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 3 : 1);
 }
 
-template <int NT>
-static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    // AUTO: NT = 2 with at least half of the 1024 SIMDs busy -> one wave per (seed, chunk) on v_mfma_f64_4x4x4 (0.92 vs 1.21 ms
-    // per launch at C2 x 64); NT = 1 and small launches keep the 16x16x4 kernel (C1: 0.072 vs 0.074 ms; one C2 trajectory:
-    // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
-    const int v = qoc_mfma_expm_variant(mf, d);
-    if (v == 3 && NT <= 2) hipLaunchKernelGGL(k_mfma_expm_chunk4w<NT>, dim3(d.B * mf.C), dim3(64), 0, s, d, mf);
-    else if (v == 2) hipLaunchKernelGGL(k_mfma_expm_chunk4<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
-    else hipLaunchKernelGGL(k_mfma_expm_chunk<NT>, dim3(d.B * mf.C), dim3(64 * NT), 0, s, d, mf);
-}
-static inline void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    if (mf.NT == 1) qoc_mfma_launch_all_expm<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_expm<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_expm<3>(mf, d, s); else qoc_mfma_launch_all_expm<4>(mf, d, s);
-}
-static inline void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    const int items = d.B * mf.C + d.B * mf.NT;
-    if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    else if (mf.NT == 2 && mf.variant != 1) {
-        // 4x4x4 sweep; like the backward choice this must not depend on the batch size (bit-identical seeds across shardings)
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-        else hipLaunchKernelGGL((k_mfma_forward2<2, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    }
-    else if (mf.NT == 3 && mf.variant != 1) {
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-        else hipLaunchKernelGGL((k_mfma_forward2<3, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    }
-    else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    if (!d.uscale_in_loss) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
-}
-template <int NT>
-static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    const int items = d.B * mf.C;
-    if ((d.n_forb > 0 || d.has_speed) && mf.C > 1) {
-        if (NT == 2 && mf.variant != 1) {
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, false>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, false>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-        } else {
-            hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-        }
-    }
-    // NT = 2: k <= 5 -> k_mfma_backward3 (pair of waves per item, control images in LDS); k >= 6 -> costate sweep + k_mfma_grad.
-    // The choice must not depend on the batch size: the gradient sums associate differently between the kernels, and a seed has
-    // to evolve bit-identically whatever batch / GPU it is sharded into.  variant 1 keeps the one-wave 16x16x4 kernel (A/B).
-    if (NT == 2 && mf.variant != 1) {
-        if (d.k <= 5) {
-            const bool src = d.n_forb > 0 || d.has_speed;
-            const dim3 g3((items + 3) / 4), b3(512);
-#define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
-                               else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
-            if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
-            else { if (src) QOC_B3(4, true); else QOC_B3(4, false); }
-#undef QOC_B3
-            return;
-        }
-        {
-            // k >= 6: the control images fit in LDS next to no sweep's pads; costate sweep + slice-parallel gradient kernel (4 images
-            // per pass) instead of the row-split 16x16x4 sweep reading them from L2 (C2 x 64 with k = 8: 1.55 vs 1.71 ms per iteration)
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-            const int slices = d.B * d.steps;
-            int gg = (slices + 3) / 4; if (gg > 2048) gg = 2048;
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<2, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_grad<2, 4>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
-        }
-        return;
-    }
-    if (NT > 2 && mf.variant != 1) {
-        // n > 32: the sweep only propagates the costates, the gradients are formed slice-parallel with the control images in LDS
-        hipLaunchKernelGGL((k_mfma_backward<NT, false, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 0);   // no pad, no images
-        const int slices = d.B * d.steps;
-        int gg = (slices + 3) / 4; if (gg > 1024) gg = 1024;
-        constexpr int GN = NT > 2 ? NT : 3;                                  // (never launched for NT <= 2)
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<GN, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
-        else hipLaunchKernelGGL((k_mfma_grad<GN, 4>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
-        return;
-    }
-    if (mf.h_in_lds)
-        hipLaunchKernelGGL((k_mfma_backward<NT, true>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
-    else
-        hipLaunchKernelGGL((k_mfma_backward<NT, false>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
-}
-static inline void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_backward<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_backward<3>(mf, d, s); else qoc_mfma_launch_all_backward<4>(mf, d, s);
-}
 
+// host entry points (defined next to their kernels)
+int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg);   // qoc_mfma_backward.hip
+void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip
+void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s);    // qoc_mfma_forward.hip
+void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_backward.hip

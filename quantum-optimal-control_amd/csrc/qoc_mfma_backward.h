@@ -2,7 +2,7 @@
 // the control gradients dL/du_{k,t} = Re <Lambda_t, H_k' Psi_t>.  Reference semantics: core/tensorflow_state.py:49-65.
 #pragma once
 #include "qoc_mfma_frag.h"
-#include "qoc_kernels_generic.h"   // source_at()
+#include "qoc_state_source.h"   // source_at()
 
 // ---- kernel B0: affine offsets of the backward recursion when state regularisers add a source at every slice --------
 // Lambda_{t-1} = K_t^dagger Lambda_t + S_{t-1} is affine; over chunk c it maps the chunk-end costate E to
@@ -567,14 +567,15 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
 #pragma unroll
         for (int jb = 0; jb < MQ; ++jb) wown[jb] = d.W[min(16 * h + lc, d.n - 1) * d.m + min(4 * jb + lk, d.m - 1)];
     }
+    double wrow = 0.0;                      // this lane's row: sum of 2 a_f over the forbidden levels equal to it (loop invariant)
+    if (SRC) for (int f = 0; f < d.n_forb; ++f) wrow += (16 * h + lc == d.forb_state[f]) ? 2.0 * d.forb_a[f] : 0.0;
     auto source_fast = [&](const PsiReg& ps, int i, double (&fre)[MQ], double (&fim)[MQ]) {
         const int t = t1 - 1 - i, row = 16 * h + lc;
 #pragma unroll
         for (int jb = 0; jb < MQ; ++jb) {
             const cplx phi = ps.own[jb];
             const double pop = phi.x * phi.x + phi.y * phi.y;
-            double w = 0.0;
-            for (int f = 0; f < d.n_forb; ++f) w += (row == d.forb_state[f]) ? 2.0 * d.forb_a[f] * pop : 0.0;
+            const double w = wrow * pop;
             cplx sv = cscale(phi, w);
             const cplx zw = cscale(cmul(ps.zt, wown[jb]), speed_coef);
             sv.x += d.has_speed ? zw.x : 0.0; sv.y += d.has_speed ? zw.y : 0.0;

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
 // result register (I, jb) holds Psi[row 16 I + lane % 16][column 4 jb + lane / 16]: no output column is padding (a 16x16x4
 // tile spends half of its columns on m = 8) -- 48 MQ MFMAs of 17 cycles per slice instead of 48 of ~100.  K_{t+1} is fetched
 // while slice t multiplies.  Final-unitary waves as in k_mfma_forward.
-#define F2_LDP 33
+
 template <int NT, int MQ>
 __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
     constexpr int LDP = 16 * NT + 1;

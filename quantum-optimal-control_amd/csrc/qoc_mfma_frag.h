@@ -14,6 +14,7 @@
 #define QQS (4 * NT)
 #define QLDR (16 * NT + 1)
 #define QFR (256 * NT * NT)
+#define F2_LDP 33                 // row stride of the per-wave vector images of the 4x4x4 sweeps (forward2, bwd_offsets2)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define QMFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)

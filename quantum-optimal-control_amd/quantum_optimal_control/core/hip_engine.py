@@ -58,6 +58,17 @@ _SIGNATURES = {
     'qoc_time_iterations': (C.c_int, [C.c_void_p, C.POINTER(QocAdamParams), C.c_int32, _DP]),
     'qoc_path_in_use': (C.c_int, [C.c_void_p]),
     'qoc_chunks_in_use': (C.c_int, [C.c_void_p]),
+    'qoc_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'qoc_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    'qoc_comm_destroy': (C.c_int, [C.c_void_p]),
+    'qoc_comm_world': (C.c_int, [C.c_void_p]),
+    'qoc_comm_rank': (C.c_int, [C.c_void_p]),
+    'qoc_comm_library': (C.c_char_p, []),
+    'qoc_comm_all_gather_scalar': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _DP]),
+    'qoc_comm_all_gather_f64': (C.c_int, [C.c_void_p, _DP, C.c_int32, _DP]),
+    'qoc_comm_all_reduce_max_f64': (C.c_int, [C.c_void_p, _DP, C.c_int32]),
+    'qoc_comm_broadcast_f64': (C.c_int, [C.c_void_p, _DP, C.c_int64, C.c_int32]),
+    'qoc_comm_barrier': (C.c_int, [C.c_void_p]),
     'qoc_device_count': (C.c_int, []),
     'qoc_device_info': (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _IP, C.POINTER(C.c_int64)]),
     'qoc_last_error': (C.c_char_p, []),
@@ -131,6 +142,67 @@ def reg_config(reg_coeffs, total_time):
         out['forbidden_coeffs'] = np.array([float(c) for c, _ in pairs], dtype=np.float64)
         out['forbidden_states'] = np.array([int(s) for _, s in pairs], dtype=np.int32)
     return out
+
+
+COMM_ID_BYTES = 128
+SCALAR_LOSS, SCALAR_REG_LOSS, SCALAR_GRAD_SQUARED, SCALAR_UNITARY_SCALE = 0, 1, 2, 3
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it, the launcher hands it to the other ranks: parallel_seeds.rendezvous)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().qoc_comm_unique_id(buf))
+    return buf.raw
+
+
+class QocComm(object):
+    """One RCCL communicator per process (one process per GPU) behind the C ABI (include/qoc.h, multi-GPU section).
+    No torch involved: the collectives run from the engine's device buffers on the engine's HIP stream."""
+
+    def __init__(self, unique_id, world, rank, device=0):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.world, self.rank, self.device = int(world), int(rank), int(device)
+        _check(self._lib.qoc_comm_create(C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES), self.world, self.rank,
+                                         self.device, C.byref(self._h)))
+        self.library = self._lib.qoc_comm_library().decode()
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.qoc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather_scalar(self, engine, which, width):
+        """[world][width] rows of one per-seed scalar array of `engine` (device to device on the engine's stream)."""
+        out = np.empty((self.world, int(width)))
+        _check(self._lib.qoc_comm_all_gather_scalar(self._h, engine._h, int(which), int(width), _dp(out)))
+        return out
+
+    def all_gather(self, values):
+        values = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+        out = np.empty((self.world, values.shape[0]))
+        _check(self._lib.qoc_comm_all_gather_f64(self._h, _dp(values), values.shape[0], _dp(out)))
+        return out
+
+    def all_reduce_max(self, values):
+        buf = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1)).copy()
+        _check(self._lib.qoc_comm_all_reduce_max_f64(self._h, _dp(buf), buf.shape[0]))
+        return buf
+
+    def broadcast(self, array, root):
+        buf = np.ascontiguousarray(np.asarray(array, dtype=np.float64)).copy()
+        _check(self._lib.qoc_comm_broadcast_f64(self._h, _dp(buf.reshape(-1)), buf.size, int(root)))
+        return buf
+
+    def barrier(self):
+        _check(self._lib.qoc_comm_barrier(self._h))
 
 
 class HipEngine(object):

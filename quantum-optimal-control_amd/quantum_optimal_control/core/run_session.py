@@ -46,12 +46,15 @@ class run_session(object):
                                  conv_target=conv.conv_target, min_grad=conv.min_grad,
                                  max_iterations=conv.max_iterations, poll_every=max(1, int(conv.update_step)))
         budget = int(conv.max_iterations) + 1          # evaluations: one per update + the one that trips the stop rule
-        launched = 0
-        burst = max(1, int(conv.update_step))
-        first = True
+        u, ev = max(1, int(conv.update_step)), max(1, int(conv.evol_save_step))
+        launched = 0                                   # evaluations enqueued so far; the last one has index launched - 1
         while True:
-            n = 1 if first else min(burst, budget - launched)   # first line is printed at iteration 0 like the reference
-            first = False
+            # run to the next evaluation whose index is a multiple of update_step OR of evol_save_step: the reference logs
+            # at both, independently (run_session.py:75-91); evaluation 0 is both
+            it = launched
+            while it % u != 0 and it % ev != 0:
+                it += 1
+            n = min(it + 1, budget) - launched
             eng.iterate(params, n)
             launched += n
             s = eng.scalars()
@@ -59,11 +62,11 @@ class run_session(object):
             self.end = bool(np.all(s['done']))
             if self.end or launched >= budget:
                 break
-            self.update_and_save()
+            self.update_and_save(launched - 1)
         self.end = True
         self.get_end_results()
 
-    def _take_scalars(self, s):
+    def _take_scalars(self, s, replace_last=False):
         b = self.seed
         self.l, self.rl = float(s['loss'][b]), float(s['reg_loss'][b])
         self.g_squared, self.metric = float(s['grad_squared'][b]), float(s['unitary_scale'][b])
@@ -71,17 +74,29 @@ class run_session(object):
             # the device counter is already one past the evaluation these scalars belong to, unless that evaluation
             # tripped the stop rule (run_session.py:53-60 evaluates, checks, then increments)
             self.iterations = int(s['iterations'][b]) - (0 if int(s['done'][b]) else 1)
-        self.conv.record(self.iterations, self.l, self.rl)
+        if replace_last and self.conv.iterations:
+            self.conv.iterations[-1], self.conv.costs[-1], self.conv.reg_costs[-1] = self.iterations, self.l, self.rl
+        else:
+            self.conv.record(self.iterations, self.l, self.rl)
 
-    def update_and_save(self):
-        """Host poll at a multiple of update_step (run_session.py:75-91): progress line, run-log row, and every
-        evol_save_step iterations the propagation snapshot."""
+    def update_and_save(self, it=None):
+        """Host stop at evaluation `it` (run_session.py:75-91): at multiples of update_step the progress line and a run-log
+        row; at multiples of evol_save_step the propagation snapshot (plus a run-log row if update_step did not write one),
+        unless the live figure of this same stop already took it."""
+        it = self.iterations if it is None else it
+        upd = it % max(1, int(self.conv.update_step)) == 0
+        evo = it % max(1, int(self.conv.evol_save_step)) == 0
         self.anly = Analysis(self.sys_para, self.engine, self.seed)
-        self.save_data()
-        self.display()
-        if self.show_plots and self.conv.in_notebook():
-            self.conv.plot_summary(self.l, self.rl, self.anly, self.metric)       # redraws the live figure (and snapshots)
-        elif self.iterations % max(1, int(self.conv.evol_save_step)) == 0:
+        plotted = False
+        if upd:
+            self.save_data()
+            self.display()
+            if self.show_plots and self.conv.in_notebook():
+                self.conv.plot_summary(self.l, self.rl, self.anly, self.metric)   # redraws the live figure (and snapshots)
+                plotted = True
+        if evo and not plotted:
+            if not upd:
+                self.save_data()
             self.conv.save_evol(self.anly)
 
     # ---- results ------------------------------------------------------------------------------------------------
@@ -89,7 +104,7 @@ class run_session(object):
         if self.engine.n_seeds > 1:                       # report / return the best restart
             s = self.engine.scalars()
             self.seed = int(np.argmin(s['loss']))
-            self._take_scalars(s)
+            self._take_scalars(s, replace_last=True)      # the final point was recorded for seed 0: report the best restart instead
         self.anly = Analysis(self.sys_para, self.engine, self.seed)
         self.save_data()
         self.display()
@@ -146,7 +161,7 @@ class run_session(object):
             print('Target fidelity reached')
             self.grads = 0 * self.grads          # zero gradient terminates the scipy optimisation
         if not self.end:
-            if self.iterations % self.conv.update_step == 0:
+            if self.iterations % self.conv.update_step == 0 or self.iterations % self.conv.evol_save_step == 0:
                 self.update_and_save()
             self.iterations += 1
         return np.float64(self.rl), np.asarray(self.grads, dtype=np.float64)

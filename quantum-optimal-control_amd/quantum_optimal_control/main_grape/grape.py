@@ -113,39 +113,43 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
         tfs.close()
 
 
-def GrapeSharded(*args, restarts=8, dist=None, **kwargs):
-    """`Grape(...)` with `restarts` control sets block-partitioned over the ranks of a torch.distributed process group
-    (one process per GPU; `dist` = the initialised `torch.distributed` module, or None for a single process).  Every rank
-    optimises its own restarts on its own GPU -- no data-path collective --, the best final losses are all-gathered once
-    (RCCL when the backend is "nccl"), and the winner's (uks, U_final) is broadcast, so every rank returns the same pair.
+def GrapeSharded(*args, restarts=8, dist=None, comm=None, **kwargs):
+    """`Grape(...)` with `restarts` control sets block-partitioned over the ranks of a one-node job (one process per GPU).
+    Transport: `comm` = a `hip_engine.QocComm` (RCCL over xGMI behind the C ABI; `parallel_seeds.open_comm()` builds it from the
+    launcher's RANK/LOCAL_RANK/WORLD_SIZE) or `dist` = an initialised `torch.distributed` module (gloo in the CPU tests); neither
+    = a single process.  Every rank optimises its own restarts on its own GPU -- no data-path collective --, the best final
+    losses are all-gathered once, and the winner's (uks, U_final) is broadcast, so every rank returns the same pair.
     Global restart g starts from the same point whatever the number of ranks (restart 0 = the reference's own draw)."""
     from quantum_optimal_control.parallel_seeds import SeedShard
-    world = dist.get_world_size() if dist is not None else 1
-    rank = dist.get_rank() if dist is not None else 0
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    elif dist is not None:
+        world, rank = dist.get_world_size(), dist.get_rank()
+    else:
+        world, rank = 1, 0
     shard = SeedShard(total_seeds=int(restarts), rank=rank, world=world)
-    if shard.count == 0:
+    if min(shard.counts) == 0:           # the same verdict on EVERY rank: nobody is left waiting in a collective
         raise ValueError('GrapeSharded: more ranks (%d) than restarts (%d)' % (world, restarts))
-    device = int(kwargs.pop('device', os.environ.get('LOCAL_RANK', 0) if dist is not None else 0))
+    default_device = comm.device if comm is not None else (os.environ.get('LOCAL_RANK', 0) if dist is not None else 0)
+    device = int(kwargs.pop('device', default_device))
     if rank != 0:
         kwargs['save'] = False                                       # only rank 0 may write the run log
     out = Grape(*args, restarts=shard.count, _first_seed=shard.first, _device=device, _return_session=True, **kwargs)
-    if out is None:
+    if world == 1:
+        return None if out is None else out[:2]
+    # one value per RANK (its best restart): gather, pick the winner, broadcast its pulse and unitary.  A rank whose run was
+    # interrupted still takes part (loss = +inf), so the others are not left waiting.
+    ranks = SeedShard(total_seeds=world, rank=rank, world=world)     # one slot per rank
+    loss = np.inf if out is None else out[2]
+    losses = ranks.all_gather(np.array([loss]), dist=dist, comm=comm)
+    if not np.all(np.isfinite(losses)):
         return None
-    uks, Uf, loss = out
-    if dist is None or world == 1:
-        return uks, Uf
-    # one value per RANK (its best restart): gather, pick the winner, broadcast its pulse and unitary
-    import torch
-    dev = shard._device(dist)
-    mine = torch.tensor([loss], dtype=torch.float64, device=dev)
-    allv = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-    dist.all_gather(allv, mine)
-    best = int(np.argmin([float(v.item()) for v in allv]))
-    t = torch.from_numpy(np.ascontiguousarray(uks, dtype=np.float64)).to(dev)
-    dist.broadcast(t, src=best)
-    uks = t.cpu().numpy()
+    best = int(np.argmin(losses))
+    uks, Uf = out[0], out[1]
+    uks = ranks.broadcast_from_owner(best, lambda i: np.asarray(uks, dtype=np.float64), np.shape(uks), dist=dist, comm=comm)
     if not isinstance(Uf, list):
-        tu = torch.from_numpy(np.ascontiguousarray(Uf).view(np.float64).copy()).to(dev)
-        dist.broadcast(tu, src=best)
-        Uf = tu.cpu().numpy().view(np.complex128)
+        shape = np.shape(Uf)
+        flat = ranks.broadcast_from_owner(best, lambda i: np.ascontiguousarray(Uf, dtype=np.complex128).view(np.float64),
+                                          shape[:-1] + (2 * shape[-1],), dist=dist, comm=comm)
+        Uf = np.ascontiguousarray(flat).view(np.complex128)
     return uks, Uf

@@ -4,10 +4,86 @@ The reference optimises exactly one control set per Grape() call and draws its i
 (core/system_parameters.py:272-284); random restarts are an embarrassingly-parallel loop around it.  Here the
 restarts become the leading `n_seeds` dimension of one engine per GPU (one process per GPU), block-partitioned over
 ranks.  Seeds never interact, so there is NO data-path collective: the only exchange is one all-gather of the
-per-seed scalars (fidelity, iterations) at the end -- RCCL over xGMI when the process group backend is "nccl",
-gloo in the CPU tests -- followed by an optional broadcast of the winner's controls.
+per-seed scalars (fidelity, iterations) at the end, followed by an optional broadcast of the winner's controls.
+
+Two transports, same partition and same results:
+  * `comm`  -- a `hip_engine.QocComm`: RCCL over xGMI behind the C ABI (include/qoc.h); the all-gather runs device to
+               device on the engine's own HIP stream.  No torch in the process.  The 128-byte RCCL id travels from rank 0
+               to the other ranks through `rendezvous()` below (a file on the node, one node per job).
+  * `dist`  -- an initialised `torch.distributed` module (gloo in the CPU tests): host tensors.
 """
+import os
+import time
+
 import numpy as np
+
+
+def launch_env():
+    """(rank, local_rank, world) as torch.distributed.run / bench.py's own launcher export them."""
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=300.0):
+    """Hand `make_payload()` (bytes, evaluated on rank 0 only) to every rank of a one-node job through a file.
+
+    key: anything all ranks agree on and no other live job shares; default = master port + the launcher's PID (the
+    ranks of one torch.distributed.run / bench.py launch are siblings, so os.getppid() is the same number on all of
+    them and differs between concurrent launches)."""
+    if world == 1:
+        return make_payload()
+    if key is None:
+        key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+    directory = directory or os.environ.get('QOC_RDZV_DIR', '/tmp')
+    path = os.path.join(directory, 'qoc_rdzv_%s' % key)
+    if rank == 0:
+        payload = make_payload()
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        with open(tmp, 'wb') as f:
+            f.write(payload)
+        os.replace(tmp, path)                     # atomic: a reader sees nothing or everything
+        return payload
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                data = f.read()
+            if data:
+                return data
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError('rendezvous: rank %d saw no %s within %.0f s' % (rank, path, timeout))
+        time.sleep(0.01)
+
+
+def rendezvous_cleanup(rank, world, key=None, directory=None):
+    """Rank 0 removes the rendezvous file (call after every rank holds the payload, e.g. behind a barrier)."""
+    if world == 1 or rank != 0:
+        return
+    if key is None:
+        key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+    directory = directory or os.environ.get('QOC_RDZV_DIR', '/tmp')
+    try:
+        os.remove(os.path.join(directory, 'qoc_rdzv_%s' % key))
+    except OSError:
+        pass
+
+
+def open_comm(rank=None, world=None, device=None, key=None):
+    """RCCL communicator for this rank (None for a single process).  Collective: every rank of the launch calls it."""
+    from quantum_optimal_control.core import hip_engine
+    erank, elocal, eworld = launch_env()
+    rank = erank if rank is None else rank
+    world = eworld if world is None else world
+    device = elocal if device is None else device
+    if world == 1:
+        return None
+    uid = rendezvous(rank, world, hip_engine.comm_unique_id, key=key)
+    comm = hip_engine.QocComm(uid, world, rank, device)
+    comm.barrier()                                  # every rank holds the id: the file can go
+    rendezvous_cleanup(rank, world, key=key)
+    return comm
 
 
 class SeedShard(object):
@@ -22,26 +98,34 @@ class SeedShard(object):
         self.firsts = [int(np.sum(self.counts[:r])) for r in range(self.world)]
         self.first, self.count = self.firsts[self.rank], self.counts[self.rank]
 
-    def _device(self, dist):
-        import torch
-        if dist is not None and dist.get_backend() == 'nccl':
-            return torch.device('cuda', torch.cuda.current_device())
-        return torch.device('cpu')
+    def _rows_to_global(self, rows):
+        return np.concatenate([np.asarray(rows[r])[:self.counts[r]] for r in range(self.world)])
 
-    def all_gather(self, local_values, dist=None):
+    def all_gather(self, local_values, dist=None, comm=None):
         """Gather one float64 per seed from every rank, returned in global seed order (length total_seeds)."""
         local_values = np.asarray(local_values, dtype=np.float64).reshape(-1)
         assert local_values.shape[0] == self.count
-        if dist is None or self.world == 1:
+        if self.world == 1 or (dist is None and comm is None):
             return local_values.copy()
-        import torch
-        dev = self._device(dist)
         width = max(self.counts)
-        buf = torch.zeros(width, dtype=torch.float64, device=dev)
-        buf[:self.count] = torch.from_numpy(local_values).to(dev)
-        out = [torch.zeros(width, dtype=torch.float64, device=dev) for _ in range(self.world)]
+        if comm is not None:
+            buf = np.zeros(width)
+            buf[:self.count] = local_values
+            return self._rows_to_global(comm.all_gather(buf))
+        import torch
+        buf = torch.zeros(width, dtype=torch.float64)
+        buf[:self.count] = torch.from_numpy(local_values)
+        out = [torch.zeros(width, dtype=torch.float64) for _ in range(self.world)]
         dist.all_gather(out, buf)
-        return np.concatenate([out[r][:self.counts[r]].cpu().numpy() for r in range(self.world)])
+        return self._rows_to_global([o.numpy() for o in out])
+
+    def all_gather_engine_scalar(self, engine, which, comm):
+        """The same gather straight from the engine's device array `which` (hip_engine.SCALAR_*), device to device on
+        the engine's stream behind the iterations already enqueued (RCCL); global seed order."""
+        if self.world == 1 or comm is None:
+            s = engine.scalars()
+            return np.asarray(s[('loss', 'reg_loss', 'grad_squared', 'unitary_scale')[which]], dtype=np.float64).copy()
+        return self._rows_to_global(comm.all_gather_scalar(engine, which, max(self.counts)))
 
     def owner_of(self, seed):
         for r in range(self.world):
@@ -49,19 +133,21 @@ class SeedShard(object):
                 return r
         raise IndexError(seed)
 
-    def broadcast_from_owner(self, seed, local_array_fn, shape, dist=None):
+    def broadcast_from_owner(self, seed, local_array_fn, shape, dist=None, comm=None):
         """Broadcast a float64 array (e.g. the winner's uks) from the rank that owns `seed` to all ranks."""
         owner = self.owner_of(seed)
-        if dist is None or self.world == 1:
+        if self.world == 1 or (dist is None and comm is None):
             return np.asarray(local_array_fn(seed - self.first), dtype=np.float64).reshape(shape)
-        import torch
-        dev = self._device(dist)
         if self.rank == owner:
-            t = torch.from_numpy(np.ascontiguousarray(local_array_fn(seed - self.first), dtype=np.float64)).reshape(shape).to(dev)
+            mine = np.ascontiguousarray(local_array_fn(seed - self.first), dtype=np.float64).reshape(shape)
         else:
-            t = torch.zeros(shape, dtype=torch.float64, device=dev)
+            mine = np.zeros(shape)
+        if comm is not None:
+            return comm.broadcast(mine, owner).reshape(shape)
+        import torch
+        t = torch.from_numpy(mine.copy())
         dist.broadcast(t, src=owner)
-        return t.cpu().numpy()
+        return t.numpy()
 
 
 def restart_guesses(k, steps, first_seed, count, base_seed=1000):

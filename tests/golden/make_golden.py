@@ -25,6 +25,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference/quantum_optimal_control'
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "quantum-optimal-control_amd"))
 
 from tests.golden import cases  # noqa: E402
 

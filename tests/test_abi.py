@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, 'include', 'qoc.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(qoc_[a-z_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(qoc_[a-z0-9_]+)\s*\(', text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -101,3 +101,96 @@ def test_bench_two_ranks_prints_one_aggregate_line():
     assert len(lines) == 1, r.stdout[-1500:]
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['config']['total_seeds'] == 16 and j['steps'] == 3 and j['value'] > 0 and j['scaling'] == 'weak'
+
+
+def _rdzv_worker(rank, world, key, directory, q):
+    sys.path.insert(0, os.path.join(ROOT, 'quantum-optimal-control_amd'))
+    from quantum_optimal_control.parallel_seeds import rendezvous
+    calls = []
+
+    def payload():
+        calls.append(1)
+        return bytes(range(128))
+    got = rendezvous(rank, world, payload, key=key, directory=directory, timeout=60)
+    q.put((rank, got, len(calls)))
+
+
+def test_file_rendezvous_world2_hands_rank0_payload_to_every_rank(tmp_path):
+    """The RCCL id travels from rank 0 to the other ranks through a file on the node (no torch in the product path)."""
+    import multiprocessing as mp
+    from quantum_optimal_control.parallel_seeds import rendezvous_cleanup
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 2, 'unit_test', str(tmp_path), q)) for r in (1, 0)]   # reader first
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == (0, bytes(range(128)), 1) and res[1] == (1, bytes(range(128)), 0)    # only rank 0 evaluates the payload
+    rendezvous_cleanup(0, 2, key='unit_test', directory=str(tmp_path))
+    assert not os.listdir(str(tmp_path))
+
+
+def test_grape_sharded_refuses_more_ranks_than_restarts_on_every_rank():
+    """the verdict must be collective -- rank 0 (which would own a restart) raises too instead of entering a
+    collective the empty ranks never join."""
+    from quantum_optimal_control.main_grape.grape import GrapeSharded
+
+    class FakeComm(object):
+        world, rank, device = 8, 0, 0
+    with pytest.raises(ValueError, match='more ranks'):
+        GrapeSharded(None, None, None, None, 1.0, 4, [0], restarts=3, comm=FakeComm())
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_world1_on_the_engine_stream():
+    """The RCCL branch behind the C ABI executes: id, ncclCommInitRank, all-gather of the engine's device-resident losses on the
+    engine's stream, max all-reduce, broadcast, barrier (world size 1 is all a one-GPU box can run; RCCL refuses two ranks on
+    one device)."""
+    from quantum_optimal_control.core import hip_engine
+    from quantum_optimal_control.parallel_seeds import SeedShard
+    from tests.golden import cases
+    from tests.helpers import oracle_system
+    sp = oracle_system(cases.case_c2(n=8, k=2, steps=12, m=4, taylor=(4, 1), seed=2))
+    B = 5
+    eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
+                               reg_coeffs={}, n_seeds=B)
+    eng.set_base(np.random.default_rng(0).normal(0, 0.3, (B, sp.k, sp.steps)))
+    p = eng.adam_params(max_iterations=10 ** 6, conv_target=-1.0, min_grad=-1.0)
+    comm = hip_engine.QocComm(hip_engine.comm_unique_id(), 1, 0, 0)
+    assert 'rccl' in comm.library
+    eng.iterate(p, 3)                                        # no sync: the gather is ordered behind these on the stream
+    rows = comm.all_gather_scalar(eng, hip_engine.SCALAR_LOSS, B + 2)
+    assert rows.shape == (1, B + 2)
+    np.testing.assert_array_equal(rows[0, :B], eng.scalars()['loss'])
+    assert np.all(rows[0, B:] == 0.0)
+    sh = SeedShard(B, 0, 1)
+    np.testing.assert_array_equal(comm.all_gather([1.5, -2.0]), [[1.5, -2.0]])
+    np.testing.assert_array_equal(comm.all_reduce_max([3.0, -1.0]), [3.0, -1.0])
+    np.testing.assert_array_equal(comm.broadcast(np.arange(6.0).reshape(2, 3), 0), np.arange(6.0).reshape(2, 3))
+    comm.barrier()
+    np.testing.assert_array_equal(sh.all_gather_engine_scalar(eng, hip_engine.SCALAR_LOSS, None), eng.scalars()['loss'])
+    with pytest.raises(hip_engine.QocError):
+        comm.all_gather_scalar(eng, 7, B)
+    comm.close()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start two ranks itself and print n_gpus 2.
+    On the one-GPU box both ranks share GPU 0 through the gloo test hook."""
+    import json
+    import subprocess
+    env = dict(os.environ, QOC_BENCH_BACKEND='gloo', QOC_BENCH_SAME_DEVICE='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--seeds-per-gpu', '8', '--no-cpu-baseline', '--no-single'], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1500:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['ranks_seen'] == 2 and j['config']['fidelities_gathered'] == 16
