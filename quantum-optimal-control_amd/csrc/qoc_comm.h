@@ -41,6 +41,15 @@ static int load(std::string& err) {
     Dl_info info;
     if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {       // the ROCm tree of OUR HIP runtime
         std::string dir(info.dli_fname);
+        // A process that imported PyTorch BEFORE this library has resolved our libamdhip64.so.7 to PyTorch's private copy (same
+        // soname), and PyTorch's private librccl faults when driven from outside torch (observed: SIGSEGV in ncclGetUniqueId).
+        // Refuse instead of crashing: the RCCL transport belongs to torch-free processes (bench.py, GrapeSharded(comm=...));
+        // a torch process passes dist= and uses torch.distributed.
+        if (dir.find("/torch/lib/") != std::string::npos && !getenv("QOC_RCCL_LIBRARY")) {
+            err = "this process runs on PyTorch's private HIP runtime (" + dir + "): import quantum_optimal_control before torch, or "
+                  "use the torch.distributed transport (dist=), or set QOC_RCCL_LIBRARY";
+            return -1;
+        }
         const size_t slash = dir.rfind('/');
         if (slash != std::string::npos) {
             candidates.push_back(dir.substr(0, slash) + "/librccl.so.1");

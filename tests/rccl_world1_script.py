@@ -1,0 +1,55 @@
+"""Body of tests/test_seed_sharding.py::test_rccl_communicator_world1_on_the_engine_stream (fresh interpreter, no pytest, no
+torch unless argv[1] == 'torch-first')."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'quantum-optimal-control_amd')]
+if len(sys.argv) > 1 and sys.argv[1] == 'torch-first':
+    import torch  # noqa: F401  (binds libamdhip64.so.7 to torch's private copy before libqoc_hip.so is loaded)
+from quantum_optimal_control.core import hip_engine  # noqa: E402
+from quantum_optimal_control.parallel_seeds import SeedShard, open_comm  # noqa: E402
+from tests.golden import cases  # noqa: E402
+from tests.helpers import oracle_system  # noqa: E402
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'torch-first':
+        try:
+            hip_engine.comm_unique_id()
+        except hip_engine.QocError as exc:
+            assert 'private HIP runtime' in str(exc), exc
+            print('OK refused')
+            sys.exit(0)
+        # torch was imported but our library still got the system runtime (load order differs): the transport must work then
+        print('OK refused (not applicable: system HIP runtime in use)')
+        sys.exit(0)
+    assert open_comm(rank=0, world=1, device=0) is None            # a single process needs no communicator
+    sp = oracle_system(cases.case_c2(n=8, k=2, steps=12, m=4, taylor=(4, 1), seed=2))
+    B = 5
+    eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
+                               reg_coeffs={}, n_seeds=B)
+    eng.set_base(np.random.default_rng(0).normal(0, 0.3, (B, sp.k, sp.steps)))
+    p = eng.adam_params(max_iterations=10 ** 6, conv_target=-1.0, min_grad=-1.0)
+    comm = hip_engine.QocComm(hip_engine.comm_unique_id(), 1, 0, 0)
+    assert 'rccl' in comm.library, comm.library
+    eng.iterate(p, 3)                                        # no sync: the gather is ordered behind these on the stream
+    rows = comm.all_gather_scalar(eng, hip_engine.SCALAR_LOSS, B + 2)
+    assert rows.shape == (1, B + 2)
+    np.testing.assert_array_equal(rows[0, :B], eng.scalars()['loss'])
+    assert np.all(rows[0, B:] == 0.0)
+    sh = SeedShard(B, 0, 1)
+    np.testing.assert_array_equal(comm.all_gather([1.5, -2.0]), [[1.5, -2.0]])
+    np.testing.assert_array_equal(comm.all_reduce_max([3.0, -1.0]), [3.0, -1.0])
+    np.testing.assert_array_equal(comm.broadcast(np.arange(6.0).reshape(2, 3), 0), np.arange(6.0).reshape(2, 3))
+    comm.barrier()
+    np.testing.assert_array_equal(sh.all_gather_engine_scalar(eng, hip_engine.SCALAR_LOSS, None), eng.scalars()['loss'])
+    try:
+        comm.all_gather_scalar(eng, 7, B)
+        raise SystemExit('unknown scalar index was accepted')
+    except hip_engine.QocError:
+        pass
+    comm.close()
+    eng.close()
+    print('OK rccl world1 via', comm.library)

@@ -148,34 +148,14 @@ def test_grape_sharded_refuses_more_ranks_than_restarts_on_every_rank():
 def test_rccl_communicator_world1_on_the_engine_stream():
     """The RCCL branch behind the C ABI executes: id, ncclCommInitRank, all-gather of the engine's device-resident losses on the
     engine's stream, max all-reduce, broadcast, barrier (world size 1 is all a one-GPU box can run; RCCL refuses two ranks on
-    one device)."""
-    from quantum_optimal_control.core import hip_engine
-    from quantum_optimal_control.parallel_seeds import SeedShard
-    from tests.golden import cases
-    from tests.helpers import oracle_system
-    sp = oracle_system(cases.case_c2(n=8, k=2, steps=12, m=4, taylor=(4, 1), seed=2))
-    B = 5
-    eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
-                               reg_coeffs={}, n_seeds=B)
-    eng.set_base(np.random.default_rng(0).normal(0, 0.3, (B, sp.k, sp.steps)))
-    p = eng.adam_params(max_iterations=10 ** 6, conv_target=-1.0, min_grad=-1.0)
-    comm = hip_engine.QocComm(hip_engine.comm_unique_id(), 1, 0, 0)
-    assert 'rccl' in comm.library
-    eng.iterate(p, 3)                                        # no sync: the gather is ordered behind these on the stream
-    rows = comm.all_gather_scalar(eng, hip_engine.SCALAR_LOSS, B + 2)
-    assert rows.shape == (1, B + 2)
-    np.testing.assert_array_equal(rows[0, :B], eng.scalars()['loss'])
-    assert np.all(rows[0, B:] == 0.0)
-    sh = SeedShard(B, 0, 1)
-    np.testing.assert_array_equal(comm.all_gather([1.5, -2.0]), [[1.5, -2.0]])
-    np.testing.assert_array_equal(comm.all_reduce_max([3.0, -1.0]), [3.0, -1.0])
-    np.testing.assert_array_equal(comm.broadcast(np.arange(6.0).reshape(2, 3), 0), np.arange(6.0).reshape(2, 3))
-    comm.barrier()
-    np.testing.assert_array_equal(sh.all_gather_engine_scalar(eng, hip_engine.SCALAR_LOSS, None), eng.scalars()['loss'])
-    with pytest.raises(hip_engine.QocError):
-        comm.all_gather_scalar(eng, 7, B)
-    comm.close()
-    eng.close()
+    one device).  Runs in a fresh torch-free interpreter, like bench.py: the RCCL transport refuses a process whose HIP runtime
+    is PyTorch's private copy (second half of the test)."""
+    import subprocess
+    script = os.path.join(ROOT, 'tests', 'rccl_world1_script.py')
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and 'OK rccl world1' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    r = subprocess.run([sys.executable, script, 'torch-first'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and 'OK refused' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 @pytest.mark.gpu

@@ -37,6 +37,12 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'c3':           # profiling hook: C3 single trajectory only
         run('C3 state transfer (propagator route)', cases.case_c3(), 1, 20)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'c3x64':        # profiling hook: batched state transfer only
+        run('C3 state transfer x64 seeds', cases.case_c3(), 64, 5)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'c5':           # profiling hook: large Hilbert space only
+        run('C5 n=512 k=8 steps=2000 (GEMM path)', cases.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2), 1, 2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'c2reg':        # profiling hook: regularised C2 x 64 only
         c = cases.case_c2(); c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [30, 31]}
         run('C2 x64 + dwdt + forbidden', c, 64, 20)
