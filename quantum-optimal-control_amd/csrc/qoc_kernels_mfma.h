@@ -51,12 +51,14 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
         }
 }
 
-// which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave)
+// which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave, image written before each product,
+// 4 = 4x4x4 one wave, image written strip by strip under the product's own MFMAs)
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     if (mf.NT > 2) return mf.variant == 1 ? 1 : 2;      // n > 32: NT waves per item on 4x4x4 (n = 48 x 64: 4.3 vs 11.9 ms per launch)
-    return mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 3 : 1);
+    int v = mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 4 : 1);
+    if (v == 4 && (d.T < 2 || mf.NT != 2)) v = 3;                      // the streamed kernel starts from the product A * A
+    return v;
 }
-
 
 // host entry points (defined next to their kernels)
 int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg);   // qoc_mfma_backward.hip

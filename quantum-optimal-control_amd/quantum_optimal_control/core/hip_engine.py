@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libqoc_hip.so'))
+LIB_PATH = os.environ.get('QOC_HIP_LIBRARY') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libqoc_hip.so'))   # override: A/B builds
 
 PATH_AUTO, PATH_GENERIC, PATH_MFMA, PATH_ST_FUSED, PATH_GEMM = 0, 1, 2, 3, 4
 

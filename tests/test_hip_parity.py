@@ -88,11 +88,13 @@ def test_mfma_path_parity(chunks, variant):
     _mfma_path_parity(chunks, variant, 0)
 
 
-@pytest.mark.parametrize('kernel', [1, 2, 3], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave'])
-@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4'])
+@pytest.mark.parametrize('kernel', [1, 2, 3, 4], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image'])
+@pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
+                                     'n25_k8_T7', 'n17_k1_T4_s4'])
 @pytest.mark.parametrize('chunks', [1, 7])
 def test_mfma_exponential_kernels(chunks, variant, kernel):
-    """The three kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variant 3 = variant 2)."""
+    """The four kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variants 3, 4 = variant 2;
+    n <= 16: variant 4 = variant 3)."""
     _mfma_path_parity(chunks, variant, kernel)
 
 
@@ -126,6 +128,14 @@ def _mfma_path_parity(chunks, variant, kernel):
     elif variant == 'n64_nt4':
         c = cases.case_c2(n=64, k=3, steps=11, m=8, taylor=(5, 2), seed=14)
         c['reg_coeffs'] = {'forbidden_coeff_list': [3.0], 'states_forbidden_list': [63], 'amplitude': 0.1}
+    elif variant == 'n18_T2_s1':         # no Horner product at all: polynomial = c0 I + c1 A + c2 A^2 straight from the first product
+        c = cases.case_c2(n=18, k=2, steps=21, m=5, taylor=(2, 1), seed=31)
+    elif variant == 'n32_T3_s0':         # one Horner product, no squaring: the chunk product follows the polynomial directly
+        c = cases.case_c2(n=32, k=3, steps=13, m=8, taylor=(3, 0), seed=32)
+    elif variant == 'n25_k8_T7':         # k = 8: the 8-control flavour of the assembly pipelined under the chunk product; 3 Horner products
+        c = cases.case_c2(n=25, k=8, steps=15, m=6, taylor=(7, 2), seed=33)
+    elif variant == 'n17_k1_T4_s4':      # even order with one Horner product, one control
+        c = cases.case_c2(n=17, k=1, steps=10, m=3, taylor=(4, 4), seed=34)
     elif variant == 'n57_k1_nt4':
         c = cases.case_c2(n=57, k=1, steps=9, m=3, taylor=(4, 1), seed=15)
     else:

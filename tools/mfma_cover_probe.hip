@@ -28,13 +28,21 @@ __device__ __forceinline__ void side(double& x, double y, double z, float& f, un
 }
 
 template <int KIND, int NS, int PER>    // NS side instructions after every PER-th MFMA
-__global__ void __launch_bounds__(256, 1) k_probe(double* out, const double2* gsrc, int iters) {
+__global__ void __launch_bounds__(256, 1) k_probe(double* out, const double2* gsrc, int iters, int data = 1) {
     extern __shared__ double2 smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned lds = (unsigned)(wv * 1024 + lane * 2) * 16u;   // byte offset in the dynamic LDS segment (no static LDS): conflict-free 16 B per lane
     if (iters < 0) smem[threadIdx.x] = make_double2(0.0, 0.0);
     const double2* g = gsrc + (size_t)(blockIdx.x * 256 + threadIdx.x);
     double a = 1.0 + lane * 1e-3, b = 1.0 - lane * 1e-3;
+    if (data == 0) { a = 0.0; b = 0.0; }                                   // operand data: 0 = zeros, 1 = smooth, 2 = random mantissas
+    if (data == 2) {
+        unsigned long long x = 0x9E3779B97F4A7C15ull * (unsigned long long)(blockIdx.x * 256 + threadIdx.x + 1);
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        a = __longlong_as_double((long long)((x & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull)) - 1.5;
+        x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        b = __longlong_as_double((long long)((x & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull)) - 1.5;
+    }
     double acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0;
@@ -63,16 +71,16 @@ __global__ void __launch_bounds__(256, 1) k_probe(double* out, const double2* gs
 }
 
 template <int KIND, int NS, int PER>
-static void run(const char* name, double* out, const double2* gsrc) {
-    const int iters = 20000;
+static void run(const char* name, double* out, const double2* gsrc, int data = 1) {
+    const int iters = 200000;
     const size_t lds = 100 * 1024;
     CHECK(hipFuncSetAttribute((const void*)k_probe<KIND, NS, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_probe<KIND, NS, PER>), dim3(256), dim3(256), lds, 0, out, gsrc, 200);
+    hipLaunchKernelGGL((k_probe<KIND, NS, PER>), dim3(256), dim3(256), lds, 0, out, gsrc, 200, data);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_probe<KIND, NS, PER>), dim3(256), dim3(256), lds, 0, out, gsrc, iters);
+    hipLaunchKernelGGL((k_probe<KIND, NS, PER>), dim3(256), dim3(256), lds, 0, out, gsrc, iters, data);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -89,6 +97,8 @@ int main() {
     CHECK(hipMalloc((void**)&out, 256 * 256 * sizeof(double)));
     CHECK(hipMalloc((void**)&gsrc, 256 * 256 * sizeof(double2)));
     CHECK(hipMemset(gsrc, 0, 256 * 256 * sizeof(double2)));
+    run<NONE, 0, 1>("MFMA only, operands all zero", out, gsrc, 0);
+    run<NONE, 0, 1>("MFMA only, random mantissas", out, gsrc, 2);
     run<NONE, 0, 1>("MFMA only", out, gsrc);
     run<FMA64, 1, 1>("+1 v_fma_f64 per MFMA", out, gsrc);
     run<FMA64, 2, 1>("+2 v_fma_f64 per MFMA", out, gsrc);
