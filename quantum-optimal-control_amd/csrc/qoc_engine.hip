@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,6 +23,9 @@
 #include "qoc_kernels_st.h"
 #include "qoc_kernels_gemm.h"
 
+#ifndef QOC_LATENCY_MAX_SEEDS
+#define QOC_LATENCY_MAX_SEEDS 16        // measured on C2 (profiles/r02_latency_sweep.txt): latency mode wins up to 16 seeds, the batch kernels from 24 on
+#endif
 static thread_local std::string g_err;
 
 static int fail(int code, const char* fmt, ...) {
@@ -59,6 +63,8 @@ struct qoc_engine {
     QocMfma mf;
     QocGemm gm;
     bool evaluated = false;
+    int skip_mask = 0;          // QOC_DEBUG_SKIP (timing experiments only): 1 controls, 2 exponentials, 4 forward, 8 loss, 16 backward, 32 finish
+    bool final_stale = false;   // MFMA latency mode: Xfinal / uscale not yet formed for the last evaluation
     double* step_lr = nullptr;  // [B] per-seed learning rates of qoc_adam_step
     // profiling of the dominant kernel
     bool profiling = false;
@@ -140,18 +146,21 @@ static int prof_collect(qoc_engine* e) {
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     QocDev d = e->d;
     d.skip_done = ap.mode == 1 ? 1 : 0;      // qoc_eval / explicit steps always evaluate every seed
-    d.uscale_in_loss = e->path == QOC_PATH_MFMA ? 1 : 0;
+    d.uscale_in_loss = (e->path == QOC_PATH_MFMA && !e->mf.latency) ? 1 : 0;
     const int total = d.B * d.k * d.steps;
     int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
     if (cgrid > 2048) cgrid = 2048;
-    hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
+    const int skip = e->skip_mask;
+    if (!(skip & 1)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {
         TRY(prof_begin(e));
-        qoc_mfma_launch_expm(e->mf, d, e->stream);
+        if (!(skip & 2)) qoc_mfma_launch_expm(e->mf, d, e->stream);
         TRY(prof_end(e));
-        qoc_mfma_launch_forward(e->mf, d, e->stream);
-        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
-        qoc_mfma_launch_backward(e->mf, d, e->stream);
+        if (!(skip & 4)) qoc_mfma_launch_forward(e->mf, d, e->stream);
+        if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
+        if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
+        if (!(skip & 8)) hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        if (!(skip & 16)) qoc_mfma_launch_backward(e->mf, d, e->stream);
     } else if (e->path == QOC_PATH_GEMM) {
         TRY(prof_begin(e));
         qoc_gemm_expm(e->gm, d, e->stream);
@@ -179,9 +188,19 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
         hipLaunchKernelGGL(k_st_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
     }
-    hipLaunchKernelGGL(k_finish, dim3(d.B), dim3(d.k * d.steps >= 2048 ? 1024 : QOC_BLOCK), 0, e->stream, d, ap);
+    if (!(skip & 32)) hipLaunchKernelGGL(k_finish, dim3(d.B), dim3(d.k * d.steps >= 2048 ? 1024 : QOC_BLOCK), 0, e->stream, d, ap);
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
+    e->final_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale are formed when read back
+    return QOC_OK;
+}
+
+// latency mode of the MFMA path: final_state and unitary_scale of the last evaluation, formed on demand
+static int refresh_final(qoc_engine* e) {
+    if (!e->final_stale) return QOC_OK;
+    qoc_mfma_final_state(e->mf, e->d, e->stream);
+    HIP_TRY(hipGetLastError());
+    e->final_stale = false;
     return QOC_OK;
 }
 
@@ -350,8 +369,13 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));
     if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
+    // a handful of control sets of a 16 < n <= 32 unitary problem (the reference's own use is ONE per Grape() call): the latency mode
+    // of the MFMA path -- one wave per slice for the exponentials, row-split chain products, two-level chunk boundaries, final_state
+    // on read-back: one C2 trajectory 0.164 ms per iteration against 0.193 (GEMM latency route) and 0.56 (batch kernels)
+    const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && B <= QOC_LATENCY_MAX_SEEDS && steps >= 64;
     if (path == QOC_PATH_AUTO)
-        path = (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
+        path = latency_auto ? QOC_PATH_MFMA
+                            : (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
     if (path == QOC_PATH_MFMA && !mfma_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 64, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
@@ -361,9 +385,13 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
+    if (const char* sk = getenv("QOC_DEBUG_SKIP")) e->skip_mask = atoi(sk);   // wall-clock attribution of one kernel group (results are garbage)
     if (path == QOC_PATH_MFMA) {
         std::string msg;
-        e->mf.variant = cfg->variant;
+        e->mf.variant = latency_auto ? 5 : cfg->variant;
+        if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
+            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, 16 < n <= 32, k <= 5, "
+                                              "taylor_terms >= 2 and no state regulariser (n=%d k=%d T=%d)", n, k, d.T));
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         e->chunks = e->mf.C;
@@ -436,6 +464,7 @@ int qoc_get_scalars(qoc_handle e, double* loss, double* reg_loss, double* grad_s
                     int32_t* iterations, int32_t* done) {
     CHECK_H(e);
     const QocDev& d = e->d;
+    if (unitary_scale) TRY(refresh_final(e));
     HIP_TRY(hipStreamSynchronize(e->stream));
     const size_t sz = (size_t)d.B * sizeof(double);
     if (loss) HIP_TRY(hipMemcpy(loss, d.loss, sz, hipMemcpyDeviceToHost));
@@ -542,6 +571,7 @@ int qoc_get_final_unitary(qoc_handle e, double* Uf) {
     CHECK_H(e);
     if (e->d.state_transfer) return fail(QOC_ERR_STATE, "qoc_get_final_unitary: state-transfer mode has no final unitary");
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_final_unitary: nothing evaluated yet");
+    TRY(refresh_final(e));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(Uf, e->d.Xfinal, (size_t)e->d.B * e->d.n * e->d.n * sizeof(cplx), hipMemcpyDeviceToHost));
     return QOC_OK;
@@ -569,7 +599,7 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     TRY(prof_collect(e));
     if (kernel_name)
         *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm32 (batched matexp sequence)")
-                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
+                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 5 ? "k_mfma_expm_chunk4s (one wave per slice) + k_mfma_chain_products" : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
                        : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;

@@ -52,12 +52,18 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
 }
 
 // which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave, image written before each product,
-// 4 = 4x4x4 one wave, image written strip by strip under the product's own MFMAs)
+// 4 = 4x4x4 one wave, image written strip by strip under the product's own MFMAs, 5 = latency mode: kernel 4 with one wave per
+// slice + k_mfma_chain_products)
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     if (mf.NT > 2) return mf.variant == 1 ? 1 : 2;      // n > 32: NT waves per item on 4x4x4 (n = 48 x 64: 4.3 vs 11.9 ms per launch)
+    if (mf.latency) return 5;
     int v = mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 4 : 1);
     if (v == 4 && (d.T < 2 || mf.NT != 2)) v = 3;                      // the streamed kernel starts from the product A * A
     return v;
+}
+// latency mode needs the NT = 2 streamed kernels, the pair-of-waves backward sweep (k <= 5) and a linear costate recursion
+static inline bool qoc_mfma_latency_ok(const QocDev& d) {
+    return !d.state_transfer && d.n > 16 && d.n <= 32 && d.m <= 16 && d.k <= 5 && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
 }
 
 // host entry points (defined next to their kernels)
@@ -65,3 +71,4 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
 void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s);    // qoc_mfma_forward.hip
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_backward.hip
+void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip: latency mode, on read-back

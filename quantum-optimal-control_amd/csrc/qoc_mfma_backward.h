@@ -502,11 +502,10 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     put_own(0);
     lds_barrier();
     int buf = 0;
-    // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc, uniform trip count, result kept only while cc > c ----
+    // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc, uniform trip count, result kept only while cc > c.
+    //      Latency mode (mf.G > 1): first over whole groups of G chunks (their products GfD), then inside the own group ----
     {
-        const cplx* Pb = mf.PfD + (size_t)b * mf.C * QFR;
-        Frag f0, f1;
-        auto bstep = [&](const Frag& fr, int cc) {
+        auto bstep = [&](const Frag& fr, bool keep, int cc) {
             double nre[MQ], nim[MQ];
             cplx off[MQ];
             if (SRC) {                                               // E_{cc-1} = P_cc^dagger E_cc + a_cc; a_cc is a D-layout 16x16x4 column block
@@ -519,20 +518,34 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) { nre[jb] += off[jb].x; nim[jb] += off[jb].y; }
             }
-            const bool keep = cc > c;
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) { ore[jb] = keep ? nre[jb] : ore[jb]; oim[jb] = keep ? nim[jb] : oim[jb]; }
             put_own(buf ^ 1);
             lds_barrier();
             buf ^= 1;
         };
-        if (mf.C > 1) load_frag(Pb + (size_t)(mf.C - 1) * QFR, f0);
-        int cc = mf.C - 1;
-        for (; cc >= 2; cc -= 2) {
-            load_frag(Pb + (size_t)(cc - 1) * QFR, f1); asm volatile("" ::: "memory"); bstep(f0, cc);
-            load_frag(Pb + (size_t)max(cc - 2, 1) * QFR, f0); asm volatile("" ::: "memory"); bstep(f1, cc - 1);
+        // n_steps matrices base[idx_of(s)], s = 0 .. n_steps - 1, the next one fetched while this one multiplies; the trip count is
+        // the same for every wave of the workgroup (bstep holds a barrier)
+        auto bsteps = [&](const cplx* base, int n_steps, auto idx_of, auto keep_of) {
+            if (n_steps <= 0) return;
+            Frag f0, f1;
+            load_frag(base + (size_t)idx_of(0) * QFR, f0);
+            int s = 0;
+            for (; s + 2 <= n_steps; s += 2) {
+                load_frag(base + (size_t)idx_of(s + 1) * QFR, f1); asm volatile("" ::: "memory"); bstep(f0, keep_of(s), idx_of(s));
+                load_frag(base + (size_t)idx_of(min(s + 2, n_steps - 1)) * QFR, f0); asm volatile("" ::: "memory"); bstep(f1, keep_of(s + 1), idx_of(s + 1));
+            }
+            if (s < n_steps) bstep(f0, keep_of(s), idx_of(s));
+        };
+        const cplx* Pb = mf.PfD + (size_t)b * mf.C * QFR;
+        if (mf.G > 1) {
+            const int G = mf.G, NG = mf.NG, g = c / G, C = mf.C;
+            bsteps(mf.GfD + (size_t)b * NG * QFR, NG - 1, [&](int s) { return NG - 1 - s; }, [&](int s) { return NG - 1 - s > g; });
+            bsteps(Pb, G - 1, [&](int s) { return min(g * G + G - 1 - s, C - 1); }, [&](int s) { const int cc = g * G + G - 1 - s; return cc < C && cc > c; });
+        } else {
+            const int C = mf.C;
+            bsteps(Pb, C - 1, [&](int s) { return C - 1 - s; }, [&](int s) { return C - 1 - s > c; });
         }
-        if (cc == 1) bstep(f0, 1);
     }
     // ---- slices of the chunk, last to first ------------------------------------------------------------------------------
     const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;

@@ -16,12 +16,18 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         C = NT == 2 ? 1024 / d.B : (1024 + d.B - 1) / d.B;
         if (C > 32) C = 32;
     }
+    // latency mode (variant 5; AUTO for a handful of seeds, qoc_mfma_latency_ok): one wave per SLICE for the exponentials, short
+    // chunks whose products come from k_mfma_chain_products, groups of G chunks for two-level chunk boundaries in the sweeps
+    mf.latency = mf.variant == 5;
+    if (mf.latency && chunks_req <= 0) C = (d.steps + 7) / 8;   // chunks of 8 slices
     if (C > d.steps) C = d.steps;
     if (C > QOC_MAXC) C = QOC_MAXC;
     if (C < 1) C = 1;
     int L = (d.steps + C - 1) / C;
     C = (d.steps + L - 1) / L;                       // no empty chunks
     mf.C = C; mf.L = L;
+    mf.G = 0; mf.NG = 0;
+    if (mf.latency) { mf.G = 8; mf.NG = (C + mf.G - 1) / mf.G; }
     mf.mq = (d.m + 3) / 4;
     {
         double f = 1.0;
@@ -55,6 +61,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k <= 5: backward3 (5 images still fit next to its pads)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
+    if (mf.latency && (!al(&mf.GfD, (size_t)d.B * mf.NG * FR) || !al(&mf.TfD, (size_t)d.B * FR))) { msg = "MFMA path: out of device memory"; return -3; }
     if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     {
         size_t total = 0;

@@ -9,7 +9,14 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     // per launch at C2 x 64); NT = 1 and small launches keep the 16x16x4 kernel (C1: 0.072 vs 0.074 ms; one C2 trajectory:
     // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
     const int v = qoc_mfma_expm_variant(mf, d);
-    if (v == 4 && NT == 2) {
+    if (v == 5 && NT == 2) {
+        // latency mode: K_t by one wave per slice, then the chunk products and the products of groups of G chunks
+        if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_chunk4s<2, 4, true>), dim3(d.B * d.steps), dim3(64), 0, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_expm_chunk4s<2, 8, true>), dim3(d.B * d.steps), dim3(64), 0, s, d, mf);
+        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.C * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr);
+        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.NG * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr);
+    }
+    else if (v == 4 && NT == 2) {
         constexpr int NTS = 2;
         if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_chunk4s<NTS, 4>), dim3(d.B * mf.C), dim3(64), 0, s, d, mf);
         else hipLaunchKernelGGL((k_mfma_expm_chunk4s<NTS, 8>), dim3(d.B * mf.C), dim3(64), 0, s, d, mf);
@@ -20,4 +27,33 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
 }
 void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.NT == 1) qoc_mfma_launch_all_expm<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_expm<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_expm<3>(mf, d, s); else qoc_mfma_launch_all_expm<4>(mf, d, s);
+}
+
+// final_state = P_{C-1} ... P_0 U0 and unitary_scale (tensorflow_state.py:223-225) for the latency mode, where the sweeps do not
+// form them: one chain over the group products and U0, then the unpack.  Called by the engine before a read-back.
+__global__ void __launch_bounds__(64) k_mfma_unpack_final(QocDev d, QocMfma mf) {
+    const int b = blockIdx.x, lane = threadIdx.x, n = d.n;
+    const cplx* T = mf.TfD + (size_t)b * mf.FR;
+    cplx* Xf = d.Xfinal + (size_t)b * n * n;
+    const int QS = 4 * mf.NT;
+    for (int f = 0; f < mf.NT * QS; ++f) {
+        const int cb = f / QS, q = f - cb * QS, row = 4 * q + (lane >> 4), col = 16 * cb + (lane & 15);
+        if (row < n && col < n) Xf[row * n + col] = T[f * 64 + lane];
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int c = lane; c < n; c += 64) {
+        cplx rs = cmake(0.0, 0.0);
+        for (int a = 0; a < n; ++a) rs = cadd(rs, Xf[c * n + a]);
+        part += rs.x * rs.x + rs.y * rs.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) d.uscale[b] = part / (double)n;
+}
+void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    QocDev dd = d;
+    dd.skip_done = 0;                                                     // every seed's last evaluation is still in GfD
+    hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * 8), dim3(64), 0, s, dd, mf, (const cplx*)mf.GfD, 0, mf.NG, mf.NG, mf.TfD, 1, (const cplx*)mf.U0fD);
+    hipLaunchKernelGGL(k_mfma_unpack_final, dim3(d.B), dim3(64), 0, s, dd, mf);
 }

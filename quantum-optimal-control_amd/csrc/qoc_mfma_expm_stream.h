@@ -114,15 +114,17 @@ __device__ __forceinline__ void mm_stream(cplx* img, double* imgs, int lane, con
 
 struct NoHook { template <class S> __device__ __forceinline__ void operator()(S) const {} };
 
-// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient)
-template <int NT, int KC>
+// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient).
+// SLICES (latency mode, few seeds): one wave per (seed, SLICE) computes K_t only -- the chunk products come from
+// k_mfma_chain_products, so that 500 slices of one trajectory are 500 waves instead of 16 chunks of 32 dependent slices.
+template <int NT, int KC, bool SLICES = false>
 __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma mf) {
     __shared__ __attribute__((aligned(16))) cplx img[QNP * QLDS];
     __shared__ __attribute__((aligned(16))) double imgs[QNP * QLDS];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
+    const int b = SLICES ? blockIdx.x / d.steps : blockIdx.x / mf.C, c = SLICES ? blockIdx.x - b * d.steps : blockIdx.x - b * mf.C;
     if (d.skip_done && d.done[b]) return;
-    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const int t0 = SLICES ? c : c * mf.L, t1 = SLICES ? c + 1 : min(t0 + mf.L, d.steps);
     const double inv_scale = 1.0 / (double)(1 << d.s);
     const int dlt = (lane & 15) - (lane >> 4);
     constexpr int NSTRIP = NT * QQS;
@@ -243,6 +245,11 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
         }
         // ---- K_t out; chunk product R <- K_t * R (image <- K_t), A_{t+1} assembled under these MFMAs --------------------
         const size_t item = kitem(mf, d.steps, b, t);
+        if constexpr (SLICES) {
+#pragma unroll
+            for (int J = 0; J < NT; ++J) colblock_store<NT>(mf.KfD + item, J, lane, X[J]);
+            return;
+        }
         strip_sums<NT>(R, Rs);
         {
             const int tn = min(t + 1, d.steps - 1);
@@ -329,4 +336,133 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
         for (int q = 0; q < QQS; ++q) mf.PfT[pitem * QFR + (J * QQS + q) * 64 + lane] = img[(4 * q + (lane >> 4)) * QLDS + 16 * J + (lane & 15)];
     QOC_LAP(9)
     QOC_LAP_DONE
+}
+
+// ---- chain products in fragD format (latency mode): OUT[b][i] = IN[b][i*len + len' - 1] ... IN[b][i*len], len' = min(len, count - i*len).
+// Used twice per iteration: chunk products P_c from the slice propagators (len = L), group products from the chunk products
+// (len = G).  One wave per output; the running product is the LEFT operand (R <- R * M_t, t descending): its image is written
+// strip by strip under the MFMAs like every other left operand here, and the right operand M_t comes straight from global memory
+// as strip registers (fragD IS the strip layout), fetched while the previous product runs.
+// in_is_K: IN is the K storage (kitem addressing with its skews), else a plain [B][count] array of fragD matrices.
+template <int NT>
+__global__ void __launch_bounds__(64, 1) k_mfma_chain_products(QocDev d, QocMfma mf, const cplx* __restrict__ IN, int in_is_K, int count, int len,
+                                                                cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail) {
+    __shared__ __attribute__((aligned(16))) cplx img[QNP * QLDS];
+    __shared__ __attribute__((aligned(16))) double imgs[QNP * QLDS];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / nout, i = blockIdx.x - b * nout;
+    if (d.skip_done && d.done[b]) return;
+    // `tail` (one fragD matrix shared by all seeds, e.g. U0) multiplies from the right after the chain: element lo - 1
+    const int hi = min(i * len + len, count) - 1, lo = i * len - (tail ? 1 : 0);
+    auto src = [&](int t) -> const cplx* { return (tail && t < i * len) ? tail : (in_is_K ? IN + kitem(mf, d.steps, b, t) : IN + ((size_t)b * count + t) * QFR); };
+    CTile R[NT][NT], M[NT][NT];
+    Sums<NT> Rs, Ms;
+    double a[NT][QQS], bb[NT][QQS], cc[NT][QQS];
+#pragma unroll
+    for (int J = 0; J < NT; ++J) colblock_load<NT>(src(hi), J, lane, R[J]);
+    if (hi > lo) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J) colblock_load<NT>(src(hi - 1), J, lane, M[J]);
+    }
+    strip_sums<NT>(R, Rs);
+    strip_store<NT>(img, imgs, lane, R, Rs, 0, 0);
+    lds_order();
+    for (int t = hi - 1; t >= lo; --t) {
+        strip_sums<NT>(M, Ms);
+        mm_stream<NT, true>(img, imgs, lane, R, Rs, M, Ms, a, bb, cc, NoHook{});
+        if (t > lo) {                                                     // next right operand: in flight under the VALU batch and the next product's head
+#pragma unroll
+            for (int J = 0; J < NT; ++J) colblock_load<NT>(src(t - 1), J, lane, M[J]);
+        }
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int ib = 0; ib < QQS; ++ib) {
+                const double re = a[J][ib] - bb[J][ib], im = cc[J][ib] - a[J][ib] - bb[J][ib];
+                R[J][ib >> 2].re[ib & 3] = re; R[J][ib >> 2].im[ib & 3] = im;
+                Rs.v[J][ib] = re + im;
+                if (J == 0 && ib == 0) { strip_store<NT>(img, imgs, lane, R, Rs, 0, 0); lds_order(); }
+            }
+    }
+    cplx* out = OUT + ((size_t)b * nout + i) * QFR;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) colblock_store<NT>(out, J, lane, R[J]);
+}
+
+// ---- the same chain products, ROW-SPLIT over 8 waves per output (latency mode) ------------------------------------------------
+// R <- R * M_t needs, for the rows 4w .. 4w+3 of the result, only the SAME rows of R as left operand (4x4 blocks of those rows
+// against the strips of M_t): wave w therefore carries its four rows through the whole chain alone -- no shared image, no barrier.
+// Its two result strips go through a wave-private 4-row transposition pad (2.5 KB + sums) to become the left blocks of the next
+// product; the right operand M_t is read by every wave straight from global memory as strip registers (fragD is the strip layout),
+// one matrix ahead.  48 MFMAs per product and wave instead of 384: a chain of 7 products takes ~4 us instead of ~23.
+template <int NT>
+__global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, const cplx* __restrict__ IN, int in_is_K, int count, int len,
+                                                        cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail) {
+    static_assert(NT == 2, "row-split chain products: n <= 32");
+    constexpr int PS = 5;                                            // pad stride (complex elements per column): conflict-free stores and block reads
+    __shared__ __attribute__((aligned(16))) cplx pad[QNP * PS];
+    __shared__ __attribute__((aligned(16))) double pads[QNP * PS];
+    const int lane = threadIdx.x, lc = lane & 15, lk = lane >> 4;
+    const int w = blockIdx.x & 7, item = blockIdx.x >> 3;            // 8 row blocks of 4 rows
+    const int b = item / nout, i = item - b * nout;
+    if (d.skip_done && d.done[b]) return;
+    const int hi = min(i * len + len, count) - 1, lo = i * len - (tail ? 1 : 0);
+    auto src = [&](int t) -> const cplx* { return (tail && t < i * len) ? tail : (in_is_K ? IN + kitem(mf, d.steps, b, t) : IN + ((size_t)b * count + t) * QFR); };
+    struct Mat { cplx s[NT][QQS]; };                                 // all strips of a right operand
+    auto load_mat = [&](const cplx* __restrict__ F, Mat& m) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int kb = 0; kb < QQS; ++kb) m.s[J][kb] = F[(J * QQS + kb) * 64 + lane];
+    };
+    cplx r[NT];                                                      // own rows of the running product: strips (J, ib = w)
+    {
+        const cplx* F = src(hi);
+#pragma unroll
+        for (int J = 0; J < NT; ++J) r[J] = F[(J * QQS + w) * 64 + lane];
+    }
+    Mat M0, M1;
+    if (hi > lo) load_mat(src(hi - 1), M0);
+    auto product = [&](const Mat& m) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {                               // R[4w + lk][16 J + lc] -> pad[column][row in block]
+            pad[(16 * J + lc) * PS + lk] = r[J];
+            pads[(16 * J + lc) * PS + lk] = r[J].x + r[J].y;
+        }
+        lds_order();
+        cplx blk[QQS]; double bls[QQS];
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) {                           // lane 16 k + 4 blk + i  <-  R[4w + i][4 kb + k]
+            blk[kb] = pad[(4 * kb + lk) * PS + (lane & 3)];
+            bls[kb] = pads[(4 * kb + lk) * PS + (lane & 3)];
+        }
+        double a[NT], bq[NT], cq[NT];
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                const double br = m.s[J][kb].x, bi = m.s[J][kb].y, bs = br + bi;
+                if (kb == 0) {
+                    a[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(blk[kb].x, br, 0.0, 0, 0, 0);
+                    bq[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(blk[kb].y, bi, 0.0, 0, 0, 0);
+                    cq[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(bls[kb], bs, 0.0, 0, 0, 0);
+                } else {
+                    a[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(blk[kb].x, br, a[J], 0, 0, 0);
+                    bq[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(blk[kb].y, bi, bq[J], 0, 0, 0);
+                    cq[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(bls[kb], bs, cq[J], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int J = 0; J < NT; ++J) r[J] = cmake(a[J] - bq[J], cq[J] - a[J] - bq[J]);
+    };
+    int t = hi - 1;
+    for (; t - 1 >= lo; t -= 2) {                                    // the next right operand is in flight while this one multiplies
+        load_mat(src(t - 1), M1); lds_order(); product(M0);
+        if (t - 2 >= lo) load_mat(src(t - 2), M0);
+        lds_order(); product(M1);
+    }
+    if (t >= lo) product(M0);
+    cplx* out = OUT + ((size_t)b * nout + i) * QFR;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) out[(J * QQS + w) * 64 + lane] = r[J];
 }

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
                     if (row < d.n && col < d.m) out[row * d.m + col] = cmake(Psi[Ib].re[r], Psi[Ib].im[r]);
                 }
         }
-    } else if (item < n_sweep + d.B * NT) {
+    } else if (!mf.latency && item < n_sweep + d.B * NT) {       // latency mode: final_state only on read-back
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
         if (d.skip_done && d.done[b]) return;
@@ -81,12 +81,14 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
 // while slice t multiplies.  Final-unitary waves as in k_mfma_forward.
 
 template <int NT, int MQ>
-__global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
+__global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int colsplit) {
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * 4 + wv;
+    // colsplit > 1: one wave per group of 4 columns of Psi (they are independent under left multiplication; MQ = 1).  Measured on
+    // one C2 trajectory: no gain (43 us either way) -- a step is bound by the fetch of its 16 KB matrix, not by its 24 MQ MFMAs
+    const int item = (blockIdx.x * 4 + wv) / colsplit, jq0 = (blockIdx.x * 4 + wv) - item * colsplit;
     const int n_sweep = d.B * mf.C;
     if (item < n_sweep) {
         const int c = item / d.B, b = item - c * d.B;      // chunk-major: the waves of a workgroup walk 4 different seeds
@@ -99,13 +101,13 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
         for (int I = 0; I < NT; ++I)
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) {
-                const int row = 16 * I + lc, col = 4 * jb + lk;
+                const int row = 16 * I + lc, col = 4 * (jb + jq0) + lk;
                 cplx v = cmake(0.0, 0.0);
                 if (row < d.n && col < d.m) v = d.Psi0[row * d.m + col];
                 pre[I][jb] = v.x; pim[I][jb] = v.y;
             }
         cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
-        if (c == 0) {                                                   // inter[0] = V  (tensorflow_state.py:232-233)
+        if (c == 0 && jq0 == 0) {                                       // inter[0] = V  (tensorflow_state.py:232-233)
             for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
         }
         struct Frag { cplx f[NT][QQS]; };
@@ -150,9 +152,33 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
                 for (int jb = 0; jb < MQ; ++jb) { pre[I][jb] = a[I][jb] - bq[I][jb]; pim[I][jb] = cq[I][jb] - a[I][jb] - bq[I][jb]; }
         };
         Frag A, A1;
-        for (int cc = 0; cc < c; ++cc) {                                // chunk boundary from the chunk products
-            load_frag(mf.PfD + ((size_t)b * mf.C + cc) * QFR, A);
-            product(A);
+        // chunk-start vectors: Psi <- P_cc Psi over the chunks before this one; in latency mode (mf.G > 1) whole groups of G chunks
+        // first (their products GfD).  The matrices were written by the previous kernel, mostly on other XCDs: each fetch is a
+        // 1-2 us round trip, so the list is walked with the next TWO matrices in flight (three register sets).
+        {
+            const int G = mf.G > 1 ? mf.G : 0, g = G ? c / G : 0;
+            const int n_grp = G ? g : 0, n_bnd = n_grp + (c - (G ? g * G : 0));
+            auto bnd_ptr = [&](int i) -> const cplx* {
+                i = min(i, n_bnd - 1);
+                return i < n_grp ? mf.GfD + ((size_t)b * mf.NG + i) * QFR : mf.PfD + ((size_t)b * mf.C + (G ? g * G : 0) + (i - n_grp)) * QFR;
+            };
+            if (n_bnd > 0) {
+                constexpr int PD = 2;                                   // matrices in flight ahead of the product (4: slower -- every wave
+                                                                        // walks the SAME group products, the walk is bound by that L2 hot spot)
+                Frag Bq[PD + 1];
+#pragma unroll
+                for (int q = 0; q < PD; ++q) load_frag(bnd_ptr(q), Bq[q]);
+                int i = 0;
+                for (; i + PD + 1 <= n_bnd; i += PD + 1) {
+#pragma unroll
+                    for (int q = 0; q <= PD; ++q) {
+                        load_frag(bnd_ptr(i + q + PD), Bq[(q + PD) % (PD + 1)]); asm volatile("" ::: "memory"); product(Bq[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q <= PD; ++q)
+                    if (i + q < n_bnd) product(Bq[q]);
+            }
         }
         auto step = [&](const Frag& fr, int t) {
             product(fr);
@@ -161,12 +187,15 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
             for (int I = 0; I < NT; ++I)
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) {
-                    const int row = 16 * I + lc, col = 4 * jb + lk;
+                    const int row = 16 * I + lc, col = 4 * (jb + jq0) + lk;
                     if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I][jb], pim[I][jb]);
                 }
         };
         const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);             // slices of one chunk are FR apart
         const int len = t1 - t0;
+        {
+        // (latency mode: three slices in flight instead of one was SLOWER, 19 vs 15 us for 8 slices -- the fetch of a 16 KB matrix
+        // by one wave takes ~2 us whatever is in flight: the gathers are bound by the load path, not by the round trip)
         load_frag(Kb, A);
         int t = 0;
         for (; t + 2 <= len; t += 2) {
@@ -174,7 +203,8 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
             load_frag(Kb + (size_t)min(t + 2, len - 1) * mf.FR, A); asm volatile("" ::: "memory"); step(A1, t0 + t + 1);
         }
         if (t < len) step(A, t0 + t);
-    } else if (item < n_sweep + d.B * NT) {
+        }
+    } else if (!mf.latency && item < n_sweep + d.B * NT) {       // latency mode: final_state only on read-back
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
         if (d.skip_done && d.done[b]) return;

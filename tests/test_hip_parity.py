@@ -88,10 +88,10 @@ def test_mfma_path_parity(chunks, variant):
     _mfma_path_parity(chunks, variant, 0)
 
 
-@pytest.mark.parametrize('kernel', [1, 2, 3, 4], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image'])
+@pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
                                      'n25_k8_T7', 'n17_k1_T4_s4'])
-@pytest.mark.parametrize('chunks', [1, 7])
+@pytest.mark.parametrize('chunks', [0, 1, 7])
 def test_mfma_exponential_kernels(chunks, variant, kernel):
     """The four kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variants 3, 4 = variant 2;
     n <= 16: variant 4 = variant 3)."""
@@ -143,6 +143,12 @@ def _mfma_path_parity(chunks, variant, kernel):
     sp = oracle_system(c)
     rng = np.random.default_rng(5)
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2, 3 * sp.base0]
+    from quantum_optimal_control.core import hip_engine
+    latency_ok = 16 < sp.n <= 32 and sp.k <= 5 and sp.exp_terms >= 2 and not ({'forbidden_coeff_list', 'speed_up'} & set(sp.reg_coeffs))
+    if kernel == 5 and not latency_ok:
+        with pytest.raises(hip_engine.QocError, match='latency mode'):
+            make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
+        return
     eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
     assert eng.path == 2
     eng.set_base(np.stack(bases))
@@ -306,14 +312,15 @@ def test_grape_lbfgs_driver_reduces_loss():
     assert l1 < 0.5 * l0
 
 
-@pytest.mark.parametrize('path,expect', [(0, 4), (2, 2)])
-def test_large_size_properties_c2(path, expect):
+@pytest.mark.parametrize('path,variant,expect', [(0, 0, 2), (4, 0, 4), (2, 4, 2)], ids=['auto_latency_mode', 'gemm_latency_route', 'mfma_batch_kernels'])
+def test_large_size_properties_c2(path, variant, expect):
     """BASELINE config C2 at full size: size-independent properties + an oracle comparison of one seed.  A couple of
-    trajectories take the latency route (AUTO -> GEMM path), large restart batches the register-resident MFMA kernels."""
+    trajectories take the latency mode of the MFMA path (AUTO), large restart batches its batch kernels; the GEMM path's latency
+    route stays selectable."""
     c = cases.case_c2()                                     # n=32, k=4, steps=500, m=8, (T,s)=(5,3)
     sp = oracle_system(c)
     bases = np.stack([sp.base0, 0.5 * sp.base0])
-    eng = make_engine(sp, n_seeds=2, path=path)
+    eng = make_engine(sp, n_seeds=2, path=path, variant=variant)
     assert eng.path == expect
     eng.set_base(bases)
     r = eng.evaluate()
