@@ -64,7 +64,7 @@ struct qoc_engine {
     QocGemm gm;
     bool evaluated = false;
     int skip_mask = 0;          // QOC_DEBUG_SKIP (timing experiments only): 1 controls, 2 exponentials, 4 forward, 8 loss, 16 backward, 32 finish
-    bool final_stale = false;   // MFMA latency mode: Xfinal / uscale not yet formed for the last evaluation
+    bool final_stale = false, inter_stale = false;   // MFMA latency mode: Xfinal / uscale not yet formed for the last evaluation
     double* step_lr = nullptr;  // [B] per-seed learning rates of qoc_adam_step
     // profiling of the dominant kernel
     bool profiling = false;
@@ -151,7 +151,8 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
     if (cgrid > 2048) cgrid = 2048;
     const int skip = e->skip_mask;
-    if (!(skip & 1)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
+    // (latency mode of the MFMA path: the slice kernel of the exponentials forms its own controls)
+    if (!(skip & 1) && !(e->path == QOC_PATH_MFMA && e->mf.latency)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {
         TRY(prof_begin(e));
         if (!(skip & 2)) qoc_mfma_launch_expm(e->mf, d, e->stream);
@@ -159,7 +160,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         if (!(skip & 4)) qoc_mfma_launch_forward(e->mf, d, e->stream);
         if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
         if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
-        if (!(skip & 8)) hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        if (!(skip & 8) && !e->mf.latency) hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);   // latency mode: inside the backward kernel
         if (!(skip & 16)) qoc_mfma_launch_backward(e->mf, d, e->stream);
     } else if (e->path == QOC_PATH_GEMM) {
         TRY(prof_begin(e));
@@ -188,10 +189,15 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
         hipLaunchKernelGGL(k_st_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
     }
-    if (!(skip & 32)) hipLaunchKernelGGL(k_finish, dim3(d.B), dim3(d.k * d.steps >= 2048 ? 1024 : QOC_BLOCK), 0, e->stream, d, ap);
+    if (!(skip & 32)) {
+        const bool plain = !(d.has_amp || d.has_env || d.has_dwdt || d.has_d2wdt2 || d.has_band);
+        const dim3 fb(d.k * d.steps >= 2048 ? 1024 : QOC_BLOCK);
+        if (plain) hipLaunchKernelGGL(k_finish_t<true>, dim3(d.B), fb, 0, e->stream, d, ap);
+        else hipLaunchKernelGGL(k_finish_t<false>, dim3(d.B), fb, 0, e->stream, d, ap);
+    }
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
-    e->final_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale are formed when read back
+    e->final_stale = e->inter_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale / inter_vecs are formed when read back
     return QOC_OK;
 }
 
@@ -580,6 +586,11 @@ int qoc_get_final_unitary(qoc_handle e, double* Uf) {
 int qoc_get_inter_vecs(qoc_handle e, double* inter) {
     CHECK_H(e);
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_inter_vecs: nothing evaluated yet");
+    if (e->inter_stale) {                                            // latency mode: the sweeps keep Psi_t in their own layout
+        qoc_mfma_unpack_inter(e->mf, e->d, e->stream);
+        HIP_TRY(hipGetLastError());
+        e->inter_stale = false;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(inter, e->d.inter, (size_t)e->d.B * (e->d.steps + 1) * e->d.n * e->d.m * sizeof(cplx), hipMemcpyDeviceToHost));
     return QOC_OK;

@@ -18,9 +18,29 @@ __device__ __forceinline__ void unit_phase(int f, int t, int N, double* c, doubl
     sincos(-2.0 * M_PI * (double)r / (double)N, s, c);
 }
 
-// Launched with 1024 threads when a seed has >= 2048 (k, t) elements: the element loops are latency-bound
-__global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
-    __shared__ double red[17];
+// two sums in one pass over the workgroup (one pair of barriers instead of two): results valid in every thread
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red /* >= 2 * (QOC waves) doubles */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { red[2 * wid] = a; red[2 * wid + 1] = b; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+    for (int i = 0; i < nw; ++i) { ta += red[2 * i]; tb += red[2 * i + 1]; }
+    a = ta; b = tb;
+}
+
+// Launched with 1024 threads when a seed has >= 2048 (k, t) elements: the element loops are latency-bound.  The kernel is one
+// dependent chain of global round trips for a single trajectory (17 us of a 133 us iteration): the Adam slots and everything else
+// an element needs are fetched up front and kept in registers (up to QF_E elements per thread), and the two reductions share their
+// barriers.
+#define QF_E 4
+// PLAIN: no pulse regulariser is configured -- the same kernel with those branches compiled out (a tenth of the code: for one
+// trajectory this single-workgroup kernel is bound by its instruction fetch and its chain of global round trips, not by arithmetic)
+template <bool PLAIN>
+__global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
+    __shared__ double red[34];
     const int b = blockIdx.x, steps = d.steps, ks = d.k * steps;
     const double* w = d.w + (size_t)b * ks;
     const double* dLdu = d.dLdu + (size_t)b * ks;
@@ -29,10 +49,23 @@ __global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
     const int it0 = d.iters[b];
     const int was_done = d.done[b];
     const double dt = d.dt;
+    const double loss = d.loss[b], reg_state_v = d.reg_state[b];
+    const int adam_t0 = d.adam_t[b];
+    double* am = d.adam_m + (size_t)b * ks;
+    double* av = d.adam_v + (size_t)b * ks;
+    const bool in_regs = ks <= QF_E * (int)blockDim.x;             // every element of this thread fits its register file
+    double g_r[QF_E], m_r[QF_E], v_r[QF_E], b_r[QF_E];
+    if (in_regs && ap.mode != 0) {
+#pragma unroll
+        for (int e = 0; e < QF_E; ++e) {
+            const int o = threadIdx.x + e * blockDim.x;
+            m_r[e] = o < ks ? am[o] : 0.0; v_r[e] = o < ks ? av[o] : 0.0;
+        }
+    }
 
     double reg = 0.0;
     // ---- values that are not sums over (k,t) elements --------------------------------------------------------
-    if (d.has_dwdt) {                                                            // :28-35
+    if (!PLAIN && d.has_dwdt) {                                                            // :28-35
         double acc = 0.0;
         for (int o = threadIdx.x; o < d.k * (steps + 3); o += blockDim.x) {
             const int kk = o / (steps + 3), i = o - kk * (steps + 3);
@@ -42,7 +75,7 @@ __global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
         }
         reg += d.a_dwdt * 0.5 * acc;
     }
-    if (d.has_d2wdt2) {                                                          // :38-45
+    if (!PLAIN && d.has_d2wdt2) {                                                          // :38-45
         double acc = 0.0;
         for (int o = threadIdx.x; o < d.k * (steps + 2); o += blockDim.x) {
             const int kk = o / (steps + 2), i = o - kk * (steps + 2);
@@ -52,10 +85,10 @@ __global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
         }
         reg += d.a_d2wdt2 * 0.5 * acc;
     }
-    cplx* ph = d.band_ph ? d.band_ph + (size_t)b * ks : nullptr;
+    cplx* ph = (!PLAIN && d.band_ph) ? d.band_ph + (size_t)b * ks : nullptr;
     const int half = steps / 2;
     const int lo = min(max(d.band_lo, 0), steps), hi = min(max(d.band_hi, 0), steps);
-    if (d.has_band) {                                                            // :47-67
+    if (!PLAIN && d.has_band) {                                                            // :47-67
         double acc = 0.0;
         for (int o = threadIdx.x; o < d.k * steps; o += blockDim.x) {
             const int kk = o / steps, f = o - kk * steps;
@@ -87,26 +120,26 @@ __global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
         const double* wk = w + (size_t)kk * steps;
         const double wv = wk[t];
         double dR = 0.0;
-        if (d.has_amp) { reg += d.a_amp * 0.5 * wv * wv; dR += d.a_amp * wv; }                    // :15-18
-        if (d.has_env) {                                                                          // :21-25
+        if (!PLAIN && d.has_amp) { reg += d.a_amp * 0.5 * wv * wv; dR += d.a_amp * wv; }                    // :15-18
+        if (!PLAIN && d.has_env) {                                                                          // :21-25
             const double e = d.omg[o];
             reg += d.a_env * 0.5 * (e * wv) * (e * wv);
             dR += d.a_env * e * e * wv;
         }
         const int p = t + 2;
-        if (d.has_dwdt) {
+        if (!PLAIN && d.has_dwdt) {
             const double dm = (padded_w(wk, steps, p) - padded_w(wk, steps, p - 1)) / dt;          // d_{p-1}
             const double dp = (padded_w(wk, steps, p + 1) - padded_w(wk, steps, p)) / dt;          // d_p
             dR += d.a_dwdt * (dm - dp) / dt;
         }
-        if (d.has_d2wdt2) {
+        if (!PLAIN && d.has_d2wdt2) {
             const double dt2 = dt * dt;
             const double e0 = (padded_w(wk, steps, p) - 2.0 * padded_w(wk, steps, p - 1) + padded_w(wk, steps, p - 2)) / dt2;      // e_{p-2}
             const double e1 = (padded_w(wk, steps, p + 1) - 2.0 * padded_w(wk, steps, p) + padded_w(wk, steps, p - 1)) / dt2;      // e_{p-1}
             const double e2 = (padded_w(wk, steps, p + 2) - 2.0 * padded_w(wk, steps, p + 1) + padded_w(wk, steps, p)) / dt2;      // e_p
             dR += d.a_d2wdt2 * (e0 - 2.0 * e1 + e2) / dt2;
         }
-        if (d.has_band) {
+        if (!PLAIN && d.has_band) {
             double acc = 0.0;
             const cplx* pk = ph + (size_t)kk * steps;
             for (int f = 0; f < half || f < lo; ++f) {
@@ -119,15 +152,20 @@ __global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
             }
             dR += d.a_band * acc;
         }
-        const double g = cos(base[o]) * (d.maxA[kk] * dLdu[o] + dR);
+        const double bv = base[o];
+        const double g = cos(bv) * (d.maxA[kk] * dLdu[o] + dR);
         grad[o] = g;
         g2 += g * g;
+        if (in_regs) {
+            const int e = (o - (int)threadIdx.x) / (int)blockDim.x;
+#pragma unroll
+            for (int q = 0; q < QF_E; ++q) if (q == e) { g_r[q] = g; b_r[q] = bv; }
+        }
     }
-    reg = block_sum(reg, red);
-    g2 = 0.5 * block_sum(g2, red);                                               // sum of tf.nn.l2_loss
-    const double loss = d.loss[b];
+    block_sum2(reg, g2, red);
+    g2 *= 0.5;                                                                   // sum of tf.nn.l2_loss
     if (threadIdx.x == 0) {
-        d.reg_loss[b] = loss + d.reg_state[b] + reg;
+        d.reg_loss[b] = loss + reg_state_v + reg;
         d.g2[b] = g2;
     }
     if (ap.mode == 0) return;
@@ -147,18 +185,29 @@ __global__ void __launch_bounds__(1024) k_finish(QocDev d, QocAdamDev ap) {
     } else {
         lr = ap.lr[b];
     }
-    tstep = d.adam_t[b] + 1;
+    tstep = adam_t0 + 1;
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
     const double lr_t = lr * sqrt(1.0 - pow(b2, (double)tstep)) / (1.0 - pow(b1, (double)tstep));
-    double* am = d.adam_m + (size_t)b * ks;
-    double* av = d.adam_v + (size_t)b * ks;
-    __syncthreads();                                                             // all reads of adam_t done
-    for (int o = threadIdx.x; o < ks; o += blockDim.x) {
-        const double g = grad[o];
-        const double mm = b1 * am[o] + (1.0 - b1) * g;
-        const double vv = b2 * av[o] + (1.0 - b2) * g * g;
-        am[o] = mm; av[o] = vv;
-        base[o] -= lr_t * mm / (sqrt(vv) + eps);
+    if (in_regs) {
+#pragma unroll
+        for (int e = 0; e < QF_E; ++e) {
+            const int o = threadIdx.x + e * blockDim.x;
+            if (o < ks) {
+                const double g = g_r[e];
+                const double mm = b1 * m_r[e] + (1.0 - b1) * g;
+                const double vv = b2 * v_r[e] + (1.0 - b2) * g * g;
+                am[o] = mm; av[o] = vv;
+                base[o] = b_r[e] - lr_t * mm / (sqrt(vv) + eps);
+            }
+        }
+    } else {
+        for (int o = threadIdx.x; o < ks; o += blockDim.x) {
+            const double g = grad[o];
+            const double mm = b1 * am[o] + (1.0 - b1) * g;
+            const double vv = b2 * av[o] + (1.0 - b2) * g * g;
+            am[o] = mm; av[o] = vv;
+            base[o] -= lr_t * mm / (sqrt(vv) + eps);
+        }
     }
     if (threadIdx.x == 0) d.adam_t[b] = tstep;
 }

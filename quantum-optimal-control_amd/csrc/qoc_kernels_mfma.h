@@ -72,3 +72,4 @@ void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s);       //
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s);    // qoc_mfma_forward.hip
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_backward.hip
 void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip: latency mode, on read-back
+void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s);      // qoc_mfma_forward.hip: latency mode, on read-back

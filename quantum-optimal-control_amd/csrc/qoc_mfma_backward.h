@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     cplx* mypad = pads + (size_t)wv * 2 * 16 * B2_LDP;
     const cplx* pad_lo = pads + (size_t)(2 * pair) * 2 * 16 * B2_LDP;
     const cplx* pad_hi = pads + (size_t)(2 * pair + 1) * 2 * 16 * B2_LDP;
-    const int item = blockIdx.x * 4 + pair;
+    const int item = blockIdx.x * (blockDim.x >> 7) + pair;           // 4 pairs per workgroup (batch) or 1 (latency mode: one item per CU)
     const bool item_ok = item < d.B * mf.C;
     const int c = item_ok ? item / d.B : 0, b = item_ok ? item - c * d.B : 0;   // chunk-major, as in k_mfma_forward2
     const bool active = item_ok && !(d.skip_done && d.done[b]);
@@ -456,7 +456,26 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     // (a 16x16x4 tile spends half of its columns on m = 8): 24 MQ MFMAs of 17 cycles instead of 24 of ~100.
     double ore[MQ], oim[MQ];
     {
-        const cplx z = d.zfin[b];
+        cplx z;
+        if (mf.latency) {
+            // latency mode: the fidelity overlap z = sum_j <w_j, psi_j(T)> (tensorflow_state.py:282-333; k_loss otherwise) is formed here,
+            // by every wave for itself (256 elements, one launch and ~5 us less on the chain); the wave of chunk 0 publishes loss and z
+            const cplx* fin = d.inter + ((size_t)b * (d.steps + 1) + d.steps) * d.n * d.m;
+            double zr = 0.0, zi = 0.0;
+            for (int o = lane; o < d.n * d.m; o += 64) {
+                const cplx f = fin[o], wv2 = d.W[o];
+                zr += f.x * wv2.x + f.y * wv2.y;
+                zi += f.y * wv2.x - f.x * wv2.y;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); }
+            z = cmake(zr, zi);
+            if (active && c == 0 && h == 0 && lane == 0) {
+                d.zfin[b] = z;
+                d.loss[b] = 1.0 - (zr * zr + zi * zi) / ((double)d.m * (double)d.m);
+                d.reg_state[b] = 0.0;
+            }
+        } else z = d.zfin[b];
         const double c0 = -2.0 / ((double)d.m * (double)d.m);
 #pragma unroll
         for (int jb = 0; jb < MQ; ++jb) {
@@ -560,7 +579,11 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
             // out-of-range (row >= n, column >= m) entries read a clamped, finite element and need no mask: they only meet
             // the zero columns of Lambda (j >= m) or the zero padding of H_k' (row >= n); a masked load would be made
             // conditional by hipcc and waited for on the spot, draining the K prefetch with it
-            const cplx p0 = psi[prow0 * d.m + jc], p1 = psi[prow1 * d.m + jc];
+            cplx p0, p1;
+            if (mf.latency) {                                                 // the forward sweep's register layout, lane-contiguous
+                const cplx* pl = mf.PsiL + ((size_t)b * d.steps + t) * (2 * MQ) * 64 + lane;
+                p0 = pl[q * 64]; p1 = pl[(MQ + q) * 64];
+            } else { p0 = psi[prow0 * d.m + jc]; p1 = psi[prow1 * d.m + jc]; }
             ps.pr[0][q] = p0.x; ps.pi[0][q] = p0.y;
             ps.pr[1][q] = p1.x; ps.pi[1][q] = p1.y;
             if (SRC) ps.own[q] = (psi - (size_t)d.n * d.m)[(h ? prow1 : prow0) * d.m + jc];    // Psi_t at this lane's costate entries

@@ -57,11 +57,12 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     mf.skew_c = 5 * 16;                            // 1280 B per chunk
     mf.skew_b = 3 * 16;                            //  768 B per seed
     const size_t nk = (size_t)d.B * ((size_t)d.steps * FR + (size_t)C * mf.skew_c + mf.skew_b), np = (size_t)d.B * C * FR;
-    mf.store_T = !((NT == 2 || NT == 3) && mf.variant != 1);     // the 4x4x4 forward sweep gathers K^T operands from fragD(K)
+    mf.store_T = !((NT == 2 || NT == 3) && mf.variant != 1) || mf.latency;     // the 4x4x4 forward sweep gathers K^T operands from fragD(K); latency mode reads transposed copies
     const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k <= 5: backward3 (5 images still fit next to its pads)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
-    if (mf.latency && (!al(&mf.GfD, (size_t)d.B * mf.NG * FR) || !al(&mf.TfD, (size_t)d.B * FR))) { msg = "MFMA path: out of device memory"; return -3; }
+    if (mf.latency && (!al(&mf.GfD, (size_t)d.B * mf.NG * FR) || !al(&mf.GfT, (size_t)d.B * mf.NG * FR) || !al(&mf.TfD, (size_t)d.B * FR) ||
+                       !al(&mf.PsiL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64))) { msg = "MFMA path: out of device memory"; return -3; }
     if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     {
         size_t total = 0;
@@ -71,6 +72,8 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         allocs.push_back(arena);
         size_t off = 0;
         for (auto& w : wanted) { *w.first = (cplx*)(arena + off); off += w.second; }
+        // column groups beyond m are never written by the forward sweep and must read as zero in the backward one
+        if (mf.PsiL && hipMemset(mf.PsiL, 0, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64 * sizeof(cplx)) != hipSuccess) { msg = "MFMA path: clearing PsiL failed"; return -2; }
     }
     const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
@@ -125,7 +128,8 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     if (NT == 2 && mf.variant != 1) {
         if (d.k <= 5) {
             const bool src = d.n_forb > 0 || d.has_speed;
-            const dim3 g3((items + 3) / 4), b3(512);
+            const int ppg = mf.latency ? 1 : 4;                          // pairs of waves per workgroup
+            const dim3 g3((items + ppg - 1) / ppg), b3(128 * ppg);
 #define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
                                else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
             if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }

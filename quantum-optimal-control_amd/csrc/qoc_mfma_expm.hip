@@ -13,8 +13,8 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
         // latency mode: K_t by one wave per slice, then the chunk products and the products of groups of G chunks
         if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_chunk4s<2, 4, true>), dim3(d.B * d.steps), dim3(64), 0, s, d, mf);
         else hipLaunchKernelGGL((k_mfma_expm_chunk4s<2, 8, true>), dim3(d.B * d.steps), dim3(64), 0, s, d, mf);
-        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.C * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr);
-        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.NG * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr);
+        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.C * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
+        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.NG * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
     }
     else if (v == 4 && NT == 2) {
         constexpr int NTS = 2;
@@ -54,6 +54,6 @@ __global__ void __launch_bounds__(64) k_mfma_unpack_final(QocDev d, QocMfma mf) 
 void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s) {
     QocDev dd = d;
     dd.skip_done = 0;                                                     // every seed's last evaluation is still in GfD
-    hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * 8), dim3(64), 0, s, dd, mf, (const cplx*)mf.GfD, 0, mf.NG, mf.NG, mf.TfD, 1, (const cplx*)mf.U0fD);
+    hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * 8), dim3(64), 0, s, dd, mf, (const cplx*)mf.GfD, 0, mf.NG, mf.NG, mf.TfD, 1, (const cplx*)mf.U0fD, (cplx*)nullptr);
     hipLaunchKernelGGL(k_mfma_unpack_final, dim3(d.B), dim3(64), 0, s, dd, mf);
 }

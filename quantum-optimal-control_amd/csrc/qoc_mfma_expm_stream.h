@@ -158,7 +158,16 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
         }
 #pragma unroll 1
         for (int kk = 0; kk < d.k; ++kk) {
-            const double ck = d.u[((size_t)b * d.k + kk) * d.steps + t0] * inv_scale;
+            double uk;
+            if constexpr (SLICES) {
+                // latency mode: the controls u = maxA sin(base) (tensorflow_state.py:176-178; k_controls otherwise) are formed here,
+                // one launch less on the chain; lane 0 publishes w and u of this slice (k_finish, read-back)
+                const size_t ci = ((size_t)b * d.k + kk) * d.steps + t0;
+                const double wk = sin(d.base[ci]);
+                uk = d.maxA[kk] * wk;
+                if (lane == 0) { d.w[ci] = wk; d.u[ci] = uk; }
+            } else uk = d.u[((size_t)b * d.k + kk) * d.steps + t0];
+            const double ck = uk * inv_scale;
             const cplx* __restrict__ HD = mf.HfD + (size_t)(kk + 1) * QFR;
 #pragma unroll
             for (int J = 0; J < NT; ++J)
@@ -248,6 +257,19 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
         if constexpr (SLICES) {
 #pragma unroll
             for (int J = 0; J < NT; ++J) colblock_store<NT>(mf.KfD + item, J, lane, X[J]);
+            // fragD(K_t^T) as well: the forward sweep of the latency mode reads its operands with lane-contiguous 1 KB loads (one wave
+            // fetches a 16 KB matrix in 0.7 us that way, in 1.8 us with the transposing gather: profiles/r02_matrix_fetch_probe.txt)
+            wave_lds_fence();
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+#pragma unroll
+                for (int ib = 0; ib < QQS; ++ib)
+                    img[(16 * J + (lane & 15)) * QLDS + 4 * ib + (lane >> 4)] = cmake(X[J][ib >> 2].re[ib & 3], X[J][ib >> 2].im[ib & 3]);
+            wave_lds_fence();
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+#pragma unroll
+                for (int q = 0; q < QQS; ++q) mf.KfT[item + (J * QQS + q) * 64 + lane] = img[(4 * q + (lane >> 4)) * QLDS + 16 * J + (lane & 15)];
             return;
         }
         strip_sums<NT>(R, Rs);
@@ -397,7 +419,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_chain_products(QocDev d, QocMfma
 // one matrix ahead.  48 MFMAs per product and wave instead of 384: a chain of 7 products takes ~4 us instead of ~23.
 template <int NT>
 __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, const cplx* __restrict__ IN, int in_is_K, int count, int len,
-                                                        cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail) {
+                                                        cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail, cplx* __restrict__ OUTT) {
     static_assert(NT == 2, "row-split chain products: n <= 32");
     constexpr int PS = 5;                                            // pad stride (complex elements per column): conflict-free stores and block reads
     __shared__ __attribute__((aligned(16))) cplx pad[QNP * PS];
@@ -465,4 +487,13 @@ __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, co
     cplx* out = OUT + ((size_t)b * nout + i) * QFR;
 #pragma unroll
     for (int J = 0; J < NT; ++J) out[(J * QQS + w) * 64 + lane] = r[J];
+    if (OUTT) {                                                      // fragD(P^T): this wave's rows are columns there (scattered 16 B stores)
+        cplx* outt = OUTT + ((size_t)b * nout + i) * QFR;
+        const int row = 4 * w + lk;
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            const int col = 16 * J + lc;                             // P[row][col] = P^T[col][row] -> fragment (row >> 4, col >> 2), lane 16 (col & 3) + (row & 15)
+            outt[((row >> 4) * QQS + (col >> 2)) * 64 + 16 * (col & 3) + (row & 15)] = r[J];
+        }
+    }
 }

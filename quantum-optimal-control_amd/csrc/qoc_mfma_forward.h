@@ -86,9 +86,11 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
     __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // colsplit > 1: one wave per group of 4 columns of Psi (they are independent under left multiplication; MQ = 1).  Measured on
-    // one C2 trajectory: no gain (43 us either way) -- a step is bound by the fetch of its 16 KB matrix, not by its 24 MQ MFMAs
-    const int item = (blockIdx.x * 4 + wv) / colsplit, jq0 = (blockIdx.x * 4 + wv) - item * colsplit;
+    // colsplit > 1 (latency mode): one wave per group of 4 columns of Psi (they are independent under left multiplication; MQ = 1):
+    // 48 instead of 96 MFMAs per step on the dependent chain
+    const int wpg = blockDim.x >> 6;                                  // waves per workgroup: 4 (batch), 1 in latency mode -- one wave per CU, so
+                                                                      // that no two sweeps share a CU's 64 B/clk load path (4 x 16 KB per step did)
+    const int item = (blockIdx.x * wpg + wv) / colsplit, jq0 = (blockIdx.x * wpg + wv) - item * colsplit;
     const int n_sweep = d.B * mf.C;
     if (item < n_sweep) {
         const int c = item / d.B, b = item - c * d.B;      // chunk-major: the waves of a workgroup walk 4 different seeds
@@ -111,12 +113,23 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
             for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
         }
         struct Frag { cplx f[NT][QQS]; };
+        // the operand is M^T in strip registers.  Batch mode gathers it from fragD(M) (no transposed copy of the 512 MB of K: the sweep is
+        // bound by the HBM stream there); latency mode reads the transposed copies KfT / PfT / GfT with lane-contiguous 1 KB loads (one
+        // wave brings a 16 KB matrix in 0.7 us that way, 1.8 us with the gather: profiles/r02_matrix_fetch_probe.txt)
+        const bool tsrc = mf.latency;
         auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
+            if (tsrc) {
 #pragma unroll
-            for (int I = 0; I < NT; ++I)
+                for (int I = 0; I < NT; ++I)
 #pragma unroll
-                for (int q = 0; q < QQS; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
-                    fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
+                    for (int q = 0; q < QQS; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+#pragma unroll
+                    for (int q = 0; q < QQS; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
+                        fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
+            }
         };
         // Psi <- M Psi with M^T given by its fragD fragment
         auto product = [&](const Frag& fr) {
@@ -160,7 +173,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
             const int n_grp = G ? g : 0, n_bnd = n_grp + (c - (G ? g * G : 0));
             auto bnd_ptr = [&](int i) -> const cplx* {
                 i = min(i, n_bnd - 1);
-                return i < n_grp ? mf.GfD + ((size_t)b * mf.NG + i) * QFR : mf.PfD + ((size_t)b * mf.C + (G ? g * G : 0) + (i - n_grp)) * QFR;
+                return i < n_grp ? (tsrc ? mf.GfT : mf.GfD) + ((size_t)b * mf.NG + i) * QFR : (tsrc ? mf.PfT : mf.PfD) + ((size_t)b * mf.C + (G ? g * G : 0) + (i - n_grp)) * QFR;
             };
             if (n_bnd > 0) {
                 constexpr int PD = 2;                                   // matrices in flight ahead of the product (4: slower -- every wave
@@ -182,6 +195,18 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
         }
         auto step = [&](const Frag& fr, int t) {
             product(fr);
+            if (tsrc) {
+                // latency mode: Psi_t goes out in this kernel's own register layout (lane-contiguous 1 KB stores; k_mfma_backward3 holds
+                // Psi in the same layout) -- the scattered 16 B stores of the API layout are as slow in the load/store path as the
+                // gathers; d.inter gets only the last slice (k_loss reads it), the rest is unpacked when read back
+                const int MQs = mf.mq <= 2 ? 2 : 4;                         // column groups per slice as k_mfma_backward3 reads them
+                cplx* pl = mf.PsiL + ((size_t)b * d.steps + t) * (NT * MQs) * 64;
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+#pragma unroll
+                    for (int jb = 0; jb < MQ; ++jb) pl[(I * MQs + jb + jq0) * 64 + lane] = cmake(pre[I][jb], pim[I][jb]);
+                if (t + 1 < d.steps) return;
+            }
             cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
 #pragma unroll
             for (int I = 0; I < NT; ++I)
@@ -191,7 +216,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
                     if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I][jb], pim[I][jb]);
                 }
         };
-        const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);             // slices of one chunk are FR apart
+        const cplx* Kb = (tsrc ? mf.KfT : mf.KfD) + kitem(mf, d.steps, b, t0);   // slices of one chunk are FR apart
         const int len = t1 - t0;
         {
         // (latency mode: three slices in flight instead of one was SLOWER, 19 vs 15 us for 8 slices -- the fetch of a 16 KB matrix
@@ -243,3 +268,18 @@ __global__ void __launch_bounds__(64) k_mfma_uscale(QocDev d) {
     if (lane == 0) d.uscale[b] = part / (double)n;
 }
 
+
+// latency mode: d.inter[b][t + 1] (API layout, analysis.py:60) from PsiL[b][t]; launched when the vectors are read back
+__global__ void __launch_bounds__(256) k_mfma_unpack_inter(QocDev d, QocMfma mf, int MQ) {
+    const int NT = mf.NT, per = NT * MQ;
+    const size_t total = (size_t)d.B * d.steps * per * 64;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(o & 63);
+        const size_t rg = o >> 6;
+        const int r = (int)(rg % per);
+        const size_t bt = rg / per;
+        const int I = r / MQ, jb = r - I * MQ, row = 16 * I + (lane & 15), col = 4 * jb + (lane >> 4);
+        const size_t b = bt / d.steps, t = bt - b * d.steps;
+        if (row < d.n && col < d.m) d.inter[(b * (d.steps + 1) + t + 1) * d.n * d.m + (size_t)row * d.m + col] = mf.PsiL[o];
+    }
+}

@@ -7,8 +7,10 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 2 && mf.variant != 1) {
         // 4x4x4 sweep; like the backward choice this must not depend on the batch size (bit-identical seeds across shardings)
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 1);
-        else hipLaunchKernelGGL((k_mfma_forward2<2, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 1);
+        const int wpg = mf.latency ? 1 : 4;                              // latency mode: one sweep per workgroup, i.e. per CU
+        if (mf.latency) hipLaunchKernelGGL((k_mfma_forward2<2, 1>), dim3(items * mf.mq), dim3(64), 0, s, d, mf, mf.mq);   // and per 4 columns
+        else if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf, 1);
+        else hipLaunchKernelGGL((k_mfma_forward2<2, 4>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf, 1);
     }
     else if (mf.NT == 3 && mf.variant != 1) {
         if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 1);
@@ -18,4 +20,8 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     if (!d.uscale_in_loss && !mf.latency) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
+}
+
+void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    hipLaunchKernelGGL(k_mfma_unpack_inter, dim3(512), dim3(256), 0, s, d, mf, mf.mq <= 2 ? 2 : 4);
 }

@@ -19,7 +19,7 @@ print('%.1f' % ((time.perf_counter() - t0) / 300 * 1e6))
 path, variant = sys.argv[1], sys.argv[2]
 names = {0: 'nothing skipped', 1: 'k_controls', 2: 'exponentials (+ chain products)', 4: 'forward', 8: 'k_loss', 16: 'backward', 32: 'k_finish', 63: 'everything (empty loop)', 64: 'NOTHING, forward launched twice', 192: 'NOTHING, forward twice + backward-before-loss extra'}
 base = None
-for m in (0, 4, 64, 16):
+for m in (0, 1, 2, 4, 8, 16, 32):
     r = subprocess.run([sys.executable, '-c', code, path, variant], env=dict(os.environ, QOC_DEBUG_SKIP=str(m)), capture_output=True, text=True)
     us = float(r.stdout.strip().splitlines()[-1])
     base = us if base is None else base
