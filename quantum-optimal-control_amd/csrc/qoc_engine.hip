@@ -24,7 +24,7 @@
 #include "qoc_kernels_gemm.h"
 
 #ifndef QOC_LATENCY_MAX_SEEDS
-#define QOC_LATENCY_MAX_SEEDS 16        // measured on C2 (profiles/r02_latency_sweep.txt): latency mode wins up to 16 seeds, the batch kernels from 24 on
+#define QOC_LATENCY_MAX_SEEDS 12        // measured on C2 (profiles/r02_latency_sweep.txt): latency mode wins up to 12 seeds, the GEMM route at 16, the batch kernels from 24 on
 #endif
 static thread_local std::string g_err;
 
@@ -610,7 +610,7 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     TRY(prof_collect(e));
     if (kernel_name)
         *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm32 (batched matexp sequence)")
-                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 5 ? "k_mfma_expm_chunk4s (one wave per slice) + k_mfma_chain_products" : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
+                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 5 ? "k_mfma_expm_slice2 + k_mfma_chain_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
                        : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;

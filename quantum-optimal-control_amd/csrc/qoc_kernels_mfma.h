@@ -52,8 +52,8 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
 }
 
 // which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave, image written before each product,
-// 4 = 4x4x4 one wave, image written strip by strip under the product's own MFMAs, 5 = latency mode: kernel 4 with one wave per
-// slice + k_mfma_chain_products)
+// 4 = 4x4x4 one wave, image written strip by strip under the product's own MFMAs, 5 = latency mode: two waves per
+// slice (k_mfma_expm_slice2) + k_mfma_chain_rows)
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     if (mf.NT > 2) return mf.variant == 1 ? 1 : 2;      // n > 32: NT waves per item on 4x4x4 (n = 48 x 64: 4.3 vs 11.9 ms per launch)
     if (mf.latency) return 5;

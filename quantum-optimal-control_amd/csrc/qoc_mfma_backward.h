@@ -428,8 +428,8 @@ __global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
 //  * control gradients: 16-lane DPP butterflies, the 4 row partials of both waves go through LDS and lane kk of wave h = 0
 //    adds the 8 partials of control kk (was: six ds_bpermute levels per control).
 // Used for k <= 4 controls without state regularisers (no per-slice source term); anything else keeps backward2.
-template <int MQ, bool SRC, int KC = 4>
-__global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
+template <int MQ, bool SRC, int KC = 4, bool LAT = false>
+__global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, QocMfma mf) {
     constexpr int NT = 2;                                                       // KC = control images in LDS: 4, or 5 (k = 5 still fits the 160 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     double ore[MQ], oim[MQ];
     {
         cplx z;
-        if (mf.latency) {
+        if constexpr (LAT) {
             // latency mode: the fidelity overlap z = sum_j <w_j, psi_j(T)> (tensorflow_state.py:282-333; k_loss otherwise) is formed here,
             // by every wave for itself (256 elements, one launch and ~5 us less on the chain); the wave of chunk 0 publishes loss and z
             const cplx* fin = d.inter + ((size_t)b * (d.steps + 1) + d.steps) * d.n * d.m;
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
             if (s < n_steps) bstep(f0, keep_of(s), idx_of(s));
         };
         const cplx* Pb = mf.PfD + (size_t)b * mf.C * QFR;
-        if (mf.G > 1) {
+        if constexpr (LAT) {
             const int G = mf.G, NG = mf.NG, g = c / G, C = mf.C;
             bsteps(mf.GfD + (size_t)b * NG * QFR, NG - 1, [&](int s) { return NG - 1 - s; }, [&](int s) { return NG - 1 - s > g; });
             bsteps(Pb, G - 1, [&](int s) { return min(g * G + G - 1 - s, C - 1); }, [&](int s) { const int cc = g * G + G - 1 - s; return cc < C && cc > c; });
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
             // the zero columns of Lambda (j >= m) or the zero padding of H_k' (row >= n); a masked load would be made
             // conditional by hipcc and waited for on the spot, draining the K prefetch with it
             cplx p0, p1;
-            if (mf.latency) {                                                 // the forward sweep's register layout, lane-contiguous
+            if constexpr (LAT) {                                                 // the forward sweep's register layout, lane-contiguous
                 const cplx* pl = mf.PsiL + ((size_t)b * d.steps + t) * (2 * MQ) * 64 + lane;
                 p0 = pl[q * 64]; p1 = pl[(MQ + q) * 64];
             } else { p0 = psi[prow0 * d.m + jc]; p1 = psi[prow1 * d.m + jc]; }
@@ -644,6 +644,20 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         double g[KC];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) g[kk] = 0.0;
+        // The H_k' images do not depend on the MFMA results.  Latency mode (one pair of waves per CU, 512 registers per lane) issues
+        // all their LDS reads as one batch ahead of the MFMAs that form Q; left to itself hipcc reads them one at a time with every
+        // wait exposed (5 us of the 40 of a one-trajectory sweep).  The batch kernels have no registers to stage them in (8 waves
+        // per CU, 256 per lane: staging 16 reads spills and costs 60 %) and other waves to hide the waits behind.
+        cplx hq[LAT ? 2 : 1][KC][4];
+        if constexpr (LAT) {
+#pragma unroll
+            for (int Jp = 0; Jp < 2; ++Jp)
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hq[Jp][kk][r] = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int Jp = 0; Jp < 2; ++Jp) {
             d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
@@ -659,7 +673,9 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
                 double acc = 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const cplx hv = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
+                    cplx hv;
+                    if constexpr (LAT) hv = hq[Jp][kk][r];
+                    else hv = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
                     acc = fma(hv.x, qr[r], acc);
                     acc = fma(-hv.y, qi[r], acc);
                 }

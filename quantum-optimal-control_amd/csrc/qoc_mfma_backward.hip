@@ -84,10 +84,13 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         const int kc = d.k == 5 ? 5 : 4;
         mf.bwd_lds3 = (size_t)kc * FR * sizeof(cplx) + (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 2 * 4 * kc * sizeof(double);
     }
-    const void* b3k = d.k == 5 ? (mf.mq <= 2 ? ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<2, true, 5> : (const void*)k_mfma_backward3<2, false, 5>)
-                                             : ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<4, true, 5> : (const void*)k_mfma_backward3<4, false, 5>))
-                               : (mf.mq <= 2 ? ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<2, true, 4> : (const void*)k_mfma_backward3<2, false, 4>)
-                                             : ((d.n_forb > 0 || d.has_speed) ? (const void*)k_mfma_backward3<4, true, 4> : (const void*)k_mfma_backward3<4, false, 4>));
+    const bool b3src = d.n_forb > 0 || d.has_speed;
+    const void* b3k = nullptr;
+#define QOC_B3K(MQv, KCv) (mf.latency ? (const void*)k_mfma_backward3<MQv, false, KCv, true> \
+                                      : b3src ? (const void*)k_mfma_backward3<MQv, true, KCv> : (const void*)k_mfma_backward3<MQv, false, KCv>)
+    if (d.k == 5) b3k = mf.mq <= 2 ? QOC_B3K(2, 5) : QOC_B3K(4, 5);
+    else b3k = mf.mq <= 2 ? QOC_B3K(2, 4) : QOC_B3K(4, 4);
+#undef QOC_B3K
     if (NT == 2 && hipFuncSetAttribute(b3k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
         return -2;
@@ -130,10 +133,11 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
             const bool src = d.n_forb > 0 || d.has_speed;
             const int ppg = mf.latency ? 1 : 4;                          // pairs of waves per workgroup
             const dim3 g3((items + ppg - 1) / ppg), b3(128 * ppg);
-#define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
-                               else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
-            if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
-            else { if (src) QOC_B3(4, true); else QOC_B3(4, false); }
+#define QOC_B3(MQv, SRCv, LATv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5, LATv>), g3, b3, mf.bwd_lds3, s, d, mf); \
+                               else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4, LATv>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
+            if (mf.latency) { if (mf.mq <= 2) QOC_B3(2, false, true); else QOC_B3(4, false, true); }   // latency mode has no state regulariser
+            else if (mf.mq <= 2) { if (src) QOC_B3(2, true, false); else QOC_B3(2, false, false); }
+            else { if (src) QOC_B3(4, true, false); else QOC_B3(4, false, false); }
 #undef QOC_B3
             return;
         }

@@ -1,4 +1,5 @@
 // qoc_mfma_expm.hip -- translation unit of the MFMA-path exponential kernels (qoc_mfma_expm.h) and their launcher.
+#include <cstdlib>
 #include "qoc_kernels_mfma.h"
 #include "qoc_mfma_expm.h"
 #include "qoc_mfma_expm_stream.h"
@@ -10,9 +11,9 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
     const int v = qoc_mfma_expm_variant(mf, d);
     if (v == 5 && NT == 2) {
-        // latency mode: K_t by one wave per slice, then the chunk products and the products of groups of G chunks
-        if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_chunk4s<2, 4, true>), dim3(d.B * d.steps), dim3(64), 0, s, d, mf);
-        else hipLaunchKernelGGL((k_mfma_expm_chunk4s<2, 8, true>), dim3(d.B * d.steps), dim3(64), 0, s, d, mf);
+        // latency mode: K_t by two waves per slice, then the chunk products and the products of groups of G chunks
+        if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_slice2<4>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);
+        else hipLaunchKernelGGL(k_mfma_expm_slice2<8>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);
         hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.C * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
         hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.NG * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
     }

@@ -114,17 +114,15 @@ __device__ __forceinline__ void mm_stream(cplx* img, double* imgs, int lane, con
 
 struct NoHook { template <class S> __device__ __forceinline__ void operator()(S) const {} };
 
-// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient).
-// SLICES (latency mode, few seeds): one wave per (seed, SLICE) computes K_t only -- the chunk products come from
-// k_mfma_chain_products, so that 500 slices of one trajectory are 500 waves instead of 16 chunks of 32 dependent slices.
-template <int NT, int KC, bool SLICES = false>
+// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient)
+template <int NT, int KC>
 __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma mf) {
     __shared__ __attribute__((aligned(16))) cplx img[QNP * QLDS];
     __shared__ __attribute__((aligned(16))) double imgs[QNP * QLDS];
     const int lane = threadIdx.x;
-    const int b = SLICES ? blockIdx.x / d.steps : blockIdx.x / mf.C, c = SLICES ? blockIdx.x - b * d.steps : blockIdx.x - b * mf.C;
+    const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
     if (d.skip_done && d.done[b]) return;
-    const int t0 = SLICES ? c : c * mf.L, t1 = SLICES ? c + 1 : min(t0 + mf.L, d.steps);
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
     const double inv_scale = 1.0 / (double)(1 << d.s);
     const int dlt = (lane & 15) - (lane >> 4);
     constexpr int NSTRIP = NT * QQS;
@@ -158,16 +156,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
         }
 #pragma unroll 1
         for (int kk = 0; kk < d.k; ++kk) {
-            double uk;
-            if constexpr (SLICES) {
-                // latency mode: the controls u = maxA sin(base) (tensorflow_state.py:176-178; k_controls otherwise) are formed here,
-                // one launch less on the chain; lane 0 publishes w and u of this slice (k_finish, read-back)
-                const size_t ci = ((size_t)b * d.k + kk) * d.steps + t0;
-                const double wk = sin(d.base[ci]);
-                uk = d.maxA[kk] * wk;
-                if (lane == 0) { d.w[ci] = wk; d.u[ci] = uk; }
-            } else uk = d.u[((size_t)b * d.k + kk) * d.steps + t0];
-            const double ck = uk * inv_scale;
+            const double ck = d.u[((size_t)b * d.k + kk) * d.steps + t0] * inv_scale;
             const cplx* __restrict__ HD = mf.HfD + (size_t)(kk + 1) * QFR;
 #pragma unroll
             for (int J = 0; J < NT; ++J)
@@ -254,24 +243,6 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
         }
         // ---- K_t out; chunk product R <- K_t * R (image <- K_t), A_{t+1} assembled under these MFMAs --------------------
         const size_t item = kitem(mf, d.steps, b, t);
-        if constexpr (SLICES) {
-#pragma unroll
-            for (int J = 0; J < NT; ++J) colblock_store<NT>(mf.KfD + item, J, lane, X[J]);
-            // fragD(K_t^T) as well: the forward sweep of the latency mode reads its operands with lane-contiguous 1 KB loads (one wave
-            // fetches a 16 KB matrix in 0.7 us that way, in 1.8 us with the transposing gather: profiles/r02_matrix_fetch_probe.txt)
-            wave_lds_fence();
-#pragma unroll
-            for (int J = 0; J < NT; ++J)
-#pragma unroll
-                for (int ib = 0; ib < QQS; ++ib)
-                    img[(16 * J + (lane & 15)) * QLDS + 4 * ib + (lane >> 4)] = cmake(X[J][ib >> 2].re[ib & 3], X[J][ib >> 2].im[ib & 3]);
-            wave_lds_fence();
-#pragma unroll
-            for (int J = 0; J < NT; ++J)
-#pragma unroll
-                for (int q = 0; q < QQS; ++q) mf.KfT[item + (J * QQS + q) * 64 + lane] = img[(4 * q + (lane >> 4)) * QLDS + 16 * J + (lane & 15)];
-            return;
-        }
         strip_sums<NT>(R, Rs);
         {
             const int tn = min(t + 1, d.steps - 1);
@@ -360,58 +331,10 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
     QOC_LAP_DONE
 }
 
-// ---- chain products in fragD format (latency mode): OUT[b][i] = IN[b][i*len + len' - 1] ... IN[b][i*len], len' = min(len, count - i*len).
-// Used twice per iteration: chunk products P_c from the slice propagators (len = L), group products from the chunk products
-// (len = G).  One wave per output; the running product is the LEFT operand (R <- R * M_t, t descending): its image is written
-// strip by strip under the MFMAs like every other left operand here, and the right operand M_t comes straight from global memory
-// as strip registers (fragD IS the strip layout), fetched while the previous product runs.
-// in_is_K: IN is the K storage (kitem addressing with its skews), else a plain [B][count] array of fragD matrices.
-template <int NT>
-__global__ void __launch_bounds__(64, 1) k_mfma_chain_products(QocDev d, QocMfma mf, const cplx* __restrict__ IN, int in_is_K, int count, int len,
-                                                                cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail) {
-    __shared__ __attribute__((aligned(16))) cplx img[QNP * QLDS];
-    __shared__ __attribute__((aligned(16))) double imgs[QNP * QLDS];
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x / nout, i = blockIdx.x - b * nout;
-    if (d.skip_done && d.done[b]) return;
-    // `tail` (one fragD matrix shared by all seeds, e.g. U0) multiplies from the right after the chain: element lo - 1
-    const int hi = min(i * len + len, count) - 1, lo = i * len - (tail ? 1 : 0);
-    auto src = [&](int t) -> const cplx* { return (tail && t < i * len) ? tail : (in_is_K ? IN + kitem(mf, d.steps, b, t) : IN + ((size_t)b * count + t) * QFR); };
-    CTile R[NT][NT], M[NT][NT];
-    Sums<NT> Rs, Ms;
-    double a[NT][QQS], bb[NT][QQS], cc[NT][QQS];
-#pragma unroll
-    for (int J = 0; J < NT; ++J) colblock_load<NT>(src(hi), J, lane, R[J]);
-    if (hi > lo) {
-#pragma unroll
-        for (int J = 0; J < NT; ++J) colblock_load<NT>(src(hi - 1), J, lane, M[J]);
-    }
-    strip_sums<NT>(R, Rs);
-    strip_store<NT>(img, imgs, lane, R, Rs, 0, 0);
-    lds_order();
-    for (int t = hi - 1; t >= lo; --t) {
-        strip_sums<NT>(M, Ms);
-        mm_stream<NT, true>(img, imgs, lane, R, Rs, M, Ms, a, bb, cc, NoHook{});
-        if (t > lo) {                                                     // next right operand: in flight under the VALU batch and the next product's head
-#pragma unroll
-            for (int J = 0; J < NT; ++J) colblock_load<NT>(src(t - 1), J, lane, M[J]);
-        }
-#pragma unroll
-        for (int J = 0; J < NT; ++J)
-#pragma unroll
-            for (int ib = 0; ib < QQS; ++ib) {
-                const double re = a[J][ib] - bb[J][ib], im = cc[J][ib] - a[J][ib] - bb[J][ib];
-                R[J][ib >> 2].re[ib & 3] = re; R[J][ib >> 2].im[ib & 3] = im;
-                Rs.v[J][ib] = re + im;
-                if (J == 0 && ib == 0) { strip_store<NT>(img, imgs, lane, R, Rs, 0, 0); lds_order(); }
-            }
-    }
-    cplx* out = OUT + ((size_t)b * nout + i) * QFR;
-#pragma unroll
-    for (int J = 0; J < NT; ++J) colblock_store<NT>(out, J, lane, R[J]);
-}
-
-// ---- the same chain products, ROW-SPLIT over 8 waves per output (latency mode) ------------------------------------------------
+// ---- chain products in fragD format (latency mode): OUT[b][i] = IN[b][i*len + len' - 1] ... IN[b][i*len], len' = min(len, count - i*len);
+// `tail` (one matrix shared by all seeds, e.g. U0) multiplies from the right after the chain.  Used twice per iteration (chunk products
+// P_c from the slice propagators, group products from the chunk products) and once per read-back (final_state).  in_is_K: IN is the K
+// storage (kitem addressing with its skews), else a plain [B][count] array.  ROW-SPLIT over 8 waves per output:
 // R <- R * M_t needs, for the rows 4w .. 4w+3 of the result, only the SAME rows of R as left operand (4x4 blocks of those rows
 // against the strips of M_t): wave w therefore carries its four rows through the whole chain alone -- no shared image, no barrier.
 // Its two result strips go through a wave-private 4-row transposition pad (2.5 KB + sums) to become the left blocks of the next
@@ -496,4 +419,156 @@ __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, co
             outt[((row >> 4) * QQS + (col >> 2)) * 64 + 16 * (col & 3) + (row & 15)] = r[J];
         }
     }
+}
+
+// ---- latency mode: K_t by TWO waves per slice (one per 16-column block), n <= 32 -------------------------------------------------
+// Left multiplication acts on column blocks independently, so wave J carries column block J of every matrix of the slice in 8 strip
+// registers and needs the other wave only for the LEFT operand: both publish their strips of it into one of two LDS images (one
+// barrier per product), then each runs the 64 block steps with 3 MFMAs per step.  192 instead of 384 MFMAs per product on the
+// dependent chain of 6 products, half the assembly and half the epilogue per wave: 32 -> ~17 us for the 500 slices of one C2
+// trajectory (two waves per slice = 1000 waves, one per SIMD).  Also forms the controls and stores fragD(K_t) and fragD(K_t^T).
+// Measured per launch for one C2 trajectory: one wave per slice 34.2 us, this kernel 25.5 us, four waves per slice (column block x
+// row half, two barriers per product) 27.1 us -- beyond two waves the kernel is bound by its ~4 us of cold first loads after the
+// kernel boundary and by the publish / barrier / fetch latency of each product, not by its MFMAs (device-side clocks: assembly 4.2 us,
+// first product 1.3 us, the other five 7.3-10 us, output 0.6 us in the four-wave variant).
+template <int KC>
+__global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) {
+    constexpr int NT = 2;
+    __shared__ __attribute__((aligned(16))) cplx img[2][QNP * QLDS];
+    __shared__ __attribute__((aligned(16))) double imgs[2][QNP * QLDS];
+    const int lane = threadIdx.x & 63;
+    const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / d.steps, t = blockIdx.x - b * d.steps;
+    if (d.skip_done && d.done[b]) return;                               // whole workgroup: no barrier yet
+    const double inv_scale = 1.0 / (double)(1 << d.s);
+    const int dlt = (lane & 15) - (lane >> 4);
+    double idv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) idv[r] = dlt == 4 * r ? 1.0 : 0.0;
+    const int mm = d.T >> 1;
+    const bool even = (d.T & 1) == 0;
+    const int nH = even ? mm - 1 : mm;
+    const double p_c0 = even ? mf.invfact[2 * mm - 2] : mf.invfact[2 * mm], p_c1 = even ? mf.invfact[2 * mm - 1] : mf.invfact[2 * mm + 1];
+    const double p_cT = even ? mf.invfact[d.T] : 0.0;
+    struct Col { double re[QQS], im[QQS], su[QQS]; };                   // column block J: strip ib = rows 4 ib .. 4 ib + 3, plus re + im
+    // ---- A_t, own column block: every load first (one round trip to the L2-resident stack), controls meanwhile -------------------
+    cplx hst[KC + 1][QQS];
+#pragma unroll
+    for (int kk = 0; kk <= KC; ++kk) {
+        const cplx* H = mf.HfD + (size_t)(kk <= d.k ? kk : 0) * QFR + (J * QQS) * 64 + lane;
+#pragma unroll
+        for (int ib = 0; ib < QQS; ++ib) hst[kk][ib] = H[ib * 64];
+    }
+    double ck[KC], bs0[KC], ma[KC];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {                                   // every load first, unconditionally (clamped): ONE round trip, not k
+        const int kc = kk < d.k ? kk : 0;
+        bs0[kk] = d.base[((size_t)b * d.k + kc) * d.steps + t];
+        ma[kk] = d.maxA[kc];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {                                   // u = maxA sin(base)   tensorflow_state.py:176-178
+        const double wk = sin(bs0[kk]);
+        const double uk = ma[kk] * wk;
+        if (kk < d.k && J == 0 && lane == 0) { const size_t ci = ((size_t)b * d.k + kk) * d.steps + t; d.w[ci] = wk; d.u[ci] = uk; }
+        ck[kk] = kk < d.k ? uk * inv_scale : 0.0;
+    }
+    Col A, X;
+#pragma unroll
+    for (int ib = 0; ib < QQS; ++ib) {
+        double re = hst[0][ib].x * inv_scale, im = hst[0][ib].y * inv_scale;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) { re = fma(ck[kk], hst[kk + 1][ib].x, re); im = fma(ck[kk], hst[kk + 1][ib].y, im); }
+        A.re[ib] = re; A.im[ib] = im; A.su[ib] = re + im;
+    }
+    int cur = 0;
+    auto publish = [&](const Col& m) {                                  // own strips of the next left operand -> image `cur`, then meet the partner
+#pragma unroll
+        for (int ib = 0; ib < QQS; ++ib) {
+            const int o = (16 * J + (lane & 15)) * QLDS + 4 * ib + (lane >> 4);
+            img[cur][o] = cmake(m.re[ib], m.im[ib]);
+            imgs[cur][o] = m.su[ib];
+        }
+        lds_barrier();
+    };
+    double a[QQS], bq[QQS], cq[QQS];
+    auto product = [&](const Col& p) {                                  // acc = (image cur) * p; the other image is free for the next publish
+        const cplx* base = img[cur] + (lane >> 4) * QLDS + (lane & 3);
+        const double* bases = imgs[cur] + (lane >> 4) * QLDS + (lane & 3);
+        constexpr int NS = QQS * QQS, RA = 3, RS = RA + 1;
+        cplx vb[RS]; double sb[RS];
+        auto fetch = [&](int st, int slot) {
+            const int kb = st / QQS, ib = st % QQS;
+            vb[slot] = base[4 * kb * QLDS + 4 * ib];
+            sb[slot] = bases[4 * kb * QLDS + 4 * ib];
+        };
+#pragma unroll
+        for (int st = 0; st < RA; ++st) fetch(st, st);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int kb = st / QQS, ib = st % QQS;
+            if (st + RA < NS) fetch(st + RA, (st + RA) % RS);
+            lds_order();
+            const cplx v = vb[st % RS];
+            const double vs = sb[st % RS];
+            if (kb == 0) {
+                a[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, p.re[kb], 0.0, 0, 0, 0);
+                bq[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, p.im[kb], 0.0, 0, 0, 0);
+                cq[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, p.su[kb], 0.0, 0, 0, 0);
+            } else {
+                a[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, p.re[kb], a[ib], 0, 0, 0);
+                bq[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, p.im[kb], bq[ib], 0, 0, 0);
+                cq[ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, p.su[kb], cq[ib], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+    };
+    auto diag = [&](int ib) { return ((ib >> 2) == J) ? idv[ib & 3] : 0.0; };
+    // ---- A2 = A * A, polynomial start ------------------------------------------------------------------------------------------
+    publish(A);
+    product(A);
+    {
+        Col A2;
+#pragma unroll
+        for (int ib = 0; ib < QQS; ++ib) {
+            const double re = a[ib] - bq[ib], im = cq[ib] - a[ib] - bq[ib];
+            A2.re[ib] = re; A2.im[ib] = im; A2.su[ib] = re + im;
+            X.re[ib] = fma(p_cT, re, fma(p_c1, A.re[ib], p_c0 * diag(ib)));
+            X.im[ib] = fma(p_cT, im, p_c1 * A.im[ib]);
+            X.su[ib] = X.re[ib] + X.im[ib];
+        }
+        if (nH > 0) {
+            publish(A2);                                                // image of A2 stays through the Horner products
+            for (int i = nH - 1; i >= 0; --i) {
+                product(X);
+                cur ^= 1;                                               // same image again
+                const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
+#pragma unroll
+                for (int ib = 0; ib < QQS; ++ib) {
+                    X.re[ib] = (a[ib] - bq[ib]) + fma(d1, A.re[ib], d0 * diag(ib));
+                    X.im[ib] = fma(d1, A.im[ib], cq[ib] - a[ib] - bq[ib]);
+                    X.su[ib] = X.re[ib] + X.im[ib];
+                }
+            }
+            cur ^= 1;                                                   // the next publish must not overwrite A2 while the partner still reads it
+        }
+    }
+    // ---- squarings ---------------------------------------------------------------------------------------------------------------
+    for (int sq = 0; sq < d.s; ++sq) {
+        publish(X);
+        product(X);
+#pragma unroll
+        for (int ib = 0; ib < QQS; ++ib) {
+            const double re = a[ib] - bq[ib], im = cq[ib] - a[ib] - bq[ib];
+            X.re[ib] = re; X.im[ib] = im; X.su[ib] = re + im;
+        }
+    }
+    // ---- K_t out: fragD(K) from the registers, fragD(K^T) through the image ------------------------------------------------------------
+    const size_t item = kitem(mf, d.steps, b, t);
+#pragma unroll
+    for (int ib = 0; ib < QQS; ++ib) mf.KfD[item + (J * QQS + ib) * 64 + lane] = cmake(X.re[ib], X.im[ib]);
+    publish(X);
+#pragma unroll
+    for (int q = 0; q < QQS; ++q) mf.KfT[item + (J * QQS + q) * 64 + lane] = img[cur][(4 * q + (lane >> 4)) * QLDS + 16 * J + (lane & 15)];
 }

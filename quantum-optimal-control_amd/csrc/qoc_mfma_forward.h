@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
 // tile spends half of its columns on m = 8) -- 48 MQ MFMAs of 17 cycles per slice instead of 48 of ~100.  K_{t+1} is fetched
 // while slice t multiplies.  Final-unitary waves as in k_mfma_forward.
 
-template <int NT, int MQ>
+// TSRC (latency mode) is a template flag, not a run-time branch: a conditional load inside the sweep makes hipcc wait for it on the
+// spot (batch sweep 173 -> 183 us with `if (mf.latency)` around the two load patterns)
+template <int NT, int MQ, bool TSRC = false>
 __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int colsplit) {
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
@@ -116,9 +118,9 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
         // the operand is M^T in strip registers.  Batch mode gathers it from fragD(M) (no transposed copy of the 512 MB of K: the sweep is
         // bound by the HBM stream there); latency mode reads the transposed copies KfT / PfT / GfT with lane-contiguous 1 KB loads (one
         // wave brings a 16 KB matrix in 0.7 us that way, 1.8 us with the gather: profiles/r02_matrix_fetch_probe.txt)
-        const bool tsrc = mf.latency;
+        constexpr bool tsrc = TSRC;
         auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
-            if (tsrc) {
+            if constexpr (tsrc) {
 #pragma unroll
                 for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -164,7 +166,6 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) { pre[I][jb] = a[I][jb] - bq[I][jb]; pim[I][jb] = cq[I][jb] - a[I][jb] - bq[I][jb]; }
         };
-        Frag A, A1;
         // chunk-start vectors: Psi <- P_cc Psi over the chunks before this one; in latency mode (mf.G > 1) whole groups of G chunks
         // first (their products GfD).  The matrices were written by the previous kernel, mostly on other XCDs: each fetch is a
         // 1-2 us round trip, so the list is walked with the next TWO matrices in flight (three register sets).
@@ -175,7 +176,12 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
                 i = min(i, n_bnd - 1);
                 return i < n_grp ? (tsrc ? mf.GfT : mf.GfD) + ((size_t)b * mf.NG + i) * QFR : (tsrc ? mf.PfT : mf.PfD) + ((size_t)b * mf.C + (G ? g * G : 0) + (i - n_grp)) * QFR;
             };
-            if (n_bnd > 0) {
+            if constexpr (!tsrc) {
+                // batch mode: one matrix at a time -- the chunks of a seed walk the same products, and more loads in flight only deepen
+                // that L2 hot spot (32 seeds x 32 chunks: 119 us per launch like this, 170 us with two matrices ahead)
+                Frag B0;
+                for (int i = 0; i < n_bnd; ++i) { load_frag(bnd_ptr(i), B0); product(B0); }
+            } else if (n_bnd > 0) {
                 constexpr int PD = 2;                                   // matrices in flight ahead of the product (4: slower -- every wave
                                                                         // walks the SAME group products, the walk is bound by that L2 hot spot)
                 Frag Bq[PD + 1];
@@ -195,7 +201,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
         }
         auto step = [&](const Frag& fr, int t) {
             product(fr);
-            if (tsrc) {
+            if constexpr (tsrc) {
                 // latency mode: Psi_t goes out in this kernel's own register layout (lane-contiguous 1 KB stores; k_mfma_backward3 holds
                 // Psi in the same layout) -- the scattered 16 B stores of the API layout are as slow in the load/store path as the
                 // gathers; d.inter gets only the last slice (k_loss reads it), the rest is unpacked when read back
@@ -221,15 +227,25 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
         {
         // (latency mode: three slices in flight instead of one was SLOWER, 19 vs 15 us for 8 slices -- the fetch of a 16 KB matrix
         // by one wave takes ~2 us whatever is in flight: the gathers are bound by the load path, not by the round trip)
-        load_frag(Kb, A);
+#ifndef QOC_FWD_AHEAD
+#define QOC_FWD_AHEAD 1
+#endif
+        constexpr int PD = QOC_FWD_AHEAD;                               // slices in flight ahead of the product
+        Frag Kq[PD + 1];
+#pragma unroll
+        for (int q = 0; q < PD; ++q) load_frag(Kb + (size_t)min(q, len - 1) * mf.FR, Kq[q]);
         int t = 0;
-        for (; t + 2 <= len; t += 2) {
-            load_frag(Kb + (size_t)(t + 1) * mf.FR, A1); asm volatile("" ::: "memory"); step(A, t0 + t);
-            load_frag(Kb + (size_t)min(t + 2, len - 1) * mf.FR, A); asm volatile("" ::: "memory"); step(A1, t0 + t + 1);
+        for (; t + PD + 1 <= len; t += PD + 1) {
+#pragma unroll
+            for (int q = 0; q <= PD; ++q) {
+                load_frag(Kb + (size_t)min(t + q + PD, len - 1) * mf.FR, Kq[(q + PD) % (PD + 1)]); asm volatile("" ::: "memory"); step(Kq[q], t0 + t + q);
+            }
         }
-        if (t < len) step(A, t0 + t);
+#pragma unroll
+        for (int q = 0; q <= PD; ++q)
+            if (t + q < len) step(Kq[q], t0 + t + q);
         }
-    } else if (!mf.latency && item < n_sweep + d.B * NT) {       // latency mode: final_state only on read-back
+    } else if (!TSRC && item < n_sweep + d.B * NT) {       // latency mode: final_state only on read-back
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
         if (d.skip_done && d.done[b]) return;

@@ -8,7 +8,7 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     else if (mf.NT == 2 && mf.variant != 1) {
         // 4x4x4 sweep; like the backward choice this must not depend on the batch size (bit-identical seeds across shardings)
         const int wpg = mf.latency ? 1 : 4;                              // latency mode: one sweep per workgroup, i.e. per CU
-        if (mf.latency) hipLaunchKernelGGL((k_mfma_forward2<2, 1>), dim3(items * mf.mq), dim3(64), 0, s, d, mf, mf.mq);   // and per 4 columns
+        if (mf.latency) hipLaunchKernelGGL((k_mfma_forward2<2, 1, true>), dim3(items * mf.mq), dim3(64), 0, s, d, mf, mf.mq);   // and per 4 columns
         else if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf, 1);
         else hipLaunchKernelGGL((k_mfma_forward2<2, 4>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf, 1);
     }

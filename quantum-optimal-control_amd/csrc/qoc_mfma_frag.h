@@ -43,8 +43,8 @@ struct QocMfma {
     size_t bwd_lds = 0, bwd_lds3 = 0;
     bool h_in_lds = true;
     int variant = 0;              // qoc_config.variant: 0 auto, 1 16x16x4, 2 4x4x4 two waves, 3 4x4x4 one wave, 4 streamed image, 5 latency mode
-    // latency mode (few seeds, variant 5): K_t by one wave per SLICE, chunk products and products of groups of G chunks by
-    // k_mfma_chain_products, two-level chunk boundaries in the sweeps, final_state / unitary_scale formed only when read back
+    // latency mode (few seeds, variant 5): K_t by two waves per SLICE, chunk products and products of groups of G chunks by
+    // k_mfma_chain_rows, two-level chunk boundaries in the sweeps, final_state / unitary_scale formed only when read back
     int G = 0, NG = 0;            // chunks per group (0: no groups), number of groups
     cplx* GfD = nullptr;          // [B][NG] fragD(product of the chunk products of a group)
     cplx* TfD = nullptr;          // [B] fragD(P_{C-1} ... P_0 U0), formed on demand (qoc_mfma_final_state)
