@@ -24,7 +24,7 @@
 #include "qoc_kernels_gemm.h"
 
 #ifndef QOC_LATENCY_MAX_SEEDS
-#define QOC_LATENCY_MAX_SEEDS 12        // measured on C2 (profiles/r02_latency_sweep.txt): latency mode wins up to 12 seeds, the GEMM route at 16, the batch kernels from 24 on
+#define QOC_LATENCY_MAX_SEEDS 16        // measured on C2 (profiles/r02_latency_sweep.txt): latency mode wins up to 16 seeds, the batch kernels from 24 on
 #endif
 static thread_local std::string g_err;
 

@@ -428,8 +428,8 @@ __global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
 //  * control gradients: 16-lane DPP butterflies, the 4 row partials of both waves go through LDS and lane kk of wave h = 0
 //    adds the 8 partials of control kk (was: six ds_bpermute levels per control).
 // Used for k <= 4 controls without state regularisers (no per-slice source term); anything else keeps backward2.
-template <int MQ, bool SRC, int KC = 4, bool LAT = false>
-__global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, QocMfma mf) {
+template <int MQ, bool SRC, int KC = 4>
+__global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     constexpr int NT = 2;                                                       // KC = control images in LDS: 4, or 5 (k = 5 still fits the 160 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, Qo
     cplx* mypad = pads + (size_t)wv * 2 * 16 * B2_LDP;
     const cplx* pad_lo = pads + (size_t)(2 * pair) * 2 * 16 * B2_LDP;
     const cplx* pad_hi = pads + (size_t)(2 * pair + 1) * 2 * 16 * B2_LDP;
-    const int item = blockIdx.x * (blockDim.x >> 7) + pair;           // 4 pairs per workgroup (batch) or 1 (latency mode: one item per CU)
+    const int item = blockIdx.x * 4 + pair;
     const bool item_ok = item < d.B * mf.C;
     const int c = item_ok ? item / d.B : 0, b = item_ok ? item - c * d.B : 0;   // chunk-major, as in k_mfma_forward2
     const bool active = item_ok && !(d.skip_done && d.done[b]);
@@ -456,26 +456,7 @@ __global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, Qo
     // (a 16x16x4 tile spends half of its columns on m = 8): 24 MQ MFMAs of 17 cycles instead of 24 of ~100.
     double ore[MQ], oim[MQ];
     {
-        cplx z;
-        if constexpr (LAT) {
-            // latency mode: the fidelity overlap z = sum_j <w_j, psi_j(T)> (tensorflow_state.py:282-333; k_loss otherwise) is formed here,
-            // by every wave for itself (256 elements, one launch and ~5 us less on the chain); the wave of chunk 0 publishes loss and z
-            const cplx* fin = d.inter + ((size_t)b * (d.steps + 1) + d.steps) * d.n * d.m;
-            double zr = 0.0, zi = 0.0;
-            for (int o = lane; o < d.n * d.m; o += 64) {
-                const cplx f = fin[o], wv2 = d.W[o];
-                zr += f.x * wv2.x + f.y * wv2.y;
-                zi += f.y * wv2.x - f.x * wv2.y;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); }
-            z = cmake(zr, zi);
-            if (active && c == 0 && h == 0 && lane == 0) {
-                d.zfin[b] = z;
-                d.loss[b] = 1.0 - (zr * zr + zi * zi) / ((double)d.m * (double)d.m);
-                d.reg_state[b] = 0.0;
-            }
-        } else z = d.zfin[b];
+        const cplx z = d.zfin[b];
         const double c0 = -2.0 / ((double)d.m * (double)d.m);
 #pragma unroll
         for (int jb = 0; jb < MQ; ++jb) {
@@ -521,8 +502,7 @@ __global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, Qo
     put_own(0);
     lds_barrier();
     int buf = 0;
-    // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc, uniform trip count, result kept only while cc > c.
-    //      Latency mode (mf.G > 1): first over whole groups of G chunks (their products GfD), then inside the own group ----
+    // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc, uniform trip count, result kept only while cc > c ----
     {
         auto bstep = [&](const Frag& fr, bool keep, int cc) {
             double nre[MQ], nim[MQ];
@@ -556,15 +536,8 @@ __global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, Qo
             }
             if (s < n_steps) bstep(f0, keep_of(s), idx_of(s));
         };
-        const cplx* Pb = mf.PfD + (size_t)b * mf.C * QFR;
-        if constexpr (LAT) {
-            const int G = mf.G, NG = mf.NG, g = c / G, C = mf.C;
-            bsteps(mf.GfD + (size_t)b * NG * QFR, NG - 1, [&](int s) { return NG - 1 - s; }, [&](int s) { return NG - 1 - s > g; });
-            bsteps(Pb, G - 1, [&](int s) { return min(g * G + G - 1 - s, C - 1); }, [&](int s) { const int cc = g * G + G - 1 - s; return cc < C && cc > c; });
-        } else {
-            const int C = mf.C;
-            bsteps(Pb, C - 1, [&](int s) { return C - 1 - s; }, [&](int s) { return C - 1 - s > c; });
-        }
+        const int C = mf.C;
+        bsteps(mf.PfD + (size_t)b * C * QFR, C - 1, [&](int s) { return C - 1 - s; }, [&](int s) { return C - 1 - s > c; });
     }
     // ---- slices of the chunk, last to first ------------------------------------------------------------------------------
     const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
@@ -579,11 +552,7 @@ __global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, Qo
             // out-of-range (row >= n, column >= m) entries read a clamped, finite element and need no mask: they only meet
             // the zero columns of Lambda (j >= m) or the zero padding of H_k' (row >= n); a masked load would be made
             // conditional by hipcc and waited for on the spot, draining the K prefetch with it
-            cplx p0, p1;
-            if constexpr (LAT) {                                                 // the forward sweep's register layout, lane-contiguous
-                const cplx* pl = mf.PsiL + ((size_t)b * d.steps + t) * (2 * MQ) * 64 + lane;
-                p0 = pl[q * 64]; p1 = pl[(MQ + q) * 64];
-            } else { p0 = psi[prow0 * d.m + jc]; p1 = psi[prow1 * d.m + jc]; }
+            const cplx p0 = psi[prow0 * d.m + jc], p1 = psi[prow1 * d.m + jc];
             ps.pr[0][q] = p0.x; ps.pi[0][q] = p0.y;
             ps.pr[1][q] = p1.x; ps.pi[1][q] = p1.y;
             if (SRC) ps.own[q] = (psi - (size_t)d.n * d.m)[(h ? prow1 : prow0) * d.m + jc];    // Psi_t at this lane's costate entries
@@ -644,20 +613,6 @@ __global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, Qo
         double g[KC];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) g[kk] = 0.0;
-        // The H_k' images do not depend on the MFMA results.  Latency mode (one pair of waves per CU, 512 registers per lane) issues
-        // all their LDS reads as one batch ahead of the MFMAs that form Q; left to itself hipcc reads them one at a time with every
-        // wait exposed (5 us of the 40 of a one-trajectory sweep).  The batch kernels have no registers to stage them in (8 waves
-        // per CU, 256 per lane: staging 16 reads spills and costs 60 %) and other waves to hide the waits behind.
-        cplx hq[LAT ? 2 : 1][KC][4];
-        if constexpr (LAT) {
-#pragma unroll
-            for (int Jp = 0; Jp < 2; ++Jp)
-#pragma unroll
-                for (int kk = 0; kk < KC; ++kk)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hq[Jp][kk][r] = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
         for (int Jp = 0; Jp < 2; ++Jp) {
             d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
@@ -673,9 +628,7 @@ __global__ void __launch_bounds__(LAT ? 128 : 512) k_mfma_backward3(QocDev d, Qo
                 double acc = 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    cplx hv;
-                    if constexpr (LAT) hv = hq[Jp][kk][r];
-                    else hv = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
+                    const cplx hv = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
                     acc = fma(hv.x, qr[r], acc);
                     acc = fma(-hv.y, qi[r], acc);
                 }

@@ -62,7 +62,8 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
     if (mf.latency && (!al(&mf.GfD, (size_t)d.B * mf.NG * FR) || !al(&mf.GfT, (size_t)d.B * mf.NG * FR) || !al(&mf.TfD, (size_t)d.B * FR) ||
-                       !al(&mf.PsiL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64))) { msg = "MFMA path: out of device memory"; return -3; }
+                       !al(&mf.PsiL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64) ||
+                       !al(&mf.LamL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64))) { msg = "MFMA path: out of device memory"; return -3; }
     if (!al(&mf.KfD, nk) || (mf.store_T && !al(&mf.KfT, nk)) || !al(&mf.PfD, np) || !al(&mf.PfT, np) || !al(&mf.Aoff, (size_t)d.B * C * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     {
         size_t total = 0;
@@ -72,8 +73,9 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         allocs.push_back(arena);
         size_t off = 0;
         for (auto& w : wanted) { *w.first = (cplx*)(arena + off); off += w.second; }
-        // column groups beyond m are never written by the forward sweep and must read as zero in the backward one
-        if (mf.PsiL && hipMemset(mf.PsiL, 0, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64 * sizeof(cplx)) != hipSuccess) { msg = "MFMA path: clearing PsiL failed"; return -2; }
+        // column groups beyond m are never written by the sweeps and must read as zero in the gradient kernel
+        const size_t xl = (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64 * sizeof(cplx);
+        if (mf.PsiL && (hipMemset(mf.PsiL, 0, xl) != hipSuccess || hipMemset(mf.LamL, 0, xl) != hipSuccess)) { msg = "MFMA path: clearing PsiL / LamL failed"; return -2; }
     }
     const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
@@ -86,11 +88,11 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     }
     const bool b3src = d.n_forb > 0 || d.has_speed;
     const void* b3k = nullptr;
-#define QOC_B3K(MQv, KCv) (mf.latency ? (const void*)k_mfma_backward3<MQv, false, KCv, true> \
-                                      : b3src ? (const void*)k_mfma_backward3<MQv, true, KCv> : (const void*)k_mfma_backward3<MQv, false, KCv>)
+#define QOC_B3K(MQv, KCv) (b3src ? (const void*)k_mfma_backward3<MQv, true, KCv> : (const void*)k_mfma_backward3<MQv, false, KCv>)
     if (d.k == 5) b3k = mf.mq <= 2 ? QOC_B3K(2, 5) : QOC_B3K(4, 5);
     else b3k = mf.mq <= 2 ? QOC_B3K(2, 4) : QOC_B3K(4, 4);
 #undef QOC_B3K
+    if (mf.latency && qoc_mfma_latency_setup(mf, d, msg) != 0) return -2;
     if (NT == 2 && hipFuncSetAttribute(b3k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
         return -2;
@@ -131,13 +133,11 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     if (NT == 2 && mf.variant != 1) {
         if (d.k <= 5) {
             const bool src = d.n_forb > 0 || d.has_speed;
-            const int ppg = mf.latency ? 1 : 4;                          // pairs of waves per workgroup
-            const dim3 g3((items + ppg - 1) / ppg), b3(128 * ppg);
-#define QOC_B3(MQv, SRCv, LATv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5, LATv>), g3, b3, mf.bwd_lds3, s, d, mf); \
-                               else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4, LATv>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
-            if (mf.latency) { if (mf.mq <= 2) QOC_B3(2, false, true); else QOC_B3(4, false, true); }   // latency mode has no state regulariser
-            else if (mf.mq <= 2) { if (src) QOC_B3(2, true, false); else QOC_B3(2, false, false); }
-            else { if (src) QOC_B3(4, true, false); else QOC_B3(4, false, false); }
+            const dim3 g3((items + 3) / 4), b3(512);                     // 4 pairs of waves per workgroup
+#define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
+                               else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
+            if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
+            else { if (src) QOC_B3(4, true); else QOC_B3(4, false); }
 #undef QOC_B3
             return;
         }
@@ -169,6 +169,7 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
         hipLaunchKernelGGL((k_mfma_backward<NT, false>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
 }
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    if (mf.latency) { qoc_mfma_latency_gradient(mf, d, s); return; }
     if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_backward<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_backward<3>(mf, d, s); else qoc_mfma_launch_all_backward<4>(mf, d, s);
 }
 

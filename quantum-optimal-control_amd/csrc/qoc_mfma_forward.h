@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
                     if (row < d.n && col < d.m) out[row * d.m + col] = cmake(Psi[Ib].re[r], Psi[Ib].im[r]);
                 }
         }
-    } else if (!mf.latency && item < n_sweep + d.B * NT) {       // latency mode: final_state only on read-back
+    } else if (item < n_sweep + d.B * NT) {
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
         if (d.skip_done && d.done[b]) return;
@@ -80,19 +80,15 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
 // tile spends half of its columns on m = 8) -- 48 MQ MFMAs of 17 cycles per slice instead of 48 of ~100.  K_{t+1} is fetched
 // while slice t multiplies.  Final-unitary waves as in k_mfma_forward.
 
-// TSRC (latency mode) is a template flag, not a run-time branch: a conditional load inside the sweep makes hipcc wait for it on the
-// spot (batch sweep 173 -> 183 us with `if (mf.latency)` around the two load patterns)
-template <int NT, int MQ, bool TSRC = false>
-__global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int colsplit) {
+// (No run-time branch may surround the loads of the sweep: hipcc waits for a conditional load on the spot -- 173 -> 183 us with an
+// `if (mf.latency)` around two load patterns.  The latency mode has its own sweep kernel, qoc_mfma_latency.h.)
+template <int NT, int MQ>
+__global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // colsplit > 1 (latency mode): one wave per group of 4 columns of Psi (they are independent under left multiplication; MQ = 1):
-    // 48 instead of 96 MFMAs per step on the dependent chain
-    const int wpg = blockDim.x >> 6;                                  // waves per workgroup: 4 (batch), 1 in latency mode -- one wave per CU, so
-                                                                      // that no two sweeps share a CU's 64 B/clk load path (4 x 16 KB per step did)
-    const int item = (blockIdx.x * wpg + wv) / colsplit, jq0 = (blockIdx.x * wpg + wv) - item * colsplit;
+    const int item = blockIdx.x * 4 + wv;
     const int n_sweep = d.B * mf.C;
     if (item < n_sweep) {
         const int c = item / d.B, b = item - c * d.B;      // chunk-major: the waves of a workgroup walk 4 different seeds
@@ -105,33 +101,24 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
         for (int I = 0; I < NT; ++I)
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) {
-                const int row = 16 * I + lc, col = 4 * (jb + jq0) + lk;
+                const int row = 16 * I + lc, col = 4 * jb + lk;
                 cplx v = cmake(0.0, 0.0);
                 if (row < d.n && col < d.m) v = d.Psi0[row * d.m + col];
                 pre[I][jb] = v.x; pim[I][jb] = v.y;
             }
         cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
-        if (c == 0 && jq0 == 0) {                                       // inter[0] = V  (tensorflow_state.py:232-233)
+        if (c == 0) {                                       // inter[0] = V  (tensorflow_state.py:232-233)
             for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
         }
         struct Frag { cplx f[NT][QQS]; };
-        // the operand is M^T in strip registers.  Batch mode gathers it from fragD(M) (no transposed copy of the 512 MB of K: the sweep is
-        // bound by the HBM stream there); latency mode reads the transposed copies KfT / PfT / GfT with lane-contiguous 1 KB loads (one
-        // wave brings a 16 KB matrix in 0.7 us that way, 1.8 us with the gather: profiles/r02_matrix_fetch_probe.txt)
-        constexpr bool tsrc = TSRC;
+        // the operand is M^T in strip registers, gathered from fragD(M) (no transposed copy of the 512 MB of K: the sweep is bound by
+        // the HBM stream)
         auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
-            if constexpr (tsrc) {
 #pragma unroll
-                for (int I = 0; I < NT; ++I)
+            for (int I = 0; I < NT; ++I)
 #pragma unroll
-                    for (int q = 0; q < QQS; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];
-            } else {
-#pragma unroll
-                for (int I = 0; I < NT; ++I)
-#pragma unroll
-                    for (int q = 0; q < QQS; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
-                        fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
-            }
+                for (int q = 0; q < QQS; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
+                    fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
         };
         // Psi <- M Psi with M^T given by its fragD fragment
         auto product = [&](const Frag& fr) {
@@ -166,67 +153,27 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) { pre[I][jb] = a[I][jb] - bq[I][jb]; pim[I][jb] = cq[I][jb] - a[I][jb] - bq[I][jb]; }
         };
-        // chunk-start vectors: Psi <- P_cc Psi over the chunks before this one; in latency mode (mf.G > 1) whole groups of G chunks
-        // first (their products GfD).  The matrices were written by the previous kernel, mostly on other XCDs: each fetch is a
-        // 1-2 us round trip, so the list is walked with the next TWO matrices in flight (three register sets).
+        // chunk-start vectors: Psi <- P_cc Psi over the chunks before this one, one matrix at a time -- the chunks of a seed walk the
+        // same products, and more loads in flight only deepen that L2 hot spot (32 seeds x 32 chunks: 119 us per launch like this,
+        // 170 us with two matrices ahead)
         {
-            const int G = mf.G > 1 ? mf.G : 0, g = G ? c / G : 0;
-            const int n_grp = G ? g : 0, n_bnd = n_grp + (c - (G ? g * G : 0));
-            auto bnd_ptr = [&](int i) -> const cplx* {
-                i = min(i, n_bnd - 1);
-                return i < n_grp ? (tsrc ? mf.GfT : mf.GfD) + ((size_t)b * mf.NG + i) * QFR : (tsrc ? mf.PfT : mf.PfD) + ((size_t)b * mf.C + (G ? g * G : 0) + (i - n_grp)) * QFR;
-            };
-            if constexpr (!tsrc) {
-                // batch mode: one matrix at a time -- the chunks of a seed walk the same products, and more loads in flight only deepen
-                // that L2 hot spot (32 seeds x 32 chunks: 119 us per launch like this, 170 us with two matrices ahead)
-                Frag B0;
-                for (int i = 0; i < n_bnd; ++i) { load_frag(bnd_ptr(i), B0); product(B0); }
-            } else if (n_bnd > 0) {
-                constexpr int PD = 2;                                   // matrices in flight ahead of the product (4: slower -- every wave
-                                                                        // walks the SAME group products, the walk is bound by that L2 hot spot)
-                Frag Bq[PD + 1];
-#pragma unroll
-                for (int q = 0; q < PD; ++q) load_frag(bnd_ptr(q), Bq[q]);
-                int i = 0;
-                for (; i + PD + 1 <= n_bnd; i += PD + 1) {
-#pragma unroll
-                    for (int q = 0; q <= PD; ++q) {
-                        load_frag(bnd_ptr(i + q + PD), Bq[(q + PD) % (PD + 1)]); asm volatile("" ::: "memory"); product(Bq[q]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q <= PD; ++q)
-                    if (i + q < n_bnd) product(Bq[q]);
-            }
+            Frag B0;
+            for (int cc = 0; cc < c; ++cc) { load_frag(mf.PfD + ((size_t)b * mf.C + cc) * QFR, B0); product(B0); }
         }
         auto step = [&](const Frag& fr, int t) {
             product(fr);
-            if constexpr (tsrc) {
-                // latency mode: Psi_t goes out in this kernel's own register layout (lane-contiguous 1 KB stores; k_mfma_backward3 holds
-                // Psi in the same layout) -- the scattered 16 B stores of the API layout are as slow in the load/store path as the
-                // gathers; d.inter gets only the last slice (k_loss reads it), the rest is unpacked when read back
-                const int MQs = mf.mq <= 2 ? 2 : 4;                         // column groups per slice as k_mfma_backward3 reads them
-                cplx* pl = mf.PsiL + ((size_t)b * d.steps + t) * (NT * MQs) * 64;
-#pragma unroll
-                for (int I = 0; I < NT; ++I)
-#pragma unroll
-                    for (int jb = 0; jb < MQ; ++jb) pl[(I * MQs + jb + jq0) * 64 + lane] = cmake(pre[I][jb], pim[I][jb]);
-                if (t + 1 < d.steps) return;
-            }
             cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
 #pragma unroll
             for (int I = 0; I < NT; ++I)
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) {
-                    const int row = 16 * I + lc, col = 4 * (jb + jq0) + lk;
+                    const int row = 16 * I + lc, col = 4 * jb + lk;
                     if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I][jb], pim[I][jb]);
                 }
         };
-        const cplx* Kb = (tsrc ? mf.KfT : mf.KfD) + kitem(mf, d.steps, b, t0);   // slices of one chunk are FR apart
+        const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);   // slices of one chunk are FR apart
         const int len = t1 - t0;
         {
-        // (latency mode: three slices in flight instead of one was SLOWER, 19 vs 15 us for 8 slices -- the fetch of a 16 KB matrix
-        // by one wave takes ~2 us whatever is in flight: the gathers are bound by the load path, not by the round trip)
 #ifndef QOC_FWD_AHEAD
 #define QOC_FWD_AHEAD 1
 #endif
@@ -245,7 +192,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf, int
         for (int q = 0; q <= PD; ++q)
             if (t + q < len) step(Kq[q], t0 + t + q);
         }
-    } else if (!TSRC && item < n_sweep + d.B * NT) {       // latency mode: final_state only on read-back
+    } else if (item < n_sweep + d.B * NT) {
         // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
         if (d.skip_done && d.done[b]) return;

@@ -3,23 +3,22 @@
 #include "qoc_mfma_forward.h"
 
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    const int items = d.B * mf.C + (mf.latency ? 0 : d.B * mf.NT);      // latency mode: final_state only when read back (qoc_mfma_final_state)
+    if (mf.latency) { qoc_mfma_latency_sweeps(mf, d, s); return; }       // (final_state only when read back: qoc_mfma_final_state)
+    const int items = d.B * mf.C + d.B * mf.NT;
     if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 2 && mf.variant != 1) {
         // 4x4x4 sweep; like the backward choice this must not depend on the batch size (bit-identical seeds across shardings)
-        const int wpg = mf.latency ? 1 : 4;                              // latency mode: one sweep per workgroup, i.e. per CU
-        if (mf.latency) hipLaunchKernelGGL((k_mfma_forward2<2, 1, true>), dim3(items * mf.mq), dim3(64), 0, s, d, mf, mf.mq);   // and per 4 columns
-        else if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf, 1);
-        else hipLaunchKernelGGL((k_mfma_forward2<2, 4>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf, 1);
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_forward2<2, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     }
     else if (mf.NT == 3 && mf.variant != 1) {
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 1);
-        else hipLaunchKernelGGL((k_mfma_forward2<3, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 1);
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_forward2<3, 4>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     }
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    if (!d.uscale_in_loss && !mf.latency) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
+    if (!d.uscale_in_loss) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
 }
 
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s) {

@@ -1,0 +1,252 @@
+// qoc_mfma_latency.h -- the sweeps of the latency mode of the MFMA path (qoc_config.variant = 5; AUTO for a handful of control sets
+// of a 16 < n <= 32 unitary problem -- the reference's own use is ONE control set per Grape() call, main_grape/grape.py:106-109).
+//
+// With one trajectory the batch kernels are a chain of dependent sweeps: forward over the slices (tensorflow_state.py:204-227),
+// then the costate back over them (the custom gradient of tensorflow_state.py:77-133).  Without a state regulariser the costate
+//     Lambda_t = c0 z Lambda0_t,   Lambda0_t = (K_N ... K_{t+1})^dagger W,   c0 = -2/m^2,  z = tr(W^dagger Psi_N)
+// is LINEAR in the overlap z, so the z-free costate Lambda0 does not wait for the forward sweep: both sweeps run side by side in
+// ONE launch (k_mfma_sweep_lat: 2 x chunks x column groups waves, one per CU), each storing its vectors in its own register layout,
+// and the gradient
+//     dL/du_{k,t} = c0 Re( conj(z) G_{k,t} ),   G_{k,t} = tr( Lambda0_t^dagger H_k' Psi_t )
+// is one slice-parallel kernel (k_mfma_grad_lat: two waves per slice) that also forms z and the loss.  Against the pair of waves
+// per chunk that walked costate and gradient together (k_mfma_backward3, 35 us for one C2 trajectory) the dependent chain is
+// shorter by one whole sweep.
+#pragma once
+#include "qoc_mfma_frag.h"
+
+// One wave per (role, seed, chunk, group of 4 columns).  role 0: Psi_t = K_t Psi_{t-1} from Psi0, stores PsiL[t] = Psi after slice t;
+// role 1: Lambda0_{t-1} = K_t^dagger Lambda0_t from W, stores LamL[t] = Lambda0 BEFORE K_t^dagger is applied (the costate that meets
+// Psi_t in the gradient).  Both walk two-level chunk boundaries first (products of groups of G chunks, then chunk products), the
+// forward one upwards from the start of the pulse, the adjoint one downwards from its end.  The roles differ in pointers, index
+// directions and one sign only -- no branch surrounds a load (hipcc would wait for such a load on the spot):
+//   forward operand  M = K:         strip (I, kb) of lane (lk, lc) = K[16 I + lc][4 kb + lk]       = fragD(K^T)(I, kb)   (KfT / PfT / GfT)
+//   adjoint operand  M = K^dagger:  conj(K[4 kb + lk][16 I + lc])                                  = conj fragD(K)(I, kb) (KfD / PfD / GfD)
+template <int NT>
+__global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
+    constexpr int LDP = 16 * NT + 1;
+    __shared__ __attribute__((aligned(16))) cplx img[4 * LDP];                    // image[column j][row] of the wave's 4 columns
+    const int lane = threadIdx.x;
+    const int cs = mf.mq;                                                         // groups of 4 columns (independent under left multiplication)
+    const int n_sweep = d.B * mf.C * cs;
+    const int adj = __builtin_amdgcn_readfirstlane((int)blockIdx.x >= n_sweep ? 1 : 0);
+    const int w = (int)blockIdx.x - adj * n_sweep;
+    const int item = w / cs, jq0 = w - item * cs;
+    const int c = item / d.B, b = item - c * d.B;
+    if (d.skip_done && d.done[b]) return;
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps), len = t1 - t0;
+    const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
+    const double sg = adj ? -1.0 : 1.0;                                           // conjugated operand in the adjoint sweep
+    double pre[NT], pim[NT];
+    {
+        const cplx* X0 = adj ? d.W : d.Psi0;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            const int row = 16 * I + lc, col = 4 * jq0 + lk;
+            cplx v = cmake(0.0, 0.0);
+            if (row < d.n && col < d.m) v = X0[row * d.m + col];
+            pre[I] = v.x; pim[I] = v.y;
+        }
+    }
+    cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
+    if (!adj && c == 0 && jq0 == 0) {                                             // inter[0] = V  (tensorflow_state.py:232-233)
+        for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
+    }
+    struct Frag { cplx f[NT][QQS]; };
+    auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {                  // lane-contiguous 1 KB loads (one wave brings a 16 KB matrix
+#pragma unroll                                                                   // in 0.7 us that way: profiles/r02_matrix_fetch_probe.txt)
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int q = 0; q < QQS; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];
+    };
+    // X <- M X on v_mfma_f64_4x4x4 (3 real products per complex one); s = -1 multiplies by the conjugate of the strips
+    auto product = [&](const Frag& fr) {
+#pragma unroll
+        for (int I = 0; I < NT; ++I) img[lk * LDP + 16 * I + lc] = cmake(pre[I], pim[I]);
+        wave_lds_fence();
+        double a[NT], bq[NT], cq[NT];
+#pragma unroll
+        for (int I = 0; I < NT; ++I) { a[I] = 0.0; bq[I] = 0.0; cq[I] = 0.0; }
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) {
+            const cplx v = img[li4 * LDP + 4 * kb + lk];                          // X[4 kb + lk][column li4 of the group]
+#pragma unroll
+            for (int I = 0; I < NT; ++I) {
+                const double br = fr.f[I][kb].x, bi = fr.f[I][kb].y, bs = fma(sg, bi, br);
+                a[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[I], 0, 0, 0);
+                bq[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, bq[I], 0, 0, 0);
+                cq[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, cq[I], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < NT; ++I) { pre[I] = fma(-sg, bq[I], a[I]); pim[I] = fma(-sg, bq[I], cq[I] - a[I]); }
+    };
+    // ---- chunk boundary: whole groups first, then the chunks of the own group.  The matrices were written by the previous kernel,
+    //      mostly on other XCDs: each fetch is a 1-2 us round trip, so the list is walked with the next TWO matrices in flight
+    //      (four: slower -- every wave walks the SAME group products, the walk is bound by that L2 hot spot) -------------------------
+    {
+        const int G = mf.G, g = c / G, C = mf.C, NG = mf.NG;
+        const int cend = min(g * G + G, C) - 1;                                   // last chunk of the own group
+        const int n_grp = adj ? NG - 1 - g : g, n_ch = adj ? cend - c : c - g * G, n_bnd = n_grp + n_ch;
+        const int g_first = adj ? NG - 1 : 0, c_first = adj ? cend : g * G, dir = adj ? -1 : 1;
+        const cplx* Gb = (adj ? mf.GfD : mf.GfT) + (size_t)b * NG * QFR;
+        const cplx* Pb = (adj ? mf.PfD : mf.PfT) + (size_t)b * C * QFR;
+        auto bnd_ptr = [&](int i) -> const cplx* {
+            i = min(i, n_bnd - 1);
+            return i < n_grp ? Gb + (size_t)(g_first + dir * i) * QFR : Pb + (size_t)(c_first + dir * (i - n_grp)) * QFR;
+        };
+        if (n_bnd > 0) {
+            constexpr int PD = 2;
+            Frag Bq[PD + 1];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) load_frag(bnd_ptr(q), Bq[q]);
+            int i = 0;
+            for (; i + PD + 1 <= n_bnd; i += PD + 1) {
+#pragma unroll
+                for (int q = 0; q <= PD; ++q) {
+                    load_frag(bnd_ptr(i + q + PD), Bq[(q + PD) % (PD + 1)]); asm volatile("" ::: "memory"); product(Bq[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q <= PD; ++q)
+                if (i + q < n_bnd) product(Bq[q]);
+        }
+    }
+    // ---- slices of the chunk.  The vectors go out in the register layout (lane-contiguous 1 KB stores; the gradient kernel holds
+    //      them in the same layout): the scattered 16 B stores of the API layout are as slow in the load/store path as gathers;
+    //      d.inter gets only the last slice (the overlap z reads it), the rest is unpacked when read back ------------------------------
+    const int MQs = mf.mq <= 2 ? 2 : 4;                                           // column groups per slice as k_mfma_grad_lat reads them
+    cplx* XL = (adj ? mf.LamL : mf.PsiL) + (size_t)b * d.steps * (NT * MQs) * 64;
+    auto store = [&](int t) {
+        cplx* xl = XL + (size_t)t * (NT * MQs) * 64;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) xl[(I * MQs + jq0) * 64 + lane] = cmake(pre[I], pim[I]);
+    };
+    auto step = [&](const Frag& fr, int i) {
+        const int t = adj ? t1 - 1 - i : t0 + i;
+        if (adj) store(t);
+        if (!adj || i + 1 < len) product(fr);                                     // (K_{t0}^dagger would give the boundary of the chunk below)
+        if (!adj) {
+            store(t);
+            if (t + 1 == d.steps) {
+                cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
+#pragma unroll
+                for (int I = 0; I < NT; ++I) {
+                    const int row = 16 * I + lc, col = 4 * jq0 + lk;
+                    if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I], pim[I]);
+                }
+            }
+        }
+    };
+    const cplx* Kb = (adj ? mf.KfD : mf.KfT) + kitem(mf, d.steps, b, t0);           // slices of one chunk are FR apart
+    auto k_ptr = [&](int i) -> const cplx* {
+        i = min(i, len - 1);
+        return Kb + (size_t)(adj ? len - 1 - i : i) * mf.FR;
+    };
+    // (three slices in flight instead of one was SLOWER, 19 vs 15 us for 8 slices)
+    Frag K0, K1;
+    load_frag(k_ptr(0), K0);
+    int i = 0;
+    for (; i + 2 <= len; i += 2) {
+        load_frag(k_ptr(i + 1), K1); asm volatile("" ::: "memory"); step(K0, i);
+        load_frag(k_ptr(i + 2), K0); asm volatile("" ::: "memory"); step(K1, i + 1);
+    }
+    if (i < len) step(K0, i);
+}
+
+// Gradient of the latency mode: two waves (row tiles h = 0, 1 of the costate) per time slice, 8 slices per workgroup, the control
+// images H_k' (fragD layout, as k_mfma_backward3 holds them) staged in LDS once per workgroup.
+//   Q = conj(Lambda0_t) Psi_t^T  (tiles (h, 0..1) on v_mfma_f64_16x16x4),  G_k = sum_{r,c} H_k'[r][c] Q[r][c]  (complex),
+//   dL/du_{k,t} = c0 (Re z Re G_k + Im z Im G_k)                                   tensorflow_state.py:77-133 (first-order gradient)
+// Every wave forms the overlap z = sum_j <w_j, psi_j(T)> itself (256 elements; tensorflow_state.py:282-333); the first workgroup
+// of a seed publishes z and the loss (k_loss otherwise).
+template <int MQ, int KC>
+__global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf) {
+    constexpr int NT = 2, SL = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Hl = (cplx*)smem;                                                       // [KC] fragD(H_k'), zero beyond k
+    double* gpart = (double*)(Hl + (size_t)KC * QFR);                             // [SL][2 tiles][4 rows][2 (re, im)][KC]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wv & 1, sl = wv >> 1;
+    const int nblk = (d.steps + SL - 1) / SL;
+    const int b = blockIdx.x / nblk, cb = blockIdx.x - b * nblk;
+    if (d.skip_done && d.done[b]) return;
+    const int t = cb * SL + sl, tc = min(t, d.steps - 1);
+    const bool live = t < d.steps;
+    const int lk = lane >> 4, lc = lane & 15;
+    // operands of the slice: costate rows of tile h, state rows of both tiles, all lane-contiguous
+    double lr[MQ], li[MQ], pr[2][MQ], pi[2][MQ];
+    {
+        const cplx* ll = mf.LamL + ((size_t)b * d.steps + tc) * (2 * MQ) * 64 + lane;
+        const cplx* pl = mf.PsiL + ((size_t)b * d.steps + tc) * (2 * MQ) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            const cplx lv = ll[(h * MQ + q) * 64], p0 = pl[q * 64], p1 = pl[(MQ + q) * 64];
+            lr[q] = lv.x; li[q] = lv.y;
+            pr[0][q] = p0.x; pi[0][q] = p0.y;
+            pr[1][q] = p1.x; pi[1][q] = p1.y;
+        }
+    }
+    double zr = 0.0, zi = 0.0;
+    {
+        const cplx* fin = d.inter + ((size_t)b * (d.steps + 1) + d.steps) * d.n * d.m;
+        for (int o = lane; o < d.n * d.m; o += 64) {
+            const cplx f = fin[o], wv2 = d.W[o];
+            zr += f.x * wv2.x + f.y * wv2.y;
+            zi += f.y * wv2.x - f.x * wv2.y;
+        }
+    }
+    for (int o = threadIdx.x; o < KC * QFR; o += blockDim.x) Hl[o] = o < d.k * QFR ? mf.HfD[QFR + o] : cmake(0.0, 0.0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); }
+    if (cb == 0 && wv == 0 && lane == 0) {
+        d.zfin[b] = cmake(zr, zi);
+        d.loss[b] = 1.0 - (zr * zr + zi * zi) / ((double)d.m * (double)d.m);
+        d.reg_state[b] = 0.0;
+    }
+    __syncthreads();
+    double gr[KC], gi[KC];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) { gr[kk] = 0.0; gi[kk] = 0.0; }
+#pragma unroll
+    for (int Jp = 0; Jp < 2; ++Jp) {
+        d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            t1v = QMFMA(lr[q], pr[Jp][q], t1v);
+            t2v = QMFMA(li[q], pi[Jp][q], t2v);
+            t3v = QMFMA(lr[q] - li[q], pr[Jp][q] + pi[Jp][q], t3v);
+        }
+        const d4 qr = t1v + t2v, qi = t3v - t1v + t2v;                            // Re, Im of conj(lambda) psi
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            double ar = 0.0, ai = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const cplx hv = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
+                ar = fma(hv.x, qr[r], ar); ar = fma(-hv.y, qi[r], ar);
+                ai = fma(hv.x, qi[r], ai); ai = fma(hv.y, qr[r], ai);
+            }
+            gr[kk] += ar; gi[kk] += ai;
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {                                             // sum over the 16 lanes of a DPP row
+        gr[kk] += dpp_xor<1>(gr[kk]); gr[kk] += dpp_xor<2>(gr[kk]); gr[kk] += dpp_xor<4>(gr[kk]); gr[kk] += dpp_xor<8>(gr[kk]);
+        gi[kk] += dpp_xor<1>(gi[kk]); gi[kk] += dpp_xor<2>(gi[kk]); gi[kk] += dpp_xor<4>(gi[kk]); gi[kk] += dpp_xor<8>(gi[kk]);
+    }
+    if (lc == 0) {
+        double* gp = gpart + (((size_t)sl * 2 + h) * 4 + lk) * 2 * KC;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) { gp[kk] = gr[kk]; gp[KC + kk] = gi[kk]; }
+    }
+    __syncthreads();
+    if (live && h == 0 && lane < d.k) {
+        const double* gp = gpart + (size_t)sl * 8 * 2 * KC + lane;
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { sr += gp[x * 2 * KC]; si += gp[x * 2 * KC + KC]; }
+        const double c0 = -2.0 / ((double)d.m * (double)d.m);
+        d.dLdu[((size_t)b * d.k + lane) * d.steps + t] = c0 * (zr * sr + zi * si);
+    }
+}

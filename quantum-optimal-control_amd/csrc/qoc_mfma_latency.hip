@@ -1,0 +1,34 @@
+// qoc_mfma_latency.hip -- translation unit of the latency-mode sweeps (qoc_mfma_latency.h) and their launchers.
+#include "qoc_kernels_mfma.h"
+#include "qoc_mfma_latency.h"
+
+static size_t grad_lat_lds(int kc) { return (size_t)kc * 1024 * sizeof(cplx) + (size_t)8 * 2 * 4 * 2 * kc * sizeof(double); }
+
+static const void* grad_lat_kernel(const QocMfma& mf, const QocDev& d) {
+    if (d.k == 5) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 5> : (const void*)k_mfma_grad_lat<4, 5>;
+    return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 4> : (const void*)k_mfma_grad_lat<4, 4>;
+}
+
+int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
+    if (hipFuncSetAttribute(grad_lat_kernel(mf, d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grad_lat_lds(d.k == 5 ? 5 : 4)) != hipSuccess) {
+        msg = "MFMA path: cannot reserve LDS for the latency-mode gradient kernel";
+        return -2;
+    }
+    return 0;
+}
+
+// forward and z-free adjoint sweep side by side: 2 x (seed, chunk, group of 4 columns) waves, one per workgroup, i.e. per CU (no two
+// sweeps share a CU's 64 B/clk load path: 4 x 16 KB per step did)
+void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    hipLaunchKernelGGL(k_mfma_sweep_lat<2>, dim3(2 * d.B * mf.C * mf.mq), dim3(64), 0, s, d, mf);
+}
+
+void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    const dim3 g(d.B * ((d.steps + 7) / 8)), b(1024);
+    const size_t lds = grad_lat_lds(d.k == 5 ? 5 : 4);
+    if (d.k == 5) {
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 5>), g, b, lds, s, d, mf); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 5>), g, b, lds, s, d, mf);
+    } else {
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 4>), g, b, lds, s, d, mf); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 4>), g, b, lds, s, d, mf);
+    }
+}
