@@ -151,6 +151,9 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
     if (cgrid > 2048) cgrid = 2048;
     const int skip = e->skip_mask;
+    const bool plain = !(d.has_amp || d.has_env || d.has_dwdt || d.has_d2wdt2 || d.has_band);
+    // latency mode without pulse regularisers: the tail of the iteration runs in the last workgroup of the gradient kernel
+    const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && plain && !(skip & (16 | 32));
     // (latency mode of the MFMA path: the slice kernel of the exponentials forms its own controls)
     if (!(skip & 1) && !(e->path == QOC_PATH_MFMA && e->mf.latency)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {
@@ -161,7 +164,10 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
         if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
         if (!(skip & 8) && !e->mf.latency) hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);   // latency mode: inside the backward kernel
-        if (!(skip & 16)) qoc_mfma_launch_backward(e->mf, d, e->stream);
+        if (!(skip & 16)) {
+            if (fused_tail) qoc_mfma_latency_gradient(e->mf, d, &ap, e->stream);
+            else qoc_mfma_launch_backward(e->mf, d, e->stream);
+        }
     } else if (e->path == QOC_PATH_GEMM) {
         TRY(prof_begin(e));
         qoc_gemm_expm(e->gm, d, e->stream);
@@ -189,8 +195,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
         hipLaunchKernelGGL(k_st_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
     }
-    if (!(skip & 32)) {
-        const bool plain = !(d.has_amp || d.has_env || d.has_dwdt || d.has_d2wdt2 || d.has_band);
+    if (!(skip & 32) && !fused_tail) {
         const dim3 fb(d.k * d.steps >= 2048 ? 1024 : QOC_BLOCK);
         if (plain) hipLaunchKernelGGL(k_finish_t<true>, dim3(d.B), fb, 0, e->stream, d, ap);
         else hipLaunchKernelGGL(k_finish_t<false>, dim3(d.B), fb, 0, e->stream, d, ap);

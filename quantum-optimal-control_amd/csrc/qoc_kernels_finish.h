@@ -38,10 +38,10 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red /* 
 #define QF_E 4
 // PLAIN: no pulse regulariser is configured -- the same kernel with those branches compiled out (a tenth of the code: for one
 // trajectory this single-workgroup kernel is bound by its instruction fetch and its chain of global round trips, not by arithmetic)
+// (a __device__ body: the latency mode of the MFMA path runs it in the last workgroup of its gradient kernel, qoc_mfma_latency.h)
 template <bool PLAIN>
-__global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
-    __shared__ double red[34];
-    const int b = blockIdx.x, steps = d.steps, ks = d.k * steps;
+__device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */) {
+    const int steps = d.steps, ks = d.k * steps;
     const double* w = d.w + (size_t)b * ks;
     const double* dLdu = d.dLdu + (size_t)b * ks;
     double* base = d.base + (size_t)b * ks;
@@ -210,4 +210,10 @@ __global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
         }
     }
     if (threadIdx.x == 0) d.adam_t[b] = tstep;
+}
+
+template <bool PLAIN>
+__global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
+    __shared__ double red[34];
+    finish_body<PLAIN>(d, ap, blockIdx.x, red);
 }

@@ -75,4 +75,4 @@ void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s);       //
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s);      // qoc_mfma_forward.hip: latency mode, on read-back
 int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg);    // qoc_mfma_latency.hip
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s);    //   forward + z-free adjoint sweep in one launch
-void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, hipStream_t s);  //   slice-parallel gradient, overlap z, loss
+void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* fused_tail, hipStream_t s);  //   slice-parallel gradient, overlap z, loss

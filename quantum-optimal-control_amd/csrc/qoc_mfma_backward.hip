@@ -92,7 +92,14 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     if (d.k == 5) b3k = mf.mq <= 2 ? QOC_B3K(2, 5) : QOC_B3K(4, 5);
     else b3k = mf.mq <= 2 ? QOC_B3K(2, 4) : QOC_B3K(4, 4);
 #undef QOC_B3K
-    if (mf.latency && qoc_mfma_latency_setup(mf, d, msg) != 0) return -2;
+    if (mf.latency) {
+        if (qoc_mfma_latency_setup(mf, d, msg) != 0) return -2;
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)d.B * sizeof(unsigned)) != hipSuccess) { msg = "MFMA path: out of device memory"; return -3; }
+        allocs.push_back(p);
+        if (hipMemset(p, 0, (size_t)d.B * sizeof(unsigned)) != hipSuccess) { msg = "MFMA path: clearing the arrival counters failed"; return -2; }
+        mf.lat_count = (unsigned*)p;
+    }
     if (NT == 2 && hipFuncSetAttribute(b3k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
         return -2;
@@ -169,7 +176,7 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
         hipLaunchKernelGGL((k_mfma_backward<NT, false>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
 }
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    if (mf.latency) { qoc_mfma_latency_gradient(mf, d, s); return; }
+    if (mf.latency) { qoc_mfma_latency_gradient(mf, d, nullptr, s); return; }
     if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_backward<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_backward<3>(mf, d, s); else qoc_mfma_launch_all_backward<4>(mf, d, s);
 }
 

@@ -51,6 +51,7 @@ struct QocMfma {
     cplx* PsiL = nullptr;         // [B][steps][NT * MQ][64] Psi after slice t in the sweeps' own register layout (row 16 I + lane % 16, column
                                   // 4 jb + lane / 16): lane-contiguous 1 KB stores / loads; d.inter (API layout) is unpacked from it on read-back
     cplx* LamL = nullptr;         // [B][steps][NT * MQ][64] z-free costate BEFORE K_t^dagger is applied, same layout (qoc_mfma_latency.h)
+    unsigned* lat_count = nullptr; // [B] workgroups of k_mfma_grad_lat that have finished (the last one runs the tail of the iteration)
     cplx* GfT = nullptr;          // [B][NG] fragD(G_g^T): with KfT / PfT the lane-contiguous operands of the forward sweep in latency mode
     bool latency = false;
     int skew_c = 0, skew_b = 0;   // element skews per chunk / per seed that break the power-of-two strides of K storage

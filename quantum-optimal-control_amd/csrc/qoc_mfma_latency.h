@@ -13,6 +13,7 @@
 // shorter by one whole sweep.
 #pragma once
 #include "qoc_mfma_frag.h"
+#include "qoc_kernels_finish.h"
 
 // One wave per (role, seed, chunk, group of 4 columns).  role 0: Psi_t = K_t Psi_{t-1} from Psi0, stores PsiL[t] = Psi after slice t;
 // role 1: Lambda0_{t-1} = K_t^dagger Lambda0_t from W, stores LamL[t] = Lambda0 BEFORE K_t^dagger is applied (the costate that meets
@@ -159,8 +160,11 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
 //   dL/du_{k,t} = c0 (Re z Re G_k + Im z Im G_k)                                   tensorflow_state.py:77-133 (first-order gradient)
 // Every wave forms the overlap z = sum_j <w_j, psi_j(T)> itself (256 elements; tensorflow_state.py:282-333); the first workgroup
 // of a seed publishes z and the loss (k_loss otherwise).
+// fuse: the LAST workgroup of a seed to finish (a counter per seed) runs the tail of the iteration -- chain rule, stop rule, Adam
+// (finish_body, qoc_kernels_finish.h) -- instead of a separate single-workgroup launch whose start-up and first round trips were
+// 13 us of an 85 us iteration.  Only without pulse regularisers (their branch-heavy variant stays a kernel of its own).
 template <int MQ, int KC>
-__global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf) {
+__global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, QocAdamDev ap, int fuse) {
     constexpr int NT = 2, SL = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* Hl = (cplx*)smem;                                                       // [KC] fragD(H_k'), zero beyond k
@@ -248,5 +252,18 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf) {
         for (int x = 0; x < 8; ++x) { sr += gp[x * 2 * KC]; si += gp[x * 2 * KC + KC]; }
         const double c0 = -2.0 / ((double)d.m * (double)d.m);
         d.dLdu[((size_t)b * d.k + lane) * d.steps + t] = c0 * (zr * sr + zi * si);
+    }
+    if (fuse) {
+        __shared__ double red[34];
+        __shared__ int last;
+        __syncthreads();                                                          // every store of the workgroup has been issued and waited for
+        if (threadIdx.x == 0) {
+            __threadfence();                                                      // dLdu, loss: visible device-wide before the arrival is counted
+            last = atomicAdd(mf.lat_count + b, 1u) == (unsigned)(nblk - 1) ? 1 : 0;
+            if (last) { mf.lat_count[b] = 0u; __threadfence(); }                  // (reset for the next evaluation: stream order)
+        }
+        __syncthreads();
+        if (!last) return;
+        finish_body<true>(d, ap, b, red);
     }
 }

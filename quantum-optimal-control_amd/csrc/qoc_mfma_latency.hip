@@ -23,12 +23,15 @@ void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     hipLaunchKernelGGL(k_mfma_sweep_lat<2>, dim3(2 * d.B * mf.C * mf.mq), dim3(64), 0, s, d, mf);
 }
 
-void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, hipStream_t s) {
+// ap != nullptr: the tail of the iteration (k_finish_t<true>) runs inside, in the last workgroup of each seed
+void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* ap, hipStream_t s) {
     const dim3 g(d.B * ((d.steps + 7) / 8)), b(1024);
     const size_t lds = grad_lat_lds(d.k == 5 ? 5 : 4);
+    const QocAdamDev a = ap ? *ap : QocAdamDev{};
+    const int fuse = ap ? 1 : 0;
     if (d.k == 5) {
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 5>), g, b, lds, s, d, mf); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 5>), g, b, lds, s, d, mf);
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 5>), g, b, lds, s, d, mf, a, fuse); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 5>), g, b, lds, s, d, mf, a, fuse);
     } else {
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 4>), g, b, lds, s, d, mf); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 4>), g, b, lds, s, d, mf);
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 4>), g, b, lds, s, d, mf, a, fuse); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 4>), g, b, lds, s, d, mf, a, fuse);
     }
 }
