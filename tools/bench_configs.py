@@ -53,7 +53,8 @@ if __name__ == '__main__':
         sys.exit(0)
     run('C1 single qubit', cases.case_c1(), 1, 50)
     run('C1 single qubit x64 seeds', cases.case_c1(), 64, 50)
-    run('C2 single trajectory (latency route)', cases.case_c2(), 1, 20)
+    run('C2 single trajectory (AUTO: latency mode)', cases.case_c2(), 1, 20)
+    run('C2 single trajectory (GEMM route)', cases.case_c2(), 1, 20, path=4)
     run('C2 single trajectory (MFMA kernels)', cases.case_c2(), 1, 20, path=2)
     run('C2 x64', cases.case_c2(), 64, 20)
     c = cases.case_c2(); c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [30, 31]}
