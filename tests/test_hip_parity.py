@@ -406,6 +406,22 @@ def test_large_size_properties_c5():
     eng.close()
 
 
+@pytest.mark.parametrize('n,steps,chunks', [(256, 8, 0), (256, 8, 3), (384, 6, 0), (130, 12, 5)], ids=['n256', 'n256_3chunks', 'n384', 'n130_padded'])
+def test_large_matrix_full_oracle_parity(n, steps, chunks):
+    """The large-n complex-GEMM chain of C5 (k_zgemm_wg products, chunked chains, slice-parallel gradients) against the FULL oracle
+    at sizes numpy still does in seconds: every scalar, every inter vector, U_final and the whole gradient, not only the
+    size-independent properties test_large_size_properties_c5 can afford at n = 512 x 2000 slices."""
+    c = cases.case_c2(n=n, k=8, steps=steps, m=8, taylor=(5, 3), seed=7)
+    sp = oracle_system(c)
+    rng = np.random.default_rng(n)
+    bases = [sp.base0, rng.normal(0, 0.4, sp.base0.shape)]
+    eng = make_engine(sp, n_seeds=2, chunks=chunks)
+    assert eng.path == 4
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
+
+
 def test_seed_batching_is_bitwise_deterministic():
     """Seeds never interact: a seed optimised alone, inside a batch, or on another shard gives bit-identical results
     (same chunk count => same association order), so seed-sharded multi-GPU runs reproduce single-GPU runs exactly."""
