@@ -3,6 +3,7 @@
 #include "qoc_kernels_mfma.h"
 #include "qoc_mfma_expm.h"
 #include "qoc_mfma_expm_stream.h"
+#include "qoc_mfma_expm_pair.h"
 
 template <int NT>
 static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
@@ -16,6 +17,10 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
         else hipLaunchKernelGGL(k_mfma_expm_slice2<8>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);
         hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.C * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
         hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.NG * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
+    }
+    else if (v == 6 && NT == 2) {
+        if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_pair<4>, dim3(d.B * mf.C), dim3(128), 0, s, d, mf);
+        else hipLaunchKernelGGL(k_mfma_expm_pair<8>, dim3(d.B * mf.C), dim3(128), 0, s, d, mf);
     }
     else if (v == 4 && NT == 2) {
         constexpr int NTS = 2;
