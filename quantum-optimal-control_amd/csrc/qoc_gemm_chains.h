@@ -207,13 +207,18 @@ __global__ void __launch_bounds__(256) k_gemm_chain_fwd(ChainArgs a) {
 // slices (tensorflow_state.py:88-96 forward, :118-131 backward with sign = -1 -- no anti-Hermiticity assumed).  Same mapping
 // and prefetch structure as k_gemm_chain_fwd; a step is T-1 dependent mat-vecs on the register-resident B_t (the
 // generator was assembled for all slices by k_gemm_assemble, so the chain streams 1 matrix per slice instead of k+1).
+// Two argument sets in one launch (workgroups 0 .. nb0-1 run a0, the rest a1): without a state regulariser the costate is linear
+// in the overlap z, so the backward chain starts from -(2/m^2) W and runs BESIDE the forward chain (k_gemm_scale_lam applies z
+// afterwards) -- the batched direct route is two latency-bound chains of 1000 x (T-1) dependent mat-vecs, on 64 of the 256 CUs each.
 template <int N, int MV>
-__global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a) {
+__global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a0, ChainArgs a1, int nb0) {
     using BM = typename FwdMap<N, MV>::type;
     constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
     __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
     const BM bm(threadIdx.x);
-    const int b = blockIdx.x;
+    const bool second = (int)blockIdx.x >= nb0;
+    const ChainArgs a = second ? a1 : a0;
+    const int b = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
     const cplx* Kp = a.K + b * a.sKb;
     const cplx* Ep = a.E + b * a.sEb;
     cplx* Op = a.Out + b * a.sOb;
@@ -297,16 +302,22 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a) {
 }
 
 template <int N>
-static inline void qoc_taylor_chain_launch_n(const ChainArgs& a, int blocks, hipStream_t s) {
-    const int mv = a.m <= 1 ? 1 : (a.m <= 2 ? 2 : (a.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 1>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 2>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(256), 0, s, a);
+static inline void qoc_taylor_chain_launch_n(const ChainArgs& a0, const ChainArgs& a1, int nb0, int blocks, hipStream_t s) {
+    const int mv = a0.m <= 1 ? 1 : (a0.m <= 2 ? 2 : (a0.m <= 4 ? 4 : 8));
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 1>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 2>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
+    else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
 }
 static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
     if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
-    if (N == 32) qoc_taylor_chain_launch_n<32>(a, blocks, s); else qoc_taylor_chain_launch_n<64>(a, blocks, s);
+    if (N == 32) qoc_taylor_chain_launch_n<32>(a, a, blocks, blocks, s); else qoc_taylor_chain_launch_n<64>(a, a, blocks, blocks, s);
+}
+// two chains side by side: `blocks` workgroups each
+static inline void qoc_taylor_chain_launch2(int N, ChainArgs a0, ChainArgs a1, const cplx* zeros, int blocks, hipStream_t s) {
+    if (!a0.E) { a0.E = zeros; a0.sEb = a0.sEc = a0.sEs = 0; }
+    if (!a1.E) { a1.E = zeros; a1.sEb = a1.sEc = a1.sEs = 0; }
+    if (N == 32) qoc_taylor_chain_launch_n<32>(a0, a1, blocks, 2 * blocks, s); else qoc_taylor_chain_launch_n<64>(a0, a1, blocks, 2 * blocks, s);
 }
 
 template <int N, bool CONJ, bool HAS_OUT>

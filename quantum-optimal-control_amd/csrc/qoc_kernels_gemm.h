@@ -140,6 +140,27 @@ __global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict
         }
     }
 }
+// z-free costate at the end of the pulse, Ebnd[b][NC-1] = -(2/m^2) W: start of a backward chain that does not wait for the overlap
+__global__ void __launch_bounds__(256) k_gemm_zfree_end(QocDev d, cplx* __restrict__ Ebnd, int N, int NC) {
+    const size_t per = (size_t)N * QOC_TW;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * per; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = o / per, e = o - b * per;
+        const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
+        cplx v = cmake(0.0, 0.0);
+        if (row < d.n && col < d.m) v = cscale(d.W[row * d.m + col], -2.0 / ((double)d.m * (double)d.m));
+        Ebnd[(b * NC + (NC - 1)) * per + e] = v;
+    }
+}
+// Lambda_t = z Lambda0_t for the time-major wide costates of a seed (LamP[b]: N rows x ldW), z = d.zfin[b]
+__global__ void __launch_bounds__(256) k_gemm_scale_lam(QocDev d, cplx* __restrict__ LamP, int N, int ldW, int cols) {
+    const size_t per = (size_t)N * cols;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * per; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = o / per, e = o - b * per;
+        const size_t row = e / cols, col = e - row * cols;
+        cplx* p = LamP + (b * N + row) * (size_t)ldW + col;
+        *p = cmul(d.zfin[b], *p);
+    }
+}
 // LamP[b][(c+1)S-1] = (Ebnd ? Ebnd[b][c] : 0): costate at the end of every chunk
 __global__ void __launch_bounds__(256) k_gemm_set_chunk_ends(QocDev d, cplx* __restrict__ LamP, const cplx* __restrict__ Ebnd, int N, int S, int NC) {
     const size_t per = (size_t)N * QOC_TW;
@@ -443,6 +464,22 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
 
 static inline const cplx* qoc_gemm_chunk_products(const QocGemm& gm) { return gm.L > 0 ? gm.tree + gm.tree_off[gm.L] : gm.K; }
 
+// lambda_{t-1} = P(-B_t) lambda_t + S_t   tensorflow_state.py:118-131 (direct route)
+static inline ChainArgs qoc_gemm_direct_backward_args(const QocGemm& gm, const QocDev& d, bool need_src) {
+    const int N = gm.N;
+    const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
+    ChainArgs a;
+    memset(&a, 0, sizeof a);
+    a.K = gm.A + (size_t)(d.steps - 1) * NN; a.sKb = (long long)NN * gm.SP; a.sKs = -(long long)NN;
+    a.X0 = gm.Ebnd; a.sXb = (long long)thin;
+    if (need_src) { a.E = gm.SrcP + (size_t)(d.steps - 1) * thin; a.sEb = (long long)thin * gm.SP; a.sEs = -(long long)thin; }
+    a.Out = gm.LamP + (long long)(d.steps - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOs = -gm.MV; a.ldO = gm.ldW;
+    a.store_initial = 1; a.CI = 1; a.len = d.steps - 1; a.m = d.m; a.nterms = d.T; a.sign = -1.0;
+    return a;
+}
+// direct route without a state regulariser: backward chain beside the forward one (see qoc_gemm_forward)
+static inline bool qoc_gemm_zfree_backward(const QocGemm& gm, const QocDev& d) { return gm.direct && !(d.n_forb > 0 || d.has_speed) && d.steps >= 2; }
+
 static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N, xw = d.state_transfer ? 0 : N, ld = xw + QOC_TW, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
@@ -455,7 +492,13 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         a.X0 = gm.Psibnd; a.sXb = (long long)thin;
         a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOs = gm.MV; a.ldO = gm.ldW;
         a.CI = 1; a.len = d.steps; a.m = d.m; a.nterms = d.T; a.sign = 1.0;
-        qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s);
+        if (qoc_gemm_zfree_backward(gm, d)) {
+            // no state regulariser: the costate is linear in the overlap z -- the backward chain starts from -(2/m^2) W and runs
+            // beside the forward one; qoc_gemm_backward multiplies by z (C3 x 64: 13.2 -> 8 ms per iteration)
+            hipLaunchKernelGGL(k_gemm_zfree_end, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, gm.Ebnd, N, NC);
+            qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s);
+        }
+        else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s);
         hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
         return;
     }
@@ -570,16 +613,13 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const bool need_src = d.n_forb > 0 || d.has_speed;
     const cplx* Pc = qoc_gemm_chunk_products(gm);
+    if (qoc_gemm_zfree_backward(gm, d)) {                     // the chain ran beside the forward one from -(2/m^2) W: Lambda_t = z Lambda0_t
+        hipLaunchKernelGGL(k_gemm_scale_lam, dim3(gemm_grid((size_t)d.B * N * d.steps * gm.MV)), dim3(256), 0, s, d, gm.LamP, N, gm.ldW, d.steps * gm.MV);
+    } else {
     hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC);
-    if (gm.direct) {                                         // lambda_{t-1} = P(-B_t) lambda_t + S_t   tensorflow_state.py:118-131
-        ChainArgs a;
-        memset(&a, 0, sizeof a);
-        a.K = gm.A + (size_t)(d.steps - 1) * NN; a.sKb = (long long)NN * gm.SP; a.sKs = -(long long)NN;
-        a.X0 = gm.Ebnd; a.sXb = (long long)thin;
-        if (need_src) { a.E = gm.SrcP + (size_t)(d.steps - 1) * thin; a.sEb = (long long)thin * gm.SP; a.sEs = -(long long)thin; }
-        a.Out = gm.LamP + (long long)(d.steps - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOs = -gm.MV; a.ldO = gm.ldW;
-        a.store_initial = 1; a.CI = 1; a.len = d.steps - 1; a.m = d.m; a.nterms = d.T; a.sign = -1.0;
-        qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s);
+    }
+    if (gm.direct) {
+        if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s);
     } else if (gm.persistent) {
         ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
         memset(&sw, 0, sizeof sw);
