@@ -90,7 +90,7 @@ def test_mfma_path_parity(chunks, variant):
 
 @pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
-                                     'n25_k8_T7', 'n17_k1_T4_s4'])
+                                     'n25_k8_T7', 'n17_k1_T4_s4', 'n30_m13_k2', 'n32_m4_k3', 'n26_k5_plain'])
 @pytest.mark.parametrize('chunks', [0, 1, 7])
 def test_mfma_exponential_kernels(chunks, variant, kernel):
     """The four kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variants 3, 4 = variant 2;
@@ -118,6 +118,8 @@ def _mfma_path_parity(chunks, variant, kernel):
     elif variant == 'n26_k5_sources':    # k = 5: five control images next to the pads of the prefetching backward sweep
         c = cases.case_c2(n=26, k=5, steps=31, m=7, taylor=(5, 2), seed=25)
         c['reg_coeffs'] = {'forbidden_coeff_list': [3.0], 'states_forbidden_list': [25], 'speed_up': 0.3}
+    elif variant == 'n26_k5_plain':      # k = 5 without state regulariser: five control images in the latency-mode gradient kernel
+        c = cases.case_c2(n=26, k=5, steps=37, m=7, taylor=(5, 2), seed=26)
     elif variant == 'n32_m4_k3':         # one column block used out of two
         c = cases.case_c2(n=32, k=3, steps=33, m=4, taylor=(4, 2), seed=23)
     elif variant == 'n40_nt3':
