@@ -337,8 +337,9 @@ def main():
                                    '%d independent control seeds per GPU (aggregate over seeds), reg_coeffs={}' % B,
                        'seeds_per_gpu': B, 'total_seeds': total_seeds, 'path': eng.path, 'chunks': eng.chunks,
                        'stream_groups': G, 'ranks_seen': world, 'fidelities_gathered': int(fidelity.shape[0]),
-                       'transport': ('rccl (%s)' % comm.library) if comm is not None else ('gloo (test hook)' if gloo is not None else 'single process'),
-                       'parallelism': 'seed-sharded x%d, RCCL all-gather of final fidelities' % world},
+                       'transport': (comm.library if comm.library.startswith('files') else 'rccl (%s)' % comm.library) if comm is not None
+                       else ('gloo (test hook)' if gloo is not None else 'single process'),
+                       'parallelism': 'seed-sharded x%d, one all-gather of final fidelities, no collective inside the iterations' % world},
             'per_seed_iterations_per_s': args.steps / elapsed,
             'single_trajectory': single,
             'best_fidelity': float(np.max(fidelity)),

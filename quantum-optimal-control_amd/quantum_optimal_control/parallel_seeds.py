@@ -70,8 +70,98 @@ def rendezvous_cleanup(rank, world, key=None, directory=None):
         pass
 
 
+_NO_RCCL = b'NO_RCCL:'
+
+
+class FileComm(object):
+    """Host-side stand-in with QocComm's interface for a one-node job whose RCCL cannot be opened (no librccl next to the
+    HIP runtime, a process bound to PyTorch's private runtime, ...): the ranks exchange small float64 arrays through files
+    in a per-launch directory.  The seeds of a restart batch never interact, so the only traffic of the data path is one
+    gather of per-seed scalars and one broadcast of the winner -- this transport costs milliseconds where RCCL costs
+    microseconds, and nothing inside the iterations."""
+
+    def __init__(self, rank, world, key, reason='', directory=None, timeout=600.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        self.device = int(os.environ.get('LOCAL_RANK', 0))        # GrapeSharded reads the GPU of this rank from its communicator
+        self.library = 'files (host)' + ((': ' + reason) if reason else '')
+        self._dir = os.path.join(directory or os.environ.get('QOC_RDZV_DIR', '/tmp'), 'qoc_fc_%s' % key)
+        os.makedirs(self._dir, exist_ok=True)
+        self._seq = 0
+
+    def _path(self, seq, rank):
+        return os.path.join(self._dir, '%d_%d.npy' % (seq, rank))
+
+    def _exchange(self, array):
+        """Every rank contributes one array; returns the list of all of them, in rank order."""
+        seq, self._seq = self._seq, self._seq + 1
+        tmp = self._path(seq, self.rank) + '.tmp'
+        with open(tmp, 'wb') as f:
+            np.save(f, np.ascontiguousarray(np.asarray(array, dtype=np.float64)))
+        os.replace(tmp, self._path(seq, self.rank))          # atomic: a reader sees nothing or everything
+        rows, t0 = [], time.time()
+        for r in range(self.world):
+            while True:
+                try:
+                    with open(self._path(seq, r), 'rb') as f:
+                        rows.append(np.load(f))
+                    break
+                except (FileNotFoundError, ValueError, EOFError):
+                    if time.time() - t0 > self.timeout:
+                        raise TimeoutError('FileComm: rank %d saw nothing from rank %d in exchange %d' % (self.rank, r, seq))
+                    time.sleep(0.001)
+        # whoever wrote exchange seq - 1 had read all of seq - 2, and this rank has just seen every file of seq - 1 or later
+        if seq >= 2:
+            try:
+                os.remove(self._path(seq - 2, self.rank))
+            except OSError:
+                pass
+        return rows
+
+    def all_gather(self, values):
+        return np.stack(self._exchange(np.asarray(values, dtype=np.float64).reshape(-1)))
+
+    def all_gather_scalar(self, engine, which, width):
+        s = engine.scalars()[('loss', 'reg_loss', 'grad_squared', 'unitary_scale')[which]]
+        buf = np.zeros(int(width))
+        buf[:s.shape[0]] = s
+        return self.all_gather(buf)
+
+    def all_reduce_max(self, values):
+        return np.max(np.stack(self._exchange(np.asarray(values, dtype=np.float64).reshape(-1))), axis=0)
+
+    def broadcast(self, array, root):
+        array = np.asarray(array, dtype=np.float64)
+        rows = self._exchange(array if self.rank == int(root) else np.zeros(0))
+        return rows[int(root)].reshape(array.shape)
+
+    def barrier(self):
+        self._exchange(np.zeros(1))
+
+    def close(self):
+        if self._dir is None:
+            return
+        self.barrier()
+        # a rank says goodbye only after it has read the last exchange; whoever sees every goodbye is the last one out and
+        # takes the directory with it (two ranks may both see them all: removals that find nothing are fine)
+        open(os.path.join(self._dir, 'bye_%d' % self.rank), 'wb').close()
+        try:
+            names = os.listdir(self._dir)
+            if sum(1 for x in names if x.startswith('bye_')) == self.world:
+                for x in names:
+                    try:
+                        os.remove(os.path.join(self._dir, x))
+                    except OSError:
+                        pass
+                os.rmdir(self._dir)
+        except OSError:
+            pass
+        self._dir = None
+
+
 def open_comm(rank=None, world=None, device=None, key=None):
-    """RCCL communicator for this rank (None for a single process).  Collective: every rank of the launch calls it."""
+    """Communicator for this rank (None for a single process): RCCL behind the C ABI (hip_engine.QocComm), or -- when rank 0
+    cannot open RCCL, or QOC_TRANSPORT=file -- the file transport above (FileComm, same interface).  Collective: every rank
+    of the launch calls it; the choice is made by rank 0 and travels with the rendezvous payload."""
     from quantum_optimal_control.core import hip_engine
     erank, elocal, eworld = launch_env()
     rank = erank if rank is None else rank
@@ -79,9 +169,23 @@ def open_comm(rank=None, world=None, device=None, key=None):
     device = elocal if device is None else device
     if world == 1:
         return None
-    uid = rendezvous(rank, world, hip_engine.comm_unique_id, key=key)
-    comm = hip_engine.QocComm(uid, world, rank, device)
-    comm.barrier()                                  # every rank holds the id: the file can go
+    if key is None:
+        key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+
+    def payload():
+        if os.environ.get('QOC_TRANSPORT', 'rccl') == 'file':
+            return _NO_RCCL + b'QOC_TRANSPORT=file'
+        try:
+            return hip_engine.comm_unique_id()
+        except Exception as exc:                    # no librccl, PyTorch's private HIP runtime, ...
+            return _NO_RCCL + str(exc).encode()[:400]
+
+    uid = rendezvous(rank, world, payload, key=key)
+    if uid.startswith(_NO_RCCL):
+        comm = FileComm(rank, world, key, reason=uid[len(_NO_RCCL):].decode(errors='replace'))
+    else:
+        comm = hip_engine.QocComm(uid, world, rank, device)
+    comm.barrier()                                  # every rank holds the payload: the file can go
     rendezvous_cleanup(rank, world, key=key)
     return comm
 

@@ -158,6 +158,61 @@ def test_rccl_communicator_world1_on_the_engine_stream():
     assert r.returncode == 0 and 'OK refused' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def _file_comm_worker(rank, world, key, directory, out):
+    os.environ['QOC_RDZV_DIR'] = directory
+    os.environ['QOC_TRANSPORT'] = 'file'
+    from quantum_optimal_control import parallel_seeds
+    comm = parallel_seeds.open_comm(rank=rank, world=world, device=0, key=key)
+    assert isinstance(comm, parallel_seeds.FileComm) and comm.library.startswith('files')
+    shard = parallel_seeds.SeedShard(5, rank, world)
+    local = 10.0 * rank + np.arange(shard.count)
+    res = dict(gather=shard.all_gather(local, comm=comm),
+               vmax=comm.all_reduce_max([float(rank), -float(rank)]),
+               bcast=shard.broadcast_from_owner(4, lambda i: np.full((2, 3), 100.0 + i), (2, 3), comm=comm))
+    for _ in range(5):
+        comm.barrier()
+    comm.close()
+    out.put((rank, res))
+
+
+def test_file_transport_world3_matches_the_collective_contract(tmp_path):
+    """The fallback transport of parallel_seeds.open_comm (no RCCL available / QOC_TRANSPORT=file): all-gather in global seed
+    order, max-reduce, broadcast from the owner, barriers; nothing left behind in the rendezvous directory."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_file_comm_worker, args=(r, world, 'test_%d' % os.getpid(), str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = np.array([0.0, 1.0, 10.0, 11.0, 20.0])             # counts 2, 2, 1
+    for r in range(world):
+        np.testing.assert_array_equal(got[r]['gather'], expect)
+        np.testing.assert_array_equal(got[r]['vmax'], [2.0, 0.0])
+        np.testing.assert_array_equal(got[r]['bcast'], np.full((2, 3), 100.0))      # seed 4 is local index 0 of rank 2
+    assert os.listdir(str(tmp_path)) == []
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_file_transport_fallback():
+    """`python bench.py --gpus 2` when RCCL cannot be used (forced here with QOC_TRANSPORT=file; both ranks on GPU 0): the bench
+    line still carries n_gpus 2 and says which transport gathered the fidelities."""
+    import json
+    import subprocess
+    env = dict(os.environ, QOC_TRANSPORT='file', QOC_BENCH_SAME_DEVICE='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'QOC_BENCH_BACKEND'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--seeds-per-gpu', '8', '--no-cpu-baseline', '--no-single'], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert j['n_gpus'] == 2 and j['config']['fidelities_gathered'] == 16 and j['config']['transport'].startswith('files')
+
+
 @pytest.mark.gpu
 def test_bench_gpus2_without_a_launcher_starts_two_ranks():
     """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start two ranks itself and print n_gpus 2.
