@@ -23,8 +23,8 @@
 #include "qoc_kernels_st.h"
 #include "qoc_kernels_gemm.h"
 
-#ifndef QOC_LATENCY_MAX_SEEDS
-#define QOC_LATENCY_MAX_SEEDS 16        // measured on C2 (profiles/r02_latency_sweep.txt): latency mode wins up to 16 seeds, the batch kernels from 24 on
+#ifndef QOC_LATENCY_MAX_WORK
+#define QOC_LATENCY_MAX_WORK 6144       // seeds x time slices up to which AUTO takes the latency mode (see latency_auto below)
 #endif
 static thread_local std::string g_err;
 
@@ -380,10 +380,14 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));
     if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
-    // a handful of control sets of a 16 < n <= 32 unitary problem (the reference's own use is ONE per Grape() call): the latency mode
-    // of the MFMA path -- one wave per slice for the exponentials, row-split chain products, two-level chunk boundaries, final_state
-    // on read-back: one C2 trajectory 0.164 ms per iteration against 0.193 (GEMM latency route) and 0.56 (batch kernels)
-    const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && B <= QOC_LATENCY_MAX_SEEDS && steps >= 64;
+    // a handful of control sets of an n <= 32 unitary problem (the reference's own use is ONE per Grape() call): the latency mode of
+    // the MFMA path.  It spends a workgroup per time slice, so what decides is seeds x slices
+    // (profiles/r02_latency_sweep.txt, r02_small_n_sweep.txt): C2 (500 slices) 0.083 ms against 0.189 (GEMM route) and 0.56 (batch
+    // kernels) for one seed, still ahead at 12 seeds, level at 16; n <= 16 is padded to 32 and competes with the cheap NT = 1 batch
+    // kernels: ahead up to 4 seeds (n = 16 x 500 slices: 0.081 against 0.203 ms for one seed, 0.163 against 0.213 for four)
+    const long long lat_work = (long long)B * steps;
+    const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
+                              ((lat_work <= QOC_LATENCY_MAX_WORK && B <= (n > 16 ? 16 : 4)) || (B == 1 && steps <= 8192));
     if (path == QOC_PATH_AUTO)
         path = latency_auto ? QOC_PATH_MFMA
                             : (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
@@ -401,7 +405,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;
         if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
-            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, 16 < n <= 32, k <= 5, "
+            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32, k <= 5, "
                                               "taylor_terms >= 2 and no state regulariser (n=%d k=%d T=%d)", n, k, d.T));
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));

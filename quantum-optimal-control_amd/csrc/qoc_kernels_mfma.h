@@ -64,7 +64,7 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
 }
 // latency mode needs the NT = 2 streamed kernels, the pair-of-waves backward sweep (k <= 5) and a linear costate recursion
 static inline bool qoc_mfma_latency_ok(const QocDev& d) {
-    return !d.state_transfer && d.n > 16 && d.n <= 32 && d.m <= 16 && d.k <= 5 && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
+    return !d.state_transfer && d.n <= 32 && d.m <= 16 && d.k <= 5 && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
 }
 
 // host entry points (defined next to their kernels)

@@ -5,7 +5,8 @@
 
 int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
                                  std::vector<void*>& allocs, std::string& msg) {
-    const int NT = d.n <= 16 ? 1 : (d.n <= 32 ? 2 : (d.n <= 48 ? 3 : 4));
+    // (latency mode: NT = 2 kernels only -- a smaller problem is padded to 32: one trajectory of n = 16 runs 0.083 ms like n = 17, not 0.20)
+    const int NT = (mf.variant == 5 && d.n <= 32) ? 2 : d.n <= 16 ? 1 : (d.n <= 32 ? 2 : (d.n <= 48 ? 3 : 4));
     const int FR = 256 * NT * NT;
     mf.NT = NT; mf.FR = FR;
     int C = chunks_req;
@@ -21,13 +22,17 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     mf.latency = mf.variant == 5;
     if (mf.latency && chunks_req <= 0) C = (d.steps + 7) / 8;   // chunks of 8 slices
     if (C > d.steps) C = d.steps;
-    if (C > QOC_MAXC) C = QOC_MAXC;
+    if (C > (mf.latency ? 16 * QOC_MAXC : QOC_MAXC)) C = mf.latency ? 16 * QOC_MAXC : QOC_MAXC;
     if (C < 1) C = 1;
     int L = (d.steps + C - 1) / C;
     C = (d.steps + L - 1) / L;                       // no empty chunks
     mf.C = C; mf.L = L;
     mf.G = 0; mf.NG = 0;
-    if (mf.latency) { mf.G = 8; mf.NG = (C + mf.G - 1) / mf.G; }
+    if (mf.latency) {                              // groups of ~sqrt(C) chunks, at least 8: the boundary walks are <= (NG - 1) + (G - 1) thin products
+        int G = 8;
+        while (G * G < C) ++G;
+        mf.G = G; mf.NG = (C + G - 1) / G;
+    }
     mf.mq = (d.m + 3) / 4;
     {
         double f = 1.0;
