@@ -62,9 +62,9 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     if (v == 6 && mf.NT != 2) v = 3;                                    // the pair kernel is an NT = 2 kernel
     return v;
 }
-// latency mode needs the NT = 2 streamed kernels, the pair-of-waves backward sweep (k <= 5) and a linear costate recursion
+// latency mode: NT = 2 kernels (smaller problems are padded to 32) and a costate that is linear in the overlap (no state regulariser)
 static inline bool qoc_mfma_latency_ok(const QocDev& d) {
-    return !d.state_transfer && d.n <= 32 && d.m <= 16 && d.k <= 5 && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
+    return !d.state_transfer && d.n <= 32 && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
 }
 
 // host entry points (defined next to their kernels)

@@ -4,13 +4,17 @@
 
 static size_t grad_lat_lds(int kc) { return (size_t)kc * 1024 * sizeof(cplx) + (size_t)8 * 2 * 4 * 2 * kc * sizeof(double); }
 
+static int grad_lat_kc(const QocDev& d) { return d.k <= 4 ? 4 : (d.k == 5 ? 5 : 8); }      // control images in LDS (16 KB each)
+
 static const void* grad_lat_kernel(const QocMfma& mf, const QocDev& d) {
-    if (d.k == 5) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 5> : (const void*)k_mfma_grad_lat<4, 5>;
+    const int kc = grad_lat_kc(d);
+    if (kc == 8) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 8> : (const void*)k_mfma_grad_lat<4, 8>;
+    if (kc == 5) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 5> : (const void*)k_mfma_grad_lat<4, 5>;
     return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 4> : (const void*)k_mfma_grad_lat<4, 4>;
 }
 
 int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
-    if (hipFuncSetAttribute(grad_lat_kernel(mf, d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grad_lat_lds(d.k == 5 ? 5 : 4)) != hipSuccess) {
+    if (hipFuncSetAttribute(grad_lat_kernel(mf, d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grad_lat_lds(grad_lat_kc(d))) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the latency-mode gradient kernel";
         return -2;
     }
@@ -26,12 +30,12 @@ void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
 // ap != nullptr: the tail of the iteration (k_finish_t<true>) runs inside, in the last workgroup of each seed
 void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* ap, hipStream_t s) {
     const dim3 g(d.B * ((d.steps + 7) / 8)), b(1024);
-    const size_t lds = grad_lat_lds(d.k == 5 ? 5 : 4);
+    const int kc = grad_lat_kc(d);
+    const size_t lds = grad_lat_lds(kc);
     const QocAdamDev a = ap ? *ap : QocAdamDev{};
     const int fuse = ap ? 1 : 0;
-    if (d.k == 5) {
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 5>), g, b, lds, s, d, mf, a, fuse); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 5>), g, b, lds, s, d, mf, a, fuse);
-    } else {
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 4>), g, b, lds, s, d, mf, a, fuse); else hipLaunchKernelGGL((k_mfma_grad_lat<4, 4>), g, b, lds, s, d, mf, a, fuse);
-    }
+#define QOC_GL(KCv) do { if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, KCv>), g, b, lds, s, d, mf, a, fuse); \
+                         else hipLaunchKernelGGL((k_mfma_grad_lat<4, KCv>), g, b, lds, s, d, mf, a, fuse); } while (0)
+    if (kc == 8) QOC_GL(8); else if (kc == 5) QOC_GL(5); else QOC_GL(4);
+#undef QOC_GL
 }

@@ -146,7 +146,7 @@ def _mfma_path_parity(chunks, variant, kernel):
     rng = np.random.default_rng(5)
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2, 3 * sp.base0]
     from quantum_optimal_control.core import hip_engine
-    latency_ok = sp.n <= 32 and sp.k <= 5 and sp.exp_terms >= 2 and not ({'forbidden_coeff_list', 'speed_up'} & set(sp.reg_coeffs))
+    latency_ok = sp.n <= 32 and sp.k <= 8 and sp.exp_terms >= 2 and not ({'forbidden_coeff_list', 'speed_up'} & set(sp.reg_coeffs))
     if kernel == 5 and not latency_ok:
         with pytest.raises(hip_engine.QocError, match='latency mode'):
             make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
