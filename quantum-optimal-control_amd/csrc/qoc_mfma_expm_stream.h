@@ -440,6 +440,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
     const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / d.steps, t = blockIdx.x - b * d.steps;
     if (d.skip_done && d.done[b]) return;                               // whole workgroup: no barrier yet
+    QOC_LAP_INIT
     const double inv_scale = 1.0 / (double)(1 << d.s);
     const int dlt = (lane & 15) - (lane >> 4);
     double idv[4];
@@ -481,6 +482,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
         for (int kk = 0; kk < KC; ++kk) { re = fma(ck[kk], hst[kk + 1][ib].x, re); im = fma(ck[kk], hst[kk + 1][ib].y, im); }
         A.re[ib] = re; A.im[ib] = im; A.su[ib] = re + im;
     }
+    QOC_LAP(0)
     int cur = 0;
     auto publish = [&](const Col& m) {                                  // own strips of the next left operand -> image `cur`, then meet the partner
 #pragma unroll
@@ -490,6 +492,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
             imgs[cur][o] = m.su[ib];
         }
         lds_barrier();
+        QOC_LAP(1)
     };
     double a[QQS], bq[QQS], cq[QQS];
     auto product = [&](const Col& p) {                                  // acc = (image cur) * p; the other image is free for the next publish
@@ -523,6 +526,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
         }
         __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
+        QOC_LAP(2)
     };
     auto diag = [&](int ib) { return ((ib >> 2) == J) ? idv[ib & 3] : 0.0; };
     // ---- A2 = A * A, polynomial start ------------------------------------------------------------------------------------------
@@ -538,6 +542,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
             X.im[ib] = fma(p_cT, im, p_c1 * A.im[ib]);
             X.su[ib] = X.re[ib] + X.im[ib];
         }
+        QOC_LAP(3)
         if (nH > 0) {
             publish(A2);                                                // image of A2 stays through the Horner products
             for (int i = nH - 1; i >= 0; --i) {
@@ -550,6 +555,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
                     X.im[ib] = fma(d1, A.im[ib], cq[ib] - a[ib] - bq[ib]);
                     X.su[ib] = X.re[ib] + X.im[ib];
                 }
+                QOC_LAP(3)
             }
             cur ^= 1;                                                   // the next publish must not overwrite A2 while the partner still reads it
         }
@@ -563,6 +569,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
             const double re = a[ib] - bq[ib], im = cq[ib] - a[ib] - bq[ib];
             X.re[ib] = re; X.im[ib] = im; X.su[ib] = re + im;
         }
+        QOC_LAP(3)
     }
     // ---- K_t out: fragD(K) from the registers, fragD(K^T) through the image ------------------------------------------------------------
     const size_t item = kitem(mf, d.steps, b, t);
@@ -571,4 +578,6 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
     publish(X);
 #pragma unroll
     for (int q = 0; q < QQS; ++q) mf.KfT[item + (J * QQS + q) * 64 + lane] = img[cur][(4 * q + (lane >> 4)) * QLDS + 16 * J + (lane & 15)];
+    QOC_LAP(4)
+    QOC_LAP_DONE
 }
