@@ -345,6 +345,40 @@ def test_large_size_properties_c2(path, variant, expect):
     eng.close()
 
 
+@pytest.mark.parametrize('n,k,steps,m,seeds', [(6, 2, 1500, 3, 1), (20, 3, 1100, 5, 2), (2, 1, 100, 2, 1), (13, 8, 90, 4, 3)],
+                         ids=['n6_1500_slices', 'n20_1100_slices_2_seeds', 'c1_shape', 'n13_k8'])
+def test_latency_mode_long_pulses_and_small_systems(n, k, steps, m, seeds):
+    """Latency mode beyond the C2 shape: more than 64 chunks (groups of ~sqrt(C) chunks instead of 8), Hilbert spaces below 17 levels
+    padded to 32, eight controls -- AUTO picks it for these shapes -- against the full oracle."""
+    c = cases.case_c2(n=n, k=k, steps=steps, m=m, taylor=(4, 2), seed=41)
+    sp = oracle_system(c)
+    rng = np.random.default_rng(n + steps)
+    bases = [sp.base0] + [rng.normal(0, 0.5, sp.base0.shape) for _ in range(seeds - 1)]
+    eng = make_engine(sp, n_seeds=seeds)
+    assert eng.path == 2 and eng.chunks == (steps + 7) // 8
+    eng.set_base(np.stack(bases))
+    eng.profile_enable(True)
+    check_eval(eng, sp, bases)
+    assert 'slice2' in eng.profile_read()['kernel']
+    eng.close()
+
+
+def test_auto_leaves_the_latency_mode_to_few_seeds():
+    """AUTO decides by seeds x time slices: many seeds of a small system stay on the NT = 1 batch kernels, a state regulariser
+    keeps the GEMM latency route."""
+    from quantum_optimal_control.core import hip_engine
+    c = cases.case_c2(n=9, k=2, steps=300, m=4, taylor=(5, 2), seed=3)
+    sp = oracle_system(c)
+    for seeds, reg, expect in ((1, {}, 'slice2'), (4, {}, 'slice2'), (8, {}, 'chunk'), (1, {'forbidden_coeff_list': [1.0], 'states_forbidden_list': [8]}, None)):
+        eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling, reg_coeffs=reg, n_seeds=seeds)
+        eng.set_base(np.zeros((seeds, sp.k, sp.steps)))
+        eng.profile_enable(True)
+        eng.evaluate()
+        name = eng.profile_read()['kernel']
+        assert ('slice2' in name) == (expect == 'slice2'), (seeds, reg, name)
+        eng.close()
+
+
 def test_latency_mode_fused_tail_matches_the_finish_kernel():
     """Latency mode runs chain rule / stop rule / Adam in the last workgroup of its gradient kernel (a per-seed arrival counter
     decides who is last).  A zero-weight amplitude regulariser switches to the separate finish kernel, whose arithmetic is
