@@ -63,7 +63,7 @@ def test_random_problem_all_paths(seed):
         pytest.skip('ill-conditioned draw: the truncated series blows up, relative parity is meaningless')
     bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 * (i + 1) for i in range(B - 1)]
     tried = 0
-    for path, chunks, kernel in ((0, 0, 0), (1, 0, 0), (2, 0, 1), (2, 3, 2), (2, 2, 3), (2, 5, 4), (3, 0, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0)):
+    for path, chunks, kernel in ((0, 0, 0), (1, 0, 0), (2, 0, 1), (2, 3, 2), (2, 2, 3), (2, 5, 4), (2, 0, 5), (2, 4, 5), (2, 3, 6), (3, 0, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0)):
         try:
             eng = make_engine(sp, n_seeds=B, path=path, chunks=chunks, variant=kernel)
         except hip_engine.QocError:
