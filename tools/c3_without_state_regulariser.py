@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """C3 x 64 without its state regularisers (dwdt only): the direct route runs the backward chain beside the forward one."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'quantum-optimal-control_amd'), os.path.join(ROOT, 'tools')]
 import bench_configs
 from tests.golden import cases

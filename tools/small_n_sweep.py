@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Small Hilbert spaces (n <= 16): batch kernels (NT = 1) against the latency mode padded to 32, for a few seeds."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'quantum-optimal-control_amd'), os.path.join(ROOT, 'tools')]
 import numpy as np
 from quantum_optimal_control.core import hip_engine
