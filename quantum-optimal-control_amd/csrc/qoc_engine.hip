@@ -25,6 +25,7 @@
 
 #ifndef QOC_LATENCY_MAX_WORK
 #define QOC_LATENCY_MAX_WORK 6144       // seeds x time slices up to which AUTO takes the latency mode (see latency_auto below)
+#define QOC_LATENCY_MAX_WORK_SRC 4096   // the same with a state regulariser
 #endif
 static thread_local std::string g_err;
 
@@ -153,7 +154,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     const int skip = e->skip_mask;
     const bool plain = !(d.has_amp || d.has_env || d.has_dwdt || d.has_d2wdt2 || d.has_band);
     // latency mode without pulse regularisers: the tail of the iteration runs in the last workgroup of the gradient kernel
-    const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && plain && !(skip & (16 | 32));
+    const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && !e->mf.lat_sources && plain && !(skip & (16 | 32));
     // (latency mode of the MFMA path: the slice kernel of the exponentials forms its own controls)
     if (!(skip & 1) && !(e->path == QOC_PATH_MFMA && e->mf.latency)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {
@@ -163,7 +164,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         if (!(skip & 4)) qoc_mfma_launch_forward(e->mf, d, e->stream);
         if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
         if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
-        if (!(skip & 8) && !e->mf.latency) hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);   // latency mode: inside the backward kernel
+        if (!(skip & 8) && (!e->mf.latency || e->mf.lat_sources)) hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);   // latency mode: inside the backward kernel
         if (!(skip & 16)) {
             if (fused_tail) qoc_mfma_latency_gradient(e->mf, d, &ap, e->stream);
             else qoc_mfma_launch_backward(e->mf, d, e->stream);
@@ -202,7 +203,8 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     }
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
-    e->final_stale = e->inter_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale / inter_vecs are formed when read back
+    e->final_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale are formed when read back
+    e->inter_stale = e->final_stale && !e->mf.lat_sources;            // inter_vecs too, unless the state regularisers needed them anyway
     return QOC_OK;
 }
 
@@ -385,9 +387,14 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // (profiles/r02_latency_sweep.txt, r02_small_n_sweep.txt): C2 (500 slices) 0.083 ms against 0.189 (GEMM route) and 0.56 (batch
     // kernels) for one seed, still ahead at 12 seeds, level at 16; n <= 16 is padded to 32 and competes with the cheap NT = 1 batch
     // kernels: ahead up to 4 seeds (n = 16 x 500 slices: 0.081 against 0.203 ms for one seed, 0.163 against 0.213 for four)
+    // With a state regulariser (forbidden levels, speed_up) the backward half is the affine recursion of the batch kernels on the
+    // latency mode's chunks, with two-level boundaries (QocMfma::lat_sources): one C2 trajectory with dwdt + forbidden levels 0.189 ms
+    // against 0.290 (GEMM route) and 0.72 (batch kernels); ahead up to ~4096 seed-slices (tools/c2_forbidden_single.py).
     const long long lat_work = (long long)B * steps;
+    const bool lat_src = d.n_forb > 0 || d.has_speed;
     const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
-                              ((lat_work <= QOC_LATENCY_MAX_WORK && B <= (n > 16 ? 16 : 4)) || (B == 1 && steps <= 8192));
+                              ((lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && B <= (n > 16 ? 16 : (lat_src ? 2 : 4))) ||
+                               (B == 1 && steps <= 8192));
     if (path == QOC_PATH_AUTO)
         path = latency_auto ? QOC_PATH_MFMA
                             : (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
@@ -406,7 +413,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         e->mf.variant = latency_auto ? 5 : cfg->variant;
         if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
             return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32, k <= 8, "
-                                              "taylor_terms >= 2 and no state regulariser (n=%d k=%d T=%d)", n, k, d.T));
+                                              "taylor_terms >= 2 (n=%d k=%d T=%d)", n, k, d.T));
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         e->chunks = e->mf.C;

@@ -62,9 +62,10 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     if (v == 6 && mf.NT != 2) v = 3;                                    // the pair kernel is an NT = 2 kernel
     return v;
 }
-// latency mode: NT = 2 kernels (smaller problems are padded to 32) and a costate that is linear in the overlap (no state regulariser)
+// latency mode: NT = 2 kernels (smaller problems are padded to 32).  With a state regulariser the costate is not linear in the
+// overlap: the backward half then runs the batch kernels on the latency mode's chunks (QocMfma::lat_sources)
 static inline bool qoc_mfma_latency_ok(const QocDev& d) {
-    return !d.state_transfer && d.n <= 32 && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
+    return !d.state_transfer && d.n <= 32 && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22;
 }
 
 // host entry points (defined next to their kernels)
@@ -75,5 +76,5 @@ void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s);   //
 void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip: latency mode, on read-back
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s);      // qoc_mfma_forward.hip: latency mode, on read-back
 int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg);    // qoc_mfma_latency.hip
-void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s);    //   forward + z-free adjoint sweep in one launch
+void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s);    //   forward + z-free adjoint sweep in one launch (lat_sources: forward only, then d.inter unpacked)
 void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* fused_tail, hipStream_t s);  //   slice-parallel gradient, overlap z, loss

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
     __shared__ __attribute__((aligned(16))) cplx o2_img[4][16 * F2_LDP];          // per wave: image[column j][row]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * 4 + wv;
+    const int item = blockIdx.x * (blockDim.x >> 6) + wv;            // 4 waves per workgroup; one in latency mode (one sweep per CU)
     if (item >= d.B * mf.C) return;
     const int b = item / mf.C, c = item - b * mf.C;
     if ((!FULL && c == 0) || (d.skip_done && d.done[b])) return;                       // a_0 is never used; finished seeds are frozen
@@ -428,7 +428,12 @@ __global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
 //  * control gradients: 16-lane DPP butterflies, the 4 row partials of both waves go through LDS and lane kk of wave h = 0
 //    adds the 8 partials of control kk (was: six ds_bpermute levels per control).
 // Used for k <= 4 controls without state regularisers (no per-slice source term); anything else keeps backward2.
-template <int MQ, bool SRC, int KC = 4>
+// MODE (latency mode with a state regulariser, QocMfma::lat_sources -- the chunks are 8 slices short there, so the chunk-boundary
+// recursion E_{cc-1} = P_cc^dagger E_cc + a_cc would be ~60 dependent products): 1 = two-level boundaries -- whole groups of G chunks
+// first, E <- G_g^dagger E + A_g with the group products GfD of k_mfma_chain_rows and the group offsets Goff, then the chunks of the
+// own group; 2 = the pass that forms those group offsets: an item is a (seed, group), the recursion runs over the chunks of the
+// group from a zero costate and its result goes to Goff; no slices.  MODE 0 (batch kernels) has neither branch in its code.
+template <int MQ, bool SRC, int KC = 4, int MODE = 0>
 __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     constexpr int NT = 2;                                                       // KC = control images in LDS: 4, or 5 (k = 5 still fits the 160 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -438,13 +443,14 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     cplx* Hl = (cplx*)smem;                                                     // [KC] fragD(H_k'), zero beyond k
     cplx* pads = Hl + (size_t)KC * QFR;                                         // [8 waves][2 buffers][16 * B2_LDP]
     double* gpart = (double*)(pads + 8 * 2 * 16 * B2_LDP);                     // [4 pairs][2 buffers][2 waves][4 rows][KC]
-    for (int o = threadIdx.x; o < KC * QFR; o += blockDim.x) Hl[o] = o < d.k * QFR ? mf.HfD[QFR + o] : cmake(0.0, 0.0);
+    if (MODE != 2) for (int o = threadIdx.x; o < KC * QFR; o += blockDim.x) Hl[o] = o < d.k * QFR ? mf.HfD[QFR + o] : cmake(0.0, 0.0);
     // costate images of the pair: image[buffer][column j][row % 16] (row stride B2_LDP), rows 0..15 in pad_lo, 16..31 in pad_hi
     cplx* mypad = pads + (size_t)wv * 2 * 16 * B2_LDP;
     const cplx* pad_lo = pads + (size_t)(2 * pair) * 2 * 16 * B2_LDP;
     const cplx* pad_hi = pads + (size_t)(2 * pair + 1) * 2 * 16 * B2_LDP;
-    const int item = blockIdx.x * 4 + pair;
-    const bool item_ok = item < d.B * mf.C;
+    const int item = blockIdx.x * (blockDim.x >> 7) + pair;           // 4 pairs per workgroup in the batch kernels
+    const int n_items = d.B * (MODE == 2 ? mf.NG : mf.C);                // MODE 2: c is a GROUP index
+    const bool item_ok = item < n_items;
     const int c = item_ok ? item / d.B : 0, b = item_ok ? item - c * d.B : 0;   // chunk-major, as in k_mfma_forward2
     const bool active = item_ok && !(d.skip_done && d.done[b]);
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
@@ -462,7 +468,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         for (int jb = 0; jb < MQ; ++jb) {
             const int row = 16 * h + lc, col = 4 * jb + lk;
             cplx v = cmake(0.0, 0.0);
-            if (row < d.n && col < d.m) {
+            if (MODE != 2 && row < d.n && col < d.m) {
                 v = cscale(cmul(z, d.W[row * d.m + col]), c0);
                 if (SRC) v = cadd(v, source_at(d, b, d.steps, row, col));
             }
@@ -504,11 +510,12 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     int buf = 0;
     // ---- costate at the end of this chunk: E_{cc-1} = P_cc^dagger E_cc, uniform trip count, result kept only while cc > c ----
     {
+        const cplx* offs = mf.Aoff + (size_t)b * mf.C * (QQS * 64);   // offsets of the steps in flight: per chunk, or per group (Goff)
         auto bstep = [&](const Frag& fr, bool keep, int cc) {
             double nre[MQ], nim[MQ];
             cplx off[MQ];
             if (SRC) {                                               // E_{cc-1} = P_cc^dagger E_cc + a_cc; a_cc is a D-layout 16x16x4 column block
-                const cplx* ao = mf.Aoff + ((size_t)b * mf.C + cc) * (QQS * 64) + (4 * h + (lc >> 2)) * 64 + 16 * (lc & 3) + lk;
+                const cplx* ao = offs + (size_t)cc * (QQS * 64) + (4 * h + (lc >> 2)) * 64 + 16 * (lc & 3) + lk;
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) off[jb] = ao[4 * jb];
             }
@@ -537,7 +544,25 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
             if (s < n_steps) bstep(f0, keep_of(s), idx_of(s));
         };
         const int C = mf.C;
-        bsteps(mf.PfD + (size_t)b * C * QFR, C - 1, [&](int s) { return C - 1 - s; }, [&](int s) { return C - 1 - s > c; });
+        if constexpr (MODE == 0) {
+            bsteps(mf.PfD + (size_t)b * C * QFR, C - 1, [&](int s) { return C - 1 - s; }, [&](int s) { return C - 1 - s > c; });
+        } else if constexpr (MODE == 1) {
+            const int G = mf.G, NG = mf.NG, g = c / G;
+            offs = mf.Goff + (size_t)b * NG * (QQS * 64);
+            bsteps(mf.GfD + (size_t)b * NG * QFR, NG - 1, [&](int s) { return NG - 1 - s; }, [&](int s) { return NG - 1 - s > g; });
+            offs = mf.Aoff + (size_t)b * C * (QQS * 64);
+            bsteps(mf.PfD + (size_t)b * C * QFR, G - 1, [&](int s) { return min(g * G + G - 1 - s, C - 1); }, [&](int s) { const int cc = g * G + G - 1 - s; return cc < C && cc > c; });
+        } else {
+            // group offset A_g: from a zero costate over ALL chunks of group c (= g), last to first
+            const int G = mf.G, g = c;
+            bsteps(mf.PfD + (size_t)b * C * QFR, G, [&](int s) { return min(g * G + G - 1 - s, C - 1); }, [&](int s) { return g * G + G - 1 - s < C; });
+            if (active) {
+                cplx* go = mf.Goff + ((size_t)b * mf.NG + g) * (QQS * 64) + (4 * h + (lc >> 2)) * 64 + 16 * (lc & 3) + lk;
+#pragma unroll
+                for (int jb = 0; jb < MQ; ++jb) go[4 * jb] = cmake(ore[jb], oim[jb]);
+            }
+            return;
+        }
     }
     // ---- slices of the chunk, last to first ------------------------------------------------------------------------------
     const cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;

@@ -28,6 +28,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     C = (d.steps + L - 1) / L;                       // no empty chunks
     mf.C = C; mf.L = L;
     mf.G = 0; mf.NG = 0;
+    mf.lat_sources = mf.latency && (d.n_forb > 0 || d.has_speed);
     if (mf.latency) {                              // groups of ~sqrt(C) chunks, at least 8: the boundary walks are <= (NG - 1) + (G - 1) thin products
         int G = 8;
         while (G * G < C) ++G;
@@ -66,6 +67,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k <= 5: backward3 (5 images still fit next to its pads)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
+    if (mf.lat_sources && !al(&mf.Goff, (size_t)d.B * mf.NG * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     if (mf.latency && (!al(&mf.GfD, (size_t)d.B * mf.NG * FR) || !al(&mf.GfT, (size_t)d.B * mf.NG * FR) || !al(&mf.TfD, (size_t)d.B * FR) ||
                        !al(&mf.PsiL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64) ||
                        !al(&mf.LamL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64))) { msg = "MFMA path: out of device memory"; return -3; }
@@ -105,6 +107,17 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         if (hipMemset(p, 0, (size_t)d.B * sizeof(unsigned)) != hipSuccess) { msg = "MFMA path: clearing the arrival counters failed"; return -2; }
         mf.lat_count = (unsigned*)p;
     }
+    if (NT == 2 && mf.lat_sources && d.k <= 5) {
+#define QOC_B3L(MQv, KCv, MODEv) (const void*)k_mfma_backward3<MQv, true, KCv, MODEv>
+        const void* k1 = d.k == 5 ? (mf.mq <= 2 ? QOC_B3L(2, 5, 1) : QOC_B3L(4, 5, 1)) : (mf.mq <= 2 ? QOC_B3L(2, 4, 1) : QOC_B3L(4, 4, 1));
+        const void* k2 = d.k == 5 ? (mf.mq <= 2 ? QOC_B3L(2, 5, 2) : QOC_B3L(4, 5, 2)) : (mf.mq <= 2 ? QOC_B3L(2, 4, 2) : QOC_B3L(4, 4, 2));
+#undef QOC_B3L
+        if (hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
+            hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
+            msg = "MFMA path: cannot reserve LDS for the two-level backward kernel";
+            return -2;
+        }
+    }
     if (NT == 2 && hipFuncSetAttribute(b3k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the prefetching backward kernel";
         return -2;
@@ -133,8 +146,9 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     const int items = d.B * mf.C;
     if ((d.n_forb > 0 || d.has_speed) && mf.C > 1) {
         if (NT == 2 && mf.variant != 1) {
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, false>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, false>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+            const int wpg = mf.lat_sources ? 1 : 4;                      // latency mode: one sweep per workgroup, i.e. per CU
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, false>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, false>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf);
         } else {
             hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
         }
@@ -145,6 +159,16 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     if (NT == 2 && mf.variant != 1) {
         if (d.k <= 5) {
             const bool src = d.n_forb > 0 || d.has_speed;
+            if (mf.lat_sources) {
+                // latency mode with a state regulariser: group offsets first, then the sweep with two-level affine boundaries; one pair of
+                // waves per workgroup (per CU)
+                const dim3 gg(d.B * mf.NG), gc(items), b1(128);
+#define QOC_B3L(MQv, MODEv, GRID) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, true, 5, MODEv>), GRID, b1, mf.bwd_lds3, s, d, mf); \
+                                       else hipLaunchKernelGGL((k_mfma_backward3<MQv, true, 4, MODEv>), GRID, b1, mf.bwd_lds3, s, d, mf); } while (0)
+                if (mf.mq <= 2) { QOC_B3L(2, 2, gg); QOC_B3L(2, 1, gc); } else { QOC_B3L(4, 2, gg); QOC_B3L(4, 1, gc); }
+#undef QOC_B3L
+                return;
+            }
             const dim3 g3((items + 3) / 4), b3(512);                     // 4 pairs of waves per workgroup
 #define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
                                else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
@@ -181,7 +205,7 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
         hipLaunchKernelGGL((k_mfma_backward<NT, false>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
 }
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    if (mf.latency) { qoc_mfma_latency_gradient(mf, d, nullptr, s); return; }
+    if (mf.latency && !mf.lat_sources) { qoc_mfma_latency_gradient(mf, d, nullptr, s); return; }
     if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_backward<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_backward<3>(mf, d, s); else qoc_mfma_launch_all_backward<4>(mf, d, s);
 }
 

@@ -38,6 +38,7 @@ struct QocMfma {
     cplx* PfD = nullptr;      // [B][C] fragD(P_c)
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
+    cplx* Goff = nullptr;     // [B][NG] the same for whole groups of chunks (latency mode with a state regulariser)
     cplx* LamD = nullptr;     // NT > 2: [B][steps][16 NT rows][16 columns] costates for the slice-parallel gradient kernel
     size_t grad_lds = 0;
     size_t bwd_lds = 0, bwd_lds3 = 0;
@@ -54,6 +55,8 @@ struct QocMfma {
     unsigned* lat_count = nullptr; // [B] workgroups of k_mfma_grad_lat that have finished (the last one runs the tail of the iteration)
     cplx* GfT = nullptr;          // [B][NG] fragD(G_g^T): with KfT / PfT the lane-contiguous operands of the forward sweep in latency mode
     bool latency = false;
+    bool lat_sources = false;     // latency mode with a state regulariser: exponentials, chains and the forward sweep as above, then the
+                                  // affine costate recursion of the batch kernels (k_mfma_bwd_offsets2 + k_mfma_backward3<SRC> / k_mfma_grad)
     int skew_c = 0, skew_b = 0;   // element skews per chunk / per seed that break the power-of-two strides of K storage
 };
 

@@ -24,7 +24,9 @@ int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
 // forward and z-free adjoint sweep side by side: 2 x (seed, chunk, group of 4 columns) waves, one per workgroup, i.e. per CU (no two
 // sweeps share a CU's 64 B/clk load path: 4 x 16 KB per step did)
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    hipLaunchKernelGGL(k_mfma_sweep_lat<2>, dim3(2 * d.B * mf.C * mf.mq), dim3(64), 0, s, d, mf);
+    // (with a state regulariser only the forward half: the costate needs the sources, i.e. the forward states, first)
+    hipLaunchKernelGGL(k_mfma_sweep_lat<2>, dim3((mf.lat_sources ? 1 : 2) * d.B * mf.C * mf.mq), dim3(64), 0, s, d, mf);
+    if (mf.lat_sources) qoc_mfma_unpack_inter(mf, d, s);              // k_loss, the sources and the batch backward kernels read d.inter
 }
 
 // ap != nullptr: the tail of the iteration (k_finish_t<true>) runs inside, in the last workgroup of each seed
