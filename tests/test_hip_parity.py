@@ -90,7 +90,7 @@ def test_mfma_path_parity(chunks, variant):
 
 @pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
-                                     'n25_k8_T7', 'n17_k1_T4_s4', 'n30_m13_k2', 'n32_m4_k3', 'n26_k5_plain'])
+                                     'n25_k8_T7', 'n17_k1_T4_s4', 'n30_m13_k2', 'n32_m4_k3', 'n26_k5_plain', 'n28_k7_sources', 'n26_k5_sources'])
 @pytest.mark.parametrize('chunks', [0, 1, 7])
 def test_mfma_exponential_kernels(chunks, variant, kernel):
     """The four kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variants 3, 4 = variant 2;
