@@ -71,8 +71,9 @@ typedef struct qoc_config {
                                  * for one or a few control sets, decided by seeds x time slices: exponentials
                                  * per time slice, forward and z-free adjoint sweep side by side, slice-parallel gradient),
                                  * 6 = v_mfma_f64_4x4x4 exponentials by two waves per chunk, two waves
-                                 * per SIMD (n <= 32; slower than 4, kept for A/B runs); 2..6 (and auto) run the n <= 32 sweeps
-                                 * on v_mfma_f64_4x4x4 as well */
+                                 * per SIMD (n <= 32; slower than 4, kept for A/B runs), 7 = n > 32: v_mfma_f64_4x4x4
+                                 * exponentials by four waves per chunk, a block of rows each (auto for n > 32); 2..7 (and auto)
+                                 * run the n <= 32 sweeps on v_mfma_f64_4x4x4 as well */
     int32_t reserved[6];
 } qoc_config;
 

@@ -53,11 +53,15 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
 
 // which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave, image written before each product,
 // 4 = 4x4x4 one wave, image written strip by strip under the product's own MFMAs, 5 = latency mode: two waves per
-// slice (k_mfma_expm_slice2) + k_mfma_chain_rows, 6 = 4x4x4, two waves per item and two waves per SIMD, no sums image (k_mfma_expm_pair))
+// slice (k_mfma_expm_slice2) + k_mfma_chain_rows, 6 = 4x4x4, two waves per item and two waves per SIMD, no sums image (k_mfma_expm_pair), 7 = n > 32: four
+// waves per item with a block of rows each (k_mfma_expm_rows))
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
-    if (mf.NT > 2) return mf.variant == 1 ? 1 : 2;      // n > 32: NT waves per item on 4x4x4 (n = 48 x 64: 4.3 vs 11.9 ms per launch)
+    // n > 32: four waves per item, a block of rows each (7; AUTO: n = 48 x 64 seeds 3.3 ms per launch against 3.8 for 2 = one wave per
+    // 16-column block and 11.9 for 1 = the same on 16x16x4)
+    if (mf.NT > 2) return mf.variant == 1 ? 1 : (mf.variant == 2 ? 2 : 7);
     if (mf.latency) return 5;
     int v = mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 4 : 1);
+    if (v == 7) v = 4;                                                  // the row-block kernel is an NT = 3 / 4 kernel
     if (v == 4 && (d.T < 2 || mf.NT != 2)) v = 3;                      // the streamed kernel starts from the product A * A
     if (v == 6 && mf.NT != 2) v = 3;                                    // the pair kernel is an NT = 2 kernel
     return v;

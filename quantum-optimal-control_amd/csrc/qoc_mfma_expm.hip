@@ -4,6 +4,7 @@
 #include "qoc_mfma_expm.h"
 #include "qoc_mfma_expm_stream.h"
 #include "qoc_mfma_expm_pair.h"
+#include "qoc_mfma_expm_rows.h"
 
 template <int NT>
 static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStream_t s) {
@@ -11,6 +12,20 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     // per launch at C2 x 64); NT = 1 and small launches keep the 16x16x4 kernel (C1: 0.072 vs 0.074 ms; one C2 trajectory:
     // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
     const int v = qoc_mfma_expm_variant(mf, d);
+    if constexpr (NT >= 3) {
+        if (v == 7) {
+            const size_t lds = qoc_expm_rows_lds<NT>();
+            static bool reserved = false;                                 // (per NT: this function is a template)
+            if (!reserved) {
+                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                reserved = true;
+            }
+            if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_rows<NT, 4>), dim3(d.B * mf.C), dim3(256), lds, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_expm_rows<NT, 8>), dim3(d.B * mf.C), dim3(256), lds, s, d, mf);
+            return;
+        }
+    }
     if (v == 5 && NT == 2) {
         // latency mode: K_t by two waves per slice, then the chunk products and the products of groups of G chunks
         if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_slice2<4>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);

@@ -1,0 +1,227 @@
+// qoc_mfma_expm_rows.h -- MFMA path, exponentials K_t = matexp(A_t) + chunk products for 32 < n <= 64 (NT = 3, 4) by FOUR waves per
+// (seed, chunk) item, each owning a block of ROWS (qoc_config.variant = 7): k_mfma_expm_rows.  Reference semantics:
+// core/tensorflow_state.py:25-46 (get_matexp).
+//
+// k_mfma_expm_chunk4<NT> gives every 16-COLUMN block of an item a wave: NT waves per workgroup (NT = 3: one SIMD of the CU idles, the
+// 113 KB of images leave room for one workgroup) and, above all, every 1 KB block read of the left operand feeds only the 3 MFMAs of
+// that wave's column block -- 4 waves doing that are ~90 % of the CU's LDS read bandwidth (NT = 4 sits at 50 % of the matrix peak for
+// exactly that reason).  Here wave w owns the row strips 4 NT w .. 4 NT (w + 1) - 1 (rows 4 NT w .. of every column block):
+//   D(ib, J) = sum_kb L(ib, kb) R(kb, J):   the left block (ib, kb) is read once and feeds 3 NT MFMAs (all column blocks J),
+//                                           the right strips (kb, J) come from a second LDS image S in strip layout (lane-contiguous
+//                                           1 KB reads, one per kb and J, shared by the NT row strips of the wave),
+// i.e. (NT + NT) KB of LDS reads per 3 NT^2 MFMAs instead of 1.5 NT^2: 0.28 (NT = 3) / 0.17 (NT = 4) KB per MFMA against 0.5 / 0.33.
+// Every wave writes its result strips to both images (T: transposed, left operand of a later product; S: strips, right operand).
+// No re + im sums image: one v_add_f64 per block read (per 3 NT MFMAs).  NT = 3 double-buffers both images (155 KB) and needs one
+// LDS barrier per product; NT = 4 has room for one buffer each (135 KB): a second barrier before the images are overwritten.
+#pragma once
+#include "qoc_mfma_frag.h"
+#include "qoc_mfma_expm_stream.h"     // QLDS, lds_order()
+
+#ifndef QOC_ROWS_NB3
+#define QOC_ROWS_NB3 1       // image buffers of NT = 3: 1 = single-buffered, two workgroups per CU; 2 = double-buffered, one
+#endif
+template <int NT, int KC>
+__global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k_mfma_expm_rows(QocDev d, QocMfma mf) {
+    constexpr int NB = NT == 3 ? QOC_ROWS_NB3 : 1;                       // image buffers
+    extern __shared__ __attribute__((aligned(16))) char smem_rows[];
+    cplx* imgT = (cplx*)smem_rows;                                       // [NB][QNP * QLDS]   left operand: image[column][row]
+    cplx* imgS = imgT + (size_t)NB * QNP * QLDS;                         // [NB][NT * QQS * 64] right operand: strip (J, kb), lane
+    constexpr int TSZ = QNP * QLDS, SSZ = NT * QQS * 64;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // row strips NT w .. NT w + NT - 1
+    const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
+    if (d.skip_done && d.done[b]) return;                               // whole workgroup: no barrier yet
+    QOC_LAP_INIT
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const double inv_scale = 1.0 / (double)(1 << d.s);
+    const int dlt = (lane & 15) - (lane >> 4);
+    // identity: element (row 4 ib + lk, column 16 J + lc) with ib = NT w + r is diagonal iff 4 ib - 16 J == lc - lk
+    auto diag = [&](int r, int J) { return (4 * (NT * w + r) - 16 * J == dlt) ? 1.0 : 0.0; };
+    const int mm = d.T >> 1;
+    const bool even = (d.T & 1) == 0;
+    const int nH = even ? mm - 1 : mm;
+    const double p_c0 = even ? mf.invfact[2 * mm - 2] : mf.invfact[2 * mm], p_c1 = even ? mf.invfact[2 * mm - 1] : mf.invfact[2 * mm + 1];
+    const double p_cT = even ? mf.invfact[d.T] : 0.0;
+    struct Rows { double re[NT][NT], im[NT][NT]; };                     // [r][J]: strip ib = NT w + r of column block J
+    int tcur = 0, scur = 0;
+    // own strips into the images (left: T, right: S), then meet the other three waves.  One buffer (NT = 4): the images may only be
+    // overwritten when every wave has finished the product that read them -- a barrier BEFORE the stores as well.
+    auto publish = [&](const Rows& m, bool left, bool right) {
+        if (NB == 1) lds_barrier();
+        cplx* T = imgT + (size_t)tcur * TSZ;
+        cplx* S = imgS + (size_t)scur * SSZ;
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                const cplx v = cmake(m.re[r][J], m.im[r][J]);
+                if (left) T[(16 * J + (lane & 15)) * QLDS + 4 * (NT * w + r) + (lane >> 4)] = v;
+                if (right) S[(J * QQS + NT * w + r) * 64 + lane] = v;
+            }
+        lds_barrier();
+        QOC_LAP(1)
+    };
+    double a[NT][NT], bq[NT][NT], cq[NT][NT];
+    // acc = (image T[tcur]) * (strips S[scur]) for the own row strips
+    auto product = [&]() {
+        const cplx* base = imgT + (size_t)tcur * TSZ + (lane >> 4) * QLDS + (lane & 3) + 4 * NT * w;
+        const cplx* sb = imgS + (size_t)scur * SSZ + lane;
+        constexpr int NS = QQS * NT, RA = 4, RS = RA + 1;                 // block steps (kb, r), kb-major
+        cplx vb[RS], rs[2][NT];
+#pragma unroll
+        for (int J = 0; J < NT; ++J) rs[0][J] = sb[(J * QQS) * 64];
+#pragma unroll
+        for (int st = 0; st < RA; ++st) vb[st] = base[4 * (st / NT) * QLDS + 4 * (st % NT)];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int kb = st / NT, r = st % NT;
+            if (st + RA < NS) vb[(st + RA) % RS] = base[4 * ((st + RA) / NT) * QLDS + 4 * ((st + RA) % NT)];
+            if (r == 0 && kb + 1 < QQS) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J) rs[(kb + 1) & 1][J] = sb[(J * QQS + kb + 1) * 64];
+            }
+            lds_order();
+            const cplx v = vb[st % RS];
+            const double vs = v.x + v.y;
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                const cplx q = rs[kb & 1][J];
+                const double qs = q.x + q.y;
+                if (kb == 0) {
+                    a[r][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, q.x, 0.0, 0, 0, 0);
+                    bq[r][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, q.y, 0.0, 0, 0, 0);
+                    cq[r][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, qs, 0.0, 0, 0, 0);
+                } else {
+                    a[r][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, q.x, a[r][J], 0, 0, 0);
+                    bq[r][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, q.y, bq[r][J], 0, 0, 0);
+                    cq[r][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, qs, cq[r][J], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        QOC_LAP(2)
+    };
+    auto flipT = [&]() { if (NB == 2) tcur ^= 1; };
+    auto flipS = [&]() { if (NB == 2) scur ^= 1; };
+    Rows R;
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) { R.re[r][J] = diag(r, J); R.im[r][J] = 0.0; }
+    for (int t = t0; t < t1; ++t) {
+        // ---- A_t, own row strips, one column block at a time (NT (KC + 1) strips of the Hamiltonian stack in flight) ------------------
+        double ck[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) ck[kk] = kk < d.k ? d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale : 0.0;
+        Rows A, X;
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            cplx hst[KC + 1][NT];
+#pragma unroll
+            for (int kk = 0; kk <= KC; ++kk) {
+                const cplx* H = mf.HfD + (size_t)(kk <= d.k ? kk : 0) * QFR + (J * QQS + NT * w) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < NT; ++r) hst[kk][r] = H[r * 64];
+            }
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+                double re = hst[0][r].x * inv_scale, im = hst[0][r].y * inv_scale;
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk) { re = fma(ck[kk], hst[kk + 1][r].x, re); im = fma(ck[kk], hst[kk + 1][r].y, im); }
+                A.re[r][J] = re; A.im[r][J] = im;
+            }
+        }
+        QOC_LAP(0)
+        if (d.T >= 2) {
+            // ---- A2 = A * A, polynomial start ----------------------------------------------------------------------------------
+            publish(A, true, true);
+            product();
+            flipT(); flipS();
+            Rows A2;
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    const double re = a[r][J] - bq[r][J], im = cq[r][J] - a[r][J] - bq[r][J];
+                    A2.re[r][J] = re; A2.im[r][J] = im;
+                    X.re[r][J] = fma(p_cT, re, fma(p_c1, A.re[r][J], p_c0 * diag(r, J)));
+                    X.im[r][J] = fma(p_cT, im, p_c1 * A.im[r][J]);
+                }
+            if (nH > 0) {
+                publish(A2, true, false);                               // the left image of A2 stays through the Horner products
+                for (int i = nH - 1; i >= 0; --i) {
+                    publish(X, false, true);
+                    product();
+                    flipS();
+                    const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
+#pragma unroll
+                    for (int r = 0; r < NT; ++r)
+#pragma unroll
+                        for (int J = 0; J < NT; ++J) {
+                            X.re[r][J] = (a[r][J] - bq[r][J]) + fma(d1, A.re[r][J], d0 * diag(r, J));
+                            X.im[r][J] = fma(d1, A.im[r][J], cq[r][J] - a[r][J] - bq[r][J]);
+                        }
+                }
+                flipT();                                                // the next left image must not overwrite A2 while a partner still reads it
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) { X.re[r][J] = A.re[r][J] + diag(r, J); X.im[r][J] = A.im[r][J]; }
+        }
+        // ---- squarings -------------------------------------------------------------------------------------------------------
+        for (int sq = 0; sq < d.s; ++sq) {
+            publish(X, true, true);
+            product();
+            flipT(); flipS();
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) { X.re[r][J] = a[r][J] - bq[r][J]; X.im[r][J] = cq[r][J] - a[r][J] - bq[r][J]; }
+        }
+        // ---- K_t out (fragD from the registers; the transposed copy through the left image), chunk product R <- K_t R ---------------
+        const size_t item = kitem(mf, d.steps, b, t);
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) mf.KfD[item + (J * QQS + NT * w + r) * 64 + lane] = cmake(X.re[r][J], X.im[r][J]);
+        QOC_LAP(3)
+        publish(X, true, false);
+        if (mf.store_T) {
+            const cplx* T = imgT + (size_t)tcur * TSZ;
+            for (int f = w; f < NT * QQS; f += 4) {                     // fragment (cb, q) of fragD(K^T): K^T[4 q + lk][16 cb + lc] = K[16 cb + lc][4 q + lk]
+                const int cb = f / QQS, q = f - cb * QQS;
+                mf.KfT[item + (size_t)f * 64 + lane] = T[(4 * q + (lane >> 4)) * QLDS + 16 * cb + (lane & 15)];
+            }
+        }
+        publish(R, false, true);
+        product();
+        flipT(); flipS();
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) { R.re[r][J] = a[r][J] - bq[r][J]; R.im[r][J] = cq[r][J] - a[r][J] - bq[r][J]; }
+        QOC_LAP(3)
+    }
+    // ---- P_c out: fragD(P) from the registers, fragD(P^T) through the left image ------------------------------------------------------
+    const size_t pitem = ((size_t)b * mf.C + c) * QFR;
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) mf.PfD[pitem + (J * QQS + NT * w + r) * 64 + lane] = cmake(R.re[r][J], R.im[r][J]);
+    publish(R, true, false);
+    {
+        const cplx* T = imgT + (size_t)tcur * TSZ;
+        for (int f = w; f < NT * QQS; f += 4) {
+            const int cb = f / QQS, q = f - cb * QQS;
+            mf.PfT[pitem + (size_t)f * 64 + lane] = T[(4 * q + (lane >> 4)) * QLDS + 16 * cb + (lane & 15)];
+        }
+    }
+    QOC_LAP(4)
+    QOC_LAP_DONE
+}
+
+template <int NT> static inline size_t qoc_expm_rows_lds() {
+    return (size_t)(NT == 3 ? QOC_ROWS_NB3 : 1) * ((size_t)QNP * QLDS + (size_t)NT * QQS * 64) * sizeof(cplx);
+}

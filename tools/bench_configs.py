@@ -15,11 +15,11 @@ from tests.golden import cases  # noqa: E402
 from tests.helpers import oracle_system  # noqa: E402
 
 
-def run(name, c, n_seeds, iters, path=0):
+def run(name, c, n_seeds, iters, path=0, variant=0):
     sp = oracle_system(c)
     eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms,
                                sp.scaling, state_transfer=sp.state_transfer, reg_coeffs=sp.reg_coeffs,
-                               one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=n_seeds, path=path)
+                               one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=n_seeds, path=path, variant=variant)
     rng = np.random.default_rng(0)
     eng.set_base(rng.normal(0, 1 / np.sqrt(sp.steps), (n_seeds, sp.k, sp.steps)))
     p = eng.adam_params(max_iterations=10 ** 9, conv_target=-1.0, min_grad=-1.0)
@@ -45,7 +45,7 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ('n48', 'n64'):  # profiling hooks: NT = 3 / NT = 4 unitary gates x 64 seeds on the MFMA path
         nn = int(sys.argv[1][1:])
-        run('n=%d unitary (MFMA NT=%d) x64' % (nn, nn // 16), cases.case_c2(n=nn, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 5, path=2)
+        run('n=%d unitary (MFMA NT=%d) x64' % (nn, nn // 16), cases.case_c2(n=nn, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 5, path=2, variant=int(os.environ.get('QOC_VARIANT', '0')))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'c2reg':        # profiling hook: regularised C2 x 64 only
         c = cases.case_c2(); c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [30, 31]}
