@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
     int tcur = 0, scur = 0;
     // own strips into the images (left: T, right: S), then meet the other three waves.  One buffer (NT = 4): the images may only be
     // overwritten when every wave has finished the product that read them -- a barrier BEFORE the stores as well.
-    auto publish = [&](const Rows& m, bool left, bool right) {
+    auto publish = [&](const Rows& ml, bool left, const Rows& mr, bool right) {   // ml -> left image T, mr -> right image S
         if (NB == 1) lds_barrier();
         cplx* T = imgT + (size_t)tcur * TSZ;
         cplx* S = imgS + (size_t)scur * SSZ;
@@ -54,9 +54,8 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
         for (int r = 0; r < NT; ++r)
 #pragma unroll
             for (int J = 0; J < NT; ++J) {
-                const cplx v = cmake(m.re[r][J], m.im[r][J]);
-                if (left) T[(16 * J + (lane & 15)) * QLDS + 4 * (NT * w + r) + (lane >> 4)] = v;
-                if (right) S[(J * QQS + NT * w + r) * 64 + lane] = v;
+                if (left) T[(16 * J + (lane & 15)) * QLDS + 4 * (NT * w + r) + (lane >> 4)] = cmake(ml.re[r][J], ml.im[r][J]);
+                if (right) S[(J * QQS + NT * w + r) * 64 + lane] = cmake(mr.re[r][J], mr.im[r][J]);
             }
         lds_barrier();
         QOC_LAP(1)
@@ -134,7 +133,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
         QOC_LAP(0)
         if (d.T >= 2) {
             // ---- A2 = A * A, polynomial start ----------------------------------------------------------------------------------
-            publish(A, true, true);
+            publish(A, true, A, true);
             product();
             flipT(); flipS();
             Rows A2;
@@ -148,9 +147,8 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
                     X.im[r][J] = fma(p_cT, im, p_c1 * A.im[r][J]);
                 }
             if (nH > 0) {
-                publish(A2, true, false);                               // the left image of A2 stays through the Horner products
                 for (int i = nH - 1; i >= 0; --i) {
-                    publish(X, false, true);
+                    publish(A2, i == nH - 1, X, true);                  // the left image of A2 stays through the Horner products
                     product();
                     flipS();
                     const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
@@ -172,7 +170,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
         }
         // ---- squarings -------------------------------------------------------------------------------------------------------
         for (int sq = 0; sq < d.s; ++sq) {
-            publish(X, true, true);
+            publish(X, true, X, true);
             product();
             flipT(); flipS();
 #pragma unroll
@@ -187,7 +185,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
 #pragma unroll
             for (int J = 0; J < NT; ++J) mf.KfD[item + (J * QQS + NT * w + r) * 64 + lane] = cmake(X.re[r][J], X.im[r][J]);
         QOC_LAP(3)
-        publish(X, true, false);
+        publish(X, true, R, true);
         if (mf.store_T) {
             const cplx* T = imgT + (size_t)tcur * TSZ;
             for (int f = w; f < NT * QQS; f += 4) {                     // fragment (cb, q) of fragD(K^T): K^T[4 q + lk][16 cb + lc] = K[16 cb + lc][4 q + lk]
@@ -195,7 +193,6 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
                 mf.KfT[item + (size_t)f * 64 + lane] = T[(4 * q + (lane >> 4)) * QLDS + 16 * cb + (lane & 15)];
             }
         }
-        publish(R, false, true);
         product();
         flipT(); flipS();
 #pragma unroll
@@ -210,7 +207,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
     for (int r = 0; r < NT; ++r)
 #pragma unroll
         for (int J = 0; J < NT; ++J) mf.PfD[pitem + (J * QQS + NT * w + r) * 64 + lane] = cmake(R.re[r][J], R.im[r][J]);
-    publish(R, true, false);
+    publish(R, true, R, false);
     {
         const cplx* T = imgT + (size_t)tcur * TSZ;
         for (int f = w; f < NT * QQS; f += 4) {
