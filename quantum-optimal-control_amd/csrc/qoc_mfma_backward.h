@@ -375,6 +375,19 @@ __global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
             for (int I = 0; I < NT; ++I)
 #pragma unroll
                 for (int Jp = 0; Jp < NT; ++Jp) {
+                    // the H_k' entries of this tile do not depend on the MFMAs: all their LDS reads go out as one batch ahead of them
+                    // (left to itself hipcc reads them one at a time with every wait exposed: n = 48 x 64 seeds 307 us per launch,
+                    // NT * NT * 4 KG reads of ~100 cycles each per slice)
+                    // (NT = 4, two images per pass: batching made it slower, 1.37 -> 1.58 ms; left to the compiler there)
+                    constexpr bool BATCH = NT <= 3;
+                    cplx hq[KG][4];
+                    if constexpr (BATCH) {
+#pragma unroll
+                        for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hq[kk][r] = Hl[(size_t)(kk < kn ? kk : 0) * QFR + (Jp * QQS + 4 * I + r) * 64 + lane];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
 #pragma unroll
                     for (int q = 0; q < MQ; ++q) {
@@ -389,7 +402,9 @@ __global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
                         double acc = 0.0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const cplx h = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * I + r) * 64 + lane];
+                            cplx h;
+                            if constexpr (BATCH) h = hq[kk][r];
+                            else h = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * I + r) * 64 + lane];
                             acc = fma(h.x, qr[r], acc);
                             acc = fma(-h.y, qi[r], acc);
                         }
