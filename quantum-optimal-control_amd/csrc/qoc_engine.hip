@@ -156,7 +156,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     // latency mode without pulse regularisers: the tail of the iteration runs in the last workgroup of the gradient kernel
     const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && !e->mf.lat_sources && plain && !(skip & (16 | 32));
     // (latency mode of the MFMA path: the slice kernel of the exponentials forms its own controls)
-    if (!(skip & 1) && !(e->path == QOC_PATH_MFMA && e->mf.latency)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
+    if (!(skip & 1) && !(e->path == QOC_PATH_MFMA && e->mf.latency && e->mf.NT == 2)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {
         TRY(prof_begin(e));
         if (!(skip & 2)) qoc_mfma_launch_expm(e->mf, d, e->stream);
@@ -387,13 +387,16 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // (profiles/r02_latency_sweep.txt, r02_small_n_sweep.txt): C2 (500 slices) 0.083 ms against 0.189 (GEMM route) and 0.56 (batch
     // kernels) for one seed, still ahead at 12 seeds, level at 16; n <= 16 is padded to 32 and competes with the cheap NT = 1 batch
     // kernels: ahead up to 4 seeds (n = 16 x 500 slices: 0.081 against 0.203 ms for one seed, 0.163 against 0.213 for four)
+    // 32 < n <= 48 (NT = 3 kernels: k_mfma_expm_rows per slice, the same chains, sweeps and gradient): one trajectory of n = 48 x 500
+    // slices 0.165 ms against 0.454 (GEMM route) and 0.84 (batch kernels); ahead up to 8 seeds (profiles/r02_mid_n_sweep.txt).
     // With a state regulariser (forbidden levels, speed_up) the backward half is the affine recursion of the batch kernels on the
     // latency mode's chunks, with two-level boundaries (QocMfma::lat_sources): one C2 trajectory with dwdt + forbidden levels 0.189 ms
     // against 0.290 (GEMM route) and 0.72 (batch kernels); ahead up to ~4096 seed-slices (tools/c2_forbidden_single.py).
     const long long lat_work = (long long)B * steps;
     const bool lat_src = d.n_forb > 0 || d.has_speed;
     const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
-                              ((lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && B <= (n > 16 ? 16 : (lat_src ? 2 : 4))) ||
+                              ((n > 32 ? (lat_work <= 16384 && B <= 8)      // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
+                                       : (lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && B <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
                                (B == 1 && steps <= 8192));
     if (path == QOC_PATH_AUTO)
         path = latency_auto ? QOC_PATH_MFMA
@@ -412,7 +415,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;
         if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
-            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32, k <= 8, "
+            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32 with k <= 8 (or n <= 48 with k <= 4 and no state regulariser), "
                                               "taylor_terms >= 2 (n=%d k=%d T=%d)", n, k, d.T));
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
@@ -626,7 +629,7 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     TRY(prof_collect(e));
     if (kernel_name)
         *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm32 (batched matexp sequence)")
-                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 6 ? "k_mfma_expm_pair" : qoc_mfma_expm_variant(e->mf, e->d) == 5 ? "k_mfma_expm_slice2 + k_mfma_chain_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
+                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 6 ? "k_mfma_expm_pair" : qoc_mfma_expm_variant(e->mf, e->d) == 5 ? (e->mf.NT == 3 ? "k_mfma_expm_rows (per slice) + k_mfma_chain_rows" : "k_mfma_expm_slice2 + k_mfma_chain_rows") : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
                        : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;

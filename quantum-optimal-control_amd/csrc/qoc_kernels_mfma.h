@@ -58,8 +58,8 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     // n > 32: four waves per item, a block of rows each (7; AUTO: n = 48 x 64 seeds 3.3 ms per launch against 3.8 for 2 = one wave per
     // 16-column block and 11.9 for 1 = the same on 16x16x4)
-    if (mf.NT > 2) return mf.variant == 1 ? 1 : (mf.variant == 2 ? 2 : 7);
     if (mf.latency) return 5;
+    if (mf.NT > 2) return mf.variant == 1 ? 1 : (mf.variant == 2 ? 2 : 7);
     int v = mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 4 : 1);
     if (v == 7) v = 4;                                                  // the row-block kernel is an NT = 3 / 4 kernel
     if (v == 4 && (d.T < 2 || mf.NT != 2)) v = 3;                      // the streamed kernel starts from the product A * A
@@ -69,7 +69,9 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
 // latency mode: NT = 2 kernels (smaller problems are padded to 32).  With a state regulariser the costate is not linear in the
 // overlap: the backward half then runs the batch kernels on the latency mode's chunks (QocMfma::lat_sources)
 static inline bool qoc_mfma_latency_ok(const QocDev& d) {
-    return !d.state_transfer && d.n <= 32 && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22;
+    if (d.n > 32)    // 32 < n <= 48 (NT = 3): no state regulariser (the affine backward half is an NT = 2 kernel), four control images in LDS
+        return !d.state_transfer && d.n <= 48 && d.m <= 16 && d.k <= 4 && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
+    return !d.state_transfer && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22;
 }
 
 // host entry points (defined next to their kernels)

@@ -20,7 +20,9 @@
 #ifndef QOC_ROWS_NB3
 #define QOC_ROWS_NB3 1       // image buffers of NT = 3: 1 = single-buffered, two workgroups per CU; 2 = double-buffered, one
 #endif
-template <int NT, int KC>
+// SLICE (latency mode of n > 32): an item is one time slice -- K_t and its transposed copy only; the chunk products are left to
+// k_mfma_chain_rows.
+template <int NT, int KC, bool SLICE = false>
 __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k_mfma_expm_rows(QocDev d, QocMfma mf) {
     constexpr int NB = NT == 3 ? QOC_ROWS_NB3 : 1;                       // image buffers
     extern __shared__ __attribute__((aligned(16))) char smem_rows[];
@@ -29,10 +31,11 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
     constexpr int TSZ = QNP * QLDS, SSZ = NT * QQS * 64;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // row strips NT w .. NT w + NT - 1
-    const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
+    const int per = SLICE ? d.steps : mf.C;
+    const int b = blockIdx.x / per, c = blockIdx.x - b * per;
     if (d.skip_done && d.done[b]) return;                               // whole workgroup: no barrier yet
     QOC_LAP_INIT
-    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const int t0 = SLICE ? c : c * mf.L, t1 = SLICE ? c + 1 : min(t0 + mf.L, d.steps);
     const double inv_scale = 1.0 / (double)(1 << d.s);
     const int dlt = (lane & 15) - (lane >> 4);
     // identity: element (row 4 ib + lk, column 16 J + lc) with ib = NT w + r is diagonal iff 4 ib - 16 J == lc - lk
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
 #pragma unroll
             for (int J = 0; J < NT; ++J) mf.KfD[item + (J * QQS + NT * w + r) * 64 + lane] = cmake(X.re[r][J], X.im[r][J]);
         QOC_LAP(3)
-        publish(X, true, R, true);
+        publish(X, true, R, !SLICE);
         if (mf.store_T) {
             const cplx* T = imgT + (size_t)tcur * TSZ;
             for (int f = w; f < NT * QQS; f += 4) {                     // fragment (cb, q) of fragD(K^T): K^T[4 q + lk][16 cb + lc] = K[16 cb + lc][4 q + lk]
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
                 mf.KfT[item + (size_t)f * 64 + lane] = T[(4 * q + (lane >> 4)) * QLDS + 16 * cb + (lane & 15)];
             }
         }
+        if constexpr (SLICE) return;                                    // (uniform: no barrier follows)
         product();
         flipT(); flipS();
 #pragma unroll

@@ -343,12 +343,12 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
 template <int NT>
 __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, const cplx* __restrict__ IN, int in_is_K, int count, int len,
                                                         cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail, cplx* __restrict__ OUTT) {
-    static_assert(NT == 2, "row-split chain products: n <= 32");
+    static_assert(NT == 2 || NT == 3, "row-split chain products: n <= 48 (two right operands of 16 NT^2 registers each in flight)");
     constexpr int PS = 5;                                            // pad stride (complex elements per column): conflict-free stores and block reads
     __shared__ __attribute__((aligned(16))) cplx pad[QNP * PS];
     __shared__ __attribute__((aligned(16))) double pads[QNP * PS];
     const int lane = threadIdx.x, lc = lane & 15, lk = lane >> 4;
-    const int w = blockIdx.x & 7, item = blockIdx.x >> 3;            // 8 row blocks of 4 rows
+    const int w = blockIdx.x % QQS, item = blockIdx.x / QQS;         // 4 NT row blocks of 4 rows
     const int b = item / nout, i = item - b * nout;
     if (d.skip_done && d.done[b]) return;
     const int hi = min(i * len + len, count) - 1, lo = i * len - (tail ? 1 : 0);

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
             return i < n_grp ? Gb + (size_t)(g_first + dir * i) * QFR : Pb + (size_t)(c_first + dir * (i - n_grp)) * QFR;
         };
         if (n_bnd > 0) {
-            constexpr int PD = 2;
+            constexpr int PD = NT <= 2 ? 2 : 1;                          // (NT = 3: a matrix is 144 registers)
             Frag Bq[PD + 1];
 #pragma unroll
             for (int q = 0; q < PD; ++q) load_frag(bnd_ptr(q), Bq[q]);
@@ -163,15 +163,15 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
 // fuse: the LAST workgroup of a seed to finish (a counter per seed) runs the tail of the iteration -- chain rule, stop rule, Adam
 // (finish_body, qoc_kernels_finish.h) -- instead of a separate single-workgroup launch whose start-up and first round trips were
 // 13 us of an 85 us iteration.  Only without pulse regularisers (their branch-heavy variant stays a kernel of its own).
-template <int MQ, int KC>
+template <int MQ, int KC, int NT = 2>
 __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, QocAdamDev ap, int fuse) {
-    constexpr int NT = 2, SL = 8;
+    constexpr int SL = 16 / NT;                                                   // slices per workgroup: NT waves (row tiles) each
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* Hl = (cplx*)smem;                                                       // [KC] fragD(H_k'), zero beyond k
-    double* gpart = (double*)(Hl + (size_t)KC * QFR);                             // [SL][2 tiles][4 rows][2 (re, im)][KC]
+    double* gpart = (double*)(Hl + (size_t)KC * QFR);                             // [SL][NT tiles][4 rows][2 (re, im)][KC]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = wv & 1, sl = wv >> 1;
+    const int h = wv % NT, sl = wv / NT;
     const int nblk = (d.steps + SL - 1) / SL;
     const int b = blockIdx.x / nblk, cb = blockIdx.x - b * nblk;
     if (d.skip_done && d.done[b]) return;
@@ -179,16 +179,16 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
     const bool live = t < d.steps;
     const int lk = lane >> 4, lc = lane & 15;
     // operands of the slice: costate rows of tile h, state rows of both tiles, all lane-contiguous
-    double lr[MQ], li[MQ], pr[2][MQ], pi[2][MQ];
+    double lr[MQ], li[MQ], pr[NT][MQ], pi[NT][MQ];
     {
-        const cplx* ll = mf.LamL + ((size_t)b * d.steps + tc) * (2 * MQ) * 64 + lane;
-        const cplx* pl = mf.PsiL + ((size_t)b * d.steps + tc) * (2 * MQ) * 64 + lane;
+        const cplx* ll = mf.LamL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
+        const cplx* pl = mf.PsiL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < MQ; ++q) {
-            const cplx lv = ll[(h * MQ + q) * 64], p0 = pl[q * 64], p1 = pl[(MQ + q) * 64];
+            const cplx lv = ll[(h * MQ + q) * 64];
             lr[q] = lv.x; li[q] = lv.y;
-            pr[0][q] = p0.x; pi[0][q] = p0.y;
-            pr[1][q] = p1.x; pi[1][q] = p1.y;
+#pragma unroll
+            for (int Jp = 0; Jp < NT; ++Jp) { const cplx pv = pl[(Jp * MQ + q) * 64]; pr[Jp][q] = pv.x; pi[Jp][q] = pv.y; }
         }
     }
     double zr = 0.0, zi = 0.0;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) { gr[kk] = 0.0; gi[kk] = 0.0; }
 #pragma unroll
-    for (int Jp = 0; Jp < 2; ++Jp) {
+    for (int Jp = 0; Jp < NT; ++Jp) {
         d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < MQ; ++q) {
@@ -240,16 +240,16 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
         gi[kk] += dpp_xor<1>(gi[kk]); gi[kk] += dpp_xor<2>(gi[kk]); gi[kk] += dpp_xor<4>(gi[kk]); gi[kk] += dpp_xor<8>(gi[kk]);
     }
     if (lc == 0) {
-        double* gp = gpart + (((size_t)sl * 2 + h) * 4 + lk) * 2 * KC;
+        double* gp = gpart + (((size_t)sl * NT + h) * 4 + lk) * 2 * KC;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) { gp[kk] = gr[kk]; gp[KC + kk] = gi[kk]; }
     }
     __syncthreads();
     if (live && h == 0 && lane < d.k) {
-        const double* gp = gpart + (size_t)sl * 8 * 2 * KC + lane;
+        const double* gp = gpart + (size_t)sl * (4 * NT) * 2 * KC + lane;
         double sr = 0.0, si = 0.0;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) { sr += gp[x * 2 * KC]; si += gp[x * 2 * KC + KC]; }
+        for (int x = 0; x < 4 * NT; ++x) { sr += gp[x * 2 * KC]; si += gp[x * 2 * KC + KC]; }
         const double c0 = -2.0 / ((double)d.m * (double)d.m);
         d.dLdu[((size_t)b * d.k + lane) * d.steps + t] = c0 * (zr * sr + zi * si);
     }

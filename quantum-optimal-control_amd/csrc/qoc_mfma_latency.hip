@@ -2,19 +2,19 @@
 #include "qoc_kernels_mfma.h"
 #include "qoc_mfma_latency.h"
 
-static size_t grad_lat_lds(int kc) { return (size_t)kc * 1024 * sizeof(cplx) + (size_t)8 * 2 * 4 * 2 * kc * sizeof(double); }
-
-static int grad_lat_kc(const QocDev& d) { return d.k <= 4 ? 4 : (d.k == 5 ? 5 : 8); }      // control images in LDS (16 KB each)
+static size_t grad_lat_lds(int kc, int NT) { return (size_t)kc * 256 * NT * NT * sizeof(cplx) + (size_t)16 * 4 * 2 * kc * sizeof(double); }
+static int grad_lat_kc(const QocDev& d) { return d.k <= 4 ? 4 : (d.k == 5 ? 5 : 8); }      // control images in LDS (16 KB each at NT = 2, 36 KB at NT = 3)
 
 static const void* grad_lat_kernel(const QocMfma& mf, const QocDev& d) {
     const int kc = grad_lat_kc(d);
+    if (mf.NT == 3) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 4, 3> : (const void*)k_mfma_grad_lat<4, 4, 3>;
     if (kc == 8) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 8> : (const void*)k_mfma_grad_lat<4, 8>;
     if (kc == 5) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 5> : (const void*)k_mfma_grad_lat<4, 5>;
     return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 4> : (const void*)k_mfma_grad_lat<4, 4>;
 }
 
 int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
-    if (hipFuncSetAttribute(grad_lat_kernel(mf, d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grad_lat_lds(grad_lat_kc(d))) != hipSuccess) {
+    if (hipFuncSetAttribute(grad_lat_kernel(mf, d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grad_lat_lds(grad_lat_kc(d), mf.NT)) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the latency-mode gradient kernel";
         return -2;
     }
@@ -25,17 +25,24 @@ int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
 // sweeps share a CU's 64 B/clk load path: 4 x 16 KB per step did)
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     // (with a state regulariser only the forward half: the costate needs the sources, i.e. the forward states, first)
-    hipLaunchKernelGGL(k_mfma_sweep_lat<2>, dim3((mf.lat_sources ? 1 : 2) * d.B * mf.C * mf.mq), dim3(64), 0, s, d, mf);
+    const dim3 g((mf.lat_sources ? 1 : 2) * d.B * mf.C * mf.mq);
+    if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(64), 0, s, d, mf);
+    else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(64), 0, s, d, mf);
     if (mf.lat_sources) qoc_mfma_unpack_inter(mf, d, s);              // k_loss, the sources and the batch backward kernels read d.inter
 }
 
 // ap != nullptr: the tail of the iteration (k_finish_t<true>) runs inside, in the last workgroup of each seed
 void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* ap, hipStream_t s) {
-    const dim3 g(d.B * ((d.steps + 7) / 8)), b(1024);
-    const int kc = grad_lat_kc(d);
-    const size_t lds = grad_lat_lds(kc);
+    const int kc = grad_lat_kc(d), sl = 16 / mf.NT;                      // slices per workgroup, NT waves (row tiles) each
+    const dim3 g(d.B * ((d.steps + sl - 1) / sl)), b(64 * sl * mf.NT);
+    const size_t lds = grad_lat_lds(kc, mf.NT);
     const QocAdamDev a = ap ? *ap : QocAdamDev{};
     const int fuse = ap ? 1 : 0;
+    if (mf.NT == 3) {
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 4, 3>), g, b, lds, s, d, mf, a, fuse);
+        else hipLaunchKernelGGL((k_mfma_grad_lat<4, 4, 3>), g, b, lds, s, d, mf, a, fuse);
+        return;
+    }
 #define QOC_GL(KCv) do { if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, KCv>), g, b, lds, s, d, mf, a, fuse); \
                          else hipLaunchKernelGGL((k_mfma_grad_lat<4, KCv>), g, b, lds, s, d, mf, a, fuse); } while (0)
     if (kc == 8) QOC_GL(8); else if (kc == 5) QOC_GL(5); else QOC_GL(4);
