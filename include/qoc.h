@@ -67,7 +67,7 @@ typedef struct qoc_config {
                                  * 16-column block of a chunk, one-wave sweeps), 2 = v_mfma_f64_4x4x4 exponentials by one wave per
                                  * 16-column block, 3 = v_mfma_f64_4x4x4 exponentials by one wave per chunk (n <= 32; n > 32: same
                                  * as 2), 4 = as 3 with the left-operand image written under the product's own MFMAs (auto for
-                                 * n <= 32 batches), 5 = latency mode (n <= 48; n <= 16 is padded to 32; auto
+                                 * n <= 32 batches), 5 = latency mode (n <= 64; n <= 16 is padded to 32; auto
                                  * for one or a few control sets, decided by seeds x time slices: exponentials
                                  * per time slice, forward and z-free adjoint sweep side by side, slice-parallel gradient),
                                  * 6 = v_mfma_f64_4x4x4 exponentials by two waves per chunk, two waves

@@ -12,18 +12,20 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     // per launch at C2 x 64); NT = 1 and small launches keep the 16x16x4 kernel (C1: 0.072 vs 0.074 ms; one C2 trajectory:
     // 0.67 vs 0.75 ms).  qoc_config.variant forces one of the three kernels (parity tests, A/B runs).
     const int v = qoc_mfma_expm_variant(mf, d);
-    if constexpr (NT == 3) {
+    if constexpr (NT >= 3) {
         if (v == 5) {
-            // latency mode of 32 < n <= 48: K_t per slice by the row-block kernel (two workgroups per CU), then the row-split chains
-            const size_t lds = qoc_expm_rows_lds<3>();
+            // latency mode of 32 < n <= 64: K_t per slice by the row-block kernel (NT = 3: two workgroups per CU), then the row-split chains
+            const size_t lds = qoc_expm_rows_lds<NT>();
             static bool reserved = false;
             if (!reserved) {
-                hipFuncSetAttribute((const void*)k_mfma_expm_rows<3, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 reserved = true;
             }
-            hipLaunchKernelGGL((k_mfma_expm_rows<3, 4, true>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf);
-            hipLaunchKernelGGL(k_mfma_chain_rows<3>, dim3(d.B * mf.C * 12), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
-            hipLaunchKernelGGL(k_mfma_chain_rows<3>, dim3(d.B * mf.NG * 12), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
+            if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_rows<NT, 4, true>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_expm_rows<NT, 8, true>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf);
+            hipLaunchKernelGGL(k_mfma_chain_rows<NT>, dim3(d.B * mf.C * 4 * NT), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
+            hipLaunchKernelGGL(k_mfma_chain_rows<NT>, dim3(d.B * mf.NG * 4 * NT), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
             return;
         }
     }
@@ -90,7 +92,8 @@ __global__ void __launch_bounds__(64) k_mfma_unpack_final(QocDev d, QocMfma mf) 
 void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s) {
     QocDev dd = d;
     dd.skip_done = 0;                                                     // every seed's last evaluation is still in GfD
-    if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_chain_rows<3>, dim3(d.B * 12), dim3(64), 0, s, dd, mf, (const cplx*)mf.GfD, 0, mf.NG, mf.NG, mf.TfD, 1, (const cplx*)mf.U0fD, (cplx*)nullptr);
+    if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_chain_rows<4>, dim3(d.B * 16), dim3(64), 0, s, dd, mf, (const cplx*)mf.GfD, 0, mf.NG, mf.NG, mf.TfD, 1, (const cplx*)mf.U0fD, (cplx*)nullptr);
+    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_chain_rows<3>, dim3(d.B * 12), dim3(64), 0, s, dd, mf, (const cplx*)mf.GfD, 0, mf.NG, mf.NG, mf.TfD, 1, (const cplx*)mf.U0fD, (cplx*)nullptr);
     else hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * 8), dim3(64), 0, s, dd, mf, (const cplx*)mf.GfD, 0, mf.NG, mf.NG, mf.TfD, 1, (const cplx*)mf.U0fD, (cplx*)nullptr);
     hipLaunchKernelGGL(k_mfma_unpack_final, dim3(d.B), dim3(64), 0, s, dd, mf);
 }

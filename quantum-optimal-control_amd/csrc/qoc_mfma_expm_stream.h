@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_chunk4s(QocDev d, QocMfma m
 template <int NT>
 __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, const cplx* __restrict__ IN, int in_is_K, int count, int len,
                                                         cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail, cplx* __restrict__ OUTT) {
-    static_assert(NT == 2 || NT == 3, "row-split chain products: n <= 48 (two right operands of 16 NT^2 registers each in flight)");
+    constexpr bool DB = NT <= 3;                                     // the next right operand in flight (NT = 4: a matrix is 256 registers, one at a time)
     constexpr int PS = 5;                                            // pad stride (complex elements per column): conflict-free stores and block reads
     __shared__ __attribute__((aligned(16))) cplx pad[QNP * PS];
     __shared__ __attribute__((aligned(16))) double pads[QNP * PS];
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, co
 #pragma unroll
         for (int J = 0; J < NT; ++J) r[J] = F[(J * QQS + w) * 64 + lane];
     }
-    Mat M0, M1;
+    Mat M0;
     if (hi > lo) load_mat(src(hi - 1), M0);
     auto product = [&](const Mat& m) {
 #pragma unroll
@@ -401,12 +401,20 @@ __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, co
         for (int J = 0; J < NT; ++J) r[J] = cmake(a[J] - bq[J], cq[J] - a[J] - bq[J]);
     };
     int t = hi - 1;
-    for (; t - 1 >= lo; t -= 2) {                                    // the next right operand is in flight while this one multiplies
-        load_mat(src(t - 1), M1); lds_order(); product(M0);
-        if (t - 2 >= lo) load_mat(src(t - 2), M0);
-        lds_order(); product(M1);
+    if constexpr (DB) {
+        Mat M1;
+        for (; t - 1 >= lo; t -= 2) {                                // the next right operand is in flight while this one multiplies
+            load_mat(src(t - 1), M1); lds_order(); product(M0);
+            if (t - 2 >= lo) load_mat(src(t - 2), M0);
+            lds_order(); product(M1);
+        }
+        if (t >= lo) product(M0);
+    } else {
+        for (; t >= lo; --t) {
+            product(M0);
+            if (t - 1 >= lo) load_mat(src(t - 1), M0);
+        }
     }
-    if (t >= lo) product(M0);
     cplx* out = OUT + ((size_t)b * nout + i) * QFR;
 #pragma unroll
     for (int J = 0; J < NT; ++J) out[(J * QQS + w) * 64 + lane] = r[J];

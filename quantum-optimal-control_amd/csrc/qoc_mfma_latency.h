@@ -96,8 +96,11 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
             return i < n_grp ? Gb + (size_t)(g_first + dir * i) * QFR : Pb + (size_t)(c_first + dir * (i - n_grp)) * QFR;
         };
         if (n_bnd > 0) {
-            constexpr int PD = NT <= 2 ? 2 : 1;                          // (NT = 3: a matrix is 144 registers)
+            constexpr int PD = NT <= 2 ? 2 : (NT == 3 ? 1 : 0);          // (a matrix is 144 registers at NT = 3, 256 at NT = 4: one at a time there)
             Frag Bq[PD + 1];
+            if constexpr (PD == 0) {
+                for (int i = 0; i < n_bnd; ++i) { load_frag(bnd_ptr(i), Bq[0]); product(Bq[0]); }
+            } else {
 #pragma unroll
             for (int q = 0; q < PD; ++q) load_frag(bnd_ptr(q), Bq[q]);
             int i = 0;
@@ -110,6 +113,7 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
 #pragma unroll
             for (int q = 0; q <= PD; ++q)
                 if (i + q < n_bnd) product(Bq[q]);
+            }
         }
     }
     // ---- slices of the chunk.  The vectors go out in the register layout (lane-contiguous 1 KB stores; the gradient kernel holds
@@ -144,14 +148,19 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
         return Kb + (size_t)(adj ? len - 1 - i : i) * mf.FR;
     };
     // (three slices in flight instead of one was SLOWER, 19 vs 15 us for 8 slices)
-    Frag K0, K1;
-    load_frag(k_ptr(0), K0);
-    int i = 0;
-    for (; i + 2 <= len; i += 2) {
-        load_frag(k_ptr(i + 1), K1); asm volatile("" ::: "memory"); step(K0, i);
-        load_frag(k_ptr(i + 2), K0); asm volatile("" ::: "memory"); step(K1, i + 1);
+    Frag K0;
+    if constexpr (NT <= 3) {
+        Frag K1;
+        load_frag(k_ptr(0), K0);
+        int i = 0;
+        for (; i + 2 <= len; i += 2) {
+            load_frag(k_ptr(i + 1), K1); asm volatile("" ::: "memory"); step(K0, i);
+            load_frag(k_ptr(i + 2), K0); asm volatile("" ::: "memory"); step(K1, i + 1);
+        }
+        if (i < len) step(K0, i);
+    } else {
+        for (int i = 0; i < len; ++i) { load_frag(k_ptr(i), K0); step(K0, i); }
     }
-    if (i < len) step(K0, i);
 }
 
 // Gradient of the latency mode: two waves (row tiles h = 0, 1 of the costate) per time slice, 8 slices per workgroup, the control
@@ -261,6 +270,114 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
             __threadfence();                                                      // dLdu, loss: visible device-wide before the arrival is counted
             last = atomicAdd(mf.lat_count + b, 1u) == (unsigned)(nblk - 1) ? 1 : 0;
             if (last) { mf.lat_count[b] = 0u; __threadfence(); }                  // (reset for the next evaluation: stream order)
+        }
+        __syncthreads();
+        if (!last) return;
+        finish_body<true>(d, ap, b, red);
+    }
+}
+
+// The same for 48 < n <= 64 (NT = 4): the control images are 64 KB each, so they pass through LDS two at a time; the Q tiles of a wave
+// (row tile h against the four column tiles) stay in registers across the passes.  Four slices per workgroup, four waves per slice.
+template <int MQ>
+__global__ void __launch_bounds__(1024) k_mfma_grad_lat4(QocDev d, QocMfma mf, QocAdamDev ap, int fuse) {
+    constexpr int NT = 4, SL = 4, KG = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Hl = (cplx*)smem;                                                       // [KG] fragD(H_k') of the current pass
+    double* gpart = (double*)(Hl + (size_t)KG * QFR);                             // [SL][NT tiles][4 rows][2 (re, im)][KG]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wv % NT, sl = wv / NT;
+    const int nblk = (d.steps + SL - 1) / SL;
+    const int b = blockIdx.x / nblk, cb = blockIdx.x - b * nblk;
+    if (d.skip_done && d.done[b]) return;
+    const int t = cb * SL + sl, tc = min(t, d.steps - 1);
+    const bool live = t < d.steps;
+    const int lk = lane >> 4, lc = lane & 15;
+    d4 qr[NT], qi[NT];
+    {
+        const cplx* ll = mf.LamL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
+        const cplx* pl = mf.PsiL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
+        double lr[MQ], li[MQ];
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) { const cplx lv = ll[(h * MQ + q) * 64]; lr[q] = lv.x; li[q] = lv.y; }
+#pragma unroll
+        for (int Jp = 0; Jp < NT; ++Jp) {
+            d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < MQ; ++q) {
+                const cplx pv = pl[(Jp * MQ + q) * 64];
+                t1v = QMFMA(lr[q], pv.x, t1v);
+                t2v = QMFMA(li[q], pv.y, t2v);
+                t3v = QMFMA(lr[q] - li[q], pv.x + pv.y, t3v);
+            }
+            qr[Jp] = t1v + t2v; qi[Jp] = t3v - t1v + t2v;                          // Re, Im of conj(lambda) psi
+        }
+    }
+    double zr = 0.0, zi = 0.0;
+    {
+        const cplx* fin = d.inter + ((size_t)b * (d.steps + 1) + d.steps) * d.n * d.m;
+        for (int o = lane; o < d.n * d.m; o += 64) {
+            const cplx f = fin[o], wv2 = d.W[o];
+            zr += f.x * wv2.x + f.y * wv2.y;
+            zi += f.y * wv2.x - f.x * wv2.y;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); }
+    if (cb == 0 && wv == 0 && lane == 0) {
+        d.zfin[b] = cmake(zr, zi);
+        d.loss[b] = 1.0 - (zr * zr + zi * zi) / ((double)d.m * (double)d.m);
+        d.reg_state[b] = 0.0;
+    }
+    const double c0 = -2.0 / ((double)d.m * (double)d.m);
+    for (int k0 = 0; k0 < d.k; k0 += KG) {
+        __syncthreads();                                                          // the readers of the previous pass are done
+        for (int o = threadIdx.x; o < KG * QFR; o += blockDim.x) Hl[o] = (size_t)k0 * QFR + o < (size_t)d.k * QFR ? mf.HfD[(size_t)(1 + k0) * QFR + o] : cmake(0.0, 0.0);
+        __syncthreads();
+        double gr[KG], gi[KG];
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) { gr[kk] = 0.0; gi[kk] = 0.0; }
+#pragma unroll
+        for (int Jp = 0; Jp < NT; ++Jp)
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+                double ar = 0.0, ai = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const cplx hv = Hl[(size_t)kk * QFR + (Jp * QQS + 4 * h + r) * 64 + lane];
+                    ar = fma(hv.x, qr[Jp][r], ar); ar = fma(-hv.y, qi[Jp][r], ar);
+                    ai = fma(hv.x, qi[Jp][r], ai); ai = fma(hv.y, qr[Jp][r], ai);
+                }
+                gr[kk] += ar; gi[kk] += ai;
+            }
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+            gr[kk] += dpp_xor<1>(gr[kk]); gr[kk] += dpp_xor<2>(gr[kk]); gr[kk] += dpp_xor<4>(gr[kk]); gr[kk] += dpp_xor<8>(gr[kk]);
+            gi[kk] += dpp_xor<1>(gi[kk]); gi[kk] += dpp_xor<2>(gi[kk]); gi[kk] += dpp_xor<4>(gi[kk]); gi[kk] += dpp_xor<8>(gi[kk]);
+        }
+        if (lc == 0) {
+            double* gp = gpart + (((size_t)sl * NT + h) * 4 + lk) * 2 * KG;
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) { gp[kk] = gr[kk]; gp[KG + kk] = gi[kk]; }
+        }
+        __syncthreads();
+        if (live && h == 0 && lane < KG && k0 + lane < d.k) {
+            const double* gp = gpart + (size_t)sl * (4 * NT) * 2 * KG + lane;
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int x = 0; x < 4 * NT; ++x) { sr += gp[x * 2 * KG]; si += gp[x * 2 * KG + KG]; }
+            d.dLdu[((size_t)b * d.k + k0 + lane) * d.steps + t] = c0 * (zr * sr + zi * si);
+        }
+    }
+    if (fuse) {
+        __shared__ double red[34];
+        __shared__ int last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last = atomicAdd(mf.lat_count + b, 1u) == (unsigned)(nblk - 1) ? 1 : 0;
+            if (last) { mf.lat_count[b] = 0u; __threadfence(); }
         }
         __syncthreads();
         if (!last) return;

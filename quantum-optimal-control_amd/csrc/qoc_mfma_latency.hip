@@ -7,6 +7,7 @@ static int grad_lat_kc(const QocDev& d) { return d.k <= 4 ? 4 : (d.k == 5 ? 5 : 
 
 static const void* grad_lat_kernel(const QocMfma& mf, const QocDev& d) {
     const int kc = grad_lat_kc(d);
+    if (mf.NT == 4) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat4<2> : (const void*)k_mfma_grad_lat4<4>;
     if (mf.NT == 3) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 4, 3> : (const void*)k_mfma_grad_lat<4, 4, 3>;
     if (kc == 8) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 8> : (const void*)k_mfma_grad_lat<4, 8>;
     if (kc == 5) return mf.mq <= 2 ? (const void*)k_mfma_grad_lat<2, 5> : (const void*)k_mfma_grad_lat<4, 5>;
@@ -14,7 +15,7 @@ static const void* grad_lat_kernel(const QocMfma& mf, const QocDev& d) {
 }
 
 int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
-    if (hipFuncSetAttribute(grad_lat_kernel(mf, d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grad_lat_lds(grad_lat_kc(d), mf.NT)) != hipSuccess) {
+    if (hipFuncSetAttribute(grad_lat_kernel(mf, d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)grad_lat_lds(mf.NT == 4 ? 2 : grad_lat_kc(d), mf.NT)) != hipSuccess) {
         msg = "MFMA path: cannot reserve LDS for the latency-mode gradient kernel";
         return -2;
     }
@@ -26,7 +27,8 @@ int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     // (with a state regulariser only the forward half: the costate needs the sources, i.e. the forward states, first)
     const dim3 g((mf.lat_sources ? 1 : 2) * d.B * mf.C * mf.mq);
-    if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(64), 0, s, d, mf);
+    if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(64), 0, s, d, mf);
+    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(64), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(64), 0, s, d, mf);
     if (mf.lat_sources) qoc_mfma_unpack_inter(mf, d, s);              // k_loss, the sources and the batch backward kernels read d.inter
 }
@@ -38,6 +40,12 @@ void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* a
     const size_t lds = grad_lat_lds(kc, mf.NT);
     const QocAdamDev a = ap ? *ap : QocAdamDev{};
     const int fuse = ap ? 1 : 0;
+    if (mf.NT == 4) {
+        const size_t lds4 = grad_lat_lds(2, 4);
+        if (mf.mq <= 2) hipLaunchKernelGGL(k_mfma_grad_lat4<2>, g, b, lds4, s, d, mf, a, fuse);
+        else hipLaunchKernelGGL(k_mfma_grad_lat4<4>, g, b, lds4, s, d, mf, a, fuse);
+        return;
+    }
     if (mf.NT == 3) {
         if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_lat<2, 4, 3>), g, b, lds, s, d, mf, a, fuse);
         else hipLaunchKernelGGL((k_mfma_grad_lat<4, 4, 3>), g, b, lds, s, d, mf, a, fuse);

@@ -147,7 +147,7 @@ def _mfma_path_parity(chunks, variant, kernel):
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2, 3 * sp.base0]
     from quantum_optimal_control.core import hip_engine
     no_src = not ({'forbidden_coeff_list', 'speed_up'} & set(sp.reg_coeffs))
-    latency_ok = sp.exp_terms >= 2 and ((sp.n <= 32 and sp.k <= 8) or (sp.n <= 48 and sp.k <= 4 and no_src))
+    latency_ok = sp.exp_terms >= 2 and ((sp.n <= 32 and sp.k <= 8) or (sp.n <= 48 and sp.k <= 4 and no_src) or (48 < sp.n <= 64 and no_src))
     if kernel == 5 and not latency_ok:
         with pytest.raises(hip_engine.QocError, match='latency mode'):
             make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
@@ -347,11 +347,13 @@ def test_large_size_properties_c2(path, variant, expect):
 
 
 @pytest.mark.parametrize('n,k,steps,m,seeds', [(6, 2, 1500, 3, 1), (20, 3, 1100, 5, 2), (2, 1, 100, 2, 1), (13, 8, 90, 4, 3),
-                                               (40, 3, 200, 5, 1), (48, 4, 130, 13, 2), (33, 1, 90, 3, 1)],
-                         ids=['n6_1500_slices', 'n20_1100_slices_2_seeds', 'c1_shape', 'n13_k8', 'n40_nt3', 'n48_m13_nt3', 'n33_nt3'])
+                                               (40, 3, 200, 5, 1), (48, 4, 130, 13, 2), (33, 1, 90, 3, 1),
+                                               (64, 4, 150, 8, 1), (57, 1, 100, 3, 2), (50, 6, 70, 13, 1)],
+                         ids=['n6_1500_slices', 'n20_1100_slices_2_seeds', 'c1_shape', 'n13_k8', 'n40_nt3', 'n48_m13_nt3', 'n33_nt3',
+                              'n64_nt4', 'n57_k1_nt4', 'n50_k6_m13_nt4'])
 def test_latency_mode_long_pulses_and_small_systems(n, k, steps, m, seeds):
     """Latency mode beyond the C2 shape: more than 64 chunks (groups of ~sqrt(C) chunks instead of 8), Hilbert spaces below 17 levels
-    padded to 32, eight controls, 32 < n <= 48 on the NT = 3 kernels -- AUTO picks it for these shapes -- against the full oracle."""
+    padded to 32, eight controls, 32 < n <= 64 on the NT = 3 / 4 kernels -- AUTO picks it for these shapes -- against the full oracle."""
     c = cases.case_c2(n=n, k=k, steps=steps, m=m, taylor=(4, 2), seed=41)
     sp = oracle_system(c)
     rng = np.random.default_rng(n + steps)
