@@ -24,8 +24,8 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
             }
             if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_rows<NT, 4, true>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf);
             else hipLaunchKernelGGL((k_mfma_expm_rows<NT, 8, true>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf);
-            hipLaunchKernelGGL(k_mfma_chain_rows<NT>, dim3(d.B * mf.C * 4 * NT), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
-            hipLaunchKernelGGL(k_mfma_chain_rows<NT>, dim3(d.B * mf.NG * 4 * NT), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
+            hipLaunchKernelGGL(k_mfma_chain_rows2<NT>, dim3(d.B * mf.C * 4 * NT), dim3(64 * NT), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
+            hipLaunchKernelGGL(k_mfma_chain_rows2<NT>, dim3(d.B * mf.NG * 4 * NT), dim3(64 * NT), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
             return;
         }
     }
@@ -47,8 +47,9 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
         // latency mode: K_t by two waves per slice, then the chunk products and the products of groups of G chunks
         if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_slice2<4>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);
         else hipLaunchKernelGGL(k_mfma_expm_slice2<8>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);
-        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.C * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
-        hipLaunchKernelGGL(k_mfma_chain_rows<2>, dim3(d.B * mf.NG * 8), dim3(64), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
+        // (k_mfma_chain_rows2: the columns of the right operand split over the waves of a workgroup -- 9.8 -> 8.5 us per launch at C2)
+        hipLaunchKernelGGL(k_mfma_chain_rows2<2>, dim3(d.B * mf.C * 8), dim3(128), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
+        hipLaunchKernelGGL(k_mfma_chain_rows2<2>, dim3(d.B * mf.NG * 8), dim3(128), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
     }
     else if (v == 6 && NT == 2) {
         if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_pair<4>, dim3(d.B * mf.C), dim3(128), 0, s, d, mf);

@@ -429,6 +429,64 @@ __global__ void __launch_bounds__(64) k_mfma_chain_rows(QocDev d, QocMfma mf, co
     }
 }
 
+// The same chains with the COLUMNS of the right operand split over the waves of a workgroup as well: workgroup = (output, row block w),
+// wave J = column block J.  A wave then loads only the strips (kb, J) of M_t -- 1/NT of the matrix, the fetch that bounds a step of
+// k_mfma_chain_rows (a 16 NT^2 KB matrix per wave and step) -- and runs 3 QQS MFMAs instead of 3 NT QQS; the price is one LDS barrier
+// per step: the left blocks need the four rows of R over ALL columns, so the waves exchange their strips through a double-buffered pad.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) k_mfma_chain_rows2(QocDev d, QocMfma mf, const cplx* __restrict__ IN, int in_is_K, int count, int len,
+                                                              cplx* __restrict__ OUT, int nout, const cplx* __restrict__ tail, cplx* __restrict__ OUTT) {
+    constexpr int PS = 5;                                            // pad stride (complex elements per column): conflict-free stores and block reads
+    __shared__ __attribute__((aligned(16))) cplx pad[2][QNP * PS];
+    const int lane = threadIdx.x & 63, lc = lane & 15, lk = lane >> 4;
+    const int J = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x % QQS, item = blockIdx.x / QQS;         // 4 NT row blocks of 4 rows
+    const int b = item / nout, i = item - b * nout;
+    if (d.skip_done && d.done[b]) return;                            // whole workgroup: no barrier yet
+    const int hi = min(i * len + len, count) - 1, lo = i * len - (tail ? 1 : 0);
+    auto src = [&](int t) -> const cplx* { return (tail && t < i * len) ? tail : (in_is_K ? IN + kitem(mf, d.steps, b, t) : IN + ((size_t)b * count + t) * QFR); };
+    struct Col { cplx s[QQS]; };                                     // strips (kb, J) of a right operand
+    auto load_col = [&](const cplx* __restrict__ F, Col& m) {
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) m.s[kb] = F[(J * QQS + kb) * 64 + lane];
+    };
+    cplx r = src(hi)[(J * QQS + w) * 64 + lane];                     // own strip of the running product: rows 4 w .., column block J
+    int buf = 0;
+    auto product = [&](const Col& m) {
+        pad[buf][(16 * J + lc) * PS + lk] = r;                       // R[4w + lk][16 J + lc] -> pad[column][row in block]
+        lds_barrier();
+        double a = 0.0, bq = 0.0, cq = 0.0;
+        cplx blk[QQS];
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) blk[kb] = pad[buf][(4 * kb + lk) * PS + (lane & 3)];   // lane 16 k + 4 blk + i  <-  R[4w + i][4 kb + k]
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) {
+            const double br = m.s[kb].x, bi = m.s[kb].y;
+            a = __builtin_amdgcn_mfma_f64_4x4x4f64(blk[kb].x, br, a, 0, 0, 0);
+            bq = __builtin_amdgcn_mfma_f64_4x4x4f64(blk[kb].y, bi, bq, 0, 0, 0);
+            cq = __builtin_amdgcn_mfma_f64_4x4x4f64(blk[kb].x + blk[kb].y, br + bi, cq, 0, 0, 0);
+        }
+        r = cmake(a - bq, cq - a - bq);
+        buf ^= 1;                                                    // the other pad: nobody reads it any more (everyone passed this step's barrier)
+    };
+    Col M0, M1;
+    if (hi > lo) load_col(src(hi - 1), M0);
+    int t = hi - 1;
+    for (; t - 1 >= lo; t -= 2) {                                    // the next right operand is in flight while this one multiplies
+        load_col(src(t - 1), M1); lds_order(); product(M0);
+        if (t - 2 >= lo) load_col(src(t - 2), M0);
+        lds_order(); product(M1);
+    }
+    if (t >= lo) product(M0);
+    cplx* out = OUT + ((size_t)b * nout + i) * QFR;
+    out[(J * QQS + w) * 64 + lane] = r;
+    if (OUTT) {                                                      // fragD(P^T): this wave's rows are columns there (scattered 16 B stores)
+        cplx* outt = OUTT + ((size_t)b * nout + i) * QFR;
+        const int row = 4 * w + lk, col = 16 * J + lc;               // P[row][col] = P^T[col][row] -> fragment (row >> 4, col >> 2), lane 16 (col & 3) + (row & 15)
+        outt[((row >> 4) * QQS + (col >> 2)) * 64 + 16 * (col & 3) + (row & 15)] = r;
+    }
+}
+
 // ---- latency mode: K_t by TWO waves per slice (one per 16-column block), n <= 32 -------------------------------------------------
 // Left multiplication acts on column blocks independently, so wave J carries column block J of every matrix of the slice in 8 strip
 // registers and needs the other wave only for the LEFT operand: both publish their strips of it into one of two LDS images (one
