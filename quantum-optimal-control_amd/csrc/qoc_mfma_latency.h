@@ -5,7 +5,7 @@
 // then the costate back over them (the custom gradient of tensorflow_state.py:77-133).  Without a state regulariser the costate
 //     Lambda_t = c0 z Lambda0_t,   Lambda0_t = (K_N ... K_{t+1})^dagger W,   c0 = -2/m^2,  z = tr(W^dagger Psi_N)
 // is LINEAR in the overlap z, so the z-free costate Lambda0 does not wait for the forward sweep: both sweeps run side by side in
-// ONE launch (k_mfma_sweep_lat: 2 x chunks x column groups waves, one per CU), each storing its vectors in its own register layout,
+// ONE launch (k_mfma_sweep_lat: 2 x chunks x column groups workgroups of NT waves), each storing its vectors in its own register layout,
 // and the gradient
 //     dL/du_{k,t} = c0 Re( conj(z) G_{k,t} ),   G_{k,t} = tr( Lambda0_t^dagger H_k' Psi_t )
 // is one slice-parallel kernel (k_mfma_grad_lat: two waves per slice) that also forms z and the loss.  Against the pair of waves
@@ -15,78 +15,72 @@
 #include "qoc_mfma_frag.h"
 #include "qoc_kernels_finish.h"
 
-// One wave per (role, seed, chunk, group of 4 columns).  role 0: Psi_t = K_t Psi_{t-1} from Psi0, stores PsiL[t] = Psi after slice t;
-// role 1: Lambda0_{t-1} = K_t^dagger Lambda0_t from W, stores LamL[t] = Lambda0 BEFORE K_t^dagger is applied (the costate that meets
-// Psi_t in the gradient).  Both walk two-level chunk boundaries first (products of groups of G chunks, then chunk products), the
-// forward one upwards from the start of the pulse, the adjoint one downwards from its end.  The roles differ in pointers, index
-// directions and one sign only -- no branch surrounds a load (hipcc would wait for such a load on the spot):
+// One workgroup per (role, seed, chunk, group of 4 columns), wave I of it = rows 16 I .. 16 I + 15 of the vectors.  role 0: Psi_t = K_t
+// Psi_{t-1} from Psi0, stores PsiL[t] = Psi after slice t; role 1: Lambda0_{t-1} = K_t^dagger Lambda0_t from W, stores LamL[t] = Lambda0
+// BEFORE K_t^dagger is applied (the costate that meets Psi_t in the gradient).  Both walk two-level chunk boundaries first (products of
+// groups of G chunks, then chunk products), the forward one upwards from the start of the pulse, the adjoint one downwards from its
+// end.  The roles differ in pointers, index directions and one sign only -- no branch surrounds a load (hipcc would wait for such a
+// load on the spot):
 //   forward operand  M = K:         strip (I, kb) of lane (lk, lc) = K[16 I + lc][4 kb + lk]       = fragD(K^T)(I, kb)   (KfT / PfT / GfT)
 //   adjoint operand  M = K^dagger:  conj(K[4 kb + lk][16 I + lc])                                  = conj fragD(K)(I, kb) (KfD / PfD / GfD)
+// X <- M X needs, for row tile I of the result, only the strips (I, kb) of the operand -- 1/NT of the matrix, lane-contiguous 1 KB
+// loads, the fetch that bounds a step -- and 3 QQS MFMAs; the left blocks need X over ALL rows, so the waves publish their 16 rows to
+// a double-buffered LDS image and meet at one barrier per step.  (With one wave carrying all row tiles, 16 NT^2 KB and 3 NT QQS MFMAs
+// per step, the launch was 18.5 instead of 13 us at C2, and at NT = 4 a 256-register matrix left no room for a prefetch.)
 template <int NT>
-__global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
+__global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
     constexpr int LDP = 16 * NT + 1;
-    __shared__ __attribute__((aligned(16))) cplx img[4 * LDP];                    // image[column j][row] of the wave's 4 columns
-    const int lane = threadIdx.x;
-    const int cs = mf.mq;                                                         // groups of 4 columns (independent under left multiplication)
+    __shared__ __attribute__((aligned(16))) cplx img[2][4 * LDP];                 // image[buffer][column j][row] of the workgroup's 4 columns
+    const int lane = threadIdx.x & 63;
+    const int I = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cs = mf.mq;
     const int n_sweep = d.B * mf.C * cs;
     const int adj = __builtin_amdgcn_readfirstlane((int)blockIdx.x >= n_sweep ? 1 : 0);
     const int w = (int)blockIdx.x - adj * n_sweep;
     const int item = w / cs, jq0 = w - item * cs;
     const int c = item / d.B, b = item - c * d.B;
-    if (d.skip_done && d.done[b]) return;
+    if (d.skip_done && d.done[b]) return;                                         // whole workgroup: no barrier yet
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps), len = t1 - t0;
     const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
-    const double sg = adj ? -1.0 : 1.0;                                           // conjugated operand in the adjoint sweep
-    double pre[NT], pim[NT];
+    const double sg = adj ? -1.0 : 1.0;
+    double pre, pim;
     {
         const cplx* X0 = adj ? d.W : d.Psi0;
-#pragma unroll
-        for (int I = 0; I < NT; ++I) {
-            const int row = 16 * I + lc, col = 4 * jq0 + lk;
-            cplx v = cmake(0.0, 0.0);
-            if (row < d.n && col < d.m) v = X0[row * d.m + col];
-            pre[I] = v.x; pim[I] = v.y;
-        }
+        const int row = 16 * I + lc, col = 4 * jq0 + lk;
+        cplx v = cmake(0.0, 0.0);
+        if (row < d.n && col < d.m) v = X0[row * d.m + col];
+        pre = v.x; pim = v.y;
     }
     cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
-    if (!adj && c == 0 && jq0 == 0) {                                             // inter[0] = V  (tensorflow_state.py:232-233)
+    if (!adj && c == 0 && jq0 == 0 && I == 0) {                                   // inter[0] = V  (tensorflow_state.py:232-233)
         for (int o = lane; o < d.n * d.m; o += 64) iv[o] = d.V[o];
     }
-    struct Frag { cplx f[NT][QQS]; };
-    auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {                  // lane-contiguous 1 KB loads (one wave brings a 16 KB matrix
-#pragma unroll                                                                   // in 0.7 us that way: profiles/r02_matrix_fetch_probe.txt)
-        for (int I = 0; I < NT; ++I)
+    struct Frag { cplx f[QQS]; };                                                 // strips (I, kb) of the operand
+    auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
 #pragma unroll
-            for (int q = 0; q < QQS; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];
+        for (int q = 0; q < QQS; ++q) fr.f[q] = F[(I * QQS + q) * 64 + lane];
     };
-    // X <- M X on v_mfma_f64_4x4x4 (3 real products per complex one); s = -1 multiplies by the conjugate of the strips
+    int buf = 0;
     auto product = [&](const Frag& fr) {
+        img[buf][lk * LDP + 16 * I + lc] = cmake(pre, pim);
+        lds_barrier();
+        double a = 0.0, bq = 0.0, cq = 0.0;
+        cplx v[QQS];
 #pragma unroll
-        for (int I = 0; I < NT; ++I) img[lk * LDP + 16 * I + lc] = cmake(pre[I], pim[I]);
-        wave_lds_fence();
-        double a[NT], bq[NT], cq[NT];
-#pragma unroll
-        for (int I = 0; I < NT; ++I) { a[I] = 0.0; bq[I] = 0.0; cq[I] = 0.0; }
+        for (int kb = 0; kb < QQS; ++kb) v[kb] = img[buf][li4 * LDP + 4 * kb + lk];   // X[4 kb + lk][column li4 of the group]
 #pragma unroll
         for (int kb = 0; kb < QQS; ++kb) {
-            const cplx v = img[li4 * LDP + 4 * kb + lk];                          // X[4 kb + lk][column li4 of the group]
-#pragma unroll
-            for (int I = 0; I < NT; ++I) {
-                const double br = fr.f[I][kb].x, bi = fr.f[I][kb].y, bs = fma(sg, bi, br);
-                a[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[I], 0, 0, 0);
-                bq[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, bq[I], 0, 0, 0);
-                cq[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, cq[I], 0, 0, 0);
-            }
+            const double br = fr.f[kb].x, bi = fr.f[kb].y, bs = fma(sg, bi, br);
+            a = __builtin_amdgcn_mfma_f64_4x4x4f64(v[kb].x, br, a, 0, 0, 0);
+            bq = __builtin_amdgcn_mfma_f64_4x4x4f64(v[kb].y, bi, bq, 0, 0, 0);
+            cq = __builtin_amdgcn_mfma_f64_4x4x4f64(v[kb].x + v[kb].y, bs, cq, 0, 0, 0);
         }
-#pragma unroll
-        for (int I = 0; I < NT; ++I) { pre[I] = fma(-sg, bq[I], a[I]); pim[I] = fma(-sg, bq[I], cq[I] - a[I]); }
+        pre = fma(-sg, bq, a); pim = fma(-sg, bq, cq - a);
+        buf ^= 1;                                                                 // the other image: everyone has passed this step's barrier
     };
-    // ---- chunk boundary: whole groups first, then the chunks of the own group.  The matrices were written by the previous kernel,
-    //      mostly on other XCDs: each fetch is a 1-2 us round trip, so the list is walked with the next TWO matrices in flight
-    //      (four: slower -- every wave walks the SAME group products, the walk is bound by that L2 hot spot) -------------------------
     {
         const int G = mf.G, g = c / G, C = mf.C, NG = mf.NG;
-        const int cend = min(g * G + G, C) - 1;                                   // last chunk of the own group
+        const int cend = min(g * G + G, C) - 1;
         const int n_grp = adj ? NG - 1 - g : g, n_ch = adj ? cend - c : c - g * G, n_bnd = n_grp + n_ch;
         const int g_first = adj ? NG - 1 : 0, c_first = adj ? cend : g * G, dir = adj ? -1 : 1;
         const cplx* Gb = (adj ? mf.GfD : mf.GfT) + (size_t)b * NG * QFR;
@@ -96,11 +90,8 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
             return i < n_grp ? Gb + (size_t)(g_first + dir * i) * QFR : Pb + (size_t)(c_first + dir * (i - n_grp)) * QFR;
         };
         if (n_bnd > 0) {
-            constexpr int PD = NT <= 2 ? 2 : (NT == 3 ? 1 : 0);          // (a matrix is 144 registers at NT = 3, 256 at NT = 4: one at a time there)
+            constexpr int PD = 2;
             Frag Bq[PD + 1];
-            if constexpr (PD == 0) {
-                for (int i = 0; i < n_bnd; ++i) { load_frag(bnd_ptr(i), Bq[0]); product(Bq[0]); }
-            } else {
 #pragma unroll
             for (int q = 0; q < PD; ++q) load_frag(bnd_ptr(q), Bq[q]);
             int i = 0;
@@ -113,54 +104,36 @@ __global__ void __launch_bounds__(64) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
 #pragma unroll
             for (int q = 0; q <= PD; ++q)
                 if (i + q < n_bnd) product(Bq[q]);
-            }
         }
     }
-    // ---- slices of the chunk.  The vectors go out in the register layout (lane-contiguous 1 KB stores; the gradient kernel holds
-    //      them in the same layout): the scattered 16 B stores of the API layout are as slow in the load/store path as gathers;
-    //      d.inter gets only the last slice (the overlap z reads it), the rest is unpacked when read back ------------------------------
-    const int MQs = mf.mq <= 2 ? 2 : 4;                                           // column groups per slice as k_mfma_grad_lat reads them
+    const int MQs = mf.mq <= 2 ? 2 : 4;
     cplx* XL = (adj ? mf.LamL : mf.PsiL) + (size_t)b * d.steps * (NT * MQs) * 64;
-    auto store = [&](int t) {
-        cplx* xl = XL + (size_t)t * (NT * MQs) * 64;
-#pragma unroll
-        for (int I = 0; I < NT; ++I) xl[(I * MQs + jq0) * 64 + lane] = cmake(pre[I], pim[I]);
-    };
+    auto store = [&](int t) { XL[((size_t)t * (NT * MQs) + I * MQs + jq0) * 64 + lane] = cmake(pre, pim); };
     auto step = [&](const Frag& fr, int i) {
         const int t = adj ? t1 - 1 - i : t0 + i;
         if (adj) store(t);
-        if (!adj || i + 1 < len) product(fr);                                     // (K_{t0}^dagger would give the boundary of the chunk below)
+        if (!adj || i + 1 < len) product(fr);
         if (!adj) {
             store(t);
             if (t + 1 == d.steps) {
-                cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
-#pragma unroll
-                for (int I = 0; I < NT; ++I) {
-                    const int row = 16 * I + lc, col = 4 * jq0 + lk;
-                    if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I], pim[I]);
-                }
+                const int row = 16 * I + lc, col = 4 * jq0 + lk;
+                if (row < d.n && col < d.m) (iv + (size_t)(t + 1) * d.n * d.m)[row * d.m + col] = cmake(pre, pim);
             }
         }
     };
-    const cplx* Kb = (adj ? mf.KfD : mf.KfT) + kitem(mf, d.steps, b, t0);           // slices of one chunk are FR apart
+    const cplx* Kb = (adj ? mf.KfD : mf.KfT) + kitem(mf, d.steps, b, t0);
     auto k_ptr = [&](int i) -> const cplx* {
         i = min(i, len - 1);
         return Kb + (size_t)(adj ? len - 1 - i : i) * mf.FR;
     };
-    // (three slices in flight instead of one was SLOWER, 19 vs 15 us for 8 slices)
-    Frag K0;
-    if constexpr (NT <= 3) {
-        Frag K1;
-        load_frag(k_ptr(0), K0);
-        int i = 0;
-        for (; i + 2 <= len; i += 2) {
-            load_frag(k_ptr(i + 1), K1); asm volatile("" ::: "memory"); step(K0, i);
-            load_frag(k_ptr(i + 2), K0); asm volatile("" ::: "memory"); step(K1, i + 1);
-        }
-        if (i < len) step(K0, i);
-    } else {
-        for (int i = 0; i < len; ++i) { load_frag(k_ptr(i), K0); step(K0, i); }
+    Frag K0, K1;
+    load_frag(k_ptr(0), K0);
+    int i = 0;
+    for (; i + 2 <= len; i += 2) {
+        load_frag(k_ptr(i + 1), K1); asm volatile("" ::: "memory"); step(K0, i);
+        load_frag(k_ptr(i + 2), K0); asm volatile("" ::: "memory"); step(K1, i + 1);
     }
+    if (i < len) step(K0, i);
 }
 
 // Gradient of the latency mode: two waves (row tiles h = 0, 1 of the costate) per time slice, 8 slices per workgroup, the control

@@ -1,4 +1,5 @@
 // qoc_mfma_latency.hip -- translation unit of the latency-mode sweeps (qoc_mfma_latency.h) and their launchers.
+#include <cstdlib>
 #include "qoc_kernels_mfma.h"
 #include "qoc_mfma_latency.h"
 
@@ -22,14 +23,13 @@ int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
     return 0;
 }
 
-// forward and z-free adjoint sweep side by side: 2 x (seed, chunk, group of 4 columns) waves, one per workgroup, i.e. per CU (no two
-// sweeps share a CU's 64 B/clk load path: 4 x 16 KB per step did)
+// forward and z-free adjoint sweep side by side: 2 x (seed, chunk, group of 4 columns) workgroups of NT waves (one row tile each)
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     // (with a state regulariser only the forward half: the costate needs the sources, i.e. the forward states, first)
     const dim3 g((mf.lat_sources ? 1 : 2) * d.B * mf.C * mf.mq);
-    if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(64), 0, s, d, mf);
-    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(64), 0, s, d, mf);
-    else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(64), 0, s, d, mf);
+    if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(256), 0, s, d, mf);
+    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(192), 0, s, d, mf);
+    else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(128), 0, s, d, mf);
     if (mf.lat_sources) qoc_mfma_unpack_inter(mf, d, s);              // k_loss, the sources and the batch backward kernels read d.inter
 }
 
