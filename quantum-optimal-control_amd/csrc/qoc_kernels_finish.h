@@ -63,6 +63,13 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
         }
     }
 
+    // Learning rate and Adam bias correction of the step that follows IF the stop rule lets it happen: they depend on the iteration
+    // counters only, so their exp / pow (a few hundred instructions on the dependent chain of a single-trajectory tail) are formed
+    // here, under the latency of the loads above, not after the reduction that decides the stop rule.
+    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    const double lr_next = ap.mode == 1 ? ap.rate * exp(-(double)(it0 + 1) / ap.decay) : (ap.mode == 2 ? ap.lr[b] : 0.0);   // run_session.py:66
+    const double lr_t = lr_next * sqrt(1.0 - pow(b2, (double)(adam_t0 + 1))) / (1.0 - pow(b1, (double)(adam_t0 + 1)));
+
     double reg = 0.0;
     // ---- values that are not sums over (k,t) elements --------------------------------------------------------
     if (!PLAIN && d.has_dwdt) {                                                            // :28-35
@@ -170,8 +177,6 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     }
     if (ap.mode == 0) return;
 
-    double lr;
-    int tstep;
     if (ap.mode == 1) {                                                          // run_session.py:56-66
         if (was_done) return;
         const bool end = (loss < ap.conv_target) || (g2 < ap.min_grad) || (it0 >= ap.max_iterations);
@@ -179,15 +184,9 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
             if (threadIdx.x == 0) d.done[b] = 1;
             return;
         }
-        const int it1 = it0 + 1;                                                 // update_and_save :92
-        lr = ap.rate * exp(-(double)it1 / ap.decay);                             // :66
-        if (threadIdx.x == 0) d.iters[b] = it1;
-    } else {
-        lr = ap.lr[b];
+        if (threadIdx.x == 0) d.iters[b] = it0 + 1;                              // update_and_save :92
     }
-    tstep = adam_t0 + 1;
-    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-    const double lr_t = lr * sqrt(1.0 - pow(b2, (double)tstep)) / (1.0 - pow(b1, (double)tstep));
+    const int tstep = adam_t0 + 1;
     if (in_regs) {
 #pragma unroll
         for (int e = 0; e < QF_E; ++e) {
