@@ -24,3 +24,11 @@ def test_transmon_state_transfer_example():
     with contextlib.redirect_stdout(io.StringIO()):
         f = transmon_state_transfer.main(iterations=200, restarts=4, quiet=True)
     assert f > 0.9
+
+
+def test_two_transmon_cz_example():
+    """One control set, n = 9, forbidden levels + dwdt: the latency mode with the affine backward half, end to end through Grape()."""
+    import two_transmon_cz
+    with contextlib.redirect_stdout(io.StringIO()):
+        f = two_transmon_cz.main(iterations=400, quiet=True)
+    assert f > 0.999
