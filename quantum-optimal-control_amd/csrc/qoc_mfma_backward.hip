@@ -68,6 +68,11 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
     if (mf.lat_sources && !al(&mf.Goff, (size_t)d.B * mf.NG * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
+    mf.lat_src_fast = mf.lat_sources && NT == 2 && !d.forbid_dressed;   // undressed forbidden levels / speed_up: thin affine sweeps (qoc_mfma_latency.h)
+    if (mf.lat_src_fast) {
+        const size_t vec = (size_t)NT * (mf.mq <= 2 ? 2 : 4) * 64;
+        if (!al(&mf.AoffL, (size_t)d.B * C * vec) || !al(&mf.GoffL, (size_t)d.B * mf.NG * vec) || !al(&mf.LamS, (size_t)d.B * d.steps * vec)) { msg = "MFMA path: out of device memory"; return -3; }
+    }
     if (mf.latency && (!al(&mf.GfD, (size_t)d.B * mf.NG * FR) || !al(&mf.GfT, (size_t)d.B * mf.NG * FR) || !al(&mf.TfD, (size_t)d.B * FR) ||
                        !al(&mf.PsiL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64) ||
                        !al(&mf.LamL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64))) { msg = "MFMA path: out of device memory"; return -3; }
@@ -205,7 +210,7 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
         hipLaunchKernelGGL((k_mfma_backward<NT, false>), dim3((items + 3) / 4), dim3(256), mf.bwd_lds, s, d, mf, 0);
 }
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s) {
-    if (mf.latency && !mf.lat_sources) { qoc_mfma_latency_gradient(mf, d, nullptr, s); return; }
+    if (mf.latency && (!mf.lat_sources || mf.lat_src_fast)) { qoc_mfma_latency_gradient(mf, d, nullptr, s); return; }
     if (mf.NT == 1) qoc_mfma_launch_all_backward<1>(mf, d, s); else if (mf.NT == 2) qoc_mfma_launch_all_backward<2>(mf, d, s); else if (mf.NT == 3) qoc_mfma_launch_all_backward<3>(mf, d, s); else qoc_mfma_launch_all_backward<4>(mf, d, s);
 }
 

@@ -52,6 +52,10 @@ struct QocMfma {
     cplx* PsiL = nullptr;         // [B][steps][NT * MQ][64] Psi after slice t in the sweeps' own register layout (row 16 I + lane % 16, column
                                   // 4 jb + lane / 16): lane-contiguous 1 KB stores / loads; d.inter (API layout) is unpacked from it on read-back
     cplx* LamL = nullptr;         // [B][steps][NT * MQ][64] z-free costate BEFORE K_t^dagger is applied, same layout (qoc_mfma_latency.h)
+    cplx* LamS = nullptr;         // [B][steps][NT * MQ][64] total costate c0 z Lambda0 + LambdaS when a state regulariser is present (k_mfma_sweep_src)
+    cplx* AoffL = nullptr;        // [B][C][NT * MQ][64] / GoffL [B][NG][...]: chunk and group offsets of the source recursion, register layout
+    cplx* GoffL = nullptr;
+    bool lat_src_fast = false;    // lat_sources on the thin affine sweeps (undressed forbidden levels / speed_up, NT = 2); else the batch kernels' recursion
     unsigned* lat_count = nullptr; // [B] workgroups of k_mfma_grad_lat that have finished (the last one runs the tail of the iteration)
     cplx* GfT = nullptr;          // [B][NG] fragD(G_g^T): with KfT / PfT the lane-contiguous operands of the forward sweep in latency mode
     bool latency = false;

@@ -136,6 +136,135 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf
     if (i < len) step(K0, i);
 }
 
+// ---- state regularisers (undressed forbidden levels, speed_up) in the latency mode ----------------------------------------------------
+// The costate splits as Lambda_t = c0 z Lambda0_t + LambdaS_t: Lambda0 is the z-free sweep above; the source part obeys the affine
+// recursion LambdaS_{t-1} = K_t^dagger LambdaS_t + S_t, LambdaS_{N-1} = S_N, with S_t = d(state regularisers)/dPsi at time t (source_at,
+// qoc_state_source.h) -- elementwise in the sweeps' register layout: an undressed forbidden level and speed_up need Psi (PsiL[t-1], the
+// state after slice t-1), W and one scalar per time step at the lane's own entry only.  Thin affine sweeps in three passes, the same
+// workgroup shape as k_mfma_sweep_lat (a wave per 16-row tile, a workgroup per 4 columns):
+//   role 0: every chunk from a zero costate over its slices            -> chunk offsets  a_c  (AoffL)
+//   role 1: every group from a zero costate over its chunks, + a_c     -> group offsets  A_g  (GoffL)
+//   role 2: from S_N down over whole groups (G_g^dagger X + A_g), the chunks of the own group (P_c^dagger X + a_c), then the slices of the
+//           chunk, storing the TOTAL costate c0 z Lambda0_t + LambdaS_t (LamS) that k_mfma_grad_lat contracts with Psi_t.
+// Against the pair-of-waves kernels of the batch path on the same chunks (k_mfma_bwd_offsets2 28 us, k_mfma_backward3<MODE 2> 8,
+// <MODE 1> 39, which also carry the gradient work) the three passes are thin products with a vector add per step.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) k_mfma_sweep_src(QocDev d, QocMfma mf, int role) {
+    constexpr int LDP = 16 * NT + 1;
+    __shared__ __attribute__((aligned(16))) cplx img[2][4 * LDP];
+    const int lane = threadIdx.x & 63;
+    const int I = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cs = mf.mq, per = role == 1 ? mf.NG : mf.C;
+    const int item = (int)blockIdx.x / cs, jq0 = (int)blockIdx.x - item * cs;
+    const int c = item / d.B, b = item - c * d.B;                                 // c: chunk (roles 0, 2) or group (role 1)
+    if (c >= per || (d.skip_done && d.done[b])) return;                           // whole workgroup: no barrier yet
+    const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
+    const int row = 16 * I + lc, col = 4 * jq0 + lk;
+    const bool inside = row < d.n && col < d.m;
+    const int MQs = mf.mq <= 2 ? 2 : 4, slot = (I * MQs + jq0) * 64 + lane, per_vec = NT * MQs * 64;
+    double wrow = 0.0;                                                            // sum of 2 a_f over the forbidden levels equal to this lane's row
+    for (int f = 0; f < d.n_forb; ++f) wrow += (row == d.forb_state[f]) ? 2.0 * d.forb_a[f] : 0.0;
+    const cplx wown = inside ? d.W[row * d.m + col] : cmake(0.0, 0.0);
+    const double speed_coef = d.has_speed ? -d.a_speed * d.su_resid[b] * 2.0 / ((double)d.m * (double)d.m) : 0.0;
+    const cplx* psil = mf.PsiL + (size_t)b * d.steps * per_vec + slot;
+    const cplx* ztau = d.has_speed ? d.ztau + (size_t)b * (d.steps + 1) : d.zfin + b;   // (a valid address either way: no branch around the load)
+    const int zstride = d.has_speed ? 1 : 0;
+    auto source = [&](int tau) -> cplx {                                          // S_tau at this lane's entry, tau = 1 .. steps (0 for tau <= 0)
+        const cplx psi = psil[(size_t)max(tau - 1, 0) * per_vec];
+        const cplx zt = ztau[(size_t)tau * zstride];
+        const double pop = psi.x * psi.x + psi.y * psi.y;
+        cplx sv = cscale(psi, wrow * pop);
+        const cplx zw = cscale(cmul(zt, wown), speed_coef);
+        sv.x += zw.x; sv.y += zw.y;
+        return (tau > 0 && inside) ? sv : cmake(0.0, 0.0);
+    };
+    double pre = 0.0, pim = 0.0;
+    struct Frag { cplx f[QQS]; };
+    auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
+#pragma unroll
+        for (int q = 0; q < QQS; ++q) fr.f[q] = F[(I * QQS + q) * 64 + lane];
+    };
+    int buf = 0;
+    auto product = [&](const Frag& fr, const cplx add) {                          // X <- M^dagger X + add, M given by fragD(M)
+        img[buf][lk * LDP + 16 * I + lc] = cmake(pre, pim);
+        lds_barrier();
+        double a = 0.0, bq = 0.0, cq = 0.0;
+        cplx v[QQS];
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) v[kb] = img[buf][li4 * LDP + 4 * kb + lk];
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) {
+            const double br = fr.f[kb].x, bi = fr.f[kb].y, bs = br - bi;
+            a = __builtin_amdgcn_mfma_f64_4x4x4f64(v[kb].x, br, a, 0, 0, 0);
+            bq = __builtin_amdgcn_mfma_f64_4x4x4f64(v[kb].y, bi, bq, 0, 0, 0);
+            cq = __builtin_amdgcn_mfma_f64_4x4x4f64(v[kb].x + v[kb].y, bs, cq, 0, 0, 0);
+        }
+        pre = a + bq + add.x; pim = cq - a + bq + add.y;
+        buf ^= 1;
+    };
+    cplx* AoffL = mf.AoffL + (size_t)b * mf.C * per_vec + slot;
+    cplx* GoffL = mf.GoffL + (size_t)b * mf.NG * per_vec + slot;
+    const int G = mf.G, C = mf.C, NG = mf.NG;
+    Frag F0, F1;
+    if (role == 1) {
+        // group offset: from zero over the chunks of group c, last to first
+        const int clast = min(c * G + G, C) - 1, cfirst = c * G, nst = clast - cfirst + 1;
+        const cplx* Pb = mf.PfD + (size_t)b * C * QFR;
+        load_frag(Pb + (size_t)clast * QFR, F0);
+        for (int s = 0; s < nst; ++s) {
+            const int cc = clast - s;
+            const cplx add = AoffL[(size_t)cc * per_vec];
+            if (s + 1 < nst) load_frag(Pb + (size_t)(cc - 1) * QFR, F1);
+            asm volatile("" ::: "memory");
+            product(F0, add);
+            if (s + 1 < nst) F0 = F1;
+        }
+        GoffL[(size_t)c * per_vec] = cmake(pre, pim);
+        return;
+    }
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps), len = t1 - t0;
+    if (role == 2) {
+        const cplx st = source(d.steps);                                          // terminal: LambdaS at the last slice = S_N
+        pre = st.x; pim = st.y;
+        const int g = c / G, clast = min(g * G + G, C) - 1;
+        const cplx* Gb = mf.GfD + (size_t)b * NG * QFR;
+        const cplx* Pb = mf.PfD + (size_t)b * C * QFR;
+        const int n_grp = NG - 1 - g, n_ch = clast - c, n_bnd = n_grp + n_ch;
+        auto bnd_mat = [&](int i) -> const cplx* { i = min(i, n_bnd - 1); return i < n_grp ? Gb + (size_t)(NG - 1 - i) * QFR : Pb + (size_t)(clast - (i - n_grp)) * QFR; };
+        auto bnd_add = [&](int i) -> const cplx* { return i < n_grp ? GoffL + (size_t)(NG - 1 - i) * per_vec : AoffL + (size_t)(clast - (i - n_grp)) * per_vec; };
+        if (n_bnd > 0) load_frag(bnd_mat(0), F0);
+        for (int i = 0; i < n_bnd; ++i) {
+            const cplx add = *bnd_add(i);
+            if (i + 1 < n_bnd) load_frag(bnd_mat(i + 1), F1);
+            asm volatile("" ::: "memory");
+            product(F0, add);
+            if (i + 1 < n_bnd) F0 = F1;
+        }
+    }
+    // slices of the chunk, last to first: role 0 accumulates the offset, role 2 stores the total costate before every step
+    const cplx z = d.zfin[b];
+    const double c0 = -2.0 / ((double)d.m * (double)d.m);
+    const cplx* lam0 = mf.LamL + (size_t)b * d.steps * per_vec + slot;
+    cplx* lams = mf.LamS + (size_t)b * d.steps * per_vec + slot;
+    const cplx* Kb = mf.KfD + kitem(mf, d.steps, b, t0);
+    load_frag(Kb + (size_t)(len - 1) * mf.FR, F0);
+    for (int i = 0; i < len; ++i) {
+        const int t = t1 - 1 - i;
+        if (role == 2) {
+            const cplx l0 = lam0[(size_t)t * per_vec];
+            const cplx zl = cscale(cmul(z, l0), c0);
+            lams[(size_t)t * per_vec] = cmake(zl.x + pre, zl.y + pim);
+            if (i + 1 == len) break;                                              // (the step over slice t0 would give the boundary of the chunk below)
+        }
+        const cplx add = source(t);
+        if (i + 1 < len) load_frag(Kb + (size_t)(len - 2 - i) * mf.FR, F1);
+        asm volatile("" ::: "memory");
+        product(F0, add);
+        if (i + 1 < len) F0 = F1;
+    }
+    if (role == 0) AoffL[(size_t)c * per_vec] = cmake(pre, pim);
+}
+
 // Gradient of the latency mode: two waves (row tiles h = 0, 1 of the costate) per time slice, 8 slices per workgroup, the control
 // images H_k' (fragD layout, as k_mfma_backward3 holds them) staged in LDS once per workgroup.
 //   Q = conj(Lambda0_t) Psi_t^T  (tiles (h, 0..1) on v_mfma_f64_16x16x4),  G_k = sum_{r,c} H_k'[r][c] Q[r][c]  (complex),
@@ -161,9 +290,10 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
     const bool live = t < d.steps;
     const int lk = lane >> 4, lc = lane & 15;
     // operands of the slice: costate rows of tile h, state rows of both tiles, all lane-contiguous
+    const bool total = (fuse & 2) != 0;          // state regularisers: LamS holds the TOTAL costate c0 z Lambda0 + LambdaS (k_mfma_sweep_src); k_loss formed z and the loss
     double lr[MQ], li[MQ], pr[NT][MQ], pi[NT][MQ];
     {
-        const cplx* ll = mf.LamL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
+        const cplx* ll = (total ? mf.LamS : mf.LamL) + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
         const cplx* pl = mf.PsiL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < MQ; ++q) {
@@ -185,7 +315,7 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
     for (int o = threadIdx.x; o < KC * QFR; o += blockDim.x) Hl[o] = o < d.k * QFR ? mf.HfD[QFR + o] : cmake(0.0, 0.0);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); }
-    if (cb == 0 && wv == 0 && lane == 0) {
+    if (!total && cb == 0 && wv == 0 && lane == 0) {
         d.zfin[b] = cmake(zr, zi);
         d.loss[b] = 1.0 - (zr * zr + zi * zi) / ((double)d.m * (double)d.m);
         d.reg_state[b] = 0.0;
@@ -233,9 +363,9 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
 #pragma unroll
         for (int x = 0; x < 4 * NT; ++x) { sr += gp[x * 2 * KC]; si += gp[x * 2 * KC + KC]; }
         const double c0 = -2.0 / ((double)d.m * (double)d.m);
-        d.dLdu[((size_t)b * d.k + lane) * d.steps + t] = c0 * (zr * sr + zi * si);
+        d.dLdu[((size_t)b * d.k + lane) * d.steps + t] = total ? sr : c0 * (zr * sr + zi * si);
     }
-    if (fuse) {
+    if (fuse & 1) {
         __shared__ double red[34];
         __shared__ int last;
         __syncthreads();                                                          // every store of the workgroup has been issued and waited for

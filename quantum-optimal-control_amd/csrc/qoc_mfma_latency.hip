@@ -26,7 +26,8 @@ int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
 // forward and z-free adjoint sweep side by side: 2 x (seed, chunk, group of 4 columns) workgroups of NT waves (one row tile each)
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     // (with a state regulariser only the forward half: the costate needs the sources, i.e. the forward states, first)
-    const dim3 g((mf.lat_sources ? 1 : 2) * d.B * mf.C * mf.mq);
+    // (state regularisers on the batch kernels' recursion: the forward half only; on the thin source sweeps both halves, Lambda0 is used)
+    const dim3 g((mf.lat_sources && !mf.lat_src_fast ? 1 : 2) * d.B * mf.C * mf.mq);
     if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(192), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(128), 0, s, d, mf);
@@ -35,11 +36,18 @@ void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
 
 // ap != nullptr: the tail of the iteration (k_finish_t<true>) runs inside, in the last workgroup of each seed
 void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* ap, hipStream_t s) {
+    if (mf.lat_src_fast) {
+        // the source part of the costate: chunk offsets, group offsets, then the sweep that stores the total costate (k_loss has run)
+        const dim3 b2(64 * 2);
+        hipLaunchKernelGGL(k_mfma_sweep_src<2>, dim3(d.B * mf.C * mf.mq), b2, 0, s, d, mf, 0);
+        hipLaunchKernelGGL(k_mfma_sweep_src<2>, dim3(d.B * mf.NG * mf.mq), b2, 0, s, d, mf, 1);
+        hipLaunchKernelGGL(k_mfma_sweep_src<2>, dim3(d.B * mf.C * mf.mq), b2, 0, s, d, mf, 2);
+    }
     const int kc = grad_lat_kc(d), sl = 16 / mf.NT;                      // slices per workgroup, NT waves (row tiles) each
     const dim3 g(d.B * ((d.steps + sl - 1) / sl)), b(64 * sl * mf.NT);
     const size_t lds = grad_lat_lds(kc, mf.NT);
     const QocAdamDev a = ap ? *ap : QocAdamDev{};
-    const int fuse = ap ? 1 : 0;
+    const int fuse = (ap ? 1 : 0) | (mf.lat_src_fast ? 2 : 0);
     if (mf.NT == 4) {
         const size_t lds4 = grad_lat_lds(2, 4);
         if (mf.mq <= 2) hipLaunchKernelGGL(k_mfma_grad_lat4<2>, g, b, lds4, s, d, mf, a, fuse);
