@@ -69,8 +69,8 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
 // latency mode: NT = 2 kernels (smaller problems are padded to 32).  With a state regulariser the costate is not linear in the
 // overlap: the backward half then runs the batch kernels on the latency mode's chunks (QocMfma::lat_sources)
 static inline bool qoc_mfma_latency_ok(const QocDev& d) {
-    if (d.n > 32)    // NT = 3 / 4: no state regulariser (the affine backward half is an NT = 2 kernel); NT = 3: four control images in LDS
-        return !d.state_transfer && d.n <= 64 && d.m <= 16 && d.k <= (d.n <= 48 ? 4 : 8) && d.T >= 2 && d.T <= 22 && d.n_forb == 0 && !d.has_speed;
+    if (d.n > 32)    // NT = 3 / 4: no DRESSED forbidden level (its affine backward half is an NT = 2 kernel); NT = 3: four control images in LDS
+        return !d.state_transfer && d.n <= 64 && d.m <= 16 && d.k <= (d.n <= 48 ? 4 : 8) && d.T >= 2 && d.T <= 22 && !(d.n_forb > 0 && d.forbid_dressed);
     return !d.state_transfer && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22;
 }
 

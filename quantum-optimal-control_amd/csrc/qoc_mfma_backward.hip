@@ -68,7 +68,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
     if (mf.lat_sources && !al(&mf.Goff, (size_t)d.B * mf.NG * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
-    mf.lat_src_fast = mf.lat_sources && NT == 2 && !d.forbid_dressed;   // undressed forbidden levels / speed_up: thin affine sweeps (qoc_mfma_latency.h)
+    mf.lat_src_fast = mf.lat_sources && !(d.n_forb > 0 && d.forbid_dressed);   // undressed forbidden levels / speed_up: thin affine sweeps (qoc_mfma_latency.h)
     if (mf.lat_src_fast) {
         const size_t vec = (size_t)NT * (mf.mq <= 2 ? 2 : 4) * 64;
         if (!al(&mf.AoffL, (size_t)d.B * C * vec) || !al(&mf.GoffL, (size_t)d.B * mf.NG * vec) || !al(&mf.LamS, (size_t)d.B * d.steps * vec)) { msg = "MFMA path: out of device memory"; return -3; }

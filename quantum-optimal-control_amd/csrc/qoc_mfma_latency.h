@@ -397,9 +397,10 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat4(QocDev d, QocMfma mf, Q
     const int t = cb * SL + sl, tc = min(t, d.steps - 1);
     const bool live = t < d.steps;
     const int lk = lane >> 4, lc = lane & 15;
+    const bool total = (fuse & 2) != 0;          // state regularisers: LamS holds the total costate, k_loss formed z and the loss
     d4 qr[NT], qi[NT];
     {
-        const cplx* ll = mf.LamL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
+        const cplx* ll = (total ? mf.LamS : mf.LamL) + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
         const cplx* pl = mf.PsiL + ((size_t)b * d.steps + tc) * (NT * MQ) * 64 + lane;
         double lr[MQ], li[MQ];
 #pragma unroll
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat4(QocDev d, QocMfma mf, Q
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); }
-    if (cb == 0 && wv == 0 && lane == 0) {
+    if (!total && cb == 0 && wv == 0 && lane == 0) {
         d.zfin[b] = cmake(zr, zi);
         d.loss[b] = 1.0 - (zr * zr + zi * zi) / ((double)d.m * (double)d.m);
         d.reg_state[b] = 0.0;
@@ -470,10 +471,10 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat4(QocDev d, QocMfma mf, Q
             double sr = 0.0, si = 0.0;
 #pragma unroll
             for (int x = 0; x < 4 * NT; ++x) { sr += gp[x * 2 * KG]; si += gp[x * 2 * KG + KG]; }
-            d.dLdu[((size_t)b * d.k + k0 + lane) * d.steps + t] = c0 * (zr * sr + zi * si);
+            d.dLdu[((size_t)b * d.k + k0 + lane) * d.steps + t] = total ? sr : c0 * (zr * sr + zi * si);
         }
     }
-    if (fuse) {
+    if (fuse & 1) {
         __shared__ double red[34];
         __shared__ int last;
         __syncthreads();

@@ -38,10 +38,11 @@ void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
 void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* ap, hipStream_t s) {
     if (mf.lat_src_fast) {
         // the source part of the costate: chunk offsets, group offsets, then the sweep that stores the total costate (k_loss has run)
-        const dim3 b2(64 * 2);
-        hipLaunchKernelGGL(k_mfma_sweep_src<2>, dim3(d.B * mf.C * mf.mq), b2, 0, s, d, mf, 0);
-        hipLaunchKernelGGL(k_mfma_sweep_src<2>, dim3(d.B * mf.NG * mf.mq), b2, 0, s, d, mf, 1);
-        hipLaunchKernelGGL(k_mfma_sweep_src<2>, dim3(d.B * mf.C * mf.mq), b2, 0, s, d, mf, 2);
+        const dim3 gc(d.B * mf.C * mf.mq), gg(d.B * mf.NG * mf.mq), bs(64 * mf.NT);
+#define QOC_SRC(NTv) do { hipLaunchKernelGGL(k_mfma_sweep_src<NTv>, gc, bs, 0, s, d, mf, 0); hipLaunchKernelGGL(k_mfma_sweep_src<NTv>, gg, bs, 0, s, d, mf, 1); \
+                          hipLaunchKernelGGL(k_mfma_sweep_src<NTv>, gc, bs, 0, s, d, mf, 2); } while (0)
+        if (mf.NT == 4) QOC_SRC(4); else if (mf.NT == 3) QOC_SRC(3); else QOC_SRC(2);
+#undef QOC_SRC
     }
     const int kc = grad_lat_kc(d), sl = 16 / mf.NT;                      // slices per workgroup, NT waves (row tiles) each
     const dim3 g(d.B * ((d.steps + sl - 1) / sl)), b(64 * sl * mf.NT);

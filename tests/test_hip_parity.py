@@ -146,8 +146,8 @@ def _mfma_path_parity(chunks, variant, kernel):
     rng = np.random.default_rng(5)
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2, 3 * sp.base0]
     from quantum_optimal_control.core import hip_engine
-    no_src = not ({'forbidden_coeff_list', 'speed_up'} & set(sp.reg_coeffs))
-    latency_ok = sp.exp_terms >= 2 and ((sp.n <= 32 and sp.k <= 8) or (sp.n <= 48 and sp.k <= 4 and no_src) or (48 < sp.n <= 64 and no_src))
+    undressed = not ('forbidden_coeff_list' in sp.reg_coeffs and sp.Vs is not None)      # dressed forbidden levels: NT = 2 kernels only
+    latency_ok = sp.exp_terms >= 2 and ((sp.n <= 32 and sp.k <= 8) or (sp.n <= 48 and sp.k <= 4 and undressed) or (48 < sp.n <= 64 and undressed))
     if kernel == 5 and not latency_ok:
         with pytest.raises(hip_engine.QocError, match='latency mode'):
             make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
