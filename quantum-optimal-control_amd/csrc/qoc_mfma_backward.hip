@@ -71,7 +71,8 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     mf.lat_src_fast = mf.lat_sources && !(d.n_forb > 0 && d.forbid_dressed);   // undressed forbidden levels / speed_up: thin affine sweeps (qoc_mfma_latency.h)
     if (mf.lat_src_fast) {
         const size_t vec = (size_t)NT * (mf.mq <= 2 ? 2 : 4) * 64;
-        if (!al(&mf.AoffL, (size_t)d.B * C * vec) || !al(&mf.GoffL, (size_t)d.B * mf.NG * vec) || !al(&mf.LamS, (size_t)d.B * d.steps * vec)) { msg = "MFMA path: out of device memory"; return -3; }
+        if (!al(&mf.AoffL, (size_t)d.B * C * vec) || !al(&mf.GoffL, (size_t)d.B * mf.NG * vec) || !al(&mf.LamS, (size_t)d.B * d.steps * vec) ||
+            !al((cplx**)&mf.loss_part, (size_t)d.B * (d.steps + 1))) { msg = "MFMA path: out of device memory"; return -3; }   // (loss_part: two doubles per time point)
     }
     if (mf.latency && (!al(&mf.GfD, (size_t)d.B * mf.NG * FR) || !al(&mf.GfT, (size_t)d.B * mf.NG * FR) || !al(&mf.TfD, (size_t)d.B * FR) ||
                        !al(&mf.PsiL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64) ||

@@ -56,6 +56,7 @@ struct QocMfma {
     cplx* AoffL = nullptr;        // [B][C][NT * MQ][64] / GoffL [B][NG][...]: chunk and group offsets of the source recursion, register layout
     cplx* GoffL = nullptr;
     bool lat_src_fast = false;    // lat_sources on the thin affine sweeps (undressed forbidden levels / speed_up, NT = 2); else the batch kernels' recursion
+    double* loss_part = nullptr;  // [B][steps + 1][2] per-time-point partials of k_mfma_loss_lat
     unsigned* lat_count = nullptr; // [B] workgroups of k_mfma_grad_lat that have finished (the last one runs the tail of the iteration)
     cplx* GfT = nullptr;          // [B][NG] fragD(G_g^T): with KfT / PfT the lane-contiguous operands of the forward sweep in latency mode
     bool latency = false;

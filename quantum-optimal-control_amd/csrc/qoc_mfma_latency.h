@@ -136,6 +136,76 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf
     if (i < len) step(K0, i);
 }
 
+// Fidelity and state-regulariser values of the latency mode with sources, straight from the register-layout vectors (k_loss reads the API
+// layout and walks all time points in ONE workgroup per seed: 20 us + 5 us of unpacking for a C2 trajectory).  One wave per time point
+// tau = 0 .. steps (tau = 0: the initial vectors V; tau >= 1: PsiL[tau - 1]), 16 per workgroup: the overlap z_tau = sum_j <w_j, psi_j(tau)>
+// (tensorflow_state.py:282-333; speed_up uses every tau, regularization_functions.py:88-95) and the forbidden-level term
+// sum_f a_f/2 |psi_f|^4 (:71-85, undressed levels).  The last workgroup of a seed to finish (arrival counter) adds the per-tau
+// partials in a fixed order and publishes z, the loss, reg_state, su_resid.
+template <int NT>
+__global__ void __launch_bounds__(1024) k_mfma_loss_lat(QocDev d, QocMfma mf) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int npts = d.steps + 1, nblk = (npts + 15) / 16;
+    const int b = blockIdx.x / nblk, cb = blockIdx.x - b * nblk;
+    if (d.skip_done && d.done[b]) return;
+    const int tau = cb * 16 + wv;
+    const int lk = lane >> 4, lc = lane & 15;
+    const int MQs = mf.mq <= 2 ? 2 : 4, per_vec = NT * MQs * 64;
+    const double mm = (double)d.m * (double)d.m;
+    double* part = mf.loss_part + (size_t)b * npts * 2;
+    if (tau < npts) {
+        double zr = 0.0, zi = 0.0, fb = 0.0;
+        const cplx* pl = mf.PsiL + ((size_t)b * d.steps + max(tau - 1, 0)) * per_vec + lane;
+        for (int g = 0; g < NT * MQs; ++g) {
+            const int I = g / MQs, jq = g - I * MQs, row = 16 * I + lc, col = 4 * jq + lk;
+            const bool inside = row < d.n && col < d.m;
+            cplx psi = pl[g * 64];
+            if (tau == 0) psi = inside ? d.V[row * d.m + col] : cmake(0.0, 0.0);
+            const cplx w = inside ? d.W[row * d.m + col] : cmake(0.0, 0.0);
+            zr += psi.x * w.x + psi.y * w.y;        // psi * conj(w)
+            zi += psi.y * w.x - psi.x * w.y;
+            double wf = 0.0;
+            for (int f = 0; f < d.n_forb; ++f) wf += (row == d.forb_state[f]) ? 0.5 * d.forb_a[f] : 0.0;
+            const double pop = inside ? psi.x * psi.x + psi.y * psi.y : 0.0;
+            fb += wf * pop * pop;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); fb += __shfl_xor(fb, off, 64); }
+        if (lane == 0) {
+            d.ztau[(size_t)b * npts + tau] = cmake(zr, zi);
+            part[2 * tau] = (zr * zr + zi * zi) / mm;
+            part[2 * tau + 1] = fb;
+        }
+    }
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(mf.lat_count + b, 1u) == (unsigned)(nblk - 1) ? 1 : 0;
+        if (last) { mf.lat_count[b] = 0u; __threadfence(); }
+    }
+    __syncthreads();
+    if (!last || wv != 0) return;
+    double sv = 0.0, sf = 0.0;                                                    // fixed order: lane l adds tau = l, l + 64, ...; then the butterfly
+    for (int t = lane; t < npts; t += 64) { sv += part[2 * t]; sf += part[2 * t + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sv += __shfl_xor(sv, off, 64); sf += __shfl_xor(sf, off, 64); }
+    if (lane == 0) {
+        const cplx z = d.ztau[(size_t)b * npts + d.steps];
+        double reg_state = 0.0;
+        if (d.has_speed) {
+            const double resid = (double)npts - sv;
+            d.su_resid[b] = resid;
+            reg_state += d.a_speed * 0.5 * resid * resid;
+        }
+        if (d.n_forb > 0) reg_state += sf;
+        d.zfin[b] = z;
+        d.loss[b] = 1.0 - (z.x * z.x + z.y * z.y) / mm;
+        d.reg_state[b] = reg_state;
+    }
+}
+
 // ---- state regularisers (undressed forbidden levels, speed_up) in the latency mode ----------------------------------------------------
 // The costate splits as Lambda_t = c0 z Lambda0_t + LambdaS_t: Lambda0 is the z-free sweep above; the source part obeys the affine
 // recursion LambdaS_{t-1} = K_t^dagger LambdaS_t + S_t, LambdaS_{N-1} = S_N, with S_t = d(state regularisers)/dPsi at time t (source_at,
