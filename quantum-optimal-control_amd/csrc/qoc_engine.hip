@@ -153,8 +153,9 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     if (cgrid > 2048) cgrid = 2048;
     const int skip = e->skip_mask;
     const bool plain = !(d.has_amp || d.has_env || d.has_dwdt || d.has_d2wdt2 || d.has_band);
-    // latency mode without pulse regularisers: the tail of the iteration runs in the last workgroup of the gradient kernel
-    const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && (!e->mf.lat_sources || e->mf.lat_src_fast) && plain && !(skip & (16 | 32));
+    // latency mode: the tail of the iteration runs in the last workgroup of the gradient kernel
+    // (with the local pulse regularisers too -- amplitude, envelope, dwdt, d2wdt2; the bandpass DFT keeps its own launch)
+    const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && (!e->mf.lat_sources || e->mf.lat_src_fast) && !d.has_band && !(skip & (16 | 32));
     // (latency mode of the MFMA path: the slice kernel of the exponentials forms its own controls)
     if (!(skip & 1) && !(e->path == QOC_PATH_MFMA && e->mf.latency && e->mf.NT == 2)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {

@@ -39,8 +39,10 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red /* 
 // PLAIN: no pulse regulariser is configured -- the same kernel with those branches compiled out (a tenth of the code: for one
 // trajectory this single-workgroup kernel is bound by its instruction fetch and its chain of global round trips, not by arithmetic)
 // (a __device__ body: the latency mode of the MFMA path runs it in the last workgroup of its gradient kernel, qoc_mfma_latency.h)
-template <bool PLAIN>
+// LEVEL: 0 = no pulse regulariser (PLAIN), 1 = the local ones (amplitude, envelope, dwdt, d2wdt2) but no bandpass DFT, 2 = all.
+template <int LEVEL>
 __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */) {
+    constexpr bool PLAIN = LEVEL == 0, BAND = LEVEL == 2;
     const int steps = d.steps, ks = d.k * steps;
     const double* w = d.w + (size_t)b * ks;
     const double* dLdu = d.dLdu + (size_t)b * ks;
@@ -92,10 +94,10 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
         }
         reg += d.a_d2wdt2 * 0.5 * acc;
     }
-    cplx* ph = (!PLAIN && d.band_ph) ? d.band_ph + (size_t)b * ks : nullptr;
+    cplx* ph = (BAND && d.band_ph) ? d.band_ph + (size_t)b * ks : nullptr;
     const int half = steps / 2;
     const int lo = min(max(d.band_lo, 0), steps), hi = min(max(d.band_hi, 0), steps);
-    if (!PLAIN && d.has_band) {                                                            // :47-67
+    if (BAND && d.has_band) {                                                              // :47-67
         double acc = 0.0;
         for (int o = threadIdx.x; o < d.k * steps; o += blockDim.x) {
             const int kk = o / steps, f = o - kk * steps;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
             const double e2 = (padded_w(wk, steps, p + 2) - 2.0 * padded_w(wk, steps, p + 1) + padded_w(wk, steps, p)) / dt2;      // e_p
             dR += d.a_d2wdt2 * (e0 - 2.0 * e1 + e2) / dt2;
         }
-        if (!PLAIN && d.has_band) {
+        if (BAND && d.has_band) {
             double acc = 0.0;
             const cplx* pk = ph + (size_t)kk * steps;
             for (int f = 0; f < half || f < lo; ++f) {
@@ -214,5 +216,5 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
 template <bool PLAIN>
 __global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
     __shared__ double red[34];
-    finish_body<PLAIN>(d, ap, blockIdx.x, red);
+    finish_body<PLAIN ? 0 : 2>(d, ap, blockIdx.x, red);
 }

@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat(QocDev d, QocMfma mf, Qo
         }
         __syncthreads();
         if (!last) return;
-        finish_body<true>(d, ap, b, red);
+        if (fuse & 4) finish_body<1>(d, ap, b, red); else finish_body<0>(d, ap, b, red);   // (4: local pulse regularisers present)
     }
 }
 
@@ -555,6 +555,6 @@ __global__ void __launch_bounds__(1024) k_mfma_grad_lat4(QocDev d, QocMfma mf, Q
         }
         __syncthreads();
         if (!last) return;
-        finish_body<true>(d, ap, b, red);
+        if (fuse & 4) finish_body<1>(d, ap, b, red); else finish_body<0>(d, ap, b, red);   // (4: local pulse regularisers present)
     }
 }

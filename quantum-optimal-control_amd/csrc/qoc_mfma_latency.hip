@@ -41,6 +41,7 @@ void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
 }
 
 // ap != nullptr: the tail of the iteration (k_finish_t<true>) runs inside, in the last workgroup of each seed
+// (no bandpass regulariser: its DFT stays in the separate k_finish_t<false>)
 void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* ap, hipStream_t s) {
     if (mf.lat_src_fast) {
         // the source part of the costate: chunk offsets, group offsets, then the sweep that stores the total costate (k_loss has run)
@@ -54,7 +55,8 @@ void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* a
     const dim3 g(d.B * ((d.steps + sl - 1) / sl)), b(64 * sl * mf.NT);
     const size_t lds = grad_lat_lds(kc, mf.NT);
     const QocAdamDev a = ap ? *ap : QocAdamDev{};
-    const int fuse = (ap ? 1 : 0) | (mf.lat_src_fast ? 2 : 0);
+    const bool local_regs = d.has_amp || d.has_env || d.has_dwdt || d.has_d2wdt2;
+    const int fuse = (ap ? 1 : 0) | (mf.lat_src_fast ? 2 : 0) | (local_regs ? 4 : 0);
     if (mf.NT == 4) {
         const size_t lds4 = grad_lat_lds(2, 4);
         if (mf.mq <= 2) hipLaunchKernelGGL(k_mfma_grad_lat4<2>, g, b, lds4, s, d, mf, a, fuse);

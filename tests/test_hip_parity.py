@@ -386,15 +386,16 @@ def test_auto_leaves_the_latency_mode_to_few_seeds():
 
 def test_latency_mode_fused_tail_matches_the_finish_kernel():
     """Latency mode runs chain rule / stop rule / Adam in the last workgroup of its gradient kernel (a per-seed arrival counter
-    decides who is last).  A zero-weight amplitude regulariser switches to the separate finish kernel, whose arithmetic is
-    the same to the bit (x + 0.0): 300 Adam iterations of 3 seeds must give identical controls, losses and iteration counts."""
+    decides who is last): the plain flavour, and with a (zero-weight) amplitude regulariser the flavour with the local pulse
+    regularisers.  A zero-weight bandpass regulariser switches to the separate finish kernel.  The arithmetic is the same to the
+    bit in all three (x + 0.0): 300 Adam iterations of 3 seeds must give identical controls, losses and iteration counts."""
     from quantum_optimal_control.core import hip_engine
     c = cases.case_c2(n=24, k=3, steps=120, m=6, taylor=(4, 2), seed=5)
     sp = oracle_system(c)
     rng = np.random.default_rng(3)
     bases = rng.normal(0, 0.3, (3, sp.k, sp.steps))
     out = []
-    for reg in ({}, {'amplitude': 0.0}):
+    for reg in ({}, {'amplitude': 0.0}, {'bandpass': 0.0, 'band': [0.5, 2.0]}):
         eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
                                    reg_coeffs=reg, n_seeds=3, path=2, variant=5)
         eng.set_base(bases)
@@ -404,8 +405,9 @@ def test_latency_mode_fused_tail_matches_the_finish_kernel():
         s = eng.scalars()
         out.append((eng.get_base().copy(), s['loss'].copy(), s['reg_loss'].copy(), s['iterations'].copy()))
         eng.close()
-    for a, b in zip(out[0], out[1]):
-        np.testing.assert_array_equal(a, b)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            np.testing.assert_array_equal(a, b)
     assert out[0][3].max() > 50
 
 
