@@ -79,15 +79,32 @@ struct BlockMap {
     __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
 #pragma unroll
         for (int x = 0; x < V; ++x) acc[x] = cmake(0.0, 0.0);
+        if constexpr (R * MV <= 8) {
+            // all vector reads in flight before the first FMA: left to itself hipcc issues one ds_read per column block and waits for
+            // it on the spot (four exposed LDS latencies per mat-vec, the step of a latency-bound chain)
+            cplx vv[R][MV];
 #pragma unroll
-        for (int cc = 0; cc < R; ++cc) {
-            cplx vv[MV];
+            for (int cc = 0; cc < R; ++cc)
 #pragma unroll
-            for (int jv = 0; jv < MV; ++jv) vv[jv] = v[(c + 16 * cc) * MV + jv];
+                for (int jv = 0; jv < MV; ++jv) vv[cc][jv] = v[(c + 16 * cc) * MV + jv];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr)
+            for (int cc = 0; cc < R; ++cc)
 #pragma unroll
-                for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); else cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); }
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * R + cc], vv[cc][jv]); else cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[cc][jv]); }
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < R; ++cc) {
+                cplx vv[MV];
+#pragma unroll
+                for (int jv = 0; jv < MV; ++jv) vv[jv] = v[(c + 16 * cc) * MV + jv];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); else cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); }
+            }
         }
         chain_butterfly<V, 8, SPLB, V>(acc, c);
     }
@@ -215,6 +232,7 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a0, ChainAr
     using BM = typename FwdMap<N, MV>::type;
     constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
     __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
+    __shared__ double tinv[64];                                            // 1 / ii!  (a division per term sat on the chain: ~14 fp64 instructions)
     const BM bm(threadIdx.x);
     const bool second = (int)blockIdx.x >= nb0;
     const ChainArgs a = second ? a1 : a0;
@@ -251,17 +269,21 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a0, ChainAr
 #pragma unroll
         for (int sl = 0; sl < SPL; ++sl) ed[sl] = ej[thin_off[sl]];
     };
+    if (threadIdx.x < 64) {
+        double fact = 1.0;
+        for (int ii = 2; ii <= (int)threadIdx.x; ++ii) fact *= (double)ii;   // the running factorial of :92-95
+        tinv[threadIdx.x] = 1.0 / fact;
+    }
     int cur = 0;
     auto step = [&](int j, const cplx (&ku)[EL], const cplx (&eu)[SPL]) {
         cplx out[SPL];
 #pragma unroll
         for (int sl = 0; sl < SPL; ++sl) out[sl] = yfin[sl];
-        double fact = 1.0;
         for (int ii = 1; ii < a.nterms; ++ii) {
+            double inv = tinv[ii & 63];
+            if (ii >= 64) { double fact = 1.0; for (int q = 2; q <= ii; ++q) fact *= (double)q; inv = 1.0 / fact; }
             cplx acc[V];
             bm.template matvec<false>(ku, y[cur], acc);
-            fact *= (double)ii;
-            const double inv = 1.0 / fact;
             const bool lastterm = ii + 1 == a.nterms;
 #pragma unroll
             for (int sl = 0; sl < SPL; ++sl) {
