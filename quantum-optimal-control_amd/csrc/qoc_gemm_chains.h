@@ -60,84 +60,68 @@ __device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
 // re-read 16 at N = 64: 64 KB of LDS traffic per mat-vec, which bound the step) and the R*MV partial sums are combined by a
 // reduce-scatter butterfly over the 16 lanes (DPP), after which lane c holds the finished values x = base + s, s < SPLB,
 // of its row group in (row, slot)-major order; addend, LDS write and output store are done by the owner of each value.
-template <int N, int MV>
+template <int N, int MV, int LG>
 struct BlockMap {
-    static constexpr int R = N / 16, EL = R * R, V = R * MV;
-    static constexpr int NSLB = V < 16 ? V : 16, SPLB = V / NSLB;
+    // LG lanes share a group of R rows; a thread owns R x CC entries: rows R*g + rr, columns c + LG*cc
+    static constexpr int R = N * LG / 256, CC = N / LG, EL = R * CC, V = R * MV;
+    static constexpr int NSLB = V < LG ? V : LG, SPLB = V / NSLB;
     int g, c, base;
-    __device__ __forceinline__ BlockMap(int tid) : g(tid >> 4), c(tid & 15), base(((tid & 15) / (16 / NSLB)) * SPLB) {}
+    __device__ __forceinline__ BlockMap(int tid) : g(tid / LG), c(tid % LG), base(((tid % LG) / (LG / NSLB)) * SPLB) {}
     __device__ __forceinline__ int row(int s) const { return R * g + (base + s) / MV; }
     __device__ __forceinline__ int slot(int s) const { return (base + s) % MV; }
     __device__ __forceinline__ void load(cplx (&kd)[EL], const cplx* Kj) const {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-            for (int cc = 0; cc < R; ++cc) kd[rr * R + cc] = Kj[(size_t)(R * g + rr) * N + c + 16 * cc];
+            for (int cc = 0; cc < CC; ++cc) kd[rr * CC + cc] = Kj[(size_t)(R * g + rr) * N + c + LG * cc];
     }
-    // acc[rr*MV + jv] = sum_cc K[rr][cc] * v[c + 16 cc][jv], then the 16-lane reduce-scatter: acc[0..SPLB) are this lane's values
+    // acc[rr*MV + jv] = sum_cc K[rr][cc] * v[c + LG cc][jv], then the LG-lane reduce-scatter: acc[0..SPLB) are this lane's values
     template <bool CONJ>
     __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
 #pragma unroll
         for (int x = 0; x < V; ++x) acc[x] = cmake(0.0, 0.0);
-        if constexpr (R * MV <= 8) {
+        if constexpr (CC * MV <= 16) {
             // all vector reads in flight before the first FMA: left to itself hipcc issues one ds_read per column block and waits for
             // it on the spot (four exposed LDS latencies per mat-vec, the step of a latency-bound chain)
-            cplx vv[R][MV];
+            cplx vv[CC][MV];
 #pragma unroll
-            for (int cc = 0; cc < R; ++cc)
+            for (int cc = 0; cc < CC; ++cc)
 #pragma unroll
-                for (int jv = 0; jv < MV; ++jv) vv[cc][jv] = v[(c + 16 * cc) * MV + jv];
+                for (int jv = 0; jv < MV; ++jv) vv[cc][jv] = v[(c + LG * cc) * MV + jv];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int cc = 0; cc < R; ++cc)
+            for (int cc = 0; cc < CC; ++cc)
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                    for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * R + cc], vv[cc][jv]); else cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[cc][jv]); }
+                    for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * CC + cc], vv[cc][jv]); else cfma(acc[rr * MV + jv], ku[rr * CC + cc], vv[cc][jv]); }
         } else {
 #pragma unroll
-            for (int cc = 0; cc < R; ++cc) {
+            for (int cc = 0; cc < CC; ++cc) {
                 cplx vv[MV];
 #pragma unroll
-                for (int jv = 0; jv < MV; ++jv) vv[jv] = v[(c + 16 * cc) * MV + jv];
+                for (int jv = 0; jv < MV; ++jv) vv[jv] = v[(c + LG * cc) * MV + jv];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                    for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); else cfma(acc[rr * MV + jv], ku[rr * R + cc], vv[jv]); }
+                    for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * CC + cc], vv[jv]); else cfma(acc[rr * MV + jv], ku[rr * CC + cc], vv[jv]); }
             }
         }
-        chain_butterfly<V, 8, SPLB, V>(acc, c);
+        chain_butterfly<V, LG / 2, SPLB, V>(acc, c);
     }
 };
 
-// Row-per-thread mapping with the same interface: thread (i, q) owns row i and the columns LPR*e + q.  Faster than the
-// blocked mapping at N = 32 (4 vector reads per slot either way, a 3-level butterfly instead of 4); measured per 1000-slice
-// direct iteration: N = 32: 4.65 (row) vs 4.81 ms (blocked); N = 64: 13.0 (row) vs 10.0 ms (blocked).
-template <int N, int MV>
-struct RowMap {
-    static constexpr int LPR = 256 / N, EL = N / LPR, V = MV;
-    static constexpr int NSLB = MV < LPR ? MV : LPR, SPLB = MV / NSLB;
-    int i, q, base;
-    __device__ __forceinline__ RowMap(int tid) : i(tid / LPR), q(tid % LPR), base(((tid % LPR) / (LPR / NSLB)) * SPLB) {}
-    __device__ __forceinline__ int row(int) const { return i; }
-    __device__ __forceinline__ int slot(int s) const { return base + s; }
-    __device__ __forceinline__ void load(cplx (&kd)[EL], const cplx* Kj) const {
-#pragma unroll
-        for (int e = 0; e < EL; ++e) kd[e] = Kj[(size_t)i * N + LPR * e + q];
-    }
-    template <bool CONJ>
-    __device__ __forceinline__ void matvec(const cplx (&ku)[EL], const cplx* __restrict__ v, cplx (&acc)[V]) const {
-#pragma unroll
-        for (int jv = 0; jv < MV; ++jv) acc[jv] = cmake(0.0, 0.0);
-#pragma unroll
-        for (int e = 0; e < EL; ++e)
-#pragma unroll
-            for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[jv], ku[e], v[(LPR * e + q) * MV + jv]); else cfma(acc[jv], ku[e], v[(LPR * e + q) * MV + jv]); }
-        chain_butterfly<MV, LPR / 2, SPLB, MV>(acc, q);
-    }
-};
-template <int N, int MV> struct FwdMap { using type = BlockMap<N, MV>; };
-template <int MV> struct FwdMap<32, MV> { using type = RowMap<32, MV>; };
+// N = 32: a row per thread (LG = 8: 4 vector reads per slot either way, a 3-level butterfly instead of 4; per 1000-slice direct
+// iteration 4.65 against 4.81 ms with LG = 16).  N = 64, one or two vectors: two rows per thread (LG = 8) -- 8 vector reads, all in
+// flight together, and a 26-instruction butterfly instead of 64; with the reads issued one at a time (before round 2's end) the
+// fewer-reads mapping LG = 16 was the faster one (10.0 against 13.0 ms with a row per thread, LG = 4).
+#ifndef QOC_CHAIN_LG64
+#define QOC_CHAIN_LG64 8
+#endif
+template <int N, int MV> struct FwdMap { using type = BlockMap<N, MV, 16>; };
+template <int MV> struct FwdMap<32, MV> { using type = BlockMap<32, MV, 8>; };
+template <> struct FwdMap<64, 1> { using type = BlockMap<64, 1, QOC_CHAIN_LG64>; };
+template <> struct FwdMap<64, 2> { using type = BlockMap<64, 2, QOC_CHAIN_LG64>; };
 
 // y <- K_j y + E_j (CONJ: conj(K_j) y + E_j) with the mapping FwdMap picks for N.  Pipeline: K_j / E_j of the next two steps
 // are in flight in three register stages used round-robin by a 3x unrolled branch-free loop; y lives in LDS (double buffer)

@@ -40,6 +40,31 @@ __global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __r
         Aout[o] = acc;
     }
 }
+// The same with the k + 1 Hamiltonian entries of a thread held in registers over a run of (seed, slice) items (k <= 8, N*N a multiple of
+// 256): k_gemm_assemble re-reads them from L2 for every output entry -- (k + 1) x the written bytes through L2, 2.0 ms for the 4.2 GB of
+// C3 x 64 -- this one is bound by the HBM writes alone.  blockIdx.x = 256-entry column of the matrix, blockIdx.y = run of items.
+__global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq, int per) {
+    const size_t NN = (size_t)N * N;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const double inv = 1.0 / (double)(1 << sq);
+    cplx h[9];
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) h[kk] = kk <= d.k ? cscale(HsP[(size_t)kk * NN + e], inv) : cmake(0.0, 0.0);
+    const size_t items = (size_t)d.B * SP;
+    const size_t i0 = (size_t)blockIdx.y * per, i1 = i0 + per < items ? i0 + per : items;
+    for (size_t item = i0; item < i1; ++item) {
+        const int b = (int)(item / SP), t = (int)(item - (size_t)b * SP);
+        cplx acc = cmake(0.0, 0.0);
+        if (t < d.steps) {
+            acc = h[0];
+            const double* ub = d.u + (size_t)b * d.k * d.steps + t;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (kk < d.k) { const double c = ub[(size_t)kk * d.steps]; acc.x = fma(c, h[kk + 1].x, acc.x); acc.y = fma(c, h[kk + 1].y, acc.y); }
+        }
+        Aout[item * NN + e] = acc;
+    }
+}
 // S = c0*I + c1*A (+ cT*A2): top block of the Paterson-Stockmeyer recursion
 __global__ void __launch_bounds__(256) k_gemm_ps_init(const cplx* __restrict__ A, const cplx* __restrict__ A2, cplx* __restrict__ S,
                                                        size_t count, int N, double c0, double c1, double cT) {
@@ -384,6 +409,17 @@ static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipSt
 }
 
 static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
+static inline void qoc_gemm_assemble_launch(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int sq, hipStream_t s) {
+    const size_t NN = (size_t)N * N, items = (size_t)d.B * SP;
+    if (d.k <= 8 && NN % 256 == 0 && items >= 64) {
+        const int gx = (int)(NN / 256);
+        int per = (int)((items * gx + 8191) / 8192);                     // ~8192 workgroups
+        if (per < 4) per = 4;
+        const int gy = (int)((items + per - 1) / per);
+        if (gy <= 65535) { hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, per); return; }
+    }
+    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(items * NN)), dim3(256), 0, s, d, HsP, Aout, N, SP, sq);
+}
 
 // pairwise product tree: T_l[i] = T_{l-1}[2i+1] * T_{l-1}[2i]  (later slice on the left), T_0 = K
 static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s) {
@@ -411,7 +447,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
     if (gm.direct) {                                             // the chains apply the Taylor series themselves
-        hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N, gm.SP, 0);
+        qoc_gemm_assemble_launch(d, gm.HsP, gm.A, N, gm.SP, 0, s);
         return;
     }
     if (N <= 64) {
@@ -423,7 +459,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         qoc_gemm_tree(gm, d, s);
         return;
     }
-    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, d, gm.HsP, gm.A, N, gm.SP, nsq);
+    qoc_gemm_assemble_launch(d, gm.HsP, gm.A, N, gm.SP, nsq, s);
     // Taylor polynomial sum_{j<=T} A^j/j! (tensorflow_state.py:37-41) in Paterson-Stockmeyer form over A2 = A*A:
     // S = B_m ; S = B_i + A2*S with B_i = c_{2i} I + c_{2i+1} A  (T = 5: 3 products instead of 4); then s squarings.
     GemmArgs g;
