@@ -55,11 +55,11 @@ __device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
 }
 
 // ---- register-blocked forward mat-vec mapping (k_gemm_chain_fwd, k_gemm_taylor_chain) ---------------------------------
-// Thread (g, c) = (tid / 16, tid % 16) owns the R x R block rows R*g + rr, columns c + 16*cc of K (R = N/16): a 16-lane DPP
-// row reads 256 contiguous bytes per load, a thread reads only R entries of the vector per slot (the row-per-thread mapping
-// re-read 16 at N = 64: 64 KB of LDS traffic per mat-vec, which bound the step) and the R*MV partial sums are combined by a
-// reduce-scatter butterfly over the 16 lanes (DPP), after which lane c holds the finished values x = base + s, s < SPLB,
-// of its row group in (row, slot)-major order; addend, LDS write and output store are done by the owner of each value.
+// Thread (g, c) = (tid / LG, tid % LG) owns the R x CC block rows R*g + rr, columns c + LG*cc of K (R = N*LG/256, CC = N/LG): an LG-lane
+// group reads LG*16 contiguous bytes per load, a thread reads CC entries of the vector per slot and the R*MV partial sums are combined by
+// a reduce-scatter butterfly over the LG lanes (DPP), after which lane c holds the finished values x = base + s, s < SPLB, of its row
+// group in (row, slot)-major order; addend, LDS write and output store are done by the owner of each value.  LG trades LDS reads of the
+// vector (CC per thread) against butterfly levels (log2 LG): see FwdMap below for the choice per N.
 template <int N, int MV, int LG>
 struct BlockMap {
     // LG lanes share a group of R rows; a thread owns R x CC entries: rows R*g + rr, columns c + LG*cc
