@@ -375,9 +375,12 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    (0.20 vs 0.57 ms for one C2 trajectory; crossover between 16 and 64 seeds); 32 < n <= 48 (NT = 3: exponentials by
     //    three waves per item on v_mfma_f64_4x4x4, costate sweep + slice-parallel gradient kernel): the MFMA path wins from 8 seeds
     //    on (1.11 vs 1.50 ms at 8, 1.70 vs 2.72 at 16, 5.27 vs 9.88 ms at 64 seeds of n = 48; the GEMM path pads to N = 64), ties at
-    //    4 (1.00 vs 0.95) and loses below (0.96 vs 0.62 ms at 2); 48 < n <= 64: the GEMM path wins for every seed count
-    //    (10.1 vs 11.3 ms at 64 seeds).
-    const bool prefer_gemm = gemm_ok && (n > 48 || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 16 && m <= 8 && steps >= 100));
+    //    4 (1.00 vs 0.95) and loses below (0.96 vs 0.62 ms at 2); 48 < n <= 64 (NT = 4; tools/n64_batch_sweep.py): with k <= 4 controls
+    //    the MFMA path is ahead from 32 seeds on (4.96 vs 5.14 ms at 32, 9.16 vs 10.05 at 64, 17.4 vs 19.8 at 128 seeds of n = 64 x 500
+    //    slices, since the row-tile gradient kernel); with more controls, or fewer seeds, the GEMM path (k = 6: 4.55 vs 4.69 ms at
+    //    64 seeds x 200 slices; k = 8: level).
+    const bool nt4_batch = n > 48 && k <= 4 && B >= 32;
+    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 16 && m <= 8 && steps >= 100));
     const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
     bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));

@@ -430,6 +430,116 @@ __global__ void __launch_bounds__(256) k_mfma_grad(QocDev d, QocMfma mf) {
     }
 }
 
+// ---- kernel G2: the same contraction split by ROW TILES of the control Hamiltonians (n > 32 batches) -------------------------
+// k_mfma_grad at NT = 4 passes the 64 KB images through LDS two at a time (every slice fetched and multiplied once per pass) and its
+// fully unrolled 16-tile body allocates badly (1742 accvgpr moves, 784 B of scratch per lane: 1.37 ms per launch at n = 64 x 64
+// seeds, ~10x its MFMA time).  A workgroup here owns ONE 16-row tile h of every H_k' (k x NT x 4 KB of LDS: all controls of k <= 8
+// resident at once, two workgroups per CU at k <= 4) and forms, for its slices, the NT tiles Q[h, Jp] = conj(Lambda_t[h]) Psi_t[Jp]^T
+// and the partial sums Re sum_{a in tile h, b} H_k'[a,b] Q[a,b]; blockIdx.x % NT = h, so the NT workgroups of a slice run side by
+// side and share its vectors through L2.  The NT partials per (seed, control, slice) go to gpart[h] and are added in fixed order by
+// k_mfma_grad_sum (deterministic: no atomics).  A tile's 4 x 4 image reads leave as one batch ahead of its MFMAs.
+template <int NT, int MQ>
+__global__ void __launch_bounds__(256, 2) k_mfma_grad_rt(QocDev d, QocMfma mf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Hl = (cplx*)smem;                                                     // [K4][NT col blocks][4 strips][64]: rows 16h .. 16h + 15 of fragD(H_k'), zero beyond k
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lk = lane >> 4, lc = lane & 15;
+    const int h = blockIdx.x % NT, g = blockIdx.x / NT;
+    const int K4 = (d.k + 3) & ~3;
+    for (int o = threadIdx.x; o < K4 * NT * 256; o += blockDim.x) {
+        const int ln = o & 63, r = (o >> 6) & 3, Jp = (o >> 8) % NT, kk = o / (NT * 256);
+        Hl[o] = kk < d.k ? mf.HfD[(size_t)(1 + kk) * QFR + (Jp * QQS + 4 * h + r) * 64 + ln] : cmake(0.0, 0.0);
+    }
+    __syncthreads();
+    const int total = d.B * d.steps, stride = (gridDim.x / NT) * 4;
+    struct Ops { double lr[MQ], li[MQ], pr[NT][MQ], pi[NT][MQ]; };
+    auto fetch = [&](Ops& o, int s) {
+        s = min(s, total - 1);
+        const int b = s / d.steps, t = s - b * d.steps;
+        const cplx* lam = mf.LamD + (size_t)s * (16 * NT * 16);
+        const cplx* psi = d.inter + ((size_t)b * (d.steps + 1) + t + 1) * d.n * d.m;
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            const int j = 4 * q + lk;
+            const cplx lv = lam[(16 * h + lc) * 16 + j];
+            o.lr[q] = lv.x; o.li[q] = lv.y;
+#pragma unroll
+            for (int Jp = 0; Jp < NT; ++Jp) {
+                // rows >= n / columns >= m: clamped, finite, unmasked (they meet zero columns of Lambda / zero padding of H')
+                const cplx pv = psi[min(16 * Jp + lc, d.n - 1) * d.m + min(j, d.m - 1)];
+                o.pr[Jp][q] = pv.x; o.pi[Jp][q] = pv.y;
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    double* part = mf.gpart + (size_t)h * d.B * d.k * d.steps;
+    // One slice: (A) the NT tiles Q[h, Jp] from the operands in registers, (B) the operands of the wave's NEXT slice requested into the
+    // same registers, (C) the contraction with the images, tile by tile, while those loads are in flight.
+    Ops o;
+    int s = g * 4 + wv;
+    fetch(o, s);
+    for (; s < total; s += stride) {
+        const int b = s / d.steps, t = s - b * d.steps;
+        d4 qr[NT], qi[NT];
+#pragma unroll
+        for (int Jp = 0; Jp < NT; ++Jp) {
+            d4 t1v = {0, 0, 0, 0}, t2v = {0, 0, 0, 0}, t3v = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < MQ; ++q) {
+                t1v = QMFMA(o.lr[q], o.pr[Jp][q], t1v);
+                t2v = QMFMA(o.li[q], o.pi[Jp][q], t2v);
+                t3v = QMFMA(o.lr[q] - o.li[q], o.pr[Jp][q] + o.pi[Jp][q], t3v);
+            }
+            qr[Jp] = t1v + t2v; qi[Jp] = t3v - t1v + t2v;                          // Re, Im of conj(lambda) psi^T, tile (h, Jp)
+            __builtin_amdgcn_sched_barrier(0);                                    // (tile by tile: 3 accumulators alive, not 3 NT)
+        }
+        fetch(o, s + stride);
+        if (d.skip_done && d.done[b]) continue;
+        double gk[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) gk[kk] = 0.0;
+#pragma unroll
+        for (int Jp = 0; Jp < NT; ++Jp)
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {                                      // two controls at a time: 8 image reads in one batch
+                if (2 * kp >= K4) continue;                                      // (uniform)
+                cplx hq[2][4];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hq[kk][r] = Hl[(((2 * kp + kk) * NT + Jp) * 4 + r) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gk[2 * kp + kk] = fma(hq[kk][r].x, qr[Jp][r], gk[2 * kp + kk]);
+                        gk[2 * kp + kk] = fma(-hq[kk][r].y, qi[Jp][r], gk[2 * kp + kk]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (kk >= d.k) continue;
+            double v = gk[kk];
+            v += dpp_xor<1>(v); v += dpp_xor<2>(v); v += dpp_xor<4>(v); v += dpp_xor<8>(v);
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane == 0) part[((size_t)b * d.k + kk) * d.steps + t] = v;
+        }
+    }
+}
+// dL/du = the NT row-tile partials of k_mfma_grad_rt, added in fixed order
+__global__ void __launch_bounds__(256) k_mfma_grad_sum(QocDev d, QocMfma mf, int NT) {
+    const size_t per = (size_t)d.k * d.steps, tot = (size_t)d.B * per;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < tot; o += (size_t)gridDim.x * blockDim.x) {
+        if (d.skip_done && d.done[o / per]) continue;
+        double v = mf.gpart[o];
+        for (int h = 1; h < NT; ++h) v += mf.gpart[(size_t)h * tot + o];
+        d.dLdu[o] = v;
+    }
+}
+
 // ---- kernel B3: the row-split backward sweep of NT = 2 with every per-slice latency taken off the dependent chain ---------
 // A pair of waves per (seed, chunk) item, one 16-row tile of the costate each, exchanged through double-buffered LDS images
 // (8 waves = 4 items per workgroup share one LDS image of the control Hamiltonians).  Against its predecessor (k_mfma_backward2:

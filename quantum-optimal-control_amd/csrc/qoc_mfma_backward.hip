@@ -67,6 +67,11 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k <= 5: backward3 (5 images still fit next to its pads)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
+    mf.grad_rt = NT >= 2 && split_grad && d.k <= 8 && !(getenv("QOC_GRAD_RT") && atoi(getenv("QOC_GRAD_RT")) == 0);
+    if (mf.grad_rt) {
+        mf.grad_lds = (size_t)((d.k + 3) & ~3) * NT * 256 * sizeof(cplx);
+        if (!al((cplx**)&mf.gpart, ((size_t)NT * d.B * d.k * d.steps + 1) / 2)) { msg = "MFMA path: out of device memory"; return -3; }
+    }
     if (mf.lat_sources && !al(&mf.Goff, (size_t)d.B * mf.NG * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     mf.lat_src_fast = mf.lat_sources && !(d.n_forb > 0 && d.forbid_dressed);   // undressed forbidden levels / speed_up: thin affine sweeps (qoc_mfma_latency.h)
     if (mf.lat_src_fast) {
@@ -132,6 +137,10 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         const void* gk = NT == 2 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<2, 2> : (const void*)k_mfma_grad<2, 4>)
                        : NT == 3 ? (mf.mq <= 2 ? (const void*)k_mfma_grad<3, 2> : (const void*)k_mfma_grad<3, 4>)
                                  : (mf.mq <= 2 ? (const void*)k_mfma_grad<4, 2> : (const void*)k_mfma_grad<4, 4>);
+        if (mf.grad_rt)
+            gk = NT == 2 ? (mf.mq <= 2 ? (const void*)k_mfma_grad_rt<2, 2> : (const void*)k_mfma_grad_rt<2, 4>)
+               : NT == 3 ? (mf.mq <= 2 ? (const void*)k_mfma_grad_rt<3, 2> : (const void*)k_mfma_grad_rt<3, 4>)
+                         : (mf.mq <= 2 ? (const void*)k_mfma_grad_rt<4, 2> : (const void*)k_mfma_grad_rt<4, 4>);
         if (hipFuncSetAttribute(gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.grad_lds) != hipSuccess) { msg = "MFMA path: cannot reserve LDS for the gradient kernel"; return -2; }
     }
     if (mf.h_in_lds) {
@@ -190,7 +199,13 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
             else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
             const int slices = d.B * d.steps;
             int gg = (slices + 3) / 4; if (gg > 2048) gg = 2048;
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<2, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
+            if (mf.grad_rt) {
+                if (gg > 512) gg = 512;
+                if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_rt<2, 2>), dim3(2 * gg), dim3(256), mf.grad_lds, s, d, mf);
+                else hipLaunchKernelGGL((k_mfma_grad_rt<2, 4>), dim3(2 * gg), dim3(256), mf.grad_lds, s, d, mf);
+                hipLaunchKernelGGL(k_mfma_grad_sum, dim3(256), dim3(256), 0, s, d, mf, 2);
+            }
+            else if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<2, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
             else hipLaunchKernelGGL((k_mfma_grad<2, 4>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
         }
         return;
@@ -201,6 +216,13 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
         const int slices = d.B * d.steps;
         int gg = (slices + 3) / 4; if (gg > 1024) gg = 1024;
         constexpr int GN = NT > 2 ? NT : 3;                                  // (never launched for NT <= 2)
+        if (mf.grad_rt) {
+            int g2 = (slices + 3) / 4; if (g2 > 512) g2 = 512;
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad_rt<GN, 2>), dim3(GN * g2), dim3(256), mf.grad_lds, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_grad_rt<GN, 4>), dim3(GN * g2), dim3(256), mf.grad_lds, s, d, mf);
+            hipLaunchKernelGGL(k_mfma_grad_sum, dim3(256), dim3(256), 0, s, d, mf, GN);
+            return;
+        }
         if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_grad<GN, 2>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
         else hipLaunchKernelGGL((k_mfma_grad<GN, 4>), dim3(gg), dim3(256), mf.grad_lds, s, d, mf);
         return;

@@ -41,6 +41,8 @@ struct QocMfma {
     cplx* Goff = nullptr;     // [B][NG] the same for whole groups of chunks (latency mode with a state regulariser)
     cplx* LamD = nullptr;     // NT > 2: [B][steps][16 NT rows][16 columns] costates for the slice-parallel gradient kernel
     size_t grad_lds = 0;
+    double* gpart = nullptr;  // NT > 2: [NT row tiles][B][k][steps] partial control gradients of k_mfma_grad_rt
+    int grad_rt = 0;          // NT > 2: row-tile gradient kernel (k <= 8)
     size_t bwd_lds = 0, bwd_lds3 = 0;
     bool h_in_lds = true;
     int variant = 0;              // qoc_config.variant: 0 auto, 1 16x16x4, 2 4x4x4 two waves, 3 4x4x4 one wave, 4 streamed image, 5 latency mode

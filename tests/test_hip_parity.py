@@ -384,6 +384,38 @@ def test_auto_leaves_the_latency_mode_to_few_seeds():
         eng.close()
 
 
+def test_row_tile_gradient_kernel_and_auto_for_large_n64_batches(monkeypatch):
+    """Slice-parallel control gradients of the MFMA path (n > 32, or n <= 32 with k >= 6): the row-tile kernel k_mfma_grad_rt + the
+    fixed-order sum of its NT partials against the one-wave-per-slice kernel it replaced (QOC_GRAD_RT=0) and against the oracle;
+    and AUTO takes the MFMA path for 48 < n <= 64 once there are >= 32 seeds of k <= 4 controls (the GEMM path otherwise)."""
+    from quantum_optimal_control.core import hip_engine
+    for n, k, m, seeds in ((64, 4, 8, 3), (40, 3, 5, 2), (30, 7, 8, 2), (52, 8, 12, 2)):
+        c = cases.case_c2(n=n, k=k, steps=13, m=m, taylor=(5, 2), seed=n + k)
+        sp = oracle_system(c)
+        bases = np.random.default_rng(n).normal(0, 0.4, (seeds, sp.k, sp.steps))
+        grads = []
+        for rt in ('1', '0'):
+            monkeypatch.setenv('QOC_GRAD_RT', rt)
+            eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
+                                       reg_coeffs={}, n_seeds=seeds, path=2, variant=7 if n > 32 else 0)
+            eng.set_base(bases)
+            grads.append(eng.evaluate()['grad'].copy())
+            eng.close()
+        monkeypatch.delenv('QOC_GRAD_RT')
+        scale = np.max(np.abs(grads[1]))
+        np.testing.assert_allclose(grads[0], grads[1], rtol=0, atol=1e-12 * scale)
+        for b in range(seeds):
+            g = go.evaluate(sp, bases[b])['grad']
+            np.testing.assert_allclose(grads[0][b], g, rtol=0, atol=1e-11 * np.max(np.abs(g)))
+    c = cases.case_c2(n=64, k=4, steps=20, m=8, taylor=(5, 2), seed=9)
+    sp = oracle_system(c)
+    for kk, seeds, expect in ((4, 32, hip_engine.PATH_MFMA), (4, 16, hip_engine.PATH_GEMM)):
+        eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling, reg_coeffs={}, n_seeds=seeds)
+        assert eng.path == expect, (seeds, eng.path)
+        eng.close()
+
+
+
 def test_latency_mode_fused_tail_matches_the_finish_kernel():
     """Latency mode runs chain rule / stop rule / Adam in the last workgroup of its gradient kernel (a per-seed arrival counter
     decides who is last): the plain flavour, and with a (zero-weight) amplitude regulariser the flavour with the local pulse

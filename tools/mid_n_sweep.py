@@ -23,8 +23,9 @@ def run(c, seeds, path, variant, iters=50):
     e.close()
     return ms
 
-for n, k, steps in ((40, 4, 500), (48, 4, 500), (48, 3, 2000), (64, 4, 500), (64, 6, 1000)):
-    c = cases.case_c2(n=n, k=k, steps=steps, m=8, taylor=(5, 3), seed=2)
-    for seeds in (1, 2, 4, 8, 16):
-        print('n=%-2d k=%d steps=%-4d seeds=%-2d : AUTO %.4f ms   GEMM %.4f ms   MFMA batch %.4f ms   latency mode %.4f ms'
-              % (n, k, steps, seeds, run(c, seeds, 0, 0), run(c, seeds, 4, 0), run(c, seeds, 2, 7), run(c, seeds, 2, 5)), flush=True)
+if __name__ == '__main__':
+  for n, k, steps in ((40, 4, 500), (48, 4, 500), (48, 3, 2000), (64, 4, 500), (64, 6, 1000)):
+      c = cases.case_c2(n=n, k=k, steps=steps, m=8, taylor=(5, 3), seed=2)
+      for seeds in (1, 2, 4, 8, 16):
+          print('n=%-2d k=%d steps=%-4d seeds=%-2d : AUTO %.4f ms   GEMM %.4f ms   MFMA batch %.4f ms   latency mode %.4f ms'
+                % (n, k, steps, seeds, run(c, seeds, 0, 0), run(c, seeds, 4, 0), run(c, seeds, 2, 7), run(c, seeds, 2, 5)), flush=True)
