@@ -372,7 +372,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // Measured with tools/path_sweep.py (profiles/r01_path_sweep.txt):
     //  * unitary, n <= 32: the register-resident MFMA chain kernels win on throughput (1.8 vs 2.3 ms per iteration of 64
     //    C2 seeds), the GEMM path (fused LDS-resident exponential + product tree + persistent thin chains) on latency
-    //    (0.20 vs 0.57 ms for one C2 trajectory; crossover between 16 and 64 seeds); 32 < n <= 48 (NT = 3: exponentials by
+    //    (0.19 vs 0.47 ms for one C2 trajectory; level at 12 seeds, 0.56 vs 0.49 ms at 16 since the batch kernels split the pulse into
+    //    up to 64 chunks: profiles/r02_latency_sweep.txt); 32 < n <= 48 (NT = 3: exponentials by
     //    three waves per item on v_mfma_f64_4x4x4, costate sweep + slice-parallel gradient kernel): the MFMA path wins from 8 seeds
     //    on (1.11 vs 1.50 ms at 8, 1.70 vs 2.72 at 16, 5.27 vs 9.88 ms at 64 seeds of n = 48; the GEMM path pads to N = 64), ties at
     //    4 (1.00 vs 0.95) and loses below (0.96 vs 0.62 ms at 2); 48 < n <= 64 (NT = 4; tools/n64_batch_sweep.py): with k <= 4 controls
@@ -380,7 +381,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    slices, since the row-tile gradient kernel); with more controls, or fewer seeds, the GEMM path (k = 6: 4.55 vs 4.69 ms at
     //    64 seeds x 200 slices; k = 8: level).
     const bool nt4_batch = n > 48 && k <= 4 && B >= 32;
-    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 16 && m <= 8 && steps >= 100));
+    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 12 && m <= 8 && steps >= 100));
     const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
     bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));

@@ -14,8 +14,11 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         // NT = 2: the default exponential kernel is ONE wave of 444 VGPRs per (seed, chunk), i.e. at most one resident wave per
         // SIMD: B*C must not exceed the 1024 SIMDs or a second, nearly empty round doubles the launch (48 seeds: C = 22 ->
         // 1056 items, 24.0k it/s; C = 21 -> 1008 items, 39.6k it/s).  Other NT: ~2 waves per SIMD.
+        // Fewer than 32 seeds (NT = 2): chunks down to 8 slices keep all SIMDs busy -- 16 seeds: 0.50 ms per iteration with 63 chunks against
+        // 0.62 with 32; 20 seeds: 0.52 (50 chunks) against 0.63; 24 seeds: 0.58 (42) against 0.64 -- the longer boundary recursion of the
+        // sweeps costs less than the idle SIMDs of the exponential kernel.
         C = NT == 2 ? 1024 / d.B : (1024 + d.B - 1) / d.B;
-        if (C > 32) C = 32;
+        if (C > (NT == 2 ? 64 : 32)) C = NT == 2 ? 64 : 32;
     }
     // latency mode (variant 5; AUTO for a handful of seeds, qoc_mfma_latency_ok): one wave per SLICE for the exponentials, short
     // chunks whose products come from k_mfma_chain_products, groups of G chunks for two-level chunk boundaries in the sweeps
