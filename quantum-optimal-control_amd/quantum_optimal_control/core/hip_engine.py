@@ -10,6 +10,8 @@ import os
 
 import numpy as np
 
+# the host driver shares device memory between processes through dmabuf only: RCCL's hipIpcGetMemHandle needs this before HIP starts
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QOC_HIP_LIBRARY') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libqoc_hip.so'))   # override: A/B builds
 

@@ -184,7 +184,26 @@ def open_comm(rank=None, world=None, device=None, key=None):
     if uid.startswith(_NO_RCCL):
         comm = FileComm(rank, world, key, reason=uid[len(_NO_RCCL):].decode(errors='replace'))
     else:
-        comm = hip_engine.QocComm(uid, world, rank, device)
+        # ncclCommInitRank may still fail on SOME rank (device binding, IPC handles ...): the ranks agree through the file transport,
+        # and one failure sends all of them to it -- a job whose only traffic is one gather of fidelities must not die of that
+        files = FileComm(rank, world, key)
+        comm, why = None, ''
+        try:
+            comm = hip_engine.QocComm(uid, world, rank, device)
+        except Exception as exc:
+            why = 'rank %d: %s' % (rank, exc)
+        ok = files.all_gather([1.0 if comm is not None else 0.0])
+        if np.all(ok > 0.5):
+            files.close()
+        else:
+            bad = [int(r) for r in np.nonzero(ok.reshape(-1) <= 0.5)[0]]
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:
+                    pass
+            files.library = 'files (host): RCCL initialisation failed on rank(s) %s%s' % (bad, ('; ' + why) if why else '')
+            comm = files
     comm.barrier()                                  # every rank holds the payload: the file can go
     rendezvous_cleanup(rank, world, key=key)
     return comm

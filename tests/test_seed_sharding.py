@@ -175,6 +175,69 @@ def _file_comm_worker(rank, world, key, directory, out):
     out.put((rank, res))
 
 
+def _failing_init_worker(rank, world, key, directory, out, bad=1):
+    os.environ['QOC_RDZV_DIR'] = directory
+    os.environ.pop('QOC_TRANSPORT', None)
+    from quantum_optimal_control import parallel_seeds
+    from quantum_optimal_control.core import hip_engine
+
+    class FakeComm(object):                                  # stands for a communicator whose ncclCommInitRank fails on rank 1 only
+        closed = False
+        library = 'fake rccl'
+
+        def __init__(self, uid, world_, rank_, device):
+            if rank_ == bad:
+                raise hip_engine.QocError('ncclCommInitRank: unhandled system error')
+
+        def close(self):
+            FakeComm.closed = True
+
+        def barrier(self):
+            pass
+
+        def all_gather(self, values):
+            return np.tile(np.asarray(values, dtype=np.float64), (world, 1))
+
+    hip_engine.comm_unique_id = lambda: b'u' * hip_engine.COMM_ID_BYTES
+    hip_engine.QocComm = FakeComm
+    comm = parallel_seeds.open_comm(rank=rank, world=world, device=0, key=key)
+    res = dict(kind=type(comm).__name__, library=comm.library, closed=FakeComm.closed,
+               gather=comm.all_gather([float(rank)]).reshape(-1))
+    comm.close()
+    out.put((rank, res))
+
+
+def test_rccl_init_failure_on_one_rank_sends_every_rank_to_the_file_transport(tmp_path):
+    """open_comm: rank 0 can hand out an RCCL id, but the communicator cannot be initialised on rank 1 -- the ranks agree through
+    files, every one of them ends up on the file transport (the healthy ranks drop their RCCL communicator), and the job goes on."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_failing_init_worker, args=(r, world, 'fail_%d' % os.getpid(), str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r]['kind'] == 'FileComm' and 'rank(s) [1]' in got[r]['library'], got[r]
+        assert got[r]['closed'] == (r != 1)
+        np.testing.assert_array_equal(got[r]['gather'], [0.0, 1.0, 2.0])
+    assert os.listdir(str(tmp_path)) == []
+    # and when every rank initialises: the RCCL communicator is what open_comm returns, the agreement files are gone
+    procs = [ctx.Process(target=_failing_init_worker, args=(r, world, 'fine_%d' % os.getpid(), str(tmp_path), out, -1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(got[r]['kind'] == 'FakeComm' for r in range(world))
+    assert os.listdir(str(tmp_path)) == []
+
+
 def test_file_transport_world3_matches_the_collective_contract(tmp_path):
     """The fallback transport of parallel_seeds.open_comm (no RCCL available / QOC_TRANSPORT=file): all-gather in global seed
     order, max-reduce, broadcast from the owner, barriers; nothing left behind in the rendezvous directory."""
