@@ -15,11 +15,11 @@ from tests.golden import cases  # noqa: E402
 from tests.helpers import oracle_system  # noqa: E402
 
 
-def run(name, c, n_seeds, iters, path=0, variant=0):
+def run(name, c, n_seeds, iters, path=0, variant=0, chunks=0):
     sp = oracle_system(c)
     eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms,
                                sp.scaling, state_transfer=sp.state_transfer, reg_coeffs=sp.reg_coeffs,
-                               one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=n_seeds, path=path, variant=variant)
+                               one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=n_seeds, path=path, variant=variant, chunks=chunks)
     rng = np.random.default_rng(0)
     eng.set_base(rng.normal(0, 1 / np.sqrt(sp.steps), (n_seeds, sp.k, sp.steps)))
     p = eng.adam_params(max_iterations=10 ** 9, conv_target=-1.0, min_grad=-1.0)
