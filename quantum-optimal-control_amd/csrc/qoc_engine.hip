@@ -144,6 +144,20 @@ static int prof_collect(qoc_engine* e) {
 }
 
 // ---- one evaluation (+ optional on-device stop rule / Adam), enqueued on the engine stream ------------------------
+// k_loss, preceded by what it needs per time point: the dressed-basis amplitudes of the forbidden levels, the overlaps of speed_up
+static inline void launch_loss(const QocDev& d, hipStream_t s) {
+    if (d.forbid_dressed && d.n_forb > 0) {
+        const size_t total = (size_t)d.B * (d.steps + 1) * d.n_forb * d.m;
+        size_t g = (total + 255) / 256;
+        hipLaunchKernelGGL(k_dress_amplitudes, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d);
+    }
+    if (d.has_speed) {
+        const size_t g = ((size_t)d.B * (d.steps + 1) + 3) / 4;
+        hipLaunchKernelGGL(k_time_overlaps, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d);
+    }
+    hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, s, d);
+}
+
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     QocDev d = e->d;
     d.skip_done = ap.mode == 1 ? 1 : 0;      // qoc_eval / explicit steps always evaluate every seed
@@ -165,7 +179,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         if (!(skip & 4)) qoc_mfma_launch_forward(e->mf, d, e->stream);
         if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
         if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
-        if (!(skip & 8) && (!e->mf.latency || (e->mf.lat_sources && !e->mf.lat_src_fast))) hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);   // latency mode: inside the backward kernel
+        if (!(skip & 8) && (!e->mf.latency || (e->mf.lat_sources && (!e->mf.lat_src_fast || e->mf.lat_dressed)))) launch_loss(d, e->stream);   // latency mode: inside the backward kernel
         if (!(skip & 16)) {
             if (fused_tail) qoc_mfma_latency_gradient(e->mf, d, &ap, e->stream);
             else qoc_mfma_launch_backward(e->mf, d, e->stream);
@@ -175,26 +189,26 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         qoc_gemm_expm(e->gm, d, e->stream);
         TRY(prof_end(e));
         qoc_gemm_forward(e->gm, d, e->stream);
-        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        launch_loss(d, e->stream);
         qoc_gemm_backward(e->gm, d, e->stream);
     } else if (!d.state_transfer) {
         TRY(prof_begin(e));
         hipLaunchKernelGGL(k_expm_generic, dim3(e->expm_grid), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->expm_scratch);
         TRY(prof_end(e));
         hipLaunchKernelGGL(k_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->seed_scratch);
-        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        launch_loss(d, e->stream);
         hipLaunchKernelGGL(k_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->seed_scratch);
     } else if (e->path == QOC_PATH_ST_FUSED) {
         TRY(prof_begin(e));
         st_fused_launch(d, e->stream, true);
         TRY(prof_end(e));
-        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        launch_loss(d, e->stream);
         st_fused_launch(d, e->stream, false);
     } else {
         TRY(prof_begin(e));
         hipLaunchKernelGGL(k_st_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
         TRY(prof_end(e));
-        hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d);
+        launch_loss(d, e->stream);
         hipLaunchKernelGGL(k_st_bwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
     }
     if (!(skip & 32) && !fused_tail) {
@@ -205,7 +219,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
     e->final_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale are formed when read back
-    e->inter_stale = e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast);   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
+    e->inter_stale = e->final_stale && (!e->mf.lat_sources || (e->mf.lat_src_fast && !e->mf.lat_dressed));   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
     return QOC_OK;
 }
 
@@ -347,6 +361,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     ALLOC(d.inter, (size_t)B * (steps + 1) * nm);
     ALLOC(d.Xfinal, (size_t)B * nn);
     ALLOC(d.ztau, (size_t)B * (steps + 1));
+    if (d.forbid_dressed && d.n_forb > 0) { ALLOC(d.Fd, (size_t)B * (steps + 1) * d.n_forb * m); ALLOC(d.Fpop, (size_t)B * (steps + 1) * d.n_forb * m); }
     ALLOC(d.zfin, (size_t)B); ALLOC(d.su_resid, (size_t)B);
     ALLOC(d.loss, (size_t)B); ALLOC(d.reg_state, (size_t)B); ALLOC(d.reg_loss, (size_t)B);
     ALLOC(d.g2, (size_t)B); ALLOC(d.uscale, (size_t)B);
@@ -421,7 +436,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;
         if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
-            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32 with k <= 8 (or, without dressed forbidden levels, n <= 48 with k <= 4 / n <= 64), "
+            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32 with k <= 8 (or, with at most 4 dressed forbidden levels, n <= 48 with k <= 4 / n <= 64), "
                                               "taylor_terms >= 2 (n=%d k=%d T=%d)", n, k, d.T));
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));

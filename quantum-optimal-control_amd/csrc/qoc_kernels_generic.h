@@ -159,6 +159,56 @@ __global__ void __launch_bounds__(QOC_BLOCK) k_st_fwd_generic(QocDev d, cplx* __
     }
 }
 
+// Dressed forbidden levels (regularization_functions.py:74-80): phi = <dressed level f | Psi_tau[:, j]> is an n-term dot product per
+// (seed, time point, level, vector).  One thread each, the operands of eight terms in flight at a time: inside k_loss (one workgroup per
+// seed, a dependent load per term) the same sums cost 0.22 ms per iteration of ONE C2 trajectory; source_at recomputed them for every row.
+// Fd = 2 a_f |phi|^2 phi feeds source_at, Fpop = a_f |phi|^4 / 2 is the entry's share of the regulariser, summed by k_loss.
+__global__ void __launch_bounds__(256) k_dress_amplitudes(QocDev d) {
+    const int n = d.n, m = d.m, per_t = d.n_forb * m;
+    const size_t per_b = (size_t)(d.steps + 1) * per_t, total = (size_t)d.B * per_b;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(o / per_b);
+        if (d.skip_done && d.done[b]) continue;
+        const size_t bt = o / per_t;                                             // b * (steps + 1) + tau
+        const int fj = (int)(o - bt * per_t), f = fj / m, j = fj - f * m, st = d.forb_state[f];
+        const cplx* p = d.inter + bt * n * m + j;
+        const cplx* v = d.Vs + st;
+        cplx phi = cmake(0.0, 0.0);
+        for (int c0 = 0; c0 < n; c0 += 8) {
+            cplx vv[8], pp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int c = min(c0 + q, n - 1); vv[q] = v[(size_t)c * n]; pp[q] = p[(size_t)c * m]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (c0 + q < n) cfma_conj(phi, vv[q], pp[q]);
+        }
+        const double pop = phi.x * phi.x + phi.y * phi.y;
+        d.Fd[o] = cscale(phi, 2.0 * d.forb_a[f] * pop);
+        d.Fpop[o] = d.forb_a[f] * 0.5 * pop * pop;
+    }
+}
+
+// speed_up (regularization_functions.py:88-95): the overlap z_tau = <W, Psi_tau> of every time point, a wave per (seed, time point).
+// Inside k_loss (one workgroup per seed walking the time points, two block reductions each) these cost 0.65 ms per iteration of one C2
+// trajectory, 0.9 ms for 64 seeds.
+__global__ void __launch_bounds__(256) k_time_overlaps(QocDev d) {
+    const int lane = threadIdx.x & 63, nm = d.n * d.m;
+    const size_t total = (size_t)d.B * (d.steps + 1);
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < total; it += (size_t)gridDim.x * 4) {
+        const int b = (int)(it / (d.steps + 1));
+        if (d.skip_done && d.done[b]) continue;
+        const cplx* p = d.inter + it * nm;
+        double tr = 0.0, ti = 0.0;
+        for (int o = lane; o < nm; o += 64) {
+            const cplx f = p[o], w = d.W[o];
+            tr += f.x * w.x + f.y * w.y;        // f * conj(w)
+            ti += f.y * w.x - f.x * w.y;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { tr += __shfl_xor(tr, off, 64); ti += __shfl_xor(ti, off, 64); }
+        if (lane == 0) d.ztau[it] = cmake(tr, ti);
+    }
+}
+
 // Fidelity, state-side regulariser values and everything the sources need; one workgroup per seed.
 // tensorflow_state.py:282-340, regularization_functions.py:71-95.
 __global__ void __launch_bounds__(QOC_BLOCK) k_loss(QocDev d) {
@@ -176,20 +226,13 @@ __global__ void __launch_bounds__(QOC_BLOCK) k_loss(QocDev d) {
     zr = block_sum(zr, red); zi = block_sum(zi, red); nrm = block_sum(nrm, red);
     const double mm = (double)m * (double)m;
     double reg_state = 0.0;
-    if (d.has_speed) {                                                           // :88-95
+    if (d.has_speed) {                                                           // :88-95  (z_tau: k_time_overlaps)
         double val = 0.0;
-        for (int tau = 0; tau <= d.steps; ++tau) {
-            double tr = 0.0, ti = 0.0;
-            const cplx* p = iv + (size_t)tau * nm;
-            for (int o = threadIdx.x; o < nm; o += blockDim.x) {
-                const cplx f = p[o], w = d.W[o];
-                tr += f.x * w.x + f.y * w.y;
-                ti += f.y * w.x - f.x * w.y;
-            }
-            tr = block_sum(tr, red); ti = block_sum(ti, red);
-            if (threadIdx.x == 0) d.ztau[(size_t)b * (d.steps + 1) + tau] = cmake(tr, ti);
-            val += (tr * tr + ti * ti) / mm;
+        for (int tau = threadIdx.x; tau <= d.steps; tau += blockDim.x) {
+            const cplx z = d.ztau[(size_t)b * (d.steps + 1) + tau];
+            val += (z.x * z.x + z.y * z.y) / mm;
         }
+        val = block_sum(val, red);
         const double resid = (double)(d.steps + 1) - val;
         if (threadIdx.x == 0) d.su_resid[b] = resid;
         reg_state += d.a_speed * 0.5 * resid * resid;
@@ -202,13 +245,11 @@ __global__ void __launch_bounds__(QOC_BLOCK) k_loss(QocDev d) {
             const cplx* p = iv + (size_t)tau * nm;
             for (int f = 0; f < d.n_forb; ++f) {
                 const int st = d.forb_state[f];
-                cplx phi;
-                if (d.forbid_dressed) {
-                    phi = cmake(0.0, 0.0);
-                    for (int c = 0; c < n; ++c) cfma_conj(phi, d.Vs[c * n + st], p[c * m + j]);
-                } else {
-                    phi = p[st * m + j];
+                if (d.forbid_dressed) {                                  // amplitudes in the dressed basis: k_dress_amplitudes has formed them
+                    acc += d.Fpop[(((size_t)b * (d.steps + 1) + tau) * d.n_forb + f) * m + j];
+                    continue;
                 }
+                const cplx phi = p[st * m + j];
                 const double pop = phi.x * phi.x + phi.y * phi.y;
                 acc += d.forb_a[f] * 0.5 * pop * pop;
             }

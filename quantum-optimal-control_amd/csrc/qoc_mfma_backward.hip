@@ -76,7 +76,10 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         if (!al((cplx**)&mf.gpart, ((size_t)NT * d.B * d.k * d.steps + 1) / 2)) { msg = "MFMA path: out of device memory"; return -3; }
     }
     if (mf.lat_sources && !al(&mf.Goff, (size_t)d.B * mf.NG * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
-    mf.lat_src_fast = mf.lat_sources && !(d.n_forb > 0 && d.forbid_dressed);   // undressed forbidden levels / speed_up: thin affine sweeps (qoc_mfma_latency.h)
+    // forbidden levels / speed_up on the thin affine sweeps of qoc_mfma_latency.h; dressed levels (up to 4 of them) take their sources from Fd
+    const bool dressed = d.n_forb > 0 && d.forbid_dressed;
+    mf.lat_src_fast = mf.lat_sources && !(dressed && d.n_forb > 4);
+    mf.lat_dressed = mf.lat_src_fast && dressed;
     if (mf.lat_src_fast) {
         const size_t vec = (size_t)NT * (mf.mq <= 2 ? 2 : 4) * 64;
         if (!al(&mf.AoffL, (size_t)d.B * C * vec) || !al(&mf.GoffL, (size_t)d.B * mf.NG * vec) || !al(&mf.LamS, (size_t)d.B * d.steps * vec) ||

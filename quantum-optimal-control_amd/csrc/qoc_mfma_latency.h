@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(1024) k_mfma_loss_lat(QocDev d, QocMfma mf) {
 //           chunk, storing the TOTAL costate c0 z Lambda0_t + LambdaS_t (LamS) that k_mfma_grad_lat contracts with Psi_t.
 // Against the pair-of-waves kernels of the batch path on the same chunks (k_mfma_bwd_offsets2 28 us, k_mfma_backward3<MODE 2> 8,
 // <MODE 1> 39, which also carry the gradient work) the three passes are thin products with a vector add per step.
-template <int NT>
+template <int NT, bool DRESS = false>
 __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_src(QocDev d, QocMfma mf, int role) {
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx img[2][4 * LDP];
@@ -239,11 +239,23 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_src(QocDev d, QocMfma mf
     const cplx* psil = mf.PsiL + (size_t)b * d.steps * per_vec + slot;
     const cplx* ztau = d.has_speed ? d.ztau + (size_t)b * (d.steps + 1) : d.zfin + b;   // (a valid address either way: no branch around the load)
     const int zstride = d.has_speed ? 1 : 0;
+    // DRESS (dressed forbidden levels, n_forb <= 4): S_tau[row][col] = sum_f Vs[row][st_f] Fd[tau][f][col] with the per-(tau, f, col)
+    // amplitudes k_loss left in Fd (qoc_state_source.h) -- the rotation's row entries are loaded once, a step reads n_forb values
+    cplx vsf[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) vsf[f] = (DRESS && f < d.n_forb && inside) ? d.Vs[row * d.n + d.forb_state[f]] : cmake(0.0, 0.0);
+    const int nfm = DRESS ? d.n_forb * d.m : 0, colc = min(col, d.m - 1);
+    const cplx* fdb = DRESS ? d.Fd + (size_t)b * (d.steps + 1) * nfm + colc : nullptr;
     auto source = [&](int tau) -> cplx {                                          // S_tau at this lane's entry, tau = 1 .. steps (0 for tau <= 0)
-        const cplx psi = psil[(size_t)max(tau - 1, 0) * per_vec];
+        const cplx psi = DRESS ? cmake(0.0, 0.0) : psil[(size_t)max(tau - 1, 0) * per_vec];
         const cplx zt = ztau[(size_t)tau * zstride];
         const double pop = psi.x * psi.x + psi.y * psi.y;
         cplx sv = cscale(psi, wrow * pop);
+        if (DRESS) {
+            const cplx* fd = fdb + (size_t)max(tau, 0) * nfm;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) cfma(sv, vsf[f], fd[(size_t)min(f, d.n_forb - 1) * d.m]);   // (f >= n_forb: a valid address, a zero factor)
+        }
         const cplx zw = cscale(cmul(zt, wown), speed_coef);
         sv.x += zw.x; sv.y += zw.y;
         return (tau > 0 && inside) ? sv : cmake(0.0, 0.0);

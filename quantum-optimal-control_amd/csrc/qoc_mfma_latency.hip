@@ -31,7 +31,7 @@ void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(192), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(128), 0, s, d, mf);
-    if (mf.lat_src_fast) {                                             // fidelity + state-regulariser values straight from PsiL (instead of unpack + k_loss)
+    if (mf.lat_src_fast && !mf.lat_dressed) {                          // fidelity + state-regulariser values straight from PsiL (instead of unpack + k_loss)
         const dim3 gl(d.B * ((d.steps + 1 + 15) / 16));
         if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_loss_lat<4>, gl, dim3(1024), 0, s, d, mf);
         else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_loss_lat<3>, gl, dim3(1024), 0, s, d, mf);
@@ -46,9 +46,11 @@ void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* a
     if (mf.lat_src_fast) {
         // the source part of the costate: chunk offsets, group offsets, then the sweep that stores the total costate (k_loss has run)
         const dim3 gc(d.B * mf.C * mf.mq), gg(d.B * mf.NG * mf.mq), bs(64 * mf.NT);
-#define QOC_SRC(NTv) do { hipLaunchKernelGGL(k_mfma_sweep_src<NTv>, gc, bs, 0, s, d, mf, 0); hipLaunchKernelGGL(k_mfma_sweep_src<NTv>, gg, bs, 0, s, d, mf, 1); \
-                          hipLaunchKernelGGL(k_mfma_sweep_src<NTv>, gc, bs, 0, s, d, mf, 2); } while (0)
+#define QOC_SRC1(NTv, DRv) do { hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gc, bs, 0, s, d, mf, 0); hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gg, bs, 0, s, d, mf, 1); \
+                          hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gc, bs, 0, s, d, mf, 2); } while (0)
+#define QOC_SRC(NTv) do { if (mf.lat_dressed) QOC_SRC1(NTv, true); else QOC_SRC1(NTv, false); } while (0)
         if (mf.NT == 4) QOC_SRC(4); else if (mf.NT == 3) QOC_SRC(3); else QOC_SRC(2);
+#undef QOC_SRC1
 #undef QOC_SRC
     }
     const int kc = grad_lat_kc(d), sl = 16 / mf.NT;                      // slices per workgroup, NT waves (row tiles) each

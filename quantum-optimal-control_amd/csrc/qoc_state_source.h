@@ -12,10 +12,10 @@ __device__ __forceinline__ cplx source_at(const QocDev& d, int b, int tau, int a
     for (int f = 0; f < d.n_forb; ++f) {
         const int st = d.forb_state[f];
         if (d.forbid_dressed) {
-            cplx phi = cmake(0.0, 0.0);
-            for (int c = 0; c < n; ++c) cfma_conj(phi, d.Vs[c * n + st], p[c * m + j]);
-            const double pop = phi.x * phi.x + phi.y * phi.y;
-            cfma(s, d.Vs[a * n + st], cscale(phi, 2.0 * d.forb_a[f] * pop));
+            // 2 a_f |phi|^2 phi, phi = <dressed level f | Psi_tau[:, j]>: formed once per (tau, f, j) by k_loss of this evaluation (an
+            // n-term dot product; recomputing it here for every row a made the dressed sources O(n) per entry: one C2 trajectory
+            // 0.52 ms per iteration on the GEMM route against 0.29 with undressed levels)
+            cfma(s, d.Vs[a * n + st], d.Fd[(((size_t)b * (d.steps + 1) + tau) * d.n_forb + f) * m + j]);
         } else if (a == st) {
             const cplx phi = p[st * m + j];
             const double pop = phi.x * phi.x + phi.y * phi.y;

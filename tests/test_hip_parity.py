@@ -90,7 +90,8 @@ def test_mfma_path_parity(chunks, variant):
 
 @pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6, 7], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd', 'mfma4_row_blocks'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
-                                     'n25_k8_T7', 'n17_k1_T4_s4', 'n30_m13_k2', 'n32_m4_k3', 'n26_k5_plain', 'n28_k7_sources', 'n26_k5_sources'])
+                                     'n25_k8_T7', 'n17_k1_T4_s4', 'n30_m13_k2', 'n32_m4_k3', 'n26_k5_plain', 'n28_k7_sources', 'n26_k5_sources',
+                                     'n22_dressed3', 'n40_dressed_nt3', 'n20_dressed5'])
 @pytest.mark.parametrize('chunks', [0, 1, 7])
 def test_mfma_exponential_kernels(chunks, variant, kernel):
     """The four kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variants 3, 4 = variant 2;
@@ -138,6 +139,17 @@ def _mfma_path_parity(chunks, variant, kernel):
         c = cases.case_c2(n=25, k=8, steps=15, m=6, taylor=(7, 2), seed=33)
     elif variant == 'n17_k1_T4_s4':      # even order with one Horner product, one control
         c = cases.case_c2(n=17, k=1, steps=10, m=3, taylor=(4, 4), seed=34)
+    elif variant in ('n22_dressed3', 'n40_dressed_nt3', 'n20_dressed5'):
+        # dressed forbidden levels (their amplitudes are formed once per time point by k_loss and reused by every source): 3 levels with
+        # speed_up on the NT = 2 kernels, 2 levels on NT = 3, and 5 levels -- more than the thin source sweeps of the latency mode take
+        from quantum_optimal_control.helper_functions import grape_functions as gf
+        nn, kk, lv = {'n22_dressed3': (22, 3, [21, 7, 13]), 'n40_dressed_nt3': (40, 2, [39, 38]), 'n20_dressed5': (20, 2, [19, 18, 3, 9, 11])}[variant]
+        c = cases.case_c2(n=nn, k=kk, steps=21, m=6, taylor=(5, 2), seed=40 + nn)
+        w, v, did = gf.get_dressed_info(c['H0'])
+        c['dressed_info'] = dict(eigenvectors=v, dressed_id=did, eigenvalues=w, is_dressed=True)
+        c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [3.0 + i for i in range(len(lv))], 'states_forbidden_list': lv, 'forbid_dressed': True}
+        if variant == 'n22_dressed3':
+            c['reg_coeffs']['speed_up'] = 0.4
     elif variant == 'n57_k1_nt4':
         c = cases.case_c2(n=57, k=1, steps=9, m=3, taylor=(4, 1), seed=15)
     else:
@@ -146,7 +158,8 @@ def _mfma_path_parity(chunks, variant, kernel):
     rng = np.random.default_rng(5)
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2, 3 * sp.base0]
     from quantum_optimal_control.core import hip_engine
-    undressed = not ('forbidden_coeff_list' in sp.reg_coeffs and sp.Vs is not None)      # dressed forbidden levels: NT = 2 kernels only
+    # more than 4 dressed forbidden levels: the batch kernels' source recursion, NT = 2 kernels only
+    undressed = not ('forbidden_coeff_list' in sp.reg_coeffs and sp.Vs is not None and len(sp.reg_coeffs['forbidden_coeff_list']) > 4)
     latency_ok = sp.exp_terms >= 2 and ((sp.n <= 32 and sp.k <= 8) or (sp.n <= 48 and sp.k <= 4 and undressed) or (48 < sp.n <= 64 and undressed))
     if kernel == 5 and not latency_ok:
         with pytest.raises(hip_engine.QocError, match='latency mode'):
