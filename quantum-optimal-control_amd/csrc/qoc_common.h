@@ -72,6 +72,7 @@ struct QocDev {
     double* g2;          // [B]
     double* uscale;      // [B]
     cplx* band_ph;       // [B][k][steps] scratch for the bandpass gradient
+    cplx* band_tw;       // [steps] e^{-2 pi i r / steps} (bandpass regulariser)
 };
 
 // Adam loop parameters handed to the finishing kernel.

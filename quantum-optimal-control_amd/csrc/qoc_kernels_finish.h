@@ -42,6 +42,10 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red /* 
 // LEVEL: 0 = no pulse regulariser (PLAIN), 1 = the local ones (amplitude, envelope, dwdt, d2wdt2) but no bandpass DFT, 2 = all.
 template <int LEVEL>
 __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */) {
+    // no implicit contraction into FMAs in here: the three flavours (and the fused / separate launches of the latency mode) must round
+    // alike -- with a regulariser of weight zero they are bit-identical -- and which a*b + c the compiler contracts depends on the code
+    // around it (an edit of the bandpass loops flipped one in the Adam update).  Every fma() below is written out.
+#pragma clang fp contract(off)
     constexpr bool PLAIN = LEVEL == 0, BAND = LEVEL == 2;
     const int steps = d.steps, ks = d.k * steps;
     const double* w = d.w + (size_t)b * ks;
@@ -106,11 +110,18 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
             if (cnt > 0) {
                 const double* wk = w + (size_t)kk * steps;
                 double fr = 0.0, fi = 0.0;
-                for (int t = 0; t < steps; ++t) {
-                    double c, s;
-                    unit_phase(f, t, steps, &c, &s);
-                    fr = fma(wk[t], c, fr);
-                    fi = fma(wk[t], s, fi);
+                int r = 0;                                                  // f t mod steps, advanced by f per slice
+                for (int t0 = 0; t0 < steps; t0 += 8) {                      // eight table entries in flight (a dependent load per term otherwise)
+                    cplx e[8]; double wv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        e[q] = d.band_tw[r];                                // e^{-2 pi i f t / N}: the table holds unit_phase's own values
+                        wv[q] = wk[min(t0 + q, steps - 1)];
+                        r += f; if (r >= steps) r -= steps;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (t0 + q < steps) { fr = fma(wv[q], e[q].x, fr); fi = fma(wv[q], e[q].y, fi); }
                 }
                 const double mag = sqrt(fr * fr + fi * fi);
                 acc += (double)cnt * mag;
@@ -151,13 +162,19 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
         if (BAND && d.has_band) {
             double acc = 0.0;
             const cplx* pk = ph + (size_t)kk * steps;
-            for (int f = 0; f < half || f < lo; ++f) {
-                if (f >= steps) break;
-                const cplx q = pk[f];
-                if (q.x == 0.0 && q.y == 0.0) continue;
-                double c, s;
-                unit_phase(f, t, steps, &c, &s);
-                acc += q.x * c - q.y * s;                              // Re(ph_f * e^{-2 pi i f t/N})
+            int r = 0;                                                      // f t mod steps, advanced by t per frequency
+            const int fend = min(max(half, lo), steps);
+            for (int f0 = 0; f0 < fend; f0 += 8) {
+                cplx qv[8], e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    qv[q] = pk[min(f0 + q, fend - 1)];
+                    e[q] = d.band_tw[r];
+                    r += t; if (r >= steps) r -= steps;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (f0 + q < fend && !(qv[q].x == 0.0 && qv[q].y == 0.0)) acc += qv[q].x * e[q].x - qv[q].y * e[q].y;   // Re(ph_f * e^{-2 pi i f t/N})
             }
             dR += d.a_band * acc;
         }
