@@ -73,6 +73,8 @@ struct QocDev {
     double* uscale;      // [B]
     cplx* band_ph;       // [B][k][steps] scratch for the bandpass gradient
     cplx* band_tw;       // [steps] e^{-2 pi i r / steps} (bandpass regulariser)
+    double* band_mag;    // [B][k][steps] cnt_f |F_f| of the pulse spectrum (k_band_spectrum -> finish)
+    double* band_dR;     // [B][k][steps] d(sum cnt |F|)/d w (k_band_gradient -> finish)
 };
 
 // Adam loop parameters handed to the finishing kernel.

@@ -151,6 +151,70 @@ __global__ void __launch_bounds__(256) k_band_twiddles(cplx* tw, int N) {
     if (r < N) { double c, s; unit_phase(r, 1, N, &c, &s); tw[r] = cmake(c, s); }
 }
 
+// Bandpass regulariser (regularization_functions.py:47-67) by direct DFT, outside the one-workgroup-per-seed finish kernel (where the
+// 2 k N^2 terms of a seed took 0.4 ms of one C2 trajectory even with the phase table):
+//   k_band_spectrum: a wave per (seed, control, frequency): F_f = sum_t w_t e^{-2 pi i f t/N}; band_mag = cnt_f |F_f|, band_ph = cnt_f conj(F_f)/|F_f|
+//   k_band_gradient: a thread per (seed, control, slice): band_dR = sum_f Re(band_ph_f e^{-2 pi i f t/N})
+// cnt_f = how often the reference's two slices (f < lo; hi <= f < N/2) contain f.
+__global__ void __launch_bounds__(256) k_band_spectrum(QocDev d) {
+    const int steps = d.steps, lane = threadIdx.x & 63, half = steps / 2;
+    const int lo = min(max(d.band_lo, 0), steps), hi = min(max(d.band_hi, 0), steps);
+    const size_t total = (size_t)d.B * d.k * steps;
+    for (size_t o = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); o < total; o += (size_t)gridDim.x * 4) {
+        const int f = (int)(o % steps);
+        const size_t bk = o / steps;
+        if (d.skip_done && d.done[bk / d.k]) continue;
+        const int cnt = (f < lo ? 1 : 0) + ((f >= hi && f < half) ? 1 : 0);
+        cplx p = cmake(0.0, 0.0);
+        double mg = 0.0;
+        if (cnt > 0) {                                                       // (uniform over the wave)
+            const double* wk = d.w + bk * steps;
+            int r = (int)(((long long)f * lane) % steps);
+            const int dr = (int)(((long long)f * 64) % steps);
+            double fr = 0.0, fi = 0.0;
+            for (int t = lane; t < steps; t += 64) {
+                const cplx e = d.band_tw[r];
+                fr = fma(wk[t], e.x, fr);
+                fi = fma(wk[t], e.y, fi);
+                r += dr; if (r >= steps) r -= steps;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { fr += __shfl_xor(fr, off, 64); fi += __shfl_xor(fi, off, 64); }
+            const double mag = sqrt(fr * fr + fi * fi);
+            mg = (double)cnt * mag;
+            if (mag > 0.0) p = cmake((double)cnt * fr / mag, -(double)cnt * fi / mag);
+        }
+        if (lane == 0) { d.band_ph[o] = p; d.band_mag[o] = mg; }
+    }
+}
+__global__ void __launch_bounds__(256) k_band_gradient(QocDev d) {
+    const int steps = d.steps, half = steps / 2;
+    const int lo = min(max(d.band_lo, 0), steps);
+    const int fend = min(max(half, lo), steps);
+    const size_t total = (size_t)d.B * d.k * steps;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(o % steps);
+        const size_t bk = o / steps;
+        if (d.skip_done && d.done[bk / d.k]) continue;
+        const cplx* pk = d.band_ph + bk * steps;
+        double acc = 0.0;
+        int r = 0;                                                           // f t mod steps, advanced by t per frequency
+        for (int f0 = 0; f0 < fend; f0 += 8) {
+            cplx qv[8], e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                qv[q] = pk[min(f0 + q, fend - 1)];
+                e[q] = d.band_tw[r];
+                r += t; if (r >= steps) r -= steps;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (f0 + q < fend) acc += qv[q].x * e[q].x - qv[q].y * e[q].y;       // Re(ph_f e^{-2 pi i f t/N}); ph = 0 outside the counted bins
+        }
+        d.band_dR[o] = acc;
+    }
+}
+
 // k_loss, preceded by what it needs per time point: the dressed-basis amplitudes of the forbidden levels, the overlaps of speed_up
 static inline void launch_loss(const QocDev& d, hipStream_t s) {
     if (d.forbid_dressed && d.n_forb > 0) {
@@ -220,6 +284,11 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     }
     if (!(skip & 32) && !fused_tail) {
         const dim3 fb(d.k * d.steps >= 2048 ? 1024 : QOC_BLOCK);
+        if (d.has_band) {
+            const size_t items = (size_t)d.B * d.k * d.steps, g1 = (items + 3) / 4, g2 = (items + 255) / 256;
+            hipLaunchKernelGGL(k_band_spectrum, dim3((unsigned)(g1 > 8192 ? 8192 : g1)), dim3(256), 0, e->stream, d);
+            hipLaunchKernelGGL(k_band_gradient, dim3((unsigned)(g2 > 8192 ? 8192 : g2)), dim3(256), 0, e->stream, d);
+        }
         if (plain) hipLaunchKernelGGL(k_finish_t<true>, dim3(d.B), fb, 0, e->stream, d, ap);
         else hipLaunchKernelGGL(k_finish_t<false>, dim3(d.B), fb, 0, e->stream, d, ap);
     }
@@ -372,7 +441,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     ALLOC(d.zfin, (size_t)B); ALLOC(d.su_resid, (size_t)B);
     ALLOC(d.loss, (size_t)B); ALLOC(d.reg_state, (size_t)B); ALLOC(d.reg_loss, (size_t)B);
     ALLOC(d.g2, (size_t)B); ALLOC(d.uscale, (size_t)B);
-    if (d.has_band) { ALLOC(d.band_ph, B * ks); ALLOC(d.band_tw, (size_t)steps); }
+    if (d.has_band) { ALLOC(d.band_ph, B * ks); ALLOC(d.band_tw, (size_t)steps); ALLOC(d.band_mag, B * ks); ALLOC(d.band_dR, B * ks); }
     ALLOC(e->step_lr, (size_t)B);
     if (hipMemset(d.base, 0, B * ks * sizeof(double)) != hipSuccess ||
         hipMemset(d.adam_m, 0, B * ks * sizeof(double)) != hipSuccess ||

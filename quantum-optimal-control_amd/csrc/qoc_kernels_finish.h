@@ -98,39 +98,11 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
         }
         reg += d.a_d2wdt2 * 0.5 * acc;
     }
-    cplx* ph = (BAND && d.band_ph) ? d.band_ph + (size_t)b * ks : nullptr;
-    const int half = steps / 2;
-    const int lo = min(max(d.band_lo, 0), steps), hi = min(max(d.band_hi, 0), steps);
-    if (BAND && d.has_band) {                                                              // :47-67
+    if (BAND && d.has_band) {                                                              // :47-67: sum of cnt |F_f| (k_band_spectrum)
         double acc = 0.0;
-        for (int o = threadIdx.x; o < d.k * steps; o += blockDim.x) {
-            const int kk = o / steps, f = o - kk * steps;
-            const int cnt = (f < lo ? 1 : 0) + ((f >= hi && f < half) ? 1 : 0);
-            cplx p = cmake(0.0, 0.0);
-            if (cnt > 0) {
-                const double* wk = w + (size_t)kk * steps;
-                double fr = 0.0, fi = 0.0;
-                int r = 0;                                                  // f t mod steps, advanced by f per slice
-                for (int t0 = 0; t0 < steps; t0 += 8) {                      // eight table entries in flight (a dependent load per term otherwise)
-                    cplx e[8]; double wv[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        e[q] = d.band_tw[r];                                // e^{-2 pi i f t / N}: the table holds unit_phase's own values
-                        wv[q] = wk[min(t0 + q, steps - 1)];
-                        r += f; if (r >= steps) r -= steps;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (t0 + q < steps) { fr = fma(wv[q], e[q].x, fr); fi = fma(wv[q], e[q].y, fi); }
-                }
-                const double mag = sqrt(fr * fr + fi * fi);
-                acc += (double)cnt * mag;
-                if (mag > 0.0) p = cmake((double)cnt * fr / mag, -(double)cnt * fi / mag);   // cnt * conj(F)/|F|
-            }
-            ph[o] = p;
-        }
+        const double* bm = d.band_mag + (size_t)b * ks;
+        for (int o = threadIdx.x; o < ks; o += blockDim.x) acc += bm[o];
         reg += d.a_band * acc;
-        __syncthreads();
     }
 
     // ---- per-element: remaining values, d reg / d w, chain rule -------------------------------------------------
@@ -159,25 +131,7 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
             const double e2 = (padded_w(wk, steps, p + 2) - 2.0 * padded_w(wk, steps, p + 1) + padded_w(wk, steps, p)) / dt2;      // e_p
             dR += d.a_d2wdt2 * (e0 - 2.0 * e1 + e2) / dt2;
         }
-        if (BAND && d.has_band) {
-            double acc = 0.0;
-            const cplx* pk = ph + (size_t)kk * steps;
-            int r = 0;                                                      // f t mod steps, advanced by t per frequency
-            const int fend = min(max(half, lo), steps);
-            for (int f0 = 0; f0 < fend; f0 += 8) {
-                cplx qv[8], e[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    qv[q] = pk[min(f0 + q, fend - 1)];
-                    e[q] = d.band_tw[r];
-                    r += t; if (r >= steps) r -= steps;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (f0 + q < fend && !(qv[q].x == 0.0 && qv[q].y == 0.0)) acc += qv[q].x * e[q].x - qv[q].y * e[q].y;   // Re(ph_f * e^{-2 pi i f t/N})
-            }
-            dR += d.a_band * acc;
-        }
+        if (BAND && d.has_band) dR += d.a_band * d.band_dR[(size_t)b * ks + o];                            // (k_band_gradient)
         const double bv = base[o];
         const double g = cos(bv) * (d.maxA[kk] * dLdu[o] + dR);
         grad[o] = g;
