@@ -62,7 +62,7 @@ struct QocDev {
     cplx* inter;         // [B][steps+1][n][m]
     cplx* Xfinal;        // [B][n][n]
     cplx* ztau;          // [B][steps+1] per-time-step overlap (speed_up)
-    double* Fpop;        // [B][steps+1][n_forb][m] dressed forbidden levels: a_f |phi|^4 / 2, the entry's share of the regulariser (k_dress_amplitudes -> k_loss)
+    double* Fpop;        // [B][steps+1][n_forb][m] forbidden levels (bare or dressed): a_f |phi|^4 / 2, the entry's share of the regulariser (k_dress_amplitudes -> k_loss)
     cplx* Fd;            // [B][steps+1][n_forb][m] dressed forbidden levels: 2 a_f |phi|^2 phi with phi = <dressed level f | Psi_tau[:, j]> (k_dress_amplitudes -> source_at); null otherwise
     cplx* zfin;          // [B]
     double* su_resid;    // [B] (steps+1 - value) of speed_up

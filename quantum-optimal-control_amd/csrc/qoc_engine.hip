@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_band_gradient(QocDev d) {
 
 // k_loss, preceded by what it needs per time point: the dressed-basis amplitudes of the forbidden levels, the overlaps of speed_up
 static inline void launch_loss(const QocDev& d, hipStream_t s) {
-    if (d.forbid_dressed && d.n_forb > 0) {
+    if (d.n_forb > 0) {
         const size_t total = (size_t)d.B * (d.steps + 1) * d.n_forb * d.m;
         size_t g = (total + 255) / 256;
         hipLaunchKernelGGL(k_dress_amplitudes, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d);
@@ -437,7 +437,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     ALLOC(d.inter, (size_t)B * (steps + 1) * nm);
     ALLOC(d.Xfinal, (size_t)B * nn);
     ALLOC(d.ztau, (size_t)B * (steps + 1));
-    if (d.forbid_dressed && d.n_forb > 0) { ALLOC(d.Fd, (size_t)B * (steps + 1) * d.n_forb * m); ALLOC(d.Fpop, (size_t)B * (steps + 1) * d.n_forb * m); }
+    if (d.n_forb > 0) ALLOC(d.Fpop, (size_t)B * (steps + 1) * d.n_forb * m);
+    if (d.forbid_dressed && d.n_forb > 0) ALLOC(d.Fd, (size_t)B * (steps + 1) * d.n_forb * m);
     ALLOC(d.zfin, (size_t)B); ALLOC(d.su_resid, (size_t)B);
     ALLOC(d.loss, (size_t)B); ALLOC(d.reg_state, (size_t)B); ALLOC(d.reg_loss, (size_t)B);
     ALLOC(d.g2, (size_t)B); ALLOC(d.uscale, (size_t)B);

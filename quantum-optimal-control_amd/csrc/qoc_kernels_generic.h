@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(QOC_BLOCK) k_st_fwd_generic(QocDev d, cplx* __
     }
 }
 
-// Dressed forbidden levels (regularization_functions.py:74-80): phi = <dressed level f | Psi_tau[:, j]> is an n-term dot product per
+// Forbidden levels (regularization_functions.py:71-85).  Dressed (:74-80): phi = <dressed level f | Psi_tau[:, j]> is an n-term dot product per
 // (seed, time point, level, vector).  One thread each, the operands of eight terms in flight at a time: inside k_loss (one workgroup per
 // seed, a dependent load per term) the same sums cost 0.22 ms per iteration of ONE C2 trajectory; source_at recomputed them for every row.
 // Fd = 2 a_f |phi|^2 phi feeds source_at, Fpop = a_f |phi|^4 / 2 is the entry's share of the regulariser, summed by k_loss.
@@ -172,6 +172,12 @@ __global__ void __launch_bounds__(256) k_dress_amplitudes(QocDev d) {
         const size_t bt = o / per_t;                                             // b * (steps + 1) + tau
         const int fj = (int)(o - bt * per_t), f = fj / m, j = fj - f * m, st = d.forb_state[f];
         const cplx* p = d.inter + bt * n * m + j;
+        if (!d.forbid_dressed) {                                                 // bare level: the amplitude is an entry of Psi (source_at reads it there)
+            const cplx phi = p[(size_t)st * m];
+            const double pop = phi.x * phi.x + phi.y * phi.y;
+            d.Fpop[o] = d.forb_a[f] * 0.5 * pop * pop;
+            continue;
+        }
         const cplx* v = d.Vs + st;
         cplx phi = cmake(0.0, 0.0);
         for (int c0 = 0; c0 < n; c0 += 8) {
@@ -240,19 +246,9 @@ __global__ void __launch_bounds__(QOC_BLOCK) k_loss(QocDev d) {
     if (d.n_forb > 0) {                                                          // :71-85
         double acc = 0.0;
         const int total = (d.steps + 1) * m;
-        for (int o = threadIdx.x; o < total; o += blockDim.x) {
+        for (int o = threadIdx.x; o < total; o += blockDim.x) {                  // a_f |phi|^4 / 2 of every (time point, level, vector): k_dress_amplitudes
             const int tau = o / m, j = o - tau * m;
-            const cplx* p = iv + (size_t)tau * nm;
-            for (int f = 0; f < d.n_forb; ++f) {
-                const int st = d.forb_state[f];
-                if (d.forbid_dressed) {                                  // amplitudes in the dressed basis: k_dress_amplitudes has formed them
-                    acc += d.Fpop[(((size_t)b * (d.steps + 1) + tau) * d.n_forb + f) * m + j];
-                    continue;
-                }
-                const cplx phi = p[st * m + j];
-                const double pop = phi.x * phi.x + phi.y * phi.y;
-                acc += d.forb_a[f] * 0.5 * pop * pop;
-            }
+            for (int f = 0; f < d.n_forb; ++f) acc += d.Fpop[(((size_t)b * (d.steps + 1) + tau) * d.n_forb + f) * m + j];
         }
         reg_state += block_sum(acc, red);
     }
