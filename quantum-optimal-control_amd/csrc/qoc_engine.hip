@@ -497,7 +497,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const long long lat_work = (long long)B * steps;
     const bool lat_src = d.n_forb > 0 || d.has_speed;
     const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
-                              ((n > 48 ? (lat_work <= 4096 && B <= 4)       // NT = 4: 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
+                              (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && B <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
                                 : n > 32 ? (lat_work <= 16384 && B <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
                                        : (lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && B <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
                                (B == 1 && steps <= 8192));
@@ -518,7 +518,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;
         if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
-            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32 with k <= 8 (or, with at most 4 dressed forbidden levels, n <= 48 with k <= 4 / n <= 64), "
+            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32 with k <= 8 (or, with at most 4 dressed forbidden levels, n <= 64), "
                                               "taylor_terms >= 2 (n=%d k=%d T=%d)", n, k, d.T));
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));

@@ -69,8 +69,9 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
 // latency mode: NT = 2 kernels (smaller problems are padded to 32).  With a state regulariser the costate is not linear in the
 // overlap: the backward half then runs the batch kernels on the latency mode's chunks (QocMfma::lat_sources)
 static inline bool qoc_mfma_latency_ok(const QocDev& d) {
-    if (d.n > 32)    // NT = 3 / 4: no DRESSED forbidden level (its affine backward half is an NT = 2 kernel); NT = 3: four control images in LDS
-        return !d.state_transfer && d.n <= 64 && d.m <= 16 && d.k <= (d.n <= 48 ? 4 : 8) && d.T >= 2 && d.T <= 22 && !(d.n_forb > 4 && d.forbid_dressed);
+    if (d.n > 32)    // NT = 3 / 4: at most 4 DRESSED forbidden levels (more need the batch kernels' affine recursion, NT = 2 only); 32 < n <= 48 with
+                     // more than 4 controls runs the NT = 4 kernels on the padded problem (NT = 3 keeps four control images in LDS)
+        return !d.state_transfer && d.n <= 64 && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22 && !(d.n_forb > 4 && d.forbid_dressed);
     return !d.state_transfer && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22;
 }
 

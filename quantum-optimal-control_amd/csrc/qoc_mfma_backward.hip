@@ -6,7 +6,8 @@
 int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
                                  std::vector<void*>& allocs, std::string& msg) {
     // (latency mode: NT = 2 kernels only -- a smaller problem is padded to 32: one trajectory of n = 16 runs 0.083 ms like n = 17, not 0.20)
-    const int NT = (mf.variant == 5 && d.n <= 32) ? 2 : d.n <= 16 ? 1 : (d.n <= 32 ? 2 : (d.n <= 48 ? 3 : 4));   // (latency mode of 32 < n <= 48: NT = 3)
+    // (latency mode of 32 < n <= 48: NT = 3 with up to four controls, the NT = 4 kernels on the problem padded to 64 with more)
+    const int NT = (mf.variant == 5 && d.n <= 32) ? 2 : d.n <= 16 ? 1 : (d.n <= 32 ? 2 : ((d.n <= 48 && !(mf.variant == 5 && d.k > 4)) ? 3 : 4));
     const int FR = 256 * NT * NT;
     mf.NT = NT; mf.FR = FR;
     int C = chunks_req;

@@ -91,7 +91,7 @@ def test_mfma_path_parity(chunks, variant):
 @pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6, 7], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd', 'mfma4_row_blocks'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
                                      'n25_k8_T7', 'n17_k1_T4_s4', 'n30_m13_k2', 'n32_m4_k3', 'n26_k5_plain', 'n28_k7_sources', 'n26_k5_sources',
-                                     'n22_dressed3', 'n40_dressed_nt3', 'n20_dressed5'])
+                                     'n22_dressed3', 'n40_dressed_nt3', 'n20_dressed5', 'n44_k6'])
 @pytest.mark.parametrize('chunks', [0, 1, 7])
 def test_mfma_exponential_kernels(chunks, variant, kernel):
     """The four kernels of the exponentials (qoc_config.variant), whatever AUTO would pick (n > 32: variants 3, 4 = variant 2;
@@ -150,6 +150,9 @@ def _mfma_path_parity(chunks, variant, kernel):
         c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [3.0 + i for i in range(len(lv))], 'states_forbidden_list': lv, 'forbid_dressed': True}
         if variant == 'n22_dressed3':
             c['reg_coeffs']['speed_up'] = 0.4
+    elif variant == 'n44_k6':            # 32 < n <= 48 with more than 4 controls: NT = 3 batch kernels, NT = 4 kernels (padded) in the latency mode
+        c = cases.case_c2(n=44, k=6, steps=17, m=7, taylor=(5, 2), seed=44)
+        c['reg_coeffs'] = {'forbidden_coeff_list': [3.0], 'states_forbidden_list': [43], 'dwdt': 0.1}
     elif variant == 'n57_k1_nt4':
         c = cases.case_c2(n=57, k=1, steps=9, m=3, taylor=(4, 1), seed=15)
     else:
@@ -160,7 +163,7 @@ def _mfma_path_parity(chunks, variant, kernel):
     from quantum_optimal_control.core import hip_engine
     # more than 4 dressed forbidden levels: the batch kernels' source recursion, NT = 2 kernels only
     undressed = not ('forbidden_coeff_list' in sp.reg_coeffs and sp.Vs is not None and len(sp.reg_coeffs['forbidden_coeff_list']) > 4)
-    latency_ok = sp.exp_terms >= 2 and ((sp.n <= 32 and sp.k <= 8) or (sp.n <= 48 and sp.k <= 4 and undressed) or (48 < sp.n <= 64 and undressed))
+    latency_ok = sp.exp_terms >= 2 and sp.k <= 8 and (sp.n <= 32 or (sp.n <= 64 and undressed))
     if kernel == 5 and not latency_ok:
         with pytest.raises(hip_engine.QocError, match='latency mode'):
             make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
