@@ -250,7 +250,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         if (!(skip & 4)) qoc_mfma_launch_forward(e->mf, d, e->stream);
         if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
         if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
-        if (!(skip & 8) && (!e->mf.latency || (e->mf.lat_sources && (!e->mf.lat_src_fast || e->mf.lat_dressed)))) launch_loss(d, e->stream);   // latency mode: inside the backward kernel
+        if (!(skip & 8) && (!e->mf.latency || (e->mf.lat_sources && !e->mf.lat_src_fast))) launch_loss(d, e->stream);   // latency mode: inside the backward kernel
         if (!(skip & 16)) {
             if (fused_tail) qoc_mfma_latency_gradient(e->mf, d, &ap, e->stream);
             else qoc_mfma_launch_backward(e->mf, d, e->stream);
@@ -295,7 +295,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
     e->final_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale are formed when read back
-    e->inter_stale = e->final_stale && (!e->mf.lat_sources || (e->mf.lat_src_fast && !e->mf.lat_dressed));   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
+    e->inter_stale = e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast);   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
     return QOC_OK;
 }
 

@@ -57,7 +57,7 @@ struct QocMfma {
     cplx* LamS = nullptr;         // [B][steps][NT * MQ][64] total costate c0 z Lambda0 + LambdaS when a state regulariser is present (k_mfma_sweep_src)
     cplx* AoffL = nullptr;        // [B][C][NT * MQ][64] / GoffL [B][NG][...]: chunk and group offsets of the source recursion, register layout
     cplx* GoffL = nullptr;
-    bool lat_dressed = false;     // lat_src_fast with dressed forbidden levels: k_loss (on the unpacked vectors) instead of k_mfma_loss_lat, sources from QocDev::Fd
+    bool lat_dressed = false;     // lat_src_fast with dressed forbidden levels (<= 4): amplitudes formed by k_mfma_loss_lat<NT, true>, sources from QocDev::Fd
     bool lat_src_fast = false;    // lat_sources on the thin affine sweeps (undressed forbidden levels / speed_up, NT = 2); else the batch kernels' recursion
     double* loss_part = nullptr;  // [B][steps + 1][2] per-time-point partials of k_mfma_loss_lat
     unsigned* lat_count = nullptr; // [B] workgroups of k_mfma_grad_lat that have finished (the last one runs the tail of the iteration)

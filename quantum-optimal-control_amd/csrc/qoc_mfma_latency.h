@@ -142,7 +142,9 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf
 // (tensorflow_state.py:282-333; speed_up uses every tau, regularization_functions.py:88-95) and the forbidden-level term
 // sum_f a_f/2 |psi_f|^4 (:71-85, undressed levels).  The last workgroup of a seed to finish (arrival counter) adds the per-tau
 // partials in a fixed order and publishes z, the loss, reg_state, su_resid.
-template <int NT>
+// DRESS (dressed forbidden levels, at most 4): the amplitudes phi_f[col] = <dressed level f | psi_col(tau)> are formed here -- a lane adds its
+// rows, a 16-lane butterfly the rest -- and 2 a_f |phi|^2 phi goes to QocDev::Fd for the source sweeps (k_dress_amplitudes's job on the other paths).
+template <int NT, bool DRESS = false>
 __global__ void __launch_bounds__(1024) k_mfma_loss_lat(QocDev d, QocMfma mf) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -157,18 +159,56 @@ __global__ void __launch_bounds__(1024) k_mfma_loss_lat(QocDev d, QocMfma mf) {
     if (tau < npts) {
         double zr = 0.0, zi = 0.0, fb = 0.0;
         const cplx* pl = mf.PsiL + ((size_t)b * d.steps + max(tau - 1, 0)) * per_vec + lane;
-        for (int g = 0; g < NT * MQs; ++g) {
-            const int I = g / MQs, jq = g - I * MQs, row = 16 * I + lc, col = 4 * jq + lk;
-            const bool inside = row < d.n && col < d.m;
-            cplx psi = pl[g * 64];
-            if (tau == 0) psi = inside ? d.V[row * d.m + col] : cmake(0.0, 0.0);
-            const cplx w = inside ? d.W[row * d.m + col] : cmake(0.0, 0.0);
-            zr += psi.x * w.x + psi.y * w.y;        // psi * conj(w)
-            zi += psi.y * w.x - psi.x * w.y;
-            double wf = 0.0;
-            for (int f = 0; f < d.n_forb; ++f) wf += (row == d.forb_state[f]) ? 0.5 * d.forb_a[f] : 0.0;
-            const double pop = inside ? psi.x * psi.x + psi.y * psi.y : 0.0;
-            fb += wf * pop * pop;
+        cplx phi[4][4];                                                           // DRESS: [level f][column quad jq], this lane's rows
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) phi[f][jq] = cmake(0.0, 0.0);
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            const int row = 16 * I + lc;
+            cplx vs[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) vs[f] = (DRESS && f < d.n_forb && row < d.n) ? d.Vs[row * d.n + d.forb_state[f]] : cmake(0.0, 0.0);
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                if (jq >= MQs) continue;
+                const int g = I * MQs + jq, col = 4 * jq + lk;
+                const bool inside = row < d.n && col < d.m;
+                cplx psi = pl[g * 64];
+                if (tau == 0) psi = inside ? d.V[row * d.m + col] : cmake(0.0, 0.0);
+                const cplx w = inside ? d.W[row * d.m + col] : cmake(0.0, 0.0);
+                zr += psi.x * w.x + psi.y * w.y;        // psi * conj(w)
+                zi += psi.y * w.x - psi.x * w.y;
+                if (DRESS) {
+                    if (inside) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) cfma_conj(phi[f][jq], vs[f], psi);
+                    }
+                } else {
+                    double wf = 0.0;
+                    for (int f = 0; f < d.n_forb; ++f) wf += (row == d.forb_state[f]) ? 0.5 * d.forb_a[f] : 0.0;
+                    const double pop = inside ? psi.x * psi.x + psi.y * psi.y : 0.0;
+                    fb += wf * pop * pop;
+                }
+            }
+        }
+        if (DRESS) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    if (jq >= MQs || f >= d.n_forb) continue;                    // (uniform)
+                    cplx v = phi[f][jq];
+                    v.x += dpp_xor<1>(v.x); v.y += dpp_xor<1>(v.y); v.x += dpp_xor<2>(v.x); v.y += dpp_xor<2>(v.y);
+                    v.x += dpp_xor<4>(v.x); v.y += dpp_xor<4>(v.y); v.x += dpp_xor<8>(v.x); v.y += dpp_xor<8>(v.y);
+                    const int col = 4 * jq + lk;
+                    if (lc == 0 && col < d.m) {
+                        const double pop = v.x * v.x + v.y * v.y;
+                        d.Fd[(((size_t)b * npts + tau) * d.n_forb + f) * d.m + col] = cscale(v, 2.0 * d.forb_a[f] * pop);
+                        fb += d.forb_a[f] * 0.5 * pop * pop;
+                    }
+                }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { zr += __shfl_xor(zr, off, 64); zi += __shfl_xor(zi, off, 64); fb += __shfl_xor(fb, off, 64); }

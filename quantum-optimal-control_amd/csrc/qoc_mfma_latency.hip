@@ -31,11 +31,12 @@ void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(192), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(128), 0, s, d, mf);
-    if (mf.lat_src_fast && !mf.lat_dressed) {                          // fidelity + state-regulariser values straight from PsiL (instead of unpack + k_loss)
+    if (mf.lat_src_fast) {                                             // fidelity + state-regulariser values straight from PsiL (instead of unpack + k_loss)
         const dim3 gl(d.B * ((d.steps + 1 + 15) / 16));
-        if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_loss_lat<4>, gl, dim3(1024), 0, s, d, mf);
-        else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_loss_lat<3>, gl, dim3(1024), 0, s, d, mf);
-        else hipLaunchKernelGGL(k_mfma_loss_lat<2>, gl, dim3(1024), 0, s, d, mf);
+#define QOC_LOSS(NTv) do { if (mf.lat_dressed) hipLaunchKernelGGL((k_mfma_loss_lat<NTv, true>), gl, dim3(1024), 0, s, d, mf); \
+                           else hipLaunchKernelGGL((k_mfma_loss_lat<NTv, false>), gl, dim3(1024), 0, s, d, mf); } while (0)
+        if (mf.NT == 4) QOC_LOSS(4); else if (mf.NT == 3) QOC_LOSS(3); else QOC_LOSS(2);
+#undef QOC_LOSS
     }
     else if (mf.lat_sources) qoc_mfma_unpack_inter(mf, d, s);         // k_loss, the sources and the batch backward kernels read d.inter
 }
