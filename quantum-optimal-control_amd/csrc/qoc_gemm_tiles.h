@@ -100,7 +100,9 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
         }
         __syncthreads();
         if (wv > 0) return;
-#pragma unroll
+        // one partial tile at a time: fully unrolled, hipcc issues the 32 (SK - 1) LDS reads of ALL partial tiles before the first add
+        // (SK = 8: 448 registers wanted, 988 B of scratch per lane -- on the thin chain steps of N > 64, which are nothing but latency)
+#pragma unroll 1
         for (int w = 1; w < SK; ++w) {
             const double* src = sk_part + (size_t)(w - 1) * 2048 + lane;
 #pragma unroll
