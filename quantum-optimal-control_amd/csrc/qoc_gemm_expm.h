@@ -10,7 +10,8 @@
 // the per-wave block of A stay in registers, and only K_t is written to HBM.  The launch-per-product route streams three
 // B*SP*N*N buffers through HBM per product (7-11 products); this kernel writes one.
 // Wave w owns tile row I = w / (N/32) and the tile-column pair Jp = w % (N/32) (2 tiles of 16x16, sharing the left operand).
-struct ExpmCoef { double c[24]; };
+#define QOC_GEMM_MAXT 48   // 1/j! tables of the GEMM path: Taylor orders up to 47
+struct ExpmCoef { double c[QOC_GEMM_MAXT]; };
 
 template <int N>
 __device__ __forceinline__ void lds_mm(const cplx* __restrict__ L, const cplx* __restrict__ R, int I, int Jp, int lane,

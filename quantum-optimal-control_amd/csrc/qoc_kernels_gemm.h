@@ -272,9 +272,9 @@ struct QocGemm {
 // Any state-transfer problem with n <= 64, m <= 8 can instead run "direct" (k_gemm_taylor_chain: the reference's own
 // mat-vec recursion, forward and backward, on pre-assembled generators; no time parallelism, so it is the large-batch mode).
 static inline bool qoc_gemm_direct_supported(const QocDev& d) { return d.state_transfer && d.n <= 64 && d.m <= 8 && d.T >= 1; }
-// the polynomial coefficient tables (ExpmCoef, invf[]) hold 1/j! for j < 24
+// the polynomial coefficient tables (ExpmCoef, invf[]) hold 1/j! for j < QOC_GEMM_MAXT (the MFMA path stops at T = 22: this path takes over)
 static inline bool qoc_gemm_supported(const QocDev& d, bool antiherm) {
-    return d.m <= QOC_TW && d.T >= 1 && d.T <= 23 && (!d.state_transfer || antiherm || qoc_gemm_direct_supported(d));
+    return d.m <= QOC_TW && d.T >= 1 && d.T <= QOC_GEMM_MAXT - 1 && (!d.state_transfer || antiherm || qoc_gemm_direct_supported(d));
 }
 static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
     for (int q = 0; q < count; ++q) {
@@ -452,7 +452,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     }
     if (N <= 64) {
         ExpmCoef cf;
-        { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
+        { double f = 1.0; for (int j = 0; j < QOC_GEMM_MAXT; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
         const size_t lds = 2 * (size_t)N * (N + 1) * sizeof(cplx);
         if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
         else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
@@ -465,8 +465,8 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.lda = g.ldb = g.ldc = g.lde = N; g.sA = g.sB = g.sC = g.sE = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.batch = (int)BS;
-    double invf[24];
-    { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; invf[j] = 1.0 / f; } }
+    double invf[QOC_GEMM_MAXT];
+    { double f = 1.0; for (int j = 0; j < QOC_GEMM_MAXT; ++j) { if (j > 0) f *= (double)j; invf[j] = 1.0 / f; } }
     const int mm = deg >> 1;
     const bool even = (deg & 1) == 0;
     const int horner = deg >= 2 ? (even ? mm - 1 : mm) : 0;      // products after A2

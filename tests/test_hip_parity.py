@@ -400,6 +400,23 @@ def test_auto_leaves_the_latency_mode_to_few_seeds():
         eng.close()
 
 
+def test_taylor_orders_beyond_the_mfma_path_stay_on_the_gemm_path():
+    """The MFMA path's coefficient table ends at Taylor order 22; orders up to 47 run on the GEMM path (fused exponential for N <= 64,
+    batched products above, the state-transfer routes) instead of falling through to the generic kernels (21.9 ms instead of 0.2 ms per
+    iteration for one C2-size trajectory with T = 24)."""
+    from quantum_optimal_control.core import hip_engine
+    rng = np.random.default_rng(8)
+    for c in (cases.case_c2(n=20, k=3, steps=15, m=6, taylor=(30, 1), seed=51), cases.case_c2(n=70, k=2, steps=9, m=4, taylor=(25, 2), seed=52),
+              cases.case_c3(n=24, k=2, steps=12, taylor=(31, 0))):
+        sp = oracle_system(c)
+        bases = [sp.base0, rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps)]
+        eng = make_engine(sp, n_seeds=len(bases))
+        assert eng.path == hip_engine.PATH_GEMM, eng.path
+        eng.set_base(np.stack(bases))
+        check_eval(eng, sp, bases)
+        eng.close()
+
+
 def test_row_tile_gradient_kernel_and_auto_for_large_n64_batches(monkeypatch):
     """Slice-parallel control gradients of the MFMA path (n > 32, or n <= 32 with k >= 6): the row-tile kernel k_mfma_grad_rt + the
     fixed-order sum of its NT partials against the one-wave-per-slice kernel it replaced (QOC_GRAD_RT=0) and against the oracle;
@@ -552,7 +569,8 @@ def edge_cases():
     out.append(('gemm_n65', cases.case_c2(n=65, k=2, steps=3, m=2, taylor=(3, 2), seed=36), 0))
     out.append(('gemm_k9', cases.case_c2(n=8, k=9, steps=4, m=3, taylor=(4, 1), seed=37), 0))
     out.append(('gemm_T23', cases.case_c2(n=40, k=1, steps=3, m=2, taylor=(23, 0), seed=38), 0))
-    out.append(('generic_T30', cases.case_c2(n=40, k=1, steps=3, m=2, taylor=(30, 1), seed=39), 0))
+    out.append(('gemm_T47', cases.case_c2(n=40, k=1, steps=3, m=2, taylor=(47, 1), seed=39), 0))
+    out.append(('generic_T50', cases.case_c2(n=40, k=1, steps=3, m=2, taylor=(50, 1), seed=39), 0))
     c = cases.case_state_small(); c['Taylor_terms'] = [9, 0]
     rng = np.random.default_rng(3)
     vs = [rng.normal(size=5) + 1j * rng.normal(size=5) for _ in range(10)]
@@ -584,7 +602,7 @@ def test_edge_cases_all_paths(name, c, path):
     sp = oracle_system(c)
     bases = [sp.base0, -1.5 * sp.base0 + 0.05]
     eng = make_engine(sp, n_seeds=2, path=path)
-    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'gemm_T23': 4, 'generic_T30': 1, 'st_m5_generic': 4, 'st_n65_generic': 4,
+    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'gemm_T23': 4, 'gemm_T47': 4, 'generic_T50': 1, 'st_m5_generic': 4, 'st_n65_generic': 4,
               'st_nonhermitian_fused': 4, 'st_nonhermitian_generic': 1, 'state_small_auto': 4}
     if name in expect:
         assert eng.path == expect[name], (name, eng.path)
