@@ -101,14 +101,19 @@ __global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restr
         d.inter[bb * (size_t)(d.steps + 1) * nm + e] = d.V[e];
     }
 }
-// copy the thin block of Y (columns N..N+31) into Psibnd[b][c]
-__global__ void __launch_bounds__(256) k_gemm_take_bnd(QocDev d, const cplx* __restrict__ Y, cplx* __restrict__ Psibnd, int N, int NC, int c, int xw) {
+// chunk-start vectors Psibnd[b][c], c = 1 .. NC-1, from the thin blocks (columns N..N+31) of the per-step results: Ys holds one
+// [B][N][ld] result per chunk step (slot c = the vectors at the START of chunk c), so the per-step products of N > 64 need no copy
+// launch between them (31 launches of ~8 us with their gaps per iteration at n = 128)
+__global__ void __launch_bounds__(256) k_gemm_take_bnd_all(QocDev d, const cplx* __restrict__ Ys, cplx* __restrict__ Psibnd, int N, int NC, int xw) {
     const int ld = xw + QOC_TW;
-    const size_t per = (size_t)N * QOC_TW;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * per; o += (size_t)gridDim.x * blockDim.x) {
-        const size_t bb = o / per, e = o - bb * per;
+    const size_t per = (size_t)N * QOC_TW, slot = (size_t)d.B * N * ld;
+    const size_t total = (size_t)d.B * (NC - 1) * per;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t bc = o / per, e = o - bc * per;
+        const size_t bb = bc / (NC - 1);
+        const int c = 1 + (int)(bc - bb * (NC - 1));
         const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
-        Psibnd[(bb * NC + c) * per + e] = Y[bb * (size_t)N * ld + (size_t)row * ld + xw + col];
+        Psibnd[(bb * NC + c) * per + e] = Ys[(size_t)c * slot + bb * (size_t)N * ld + (size_t)row * ld + xw + col];
     }
 }
 // inter[b][t+1] (API layout) from interP[b][t] (padded thin), t < steps
@@ -325,8 +330,9 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
               al((void**)&gm.K, gm.direct ? 16 : BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
               al((void**)&gm.KT, (gm.persistent && !gm.direct) ? BSP * NN * sizeof(cplx) : 16) &&
               al((void**)&gm.PcT, (gm.persistent && !gm.direct && L > 0) ? (size_t)d.B * gm.NC * NN * sizeof(cplx) : 16) &&
-              al((void**)&gm.Y0, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
-              al((void**)&gm.Y1, (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
+              // (per-step boundary products, N > 64 or m > 8: one result slot per chunk step, read back by ONE k_gemm_take_bnd_all)
+              al((void**)&gm.Y0, (size_t)(gm.persistent ? 1 : gm.NC + 1) * d.B * N * (N + QOC_TW) * sizeof(cplx)) &&
+              al((void**)&gm.Y1, gm.persistent ? (size_t)d.B * N * (N + QOC_TW) * sizeof(cplx) : 16) &&
               al((void**)&gm.interP, BSP * thin * sizeof(cplx)) && al((void**)&gm.LamP, BSP * thin * sizeof(cplx)) &&
               al((void**)&gm.Psibnd, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
               al((void**)&gm.Ebnd, (size_t)d.B * gm.NC * thin * sizeof(cplx)) &&
@@ -590,15 +596,14 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
     memset(&g, 0, sizeof g);
     g.lda = N; g.sA = (long long)NN * NC; g.ldb = g.ldc = ld; g.sB = g.sC = (long long)N * ld;
     g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = ld / 32; g.batch = d.B; g.alpha = 1.0;
-    cplx *cur = gm.Y0, *oth = gm.Y1;
+    const size_t yslot = (size_t)d.B * N * ld;
     for (int c = 0; c < (gm.persistent ? 0 : NC); ++c) {
-        g.A = Pc + (size_t)c * NN; g.Bm = cur; g.C = oth;
+        g.A = Pc + (size_t)c * NN; g.Bm = gm.Y0 + (size_t)c * yslot; g.C = gm.Y0 + (size_t)(c + 1) * yslot;
         qoc_gemm_launch(false, 0, g, s);
-        if (c + 1 < NC)
-            hipLaunchKernelGGL(k_gemm_take_bnd, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, oth, gm.Psibnd, N, NC, c + 1, xw);
-        cplx* x = cur; cur = oth; oth = x;
     }
-    if (!d.state_transfer && !gm.persistent) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, cur, N);
+    if (!gm.persistent && NC > 1)
+        hipLaunchKernelGGL(k_gemm_take_bnd_all, dim3(gemm_grid((size_t)d.B * (NC - 1) * thin)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
+    if (!d.state_transfer && !gm.persistent) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(256), 0, s, d, gm.Y0 + (size_t)NC * yslot, N);
     if (gm.persistent) {
         // every chunk swept by its own persistent workgroup: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}
         ChainArgs a;
