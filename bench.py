@@ -78,6 +78,16 @@ def oracle_problem():
                            Taylor_terms=c['Taylor_terms'])
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(budget_s=15.0):
     """CPU oracle timed on a bounded sample of the same workload: whole iterations (evaluate + Adam) of one seed per
     thread, all host threads busy (seeds are the parallel axis on the CPU too).  Compiled C port (oracle/qoc_oracle.c)
@@ -98,7 +108,7 @@ def cpu_baseline(budget_s=15.0):
                 'sample': '%d iterations x %d seeds (one seed per thread, OpenMP) of the same C2 workload in %.1f s; '
                           'compiled C restatement oracle/qoc_oracle.c, one evaluation per iteration, fp64 complex; '
                           'host has %d logical CPUs' % (iters, threads, el, os.cpu_count()),
-                'per_thread_value': iters / el}
+                'per_thread_value': iters / el, 'cpu_model': cpu_model(), 'logical_cpus': os.cpu_count()}
     except OSError:
         pass
     from oracle import grape_oracle as go
@@ -119,15 +129,32 @@ def cpu_baseline(budget_s=15.0):
         if time.perf_counter() - t0 > budget_s or its >= 200:
             break
     el = time.perf_counter() - t0
-    return {'value': its / el, 'unit': 'GRAPE iterations/s', 'cores': 1, 'kind': 'port',
+    return {'value': its / el, 'unit': 'GRAPE iterations/s', 'cores': 1, 'kind': 'port', 'cpu_model': cpu_model(), 'logical_cpus': os.cpu_count(),
             'sample': '%d iterations of 1 seed of the same C2 workload in %.1f s (NumPy complex128 oracle, BLAS limited '
                       'to one thread)' % (its, el)}
+
+
+def _reference_ops_worker(args):
+    """One process of the all-core B-faithful leg: `evals` fp32 real-embedded graph evaluations of its own seed on `threads` threads."""
+    seed, evals, threads = args
+    import torch
+    from oracle import tf_graph_emulation as tfe
+    torch.set_num_threads(threads)
+    sp = oracle_problem()
+    base = seed_bases(seed, 1)[0]
+    tfe.evaluate_graph(sp, base, dtype=torch.float32)               # warm-up
+    t0 = time.perf_counter()
+    for _ in range(evals):
+        tfe.evaluate_graph(sp, base, dtype=torch.float32)
+    return time.perf_counter() - t0
 
 
 def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
     """BASELINE.md "B-faithful": the reference's own op sequence -- real-embedded 2n x 2n float32 matrices, one Defun per
     slice with recompute inside the gradient function, TWO graph evaluations per iteration (run_session.py:53-54, 69) --
-    emulated node for node in torch-CPU (oracle/tf_graph_emulation.py).  Not TensorFlow (absent)."""
+    emulated node for node in torch-CPU (oracle/tf_graph_emulation.py).  Not TensorFlow (absent).
+    Two readings: ONE control set on 16 threads (what a Grape() call of the reference occupies: 64 x 64 matmuls do not scale
+    further), and ALL cores busy with one control set per 4-thread process (the throughput reading, comparable with `value`)."""
     import torch
     from oracle import tf_graph_emulation as tfe
     sp = oracle_problem()
@@ -140,9 +167,34 @@ def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
         tfe.evaluate_graph(sp, base, dtype=torch.float32)
         evals += 1
     el = time.perf_counter() - t0
-    return {'value': evals / el / 2.0, 'unit': 'GRAPE iterations/s', 'cores': int(torch.get_num_threads()),
-            'kind': 'port', 'sample': '%d fp32 real-embedded graph evaluations (fwd + custom-gradient bwd) of 1 seed of C2 in '
-                                      '%.1f s; 2 evaluations per reference iteration; torch-CPU emulation of the TF graph' % (evals, el)}
+    out = {'value': evals / el / 2.0, 'unit': 'GRAPE iterations/s', 'cores': int(torch.get_num_threads()), 'cpu_model': cpu_model(),
+           'kind': 'port', 'sample': '%d fp32 real-embedded graph evaluations (fwd + custom-gradient bwd) of 1 seed of C2 in '
+                                     '%.1f s; 2 evaluations per reference iteration; torch-CPU emulation of the TF graph' % (evals, el)}
+    try:                                                            # all cores: one control set per process of 4 threads
+        per = 4
+        procs = max(1, min(64, (os.cpu_count() or 4) // per))
+        w_evals = max(2, min(max_evals, int(budget_s / max(el / max(evals, 1), 1e-3) / 2)))
+        t0 = time.perf_counter()
+        kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--reference-ops-worker', '%d,%d,%d' % (i, w_evals, per)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
+        times, deadline = [], time.time() + 120.0                  # own processes, own PIDs: a straggler is killed, never waited for
+        for kid in kids:
+            try:
+                so, _ = kid.communicate(timeout=max(1.0, deadline - time.time()))
+                times.append(float(so.strip().splitlines()[-1]))
+            except Exception:
+                kid.kill()
+                kid.communicate()
+        wall = time.perf_counter() - t0
+        if len(times) < procs:
+            raise RuntimeError('%d of %d worker processes did not finish' % (procs - len(times), procs))
+        busy = max(times)
+        out['all_cores'] = {'value': procs * w_evals / busy / 2.0, 'unit': 'GRAPE iterations/s', 'cores': procs * per, 'processes': procs,
+                            'sample': '%d processes x %d threads, %d evaluations each of their own control set; slowest process %.1f s '
+                                      '(%.1f s with start-up)' % (procs, per, w_evals, busy, wall)}
+    except Exception as exc:
+        out['all_cores'] = {'error': repr(exc)}
+    return out
 
 
 def spawn_ranks(n):
@@ -198,7 +250,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-single', action='store_true', help='skip the one-trajectory latency measurement')
     ap.add_argument('--groups', type=int, default=1, help='split the seeds of this GPU over G engines/streams')
+    ap.add_argument('--reference-ops-worker', default=None, help=argparse.SUPPRESS)   # internal: one process of the all-core B-faithful CPU leg
     args = ap.parse_args()
+    if args.reference_ops_worker:
+        print(_reference_ops_worker(tuple(int(x) for x in args.reference_ops_worker.split(','))), flush=True)
+        return
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -302,7 +358,8 @@ def main():
             traffic = None
         roof = {'bound': 'mfma', 'kernel': pr['kernel'], 'achieved': ach_exec, 'peak': FP64_MATRIX_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': ach_exec / FP64_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
-                'traffic_unit': 'bytes/launch (rocprofv3 PMC pass of this command, profiles/r02_pmc_traffic.txt)',
+                'traffic_unit': 'bytes/launch',
+                'traffic_source': 'committed profile %s (rocprofv3 PMC pass of this command; NOT measured in this run)' % os.path.relpath(PMC_TRAFFIC_FILE, ROOT),
                 'avg_launch_ms': avg_ms, 'launches': pr['launches'],
                 'flops_per_launch': flops_exec, 'products_per_slice_executed': n_prod,
                 'counting': 'achieved/frac = EXECUTED MFMA flops (%d Paterson-Stockmeyer products per slice x 6 n^3: 3 real '
@@ -339,6 +396,9 @@ def main():
                        'stream_groups': G, 'ranks_seen': world, 'fidelities_gathered': int(fidelity.shape[0]),
                        'transport': (comm.library if comm.library.startswith('files') else 'rccl (%s)' % comm.library) if comm is not None
                        else ('gloo (test hook)' if gloo is not None else 'single process'),
+                       # an RCCL run that fell back to files must not look like an RCCL result: both keys say so explicitly
+                       'transport_fallback': bool(comm is not None and comm.library.startswith('files')),
+                       'rccl_error': getattr(comm, 'fallback_reason', None) if comm is not None else None,
                        'parallelism': 'seed-sharded x%d, one all-gather of final fidelities, no collective inside the iterations' % world},
             'per_seed_iterations_per_s': args.steps / elapsed,
             'single_trajectory': single,

@@ -166,6 +166,10 @@ int qoc_time_iterations(qoc_handle h, const qoc_adam_params* p, int32_t iters, d
 typedef struct qoc_comm* qoc_comm_handle;
 #define QOC_COMM_ID_BYTES 128
 int qoc_comm_unique_id(void* id128);
+/* The local preconditions of qoc_comm_create (librccl loadable, device index valid, a stream can be made on it), no collective:
+ * every rank checks them and the ranks agree on the outcome BEFORE anybody enters ncclCommInitRank, which would otherwise
+ * wait forever for a rank that failed earlier. */
+int qoc_comm_probe(int32_t device);
 int qoc_comm_create(const void* id128, int32_t world, int32_t rank, int32_t device, qoc_comm_handle* out);
 int qoc_comm_destroy(qoc_comm_handle c);
 int qoc_comm_world(qoc_comm_handle c);

@@ -119,6 +119,21 @@ int qoc_comm_unique_id(void* id128) {
     return QOC_OK;
 }
 
+/* the local preconditions of qoc_comm_create, without any collective: librccl loadable, device index valid, device usable.  Every
+ * rank checks them BEFORE anybody enters ncclCommInitRank (a rank that failed here would leave the others blocked in it). */
+int qoc_comm_probe(int32_t device) {
+    std::string err;
+    if (qoc_rccl::load(err)) return fail(QOC_ERR_HIP, "qoc_comm_probe: %s", err.c_str());
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(QOC_ERR_HIP, "qoc_comm_probe: no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(QOC_ERR_INVALID, "qoc_comm_probe: device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(QOC_ERR_HIP, "qoc_comm_probe: hipStreamCreate failed on device %d", device);
+    hipStreamDestroy(st);
+    return QOC_OK;
+}
+
 int qoc_comm_create(const void* id128, int32_t world, int32_t rank, int32_t device, qoc_comm_handle* out) {
     if (!id128 || !out) return fail(QOC_ERR_INVALID, "qoc_comm_create: null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(QOC_ERR_INVALID, "qoc_comm_create: rank %d of world %d", rank, world);
@@ -171,6 +186,7 @@ int qoc_comm_all_gather_scalar(qoc_comm_handle c, qoc_handle e, int32_t which, i
     if (width < d.B) return fail(QOC_ERR_INVALID, "qoc_comm_all_gather_scalar: width %d < n_seeds %d", width, d.B);
     const double* src = which == 0 ? d.loss : which == 1 ? d.reg_loss : which == 2 ? d.g2 : which == 3 ? d.uscale : nullptr;
     if (!src) return fail(QOC_ERR_INVALID, "qoc_comm_all_gather_scalar: unknown scalar %d", which);
+    if (which == 3) TRY(refresh_final(e));          // latency mode forms unitary_scale only on read-back (as qoc_get_scalars does)
     TRY(comm_stage(c, (size_t)width * (1 + c->world)));
     double* send = c->stage;
     double* recv = c->stage + width;

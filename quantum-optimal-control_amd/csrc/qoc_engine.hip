@@ -513,7 +513,10 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
-    if (const char* sk = getenv("QOC_DEBUG_SKIP")) e->skip_mask = atoi(sk);   // wall-clock attribution of one kernel group (results are garbage)
+    if (const char* sk = getenv("QOC_DEBUG_SKIP")) {                          // wall-clock attribution of one kernel group (results are garbage)
+        e->skip_mask = atoi(sk);
+        if (e->skip_mask) fprintf(stderr, "libqoc_hip: WARNING: QOC_DEBUG_SKIP=%d is set -- kernel groups are skipped or repeated, every result of this engine is garbage (timing experiments only)\n", e->skip_mask);
+    }
     if (path == QOC_PATH_MFMA) {
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;

@@ -10,8 +10,6 @@ import os
 
 import numpy as np
 
-# the host driver shares device memory between processes through dmabuf only: RCCL's hipIpcGetMemHandle needs this before HIP starts
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QOC_HIP_LIBRARY') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libqoc_hip.so'))   # override: A/B builds
 
@@ -61,6 +59,7 @@ _SIGNATURES = {
     'qoc_path_in_use': (C.c_int, [C.c_void_p]),
     'qoc_chunks_in_use': (C.c_int, [C.c_void_p]),
     'qoc_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'qoc_comm_probe': (C.c_int, [C.c_int32]),
     'qoc_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'qoc_comm_destroy': (C.c_int, [C.c_void_p]),
     'qoc_comm_world': (C.c_int, [C.c_void_p]),
@@ -155,6 +154,11 @@ def comm_unique_id():
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _check(load_library().qoc_comm_unique_id(buf))
     return buf.raw
+
+
+def comm_probe(device=0):
+    """Local preconditions of QocComm (librccl loadable, device usable); raises QocError with the reason.  No collective."""
+    _check(load_library().qoc_comm_probe(int(device)))
 
 
 class QocComm(object):

@@ -35,7 +35,7 @@ def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=300.
     if key is None:
         key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
     directory = directory or os.environ.get('QOC_RDZV_DIR', '/tmp')
-    path = os.path.join(directory, 'qoc_rdzv_%s' % key)
+    path = os.path.join(directory, 'qoc_rdzv_%d_%s' % (os.getuid(), key))
     if rank == 0:
         payload = make_payload()
         tmp = '%s.%d.tmp' % (path, os.getpid())
@@ -65,12 +65,24 @@ def rendezvous_cleanup(rank, world, key=None, directory=None):
         key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
     directory = directory or os.environ.get('QOC_RDZV_DIR', '/tmp')
     try:
-        os.remove(os.path.join(directory, 'qoc_rdzv_%s' % key))
+        os.remove(os.path.join(directory, 'qoc_rdzv_%d_%s' % (os.getuid(), key)))
     except OSError:
         pass
 
 
 _NO_RCCL = b'NO_RCCL:'
+_OPEN_CALLS = 0          # open_comm calls of this process: every call of one launch gets its own FileComm directory
+
+
+def _private_dir(path):
+    """Directory only this user can write (0700), created if missing; a directory somebody else planted is refused."""
+    try:
+        os.makedirs(path, mode=0o700)
+    except FileExistsError:
+        pass
+    st = os.stat(path)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise PermissionError('%s exists and is not a private directory of uid %d' % (path, os.getuid()))
 
 
 class FileComm(object):
@@ -84,8 +96,8 @@ class FileComm(object):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         self.device = int(os.environ.get('LOCAL_RANK', 0))        # GrapeSharded reads the GPU of this rank from its communicator
         self.library = 'files (host)' + ((': ' + reason) if reason else '')
-        self._dir = os.path.join(directory or os.environ.get('QOC_RDZV_DIR', '/tmp'), 'qoc_fc_%s' % key)
-        os.makedirs(self._dir, exist_ok=True)
+        self._dir = os.path.join(directory or os.environ.get('QOC_RDZV_DIR', '/tmp'), 'qoc_fc_%d_%s' % (os.getuid(), key))
+        _private_dir(self._dir)
         self._seq = 0
 
     def _path(self, seq, rank):
@@ -159,10 +171,19 @@ class FileComm(object):
 
 
 def open_comm(rank=None, world=None, device=None, key=None):
-    """Communicator for this rank (None for a single process): RCCL behind the C ABI (hip_engine.QocComm), or -- when rank 0
-    cannot open RCCL, or QOC_TRANSPORT=file -- the file transport above (FileComm, same interface).  Collective: every rank
-    of the launch calls it; the choice is made by rank 0 and travels with the rendezvous payload."""
+    """Communicator for this rank (None for a single process): RCCL behind the C ABI (hip_engine.QocComm), or -- when some rank
+    cannot use RCCL, or QOC_TRANSPORT=file -- the file transport above (FileComm, same interface), with a warning on stderr and
+    `comm.fallback_reason` set.  Collective: every rank of the launch calls it.
+
+    Order of events (a rank must never wait inside ncclCommInitRank for a rank that failed before reaching it):
+      1. every rank checks its LOCAL preconditions (librccl loadable, device usable: hip_engine.comm_probe) -- no collective;
+      2. the ranks agree on the outcome through the file transport; one failure sends everybody to it;
+      3. rank 0 creates the RCCL id and hands it out through the same transport; every rank enters ncclCommInitRank;
+      4. the ranks agree again (the initialisation itself may fail on some rank: IPC handles, device binding)."""
+    global _OPEN_CALLS
     from quantum_optimal_control.core import hip_engine
+    # the host driver shares device memory between processes through dmabuf only: RCCL's hipIpcGetMemHandle needs this before HIP starts
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     erank, elocal, eworld = launch_env()
     rank = erank if rank is None else rank
     world = eworld if world is None else world
@@ -171,42 +192,73 @@ def open_comm(rank=None, world=None, device=None, key=None):
         return None
     if key is None:
         key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+    call, _OPEN_CALLS = _OPEN_CALLS, _OPEN_CALLS + 1
+    files = FileComm(rank, world, '%s_c%d' % (key, call))
+    files.fallback_reason = None
 
-    def payload():
-        if os.environ.get('QOC_TRANSPORT', 'rccl') == 'file':
-            return _NO_RCCL + b'QOC_TRANSPORT=file'
-        try:
-            return hip_engine.comm_unique_id()
-        except Exception as exc:                    # no librccl, PyTorch's private HIP runtime, ...
-            return _NO_RCCL + str(exc).encode()[:400]
+    def fall_back(reason):
+        files.library = 'files (host): ' + reason
+        files.fallback_reason = reason
+        if rank == 0 and os.environ.get('QOC_TRANSPORT', 'rccl') != 'file':
+            import sys
+            sys.stderr.write('quantum_optimal_control.parallel_seeds: WARNING: RCCL is NOT in use, the ranks exchange their results '
+                             'through files (%s)\n' % reason)
+        return files
 
-    uid = rendezvous(rank, world, payload, key=key)
-    if uid.startswith(_NO_RCCL):
-        comm = FileComm(rank, world, key, reason=uid[len(_NO_RCCL):].decode(errors='replace'))
+    # 1 + 2: local checks, then agreement
+    why = ''
+    if os.environ.get('QOC_TRANSPORT', 'rccl') == 'file':
+        why = 'QOC_TRANSPORT=file'
     else:
-        # ncclCommInitRank may still fail on SOME rank (device binding, IPC handles ...): the ranks agree through the file transport,
-        # and one failure sends all of them to it -- a job whose only traffic is one gather of fidelities must not die of that
-        files = FileComm(rank, world, key)
-        comm, why = None, ''
         try:
-            comm = hip_engine.QocComm(uid, world, rank, device)
+            hip_engine.comm_probe(device)
+        except Exception as exc:                    # no librccl, PyTorch's private HIP runtime, bad device index ...
+            why = str(exc)[:400]
+    ok = files.all_gather([0.0 if why else 1.0]).reshape(-1)
+    if not np.all(ok > 0.5):
+        bad = [int(r) for r in np.nonzero(ok <= 0.5)[0]]
+        return fall_back(why if (why and len(bad) == world) else 'RCCL unusable on rank(s) %s%s' % (bad, ('; rank %d: %s' % (rank, why)) if why else ''))
+    # 3: the id (128 bytes travel as 128 small floats; a failure to create it is announced with a NaN)
+    uid_row = np.full(hip_engine.COMM_ID_BYTES, np.nan)
+    if rank == 0:
+        try:
+            uid_row = np.frombuffer(hip_engine.comm_unique_id(), dtype=np.uint8).astype(np.float64)
         except Exception as exc:
-            why = 'rank %d: %s' % (rank, exc)
-        ok = files.all_gather([1.0 if comm is not None else 0.0])
-        if np.all(ok > 0.5):
-            files.close()
-        else:
-            bad = [int(r) for r in np.nonzero(ok.reshape(-1) <= 0.5)[0]]
-            if comm is not None:
-                try:
-                    comm.close()
-                except Exception:
-                    pass
-            files.library = 'files (host): RCCL initialisation failed on rank(s) %s%s' % (bad, ('; ' + why) if why else '')
-            comm = files
-    comm.barrier()                                  # every rank holds the payload: the file can go
-    rendezvous_cleanup(rank, world, key=key)
-    return comm
+            why = str(exc)[:400]
+    uid_row = files.broadcast(uid_row, 0)
+    if np.any(np.isnan(uid_row)):
+        return fall_back('rank 0 could not create the RCCL id' + (': ' + why if why else ''))
+    uid = uid_row.astype(np.uint8).tobytes()
+    comm = None
+    try:
+        comm = hip_engine.QocComm(uid, world, rank, device)
+    except Exception as exc:
+        why = 'rank %d: %s' % (rank, exc)
+    # 4
+    ok = files.all_gather([1.0 if comm is not None else 0.0]).reshape(-1)
+    if np.all(ok > 0.5):
+        files.close()
+        comm.fallback_reason = None
+        comm.barrier()
+        return comm
+    bad = [int(r) for r in np.nonzero(ok <= 0.5)[0]]
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:
+            pass
+    return fall_back('RCCL initialisation failed on rank(s) %s%s' % (bad, ('; ' + why) if why else ''))
+
+
+def _dist_device(dist):
+    """Where the tensors of a `dist=` exchange live: the current GPU for the nccl (= RCCL) backend, the host otherwise (gloo)."""
+    import torch
+    try:
+        if dist.get_backend() == 'nccl':
+            return torch.device('cuda', torch.cuda.current_device())
+    except Exception:
+        pass
+    return torch.device('cpu')
 
 
 class SeedShard(object):
@@ -236,11 +288,13 @@ class SeedShard(object):
             buf[:self.count] = local_values
             return self._rows_to_global(comm.all_gather(buf))
         import torch
+        dev = _dist_device(dist)
         buf = torch.zeros(width, dtype=torch.float64)
         buf[:self.count] = torch.from_numpy(local_values)
-        out = [torch.zeros(width, dtype=torch.float64) for _ in range(self.world)]
+        buf = buf.to(dev)
+        out = [torch.zeros(width, dtype=torch.float64, device=dev) for _ in range(self.world)]
         dist.all_gather(out, buf)
-        return self._rows_to_global([o.numpy() for o in out])
+        return self._rows_to_global([o.cpu().numpy() for o in out])
 
     def all_gather_engine_scalar(self, engine, which, comm):
         """The same gather straight from the engine's device array `which` (hip_engine.SCALAR_*), device to device on
@@ -268,9 +322,9 @@ class SeedShard(object):
         if comm is not None:
             return comm.broadcast(mine, owner).reshape(shape)
         import torch
-        t = torch.from_numpy(mine.copy())
+        t = torch.from_numpy(mine.copy()).to(_dist_device(dist))
         dist.broadcast(t, src=owner)
-        return t.numpy()
+        return t.cpu().numpy()
 
 
 def restart_guesses(k, steps, first_seed, count, base_seed=1000):

@@ -1,0 +1,81 @@
+"""Oracle parity at the EXACT configuration bench.py times ("Next round" 1).
+
+bench.py resolves C2 x 64 seeds per GPU to path = MFMA, the streamed-image exponential kernel and 16 chunks of 32 slices; the other
+full-size tests use 2 seeds (63 chunks of 8) or compare HIP batches with each other.  Here the 64-seed batch itself is compared with
+the oracle (core/tensorflow_state.py:204-242,323-356; core/run_session.py:47-69) for seeds {0, 31, 63}: one evaluation (loss, U_final,
+gradient) and three iterations of the device loop.  The expected values are committed fixtures (tests/golden/make_bench_golden.py),
+so the test costs no CPU seconds on the GPU box.  The same for ONE control set with dwdt + forbidden levels (AUTO = latency mode).
+"""
+import numpy as np
+import pytest
+
+import bench
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+L_ATOL = 1e-11          # loss, scalars
+U_ATOL = 1e-11          # U_final entries (|entries| <= 1)
+G_RTOL = 1e-10          # gradient, relative to max |g|
+
+
+def bench_engine(n_seeds, reg=None, **kw):
+    from quantum_optimal_control.core import hip_engine
+    c, Hs, U0, V, W, dt = bench.build_problem()
+    return hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], bench.SLICES, bench.TAYLOR[0], bench.TAYLOR[1],
+                                reg_coeffs=reg or {}, n_seeds=n_seeds, **kw)
+
+
+def compare_evaluation(eng, r, g, rows):
+    Uf = eng.get_final_unitary()
+    for i, b in enumerate(rows):
+        for key in ('loss', 'reg_loss', 'grad_squared', 'unitary_scale'):
+            assert abs(r[key][b] - g[key][i]) <= L_ATOL * max(1.0, abs(g[key][i])), (key, b, r[key][b], g[key][i])
+        gmax = np.max(np.abs(g['grad'][i]))
+        assert np.max(np.abs(r['grad'][b] - g['grad'][i])) <= G_RTOL * gmax, (b, np.max(np.abs(r['grad'][b] - g['grad'][i])), gmax)
+        np.testing.assert_allclose(Uf[b], g['U_final'][i], rtol=0, atol=U_ATOL)
+
+
+def compare_three_iterations(eng, g, rows):
+    its = eng.run_adam(eng.adam_params(rate=0.01, learning_rate_decay=2500, conv_target=1e-8, min_grad=1e-25, max_iterations=3, poll_every=3))
+    assert np.all(its == 3)
+    base, sc, Uf = eng.get_base(), eng.scalars(), eng.get_final_unitary()
+    for i, b in enumerate(rows):
+        np.testing.assert_allclose(base[b], g['adam_base'][i], rtol=0, atol=1e-10)
+        assert abs(sc['loss'][b] - g['adam_loss'][i]) <= 1e-10
+        np.testing.assert_allclose(Uf[b], g['adam_U_final'][i], rtol=0, atol=1e-10)
+
+
+def test_bench_batch_configuration_against_the_oracle():
+    g = load_golden('c2_bench_batch.npz')
+    seeds = [int(s) for s in g['seeds']]
+    eng = bench_engine(bench.SEEDS_PER_GPU)
+    # what `python bench.py` resolves to: MFMA path, 16 chunks of 32 slices, the streamed-image kernel of the exponentials
+    assert (eng.path, eng.chunks) == (2, 16)
+    bases = bench.seed_bases(0, bench.SEEDS_PER_GPU)
+    eng.set_base(bases)
+    eng.profile_enable(True)
+    r = eng.evaluate()
+    assert 'k_mfma_expm_chunk' in eng.profile_read()['kernel']
+    eng.profile_enable(False)
+    compare_evaluation(eng, r, g, seeds)
+    eng.set_base(bases)
+    compare_three_iterations(eng, g, seeds)
+    eng.close()
+
+
+def test_single_control_set_with_regularisers_against_the_oracle():
+    from tests.golden.make_bench_golden import LAT_REG
+    g = load_golden('c2_bench_single_regularised.npz')
+    eng = bench_engine(1, reg=LAT_REG)
+    assert eng.path == 2
+    base = bench.seed_bases(0, 1)
+    eng.set_base(base)
+    eng.profile_enable(True)
+    r = eng.evaluate()
+    assert 'slice2' in eng.profile_read()['kernel']           # AUTO = latency mode
+    eng.profile_enable(False)
+    compare_evaluation(eng, r, g, [0])
+    eng.set_base(base)
+    compare_three_iterations(eng, g, [0])
+    eng.close()

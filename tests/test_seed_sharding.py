@@ -186,6 +186,7 @@ def _failing_init_worker(rank, world, key, directory, out, bad=1):
         library = 'fake rccl'
 
         def __init__(self, uid, world_, rank_, device):
+            assert uid == bytes(range(7, 7 + hip_engine.COMM_ID_BYTES))      # the id rank 0 made reached this rank unchanged
             if rank_ == bad:
                 raise hip_engine.QocError('ncclCommInitRank: unhandled system error')
 
@@ -198,10 +199,15 @@ def _failing_init_worker(rank, world, key, directory, out, bad=1):
         def all_gather(self, values):
             return np.tile(np.asarray(values, dtype=np.float64), (world, 1))
 
-    hip_engine.comm_unique_id = lambda: b'u' * hip_engine.COMM_ID_BYTES
+    def probe(device):                                       # bad <= -2: rank -bad - 2 fails BEFORE the collective (no librccl, bad device index)
+        if bad <= -2 and rank == -bad - 2:
+            raise hip_engine.QocError('qoc_comm_probe: librccl not loadable')
+
+    hip_engine.comm_probe = probe
+    hip_engine.comm_unique_id = lambda: bytes(range(7, 7 + hip_engine.COMM_ID_BYTES))
     hip_engine.QocComm = FakeComm
     comm = parallel_seeds.open_comm(rank=rank, world=world, device=0, key=key)
-    res = dict(kind=type(comm).__name__, library=comm.library, closed=FakeComm.closed,
+    res = dict(kind=type(comm).__name__, library=comm.library, closed=FakeComm.closed, reason=comm.fallback_reason,
                gather=comm.all_gather([float(rank)]).reshape(-1))
     comm.close()
     out.put((rank, res))
@@ -234,7 +240,21 @@ def test_rccl_init_failure_on_one_rank_sends_every_rank_to_the_file_transport(tm
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert all(got[r]['kind'] == 'FakeComm' for r in range(world))
+    assert all(got[r]['kind'] == 'FakeComm' and got[r]['reason'] is None for r in range(world))
+    assert os.listdir(str(tmp_path)) == []
+    # a rank that fails BEFORE ncclCommInitRank (librccl not loadable, bad device) must not leave the others waiting
+    # inside it: the local checks are agreed on first, nobody creates a communicator, everybody takes the file transport
+    procs = [ctx.Process(target=_failing_init_worker, args=(r, world, 'early_%d' % os.getpid(), str(tmp_path), out, -4)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r]['kind'] == 'FileComm' and 'rank(s) [2]' in got[r]['library'] and got[r]['reason'], got[r]
+        assert got[r]['closed'] is False
+        np.testing.assert_array_equal(got[r]['gather'], [0.0, 1.0, 2.0])
     assert os.listdir(str(tmp_path)) == []
 
 
@@ -292,3 +312,25 @@ def test_bench_gpus2_without_a_launcher_starts_two_ranks():
     assert len(lines) == 1, r.stdout[-1500:]
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['config']['ranks_seen'] == 2 and j['config']['fidelities_gathered'] == 16
+
+
+@pytest.mark.gpu
+def test_bench_gpus8_rank_bookkeeping_on_one_gpu():
+    """VERDICT r2 #6c: the 8-rank bench line before an 8-GPU node exists -- eight self-started ranks share GPU 0 (same-device hook)
+    and exchange through the file transport: 8 ranks seen, 8 x 64 = 512 fidelities gathered in global seed order (bench.py asserts
+    the local block), and the line says in so many words that RCCL was NOT what gathered them."""
+    import json
+    import subprocess
+    env = dict(os.environ, QOC_TRANSPORT='file', QOC_BENCH_SAME_DEVICE='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'QOC_BENCH_BACKEND'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-single'], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1500:]
+    j = json.loads(lines[0])
+    cfg = j['config']
+    assert j['n_gpus'] == 8 and cfg['ranks_seen'] == 8 and cfg['fidelities_gathered'] == 512 and cfg['total_seeds'] == 512
+    assert cfg['transport'].startswith('files') and cfg['transport_fallback'] is True and cfg['rccl_error'] == 'QOC_TRANSPORT=file'
+    assert cfg['chunks'] == 16 and cfg['path'] == 2                      # every rank runs the single-GPU bench configuration
