@@ -173,7 +173,7 @@ def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
     try:                                                            # all cores: one control set per process of 4 threads
         per = 4
         procs = max(1, min(64, (os.cpu_count() or 4) // per))
-        w_evals = max(2, min(max_evals, int(budget_s / max(el / max(evals, 1), 1e-3) / 2)))
+        w_evals = 2                                                 # 64 processes x 4 threads share the memory system: ~5 s per evaluation each
         t0 = time.perf_counter()
         kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--reference-ops-worker', '%d,%d,%d' % (i, w_evals, per)],
                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]

@@ -66,14 +66,16 @@ typedef struct qoc_config {
     int32_t variant;            /* MFMA path, kernel family: 0 = auto, 1 = v_mfma_f64_16x16x4 everywhere (exponentials by one wave per
                                  * 16-column block of a chunk, one-wave sweeps), 2 = v_mfma_f64_4x4x4 exponentials by one wave per
                                  * 16-column block, 3 = v_mfma_f64_4x4x4 exponentials by one wave per chunk (n <= 32; n > 32: same
-                                 * as 2), 4 = as 3 with the left-operand image written under the product's own MFMAs (auto for
-                                 * n <= 32 batches), 5 = latency mode (n <= 64; n <= 16 is padded to 32; auto
+                                 * as 2), 4 = as 3 with the left-operand image written under the product's own MFMAs (the round-2
+                                 * default), 5 = latency mode (n <= 64; n <= 16 is padded to 32; auto
                                  * for one or a few control sets, decided by seeds x time slices: exponentials
                                  * per time slice, forward and z-free adjoint sweep side by side, slice-parallel gradient),
                                  * 6 = v_mfma_f64_4x4x4 exponentials by two waves per chunk, two waves
                                  * per SIMD (n <= 32; slower than 4, kept for A/B runs), 7 = n > 32: v_mfma_f64_4x4x4
-                                 * exponentials by four waves per chunk, a block of rows each (auto for n > 32); 2..7 (and auto)
-                                 * run the n <= 32 sweeps on v_mfma_f64_4x4x4 as well */
+                                 * exponentials by four waves per chunk, a block of rows each (auto for n > 32), 8 = as 4 with
+                                 * row-strip-major products whose result rewrites the left-operand image in place (n <= 32, Taylor
+                                 * order >= 3; auto for n <= 32 batches since round 3); 2..8 (and auto) run the n <= 32 sweeps on
+                                 * v_mfma_f64_4x4x4 as well */
     int32_t reserved[6];
 } qoc_config;
 

@@ -735,7 +735,7 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     TRY(prof_collect(e));
     if (kernel_name)
         *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm32 (batched matexp sequence)")
-                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 6 ? "k_mfma_expm_pair" : qoc_mfma_expm_variant(e->mf, e->d) == 5 ? (e->mf.NT == 3 ? "k_mfma_expm_rows (per slice) + k_mfma_chain_rows" : "k_mfma_expm_slice2 + k_mfma_chain_rows") : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
+                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 6 ? "k_mfma_expm_pair" : qoc_mfma_expm_variant(e->mf, e->d) == 5 ? (e->mf.NT == 3 ? "k_mfma_expm_rows (per slice) + k_mfma_chain_rows" : "k_mfma_expm_slice2 + k_mfma_chain_rows") : qoc_mfma_expm_variant(e->mf, e->d) == 8 ? "k_mfma_expm_inplace" : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
                        : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;

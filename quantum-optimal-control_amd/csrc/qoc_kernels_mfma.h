@@ -54,14 +54,18 @@ static inline void qoc_to_fragD(const cplx* M, int n, bool transpose, cplx* F, i
 // which kernel computes the exponentials (1 = 16x16x4, 2 = 4x4x4 two waves, 3 = 4x4x4 one wave, image written before each product,
 // 4 = 4x4x4 one wave, image written strip by strip under the product's own MFMAs, 5 = latency mode: two waves per
 // slice (k_mfma_expm_slice2) + k_mfma_chain_rows, 6 = 4x4x4, two waves per item and two waves per SIMD, no sums image (k_mfma_expm_pair), 7 = n > 32: four
-// waves per item with a block of rows each (k_mfma_expm_rows))
+// waves per item with a block of rows each (k_mfma_expm_rows), 8 = 4x4x4 one wave, row-strip-major products with the image rewritten in place
+// (k_mfma_expm_inplace, qoc_mfma_expm_inplace.h; AUTO for NT = 2 batches since round 3))
 static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     // n > 32: four waves per item, a block of rows each (7; AUTO: n = 48 x 64 seeds 3.3 ms per launch against 3.8 for 2 = one wave per
     // 16-column block and 11.9 for 1 = the same on 16x16x4)
     if (mf.latency) return 5;
     if (mf.NT > 2) return mf.variant == 1 ? 1 : (mf.variant == 2 ? 2 : 7);
-    int v = mf.variant > 0 ? mf.variant : ((mf.NT == 2 && d.B * mf.C >= 512) ? 4 : 1);
+    // AUTO, NT = 2: the in-place kernel whatever the batch (few (seed, chunk) items only occur with pinned chunk counts -- AUTO gives
+    // small batches to the latency mode --, and a kernel that does not depend on the local batch keeps a restart bit-identical under any sharding)
+    int v = mf.variant > 0 ? mf.variant : (mf.NT == 2 ? ((d.T >= 3 || d.B * mf.C >= 512) ? 8 : 1) : 1);
     if (v == 7) v = 4;                                                  // the row-block kernel is an NT = 3 / 4 kernel
+    if (v == 8 && (d.T < 3 || mf.NT != 2)) v = 4;                      // the in-place kernel needs at least one Horner product (T >= 3)
     if (v == 4 && (d.T < 2 || mf.NT != 2)) v = 3;                      // the streamed kernel starts from the product A * A
     if (v == 6 && mf.NT != 2) v = 3;                                    // the pair kernel is an NT = 2 kernel
     return v;
@@ -78,6 +82,7 @@ static inline bool qoc_mfma_latency_ok(const QocDev& d) {
 // host entry points (defined next to their kernels)
 int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host, std::vector<void*>& allocs, std::string& msg);   // qoc_mfma_backward.hip
 void qoc_mfma_launch_expm(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip
+void qoc_mfma_launch_expm_inplace(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_expm_inplace.hip (variant 8)
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s);    // qoc_mfma_forward.hip
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_backward.hip
 void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip: latency mode, on read-back

@@ -55,6 +55,7 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
         if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_pair<4>, dim3(d.B * mf.C), dim3(128), 0, s, d, mf);
         else hipLaunchKernelGGL(k_mfma_expm_pair<8>, dim3(d.B * mf.C), dim3(128), 0, s, d, mf);
     }
+    else if (v == 8 && NT == 2) qoc_mfma_launch_expm_inplace(mf, d, s);
     else if (v == 4 && NT == 2) {
         constexpr int NTS = 2;
         if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_chunk4s<NTS, 4>), dim3(d.B * mf.C), dim3(64), 0, s, d, mf);

@@ -1,0 +1,344 @@
+// qoc_mfma_expm_inplace.h -- MFMA path, exponentials K_t = matexp(A_t) + chunk products, qoc_config.variant = 8 (round 3 default for
+// n <= 32 batches with Taylor order >= 3): k_mfma_expm_inplace.  Reference semantics: core/tensorflow_state.py:25-46 (get_matexp).
+//
+// Same arithmetic units as k_mfma_expm_chunk4s (one wave per (seed, chunk), products on v_mfma_f64_4x4x4_4b_f64 in the
+// 3-multiplication form, left operand block by block from a transposed LDS image + its re+im sums, right operand in strip
+// registers), re-cut around what the round-2 counters said (profiles/r02_pmc_expm_variants.txt): the kernel lost a quarter of its
+// time to ~1850 VALU instructions per slice, more than half of them v_accvgpr moves -- 48 accumulators parked in AGPRs and read back
+// after every product, operands of the next product kept in registers only to be streamed into the image.
+//
+//  * ROW-STRIP-MAJOR products.  The 64 block steps of a product run row strip by row strip: group ib = the 8 steps (ib, kb = 0..7)
+//    that complete rows 4 ib .. 4 ib + 3 of the result for both column blocks.  Only 6 accumulators are live (VGPRs, never AGPRs:
+//    the unit is compiled with -amdgpu-mfma-vgpr-form), and they are combined right at the group boundary: re = a - b,
+//    s = c - 2 b (= re + im, the sum the NEXT product needs, for free), im = s - re: 3 VALU instructions per strip.
+//  * IN-PLACE IMAGE.  Group ib is the last reader of rows 4 ib .. of the left operand's image, so the result strip of that group is
+//    stored into those rows (its four LDS stores ride under the next group's MFMAs, one per block step): at the end of a product
+//    the image holds the next left operand.  No operand waits in registers to be streamed, no product starts with an empty
+//    image: the block fetches of product N + 1 are issued during the last steps of product N and a slice is ONE stream of MFMAs.
+//  * RIGHT OPERANDS COME BACK FROM THE IMAGE.  Where the next product's right operand is this product's result (squarings), its
+//    strips are read back from the image into the very registers the current right operand vacates (strip kb after its last use in
+//    step (7, kb)): LDS -> register moves cost no VALU instruction and no second register set.
+//  * Commuting operands.  Every matrix of the polynomial is a polynomial in A_t, so the Horner step X <- A2 X + B_i is taken as
+//    X <- X A2 + B_i: the changing factor is the LEFT operand (image, in place), the fixed A2 the right one (registers).  B_i =
+//    d0 I + d1 A enters through the accumulators' initial values (a0 = B_i.re, c0 = B_i.re + B_i.im: 2 instead of 3 VALU per strip).
+//  * Registers: SA = A_t as three planes (re, im, re + im; im dies after the first product), SB = A2, then the squarings' right
+//    operand, then R' = K_t R (copied to R after the product); the running chunk product R is touched once per slice and is what
+//    the register allocator parks in AGPRs (MFMA reads B operands from there).  K_t goes to HBM strip by strip from the epilogue of
+//    the product that completes it; A_{t+1} is assembled strip by strip under the chunk product, written to the image rows that
+//    product has released, and read back as the right operand of the next A * A.
+#pragma once
+#include <type_traits>
+#include <utility>
+#include "qoc_mfma_frag.h"
+
+#define ILDS (16 * NT + 5)        // image row stride (complex elements): conflict-free strip stores and block reads (as chunk4s)
+
+#ifndef QOC_LAP
+#define QOC_LAP(ph)
+#define QOC_LAP_INIT
+#define QOC_LAP_DONE
+#endif
+
+namespace qoc_inplace {
+
+template <int NT> struct Set { double re[NT][4 * NT], im[NT][4 * NT], su[NT][4 * NT]; };   // strip (J, ib): rows 4 ib .., columns 16 J ..; lane = 16 row + col
+// left blocks in flight (RA = 3 steps ahead, NS % 4 == 0) + the result strip of the last completed group, whose four LDS stores are
+// issued one per block step under the NEXT group's MFMAs (issued together at the group boundary they occupy the wave's LDS queue for ~200
+// cycles and the block reads behind them arrive late)
+template <int NT> struct Ring { cplx v[4]; double s[4]; cplx pri[NT]; double psu[NT]; };
+
+__device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+template <class F, int... I>
+__device__ __forceinline__ void for_each(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+
+// strip (J, ib) of the matrix in the image -> the three planes of a set (strip layout = the store pattern: conflict-free)
+template <int NT>
+__device__ __forceinline__ void load_strip(const cplx* img, const double* imgs, int lane, Set<NT>& S, int J, int ib) {
+    const int o = (16 * J + (lane & 15)) * ILDS + 4 * ib + (lane >> 4);
+    const double* p = (const double*)(img + o);
+    S.re[J][ib] = p[0]; S.im[J][ib] = p[1]; S.su[J][ib] = imgs[o];
+}
+
+// One product acc = (image) * P, row strip by row strip.
+//   init(ibc, a, c) -> std::true_type if it preset the accumulators a[J], c[J] of this group (Horner term); std::false_type: they start from zero
+//   epi(ibc, a, b, c, ori, osu): the group's accumulators are complete: combine; ori / osu = the strip that replaces rows 4 ib .. of the image
+// RELOAD_OUT: the result is the NEXT product's right operand too: strip kb of P is read back from the image after its last use (step (7, kb));
+// RELOAD_IN: this product's strip QS - 1 is such a read-back still to be issued (its stores are this product's first four).
+// The ring holds the blocks of steps st .. st + RA - 1 on entry and those of the NEXT product's first steps on exit (every product
+// of this kernel reads its left operand from the same image, whose rows 0 .. are complete long before the previous product ends).
+template <int NT, bool RELOAD_IN, bool RELOAD_OUT, class Init, class Epi>
+__device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<NT>& ring, Set<NT>& P, Init&& init, Epi&& epi) {
+    constexpr int QS = 4 * NT, NS = QS * QS, RA = 3;
+    const cplx* base = img + (lane >> 4) * ILDS + (lane & 3);
+    const double* bases = imgs + (lane >> 4) * ILDS + (lane & 3);
+    cplx* wbase = img + (lane & 15) * ILDS + (lane >> 4);           // strip (J, ib) -> wbase[16 J ILDS + 4 ib]
+    double* wbases = imgs + (lane & 15) * ILDS + (lane >> 4);
+    auto fetch = [&](int st) {
+        const int s2 = st % NS, ib = s2 / QS, kb = s2 % QS;
+        ring.v[st & 3] = base[4 * kb * ILDS + 4 * ib];
+        ring.s[st & 3] = bases[4 * kb * ILDS + 4 * ib];
+    };
+    for_each([&](auto ibc) {
+        constexpr int ib = decltype(ibc)::value, pib = (ib + QS - 1) % QS;      // pending strip: the previous group's (the previous product's last)
+        double a[NT], b[NT], c[NT];
+        constexpr bool preset = decltype(init(ibc, a, c))::value;
+        init(ibc, a, c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < QS; ++kb) {
+            const int st = ib * QS + kb;
+            fetch(st + RA);
+            fence();
+            if (kb < 2 * NT) {                                          // one store of the pending strip per block step
+                if ((kb & 1) == 0) wbase[16 * (kb >> 1) * ILDS + 4 * pib] = ring.pri[kb >> 1];
+                else wbases[16 * (kb >> 1) * ILDS + 4 * pib] = ring.psu[kb >> 1];
+                fence();
+            }
+            const cplx v = ring.v[st & 3];
+            const double vs = ring.s[st & 3];
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                if (kb == 0) {
+                    a[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, P.re[J][kb], preset ? a[J] : 0.0, 0, 0, 0);
+                    b[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, P.im[J][kb], 0.0, 0, 0, 0);
+                    c[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, P.su[J][kb], preset ? c[J] : 0.0, 0, 0, 0);
+                } else {
+                    a[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, P.re[J][kb], a[J], 0, 0, 0);
+                    b[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, P.im[J][kb], b[J], 0, 0, 0);
+                    c[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, P.su[J][kb], c[J], 0, 0, 0);
+                }
+            }
+            if constexpr (RELOAD_IN) {
+                if (ib == 0 && kb == 2 * NT) {                          // the previous product's last strip is in the image now
+                    fence();
+#pragma unroll
+                    for (int J = 0; J < NT; ++J) load_strip<NT>(img, imgs, lane, P, J, QS - 1);
+                    fence();
+                }
+            }
+            if constexpr (RELOAD_OUT) {
+                if (ib == QS - 1 && kb < QS - 1) {                      // strip kb has multiplied for the last time: the new matrix's strip kb takes its registers
+                    fence();
+#pragma unroll
+                    for (int J = 0; J < NT; ++J) load_strip<NT>(img, imgs, lane, P, J, kb);
+                    fence();
+                }
+            }
+        }
+        // the group's VALU batch stays a batch: a lone wave's VALU instructions cost MFMA issue slots wherever they stand, least in a group
+        __builtin_amdgcn_sched_barrier(0);
+        epi(ibc, a, b, c, ring.pri, ring.psu);
+        __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, QS>{});
+}
+
+// fragment f of a fragD matrix at uniform address F: scalar base (whole 4 KB groups of fragments) + immediate + 32-bit lane offset, so that
+// no per-lane 64-bit address is ever formed (hipcc otherwise precomputes one per (matrix, strip) pair and spills them)
+__device__ __forceinline__ const cplx* frag_at(const cplx* F, int f) { return F + (f & ~3) * 64; }
+__device__ __forceinline__ cplx* frag_at(cplx* F, int f) { return F + (f & ~3) * 64; }
+
+}  // namespace qoc_inplace
+
+// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient)
+template <int KC>
+__global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma mf) {
+    using namespace qoc_inplace;
+    constexpr int NT = 2, QS = 4 * NT;
+    __shared__ __attribute__((aligned(16))) cplx img[QNP * ILDS];
+    __shared__ __attribute__((aligned(16))) double imgs[QNP * ILDS];
+    const int lane = threadIdx.x;
+    const unsigned ulane = threadIdx.x;
+    const int b = blockIdx.x / mf.C, c = blockIdx.x - b * mf.C;
+    if (d.skip_done && d.done[b]) return;
+    QOC_LAP_INIT
+    const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
+    const double inv_scale = 1.0 / (double)(1 << d.s);
+    const int dlt = (lane & 15) - (lane >> 4);
+    double idv[4];                                    // identity pattern of a diagonal tile: strip r of the tile holds the diagonal where dlt == 4 r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) idv[r] = dlt == 4 * r ? 1.0 : 0.0;
+    const int mm = d.T >> 1;
+    const bool even = (d.T & 1) == 0;
+    const int nH = even ? mm - 1 : mm;                // Horner products over A2 (tensorflow_state.py:37-41 in Paterson-Stockmeyer form); >= 1 here (T >= 3)
+    const double p_c0 = even ? mf.invfact[2 * mm - 2] : mf.invfact[2 * mm], p_c1 = even ? mf.invfact[2 * mm - 1] : mf.invfact[2 * mm + 1];
+    const double p_cT = even ? mf.invfact[d.T] : 0.0;
+
+    Set<NT> SA, SB, R;
+    Ring<NT> ring;
+    auto diag = [&](int J, int ib) -> double { return (ib >> 2) == J ? idv[ib & 3] : 0.0; };
+    auto no_init = [](auto, double (&)[NT], double (&)[NT]) { return std::false_type{}; };
+
+    // chunk product starts as the identity
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int ib = 0; ib < QS; ++ib) { R.re[J][ib] = diag(J, ib); R.im[J][ib] = 0.0; R.su[J][ib] = diag(J, ib); }
+
+    const cplx* hk[KC + 1];
+    hk[0] = mf.HfD;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) hk[kk + 1] = mf.HfD + (size_t)(kk < d.k ? kk + 1 : 0) * QFR;
+    auto coeffs = [&](int t, double (&ck)[KC]) {
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) ck[kk] = kk < d.k ? d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale : 0.0;
+    };
+    // strip (J, ib) of A_t = (H0' + sum_k u_k H_k') / 2^s from the staged Hamiltonian strips
+    auto assemble = [&](const cplx (&h)[KC + 1], const double (&ck)[KC], double& re, double& im) {
+        re = h[0].x * inv_scale; im = h[0].y * inv_scale;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) { re = fma(ck[kk], h[kk + 1].x, re); im = fma(ck[kk], h[kk + 1].y, im); }
+    };
+    // result strip of a plain product: re = a - b, su = c - 2 b = re + im, im = su - re
+    auto combine = [](double a, double bq, double cq, double& re, double& im, double& su) { re = a - bq; su = fma(-2.0, bq, cq); im = su - re; };
+
+    // ---- first slice of the chunk: A_t assembled in the open, image + set SA ---------------------------------------------------------
+    {
+        double ck[KC];
+        coeffs(t0, ck);
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int ib = 0; ib < QS; ++ib) {
+                cplx h[KC + 1];
+#pragma unroll
+                for (int kk = 0; kk <= KC; ++kk) h[kk] = frag_at(hk[kk], J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane];
+                double re, im;
+                assemble(h, ck, re, im);
+                SA.re[J][ib] = re; SA.im[J][ib] = im; SA.su[J][ib] = re + im;
+                if (ib == QS - 1) { ring.pri[J] = cmake(re, im); ring.psu[J] = re + im; }      // the last strip is the first product's pending one
+                else {
+                    const int o = (16 * J + (lane & 15)) * ILDS + 4 * ib + (lane >> 4);
+                    img[o] = cmake(re, im); imgs[o] = re + im;
+                }
+                fence();                                  // one strip's loads at a time: hoisted together they are 320 registers
+            }
+        {
+            const cplx* base = img + (lane >> 4) * ILDS + (lane & 3);
+            const double* bases = imgs + (lane >> 4) * ILDS + (lane & 3);
+#pragma unroll
+            for (int st = 0; st < 3; ++st) { ring.v[st] = base[4 * st * ILDS]; ring.s[st] = bases[4 * st * ILDS]; }   // steps (0, kb = 0..2)
+        }
+        fence();
+    }
+    QOC_LAP(0)
+
+    for (int t = t0; t < t1; ++t) {
+        cplx* Kout = mf.KfD + kitem(mf, d.steps, b, t);
+        // ---- A2 = A * A -> SB;  X0 = c0 I + c1 A + cT A2 -> image (left operand of the first Horner product) ---------------------------
+        product<NT, false, false>(img, imgs, lane, ring, SA, no_init,
+                                  [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
+            constexpr int ib = decltype(ibc)::value;
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                double re, im, su;
+                combine(a[J], bq[J], cq[J], re, im, su);
+                SB.re[J][ib] = re; SB.im[J][ib] = im; SB.su[J][ib] = su;
+                const double xr = fma(p_cT, re, fma(p_c1, SA.re[J][ib], p_c0 * diag(J, ib)));
+                const double xi = fma(p_cT, im, p_c1 * SA.im[J][ib]);
+                ori[J] = cmake(xr, xi); osu[J] = xr + xi;
+            }
+        });
+        QOC_LAP(1)
+        // ---- Horner over A2 with the factors commuted: X <- X * A2 + (d0 I + d1 A); the last one is followed by a product that takes its
+        //      right operand from the image (squaring) or needs none (s = 0: the result is K_t) ------------------------------------------------
+        for (int i = nH - 1; i >= 0; --i) {
+            const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
+            auto init = [&](auto ibc, double (&a)[NT], double (&cq)[NT]) {
+                constexpr int ib = decltype(ibc)::value;
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    a[J] = fma(d1, SA.re[J][ib], d0 * diag(J, ib));
+                    cq[J] = fma(d1, SA.su[J][ib], d0 * diag(J, ib));
+                }
+                return std::true_type{};
+            };
+            const bool kout = i == 0 && d.s == 0;
+            auto epi = [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
+                constexpr int ib = decltype(ibc)::value;
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    double re, im, su;
+                    combine(a[J], bq[J], cq[J], re, im, su);
+                    ori[J] = cmake(re, im); osu[J] = su;
+                    if (kout) frag_at(Kout, J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane] = ori[J];
+                }
+            };
+            if (i > 0) product<NT, false, false>(img, imgs, lane, ring, SB, init, epi);
+            else product<NT, false, true>(img, imgs, lane, ring, SB, init, epi);
+        }
+        QOC_LAP(2)
+        // ---- squarings: X <- X * X; the right operand is read back from the image into SB strip by strip ---------------------------------
+        for (int sq = 0; sq < d.s; ++sq) {
+            const bool kout = sq == d.s - 1;
+            product<NT, true, true>(img, imgs, lane, ring, SB, no_init,
+                                    [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
+                constexpr int ib = decltype(ibc)::value;
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    double re, im, su;
+                    combine(a[J], bq[J], cq[J], re, im, su);
+                    ori[J] = cmake(re, im); osu[J] = su;
+                    if (kout) frag_at(Kout, J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane] = ori[J];      // K_t, strip (J, ib)
+                }
+            });
+        }
+        QOC_LAP(3)
+        // ---- chunk product R' = K_t * R -> SB (free: the squarings' right operand is not needed any more); A_{t+1} assembled strip by
+        //      strip under the same MFMAs and written to the image rows the product has released ----------------------------------------------
+        {
+            double ck[KC];
+            coeffs(min(t + 1, d.steps - 1), ck);
+            cplx h[NT][KC + 1];
+            auto stage = [&](int ib) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+#pragma unroll
+                    for (int kk = 0; kk <= KC; ++kk) h[J][kk] = frag_at(hk[kk], J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane];
+            };
+            stage(0);
+            product<NT, false, false>(img, imgs, lane, ring, R, no_init,
+                                      [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
+                constexpr int ib = decltype(ibc)::value;
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {                          // A_{t+1}, strip (J, ib) -> image
+                    double re, im;
+                    assemble(h[J], ck, re, im);
+                    ori[J] = cmake(re, im); osu[J] = re + im;
+                }
+                if constexpr (ib + 1 < QS) stage(ib + 1);
+#pragma unroll
+                for (int J = 0; J < NT; ++J) combine(a[J], bq[J], cq[J], SB.re[J][ib], SB.im[J][ib], SB.su[J][ib]);
+            });
+            QOC_LAP(4)
+            R = SB;
+            // right operand of the next A * A: read back from the image; the last strip is still pending, i.e. in registers
+            fence();
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+#pragma unroll
+                for (int ib = 0; ib < QS - 1; ++ib) load_strip<NT>(img, imgs, lane, SA, J, ib);
+                SA.re[J][QS - 1] = ring.pri[J].x; SA.im[J][QS - 1] = ring.pri[J].y; SA.su[J][QS - 1] = ring.psu[J];
+            }
+            fence();
+            QOC_LAP(5)
+        }
+    }
+    // ---- chunk product out: fragD(P_c) from the registers, fragD(P_c^T) through the image ------------------------------------------------
+    const size_t pitem = (size_t)b * mf.C + c;
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int ib = 0; ib < QS; ++ib) frag_at(mf.PfD + pitem * QFR, J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane] = cmake(R.re[J][ib], R.im[J][ib]);
+    wave_lds_fence();
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int ib = 0; ib < QS; ++ib) img[(16 * J + (lane & 15)) * ILDS + 4 * ib + (lane >> 4)] = cmake(R.re[J][ib], R.im[J][ib]);
+    wave_lds_fence();
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int q = 0; q < QS; ++q) frag_at(mf.PfT + pitem * QFR, J * QS + q)[((J * QS + q) & 3) * 64 + ulane] = img[(4 * q + (lane >> 4)) * ILDS + 16 * J + (lane & 15)];
+    QOC_LAP(6)
+    QOC_LAP_DONE
+}

@@ -1,6 +1,6 @@
 """Oracle parity at the EXACT configuration bench.py times ("Next round" 1).
 
-bench.py resolves C2 x 64 seeds per GPU to path = MFMA, the streamed-image exponential kernel and 16 chunks of 32 slices; the other
+bench.py resolves C2 x 64 seeds per GPU to path = MFMA, the in-place-image exponential kernel and 16 chunks of 32 slices; the other
 full-size tests use 2 seeds (63 chunks of 8) or compare HIP batches with each other.  Here the 64-seed batch itself is compared with
 the oracle (core/tensorflow_state.py:204-242,323-356; core/run_session.py:47-69) for seeds {0, 31, 63}: one evaluation (loss, U_final,
 gradient) and three iterations of the device loop.  The expected values are committed fixtures (tests/golden/make_bench_golden.py),
@@ -50,13 +50,13 @@ def test_bench_batch_configuration_against_the_oracle():
     g = load_golden('c2_bench_batch.npz')
     seeds = [int(s) for s in g['seeds']]
     eng = bench_engine(bench.SEEDS_PER_GPU)
-    # what `python bench.py` resolves to: MFMA path, 16 chunks of 32 slices, the streamed-image kernel of the exponentials
+    # what `python bench.py` resolves to: MFMA path, 16 chunks of 32 slices, the in-place-image kernel of the exponentials
     assert (eng.path, eng.chunks) == (2, 16)
     bases = bench.seed_bases(0, bench.SEEDS_PER_GPU)
     eng.set_base(bases)
     eng.profile_enable(True)
     r = eng.evaluate()
-    assert 'k_mfma_expm_chunk' in eng.profile_read()['kernel']
+    assert eng.profile_read()['kernel'] == 'k_mfma_expm_inplace'
     eng.profile_enable(False)
     compare_evaluation(eng, r, g, seeds)
     eng.set_base(bases)

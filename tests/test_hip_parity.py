@@ -88,7 +88,8 @@ def test_mfma_path_parity(chunks, variant):
     _mfma_path_parity(chunks, variant, 0)
 
 
-@pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6, 7], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd', 'mfma4_row_blocks'])
+@pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6, 7, 8], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd', 'mfma4_row_blocks',
+                                                                 'mfma4_inplace_image'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
                                      'n25_k8_T7', 'n17_k1_T4_s4', 'n30_m13_k2', 'n32_m4_k3', 'n26_k5_plain', 'n28_k7_sources', 'n26_k5_sources',
                                      'n22_dressed3', 'n40_dressed_nt3', 'n20_dressed5', 'n44_k6'])
