@@ -24,7 +24,9 @@
 #include "qoc_kernels_gemm.h"
 
 #ifndef QOC_LATENCY_MAX_WORK
-#define QOC_LATENCY_MAX_WORK 6144       // seeds x time slices up to which AUTO takes the latency mode (see latency_auto below)
+#define QOC_LATENCY_MAX_WORK 4608       // seeds x time slices up to which AUTO takes the latency mode (see latency_auto below): since the batch sweeps
+                                        // take their chunk boundaries and final_state from k_mfma_bnd_scan the batch kernels are ahead from 10 seeds of 500
+                                        // slices on (0.356 ms at 12 seeds against 0.444; 8 seeds: 0.349 against 0.305; profiles/r03_latency_sweep.txt)
 #define QOC_LATENCY_MAX_WORK_SRC 4096   // the same with a state regulariser
 #endif
 static thread_local std::string g_err;
@@ -478,7 +480,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    slices, since the row-tile gradient kernel); with more controls, or fewer seeds, the GEMM path (k = 6: 4.55 vs 4.69 ms at
     //    64 seeds x 200 slices; k = 8: level).
     const bool nt4_batch = n > 48 && k <= 4 && B >= 32;
-    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 12 && m <= 8 && steps >= 100));
+    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 8 && m <= 8 && steps >= 100));
     const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
     bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));

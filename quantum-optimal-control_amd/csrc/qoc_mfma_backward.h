@@ -558,6 +558,9 @@ __global__ void __launch_bounds__(256) k_mfma_grad_sum(QocDev d, QocMfma mf, int
 // first, E <- G_g^dagger E + A_g with the group products GfD of k_mfma_chain_rows and the group offsets Goff, then the chunks of the
 // own group; 2 = the pass that forms those group offsets: an item is a (seed, group), the recursion runs over the chunks of the
 // group from a zero costate and its result goes to Goff; no slices.  MODE 0 (batch kernels) has neither branch in its code.
+// MODE 3 (batch kernels without a state regulariser, round 3): no boundary recursion at all -- the z-free costate at the end of the chunk
+// comes from k_mfma_bnd_scan (BndA) and is scaled by -(2/m^2) z here.  In MODE 0 every item ran C - 1 boundary steps on the chunk products
+// that all chunks of its seed read at the same time: 6.8 us per step against 2.0 us per slice, 100 of the kernel's 165 us at 16 chunks.
 template <int MQ, bool SRC, int KC = 4, int MODE = 0>
 __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     constexpr int NT = 2;                                                       // KC = control images in LDS: 4, or 5 (k = 5 still fits the 160 KB)
@@ -593,7 +596,10 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         for (int jb = 0; jb < MQ; ++jb) {
             const int row = 16 * h + lc, col = 4 * jb + lk;
             cplx v = cmake(0.0, 0.0);
-            if (MODE != 2 && row < d.n && col < d.m) {
+            if constexpr (MODE == 3) {
+                static_assert(MODE != 3 || !SRC, "precomputed boundaries are z-free: no state regulariser");
+                v = cscale(cmul(z, mf.BndA[(((size_t)b * mf.C + c) * NT * MQ + h * MQ + jb) * 64 + lane]), c0);
+            } else if (MODE != 2 && row < d.n && col < d.m) {
                 v = cscale(cmul(z, d.W[row * d.m + col]), c0);
                 if (SRC) v = cadd(v, source_at(d, b, d.steps, row, col));
             }
@@ -671,6 +677,8 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
         const int C = mf.C;
         if constexpr (MODE == 0) {
             bsteps(mf.PfD + (size_t)b * C * QFR, C - 1, [&](int s) { return C - 1 - s; }, [&](int s) { return C - 1 - s > c; });
+        } else if constexpr (MODE == 3) {
+            (void)C;
         } else if constexpr (MODE == 1) {
             const int G = mf.G, NG = mf.NG, g = c / G;
             offs = mf.Goff + (size_t)b * NG * (QQS * 64);

@@ -77,6 +77,12 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         if (!al((cplx**)&mf.gpart, ((size_t)NT * d.B * d.k * d.steps + 1) / 2)) { msg = "MFMA path: out of device memory"; return -3; }
     }
     if (mf.lat_sources && !al(&mf.Goff, (size_t)d.B * mf.NG * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
+    // chunk boundaries once per seed (k_mfma_bnd_scan) for the 4x4x4 batch sweeps; the adjoint ones only where k_mfma_backward3 takes them
+    // (NT = 2, k <= 5, no state regulariser: the costate is then linear in the overlap)
+    const bool bnd = (NT == 2 || NT == 3) && mf.variant != 1 && !mf.latency;
+    const bool bnd_adj = bnd && NT == 2 && d.k <= 5 && !(d.n_forb > 0 || d.has_speed);
+    const size_t nbnd = (size_t)d.B * C * NT * (mf.mq <= 2 ? 2 : 4) * 64;
+    if ((bnd && !al(&mf.BndF, nbnd)) || (bnd_adj && !al(&mf.BndA, nbnd))) { msg = "MFMA path: out of device memory"; return -3; }
     // forbidden levels / speed_up on the thin affine sweeps of qoc_mfma_latency.h; dressed levels (up to 4 of them) take their sources from Fd
     const bool dressed = d.n_forb > 0 && d.forbid_dressed;
     mf.lat_src_fast = mf.lat_sources && !(dressed && d.n_forb > 4);
@@ -133,6 +139,14 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         if (hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
             hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
             msg = "MFMA path: cannot reserve LDS for the two-level backward kernel";
+            return -2;
+        }
+    }
+    if (NT == 2 && bnd_adj) {
+        const void* k3 = d.k == 5 ? (mf.mq <= 2 ? (const void*)k_mfma_backward3<2, false, 5, 3> : (const void*)k_mfma_backward3<4, false, 5, 3>)
+                                  : (mf.mq <= 2 ? (const void*)k_mfma_backward3<2, false, 4, 3> : (const void*)k_mfma_backward3<4, false, 4, 3>);
+        if (hipFuncSetAttribute(k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
+            msg = "MFMA path: cannot reserve LDS for the backward kernel with precomputed boundaries";
             return -2;
         }
     }
@@ -194,8 +208,12 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
             const dim3 g3((items + 3) / 4), b3(512);                     // 4 pairs of waves per workgroup
 #define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
                                else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
-            if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
+#define QOC_B3B(MQv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, false, 5, 3>), g3, b3, mf.bwd_lds3, s, d, mf); \
+                          else hipLaunchKernelGGL((k_mfma_backward3<MQv, false, 4, 3>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
+            if (mf.BndA && !src) { if (mf.mq <= 2) QOC_B3B(2); else QOC_B3B(4); }
+            else if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
             else { if (src) QOC_B3(4, true); else QOC_B3(4, false); }
+#undef QOC_B3B
 #undef QOC_B3
             return;
         }

@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
 
 // (No run-time branch may surround the loads of the sweep: hipcc waits for a conditional load on the spot -- 173 -> 183 us with an
 // `if (mf.latency)` around two load patterns.  The latency mode has its own sweep kernel, qoc_mfma_latency.h.)
-template <int NT, int MQ>
+// BND: the chunk-start vectors come from k_mfma_bnd_scan (BndF) instead of a walk over the chunk products before this chunk.  Every
+// chunk of a seed walked the SAME products at the same time -- an L2 hot spot that made a boundary step 5.8 us against 2.6 us for a
+// slice of the sweep itself, half of the kernel's critical path at 16 chunks (profiles/r03_chunks_kernel_table.txt).
+template <int NT, int MQ, bool BND = false>
 __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
@@ -103,7 +106,8 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
             for (int jb = 0; jb < MQ; ++jb) {
                 const int row = 16 * I + lc, col = 4 * jb + lk;
                 cplx v = cmake(0.0, 0.0);
-                if (row < d.n && col < d.m) v = d.Psi0[row * d.m + col];
+                if constexpr (BND) v = mf.BndF[(((size_t)b * mf.C + c) * NT * MQ + I * MQ + jb) * 64 + lane];   // the sweep's own register layout
+                else if (row < d.n && col < d.m) v = d.Psi0[row * d.m + col];
                 pre[I][jb] = v.x; pim[I][jb] = v.y;
             }
         cplx* iv = d.inter + (size_t)b * (d.steps + 1) * d.n * d.m;
@@ -156,7 +160,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
         // chunk-start vectors: Psi <- P_cc Psi over the chunks before this one, one matrix at a time -- the chunks of a seed walk the
         // same products, and more loads in flight only deepen that L2 hot spot (32 seeds x 32 chunks: 119 us per launch like this,
         // 170 us with two matrices ahead)
-        {
+        if constexpr (!BND) {
             Frag B0;
             for (int cc = 0; cc < c; ++cc) { load_frag(mf.PfD + ((size_t)b * mf.C + cc) * QFR, B0); product(B0); }
         }
@@ -192,8 +196,8 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
         for (int q = 0; q <= PD; ++q)
             if (t + q < len) step(Kq[q], t0 + t + q);
         }
-    } else if (item < n_sweep + d.B * NT) {
-        // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half
+    } else if (!BND && item < n_sweep + d.B * NT) {
+        // final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), one wave per 16-column half (BND: formed by k_mfma_bnd_scan)
         const int w = item - n_sweep, b = w / NT, J = w - b * NT;
         if (d.skip_done && d.done[b]) return;
         CTile X[NT];
@@ -213,6 +217,104 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
                 const int row = 16 * Ib + (lane >> 4) + 4 * r, col = 16 * J + (lane & 15);
                 if (row < d.n && col < d.n) Xf[row * d.n + col] = cmake(X[Ib].re[r], X[Ib].im[r]);
             }
+    }
+}
+
+// ---- chunk-boundary scan (batch kernels, NT = 2 / 3): the vectors every chunk starts from, once per seed -------------------------------
+// Forward: BndF[c] = P_{c-1} ... P_0 Psi_0 (tensorflow_state.py:229-242 re-associated over the chunk products).  Adjoint, only when no
+// state regulariser makes the costate affine: BndA[c] = P_{c+1}^dagger ... P_{C-1}^dagger W, the z-FREE costate at the end of chunk c (the
+// terminal costate is -(2/m^2) z W, linear in the overlap z = tr(W^dagger Psi_N) that the loss kernel forms later; the backward sweep scales
+// by it).  One wave per (seed, direction, block of 4 vector columns): columns are independent under left multiplication, so a step is
+// 12 NT^2 MFMAs and one private LDS image; the next chunk product (lane-contiguous fragD(P^T) / conj fragD(P) strips) is fetched while this
+// one multiplies.  Vectors are stored in the sweeps' register layout (row 16 I + lane % 16, column 4 jb + lane / 16).
+// The same waves form final_state = P_{C-1} ... P_0 U0 (tensorflow_state.py:223), four columns of U0 per wave (role 2): in the sweep kernel
+// that chain was C sequential 32 x 32 products on v_mfma_f64_16x16x4 by two waves per seed -- ~5 us per chunk, the critical path of the
+// launch from ~32 chunks on (63 chunks: 405 us of which the sweep itself needs ~90).
+template <int NT>
+__global__ void __launch_bounds__(256) k_mfma_bnd_scan(QocDev d, QocMfma mf, int MQ, int adjoint_too) {
+    constexpr int LDP = 16 * NT + 1;
+    __shared__ __attribute__((aligned(16))) cplx sc_img[4][4 * LDP];               // per wave: image[column j % 4][row]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nvec = (adjoint_too ? 2 : 1) * MQ, per_seed = nvec + 4 * NT;           // roles: Psi blocks, (costate blocks,) column blocks of U0
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= d.B * per_seed) return;
+    const int b = item / per_seed, w = item - b * per_seed;
+    const int role = w < MQ ? 0 : (w < nvec ? 1 : 2), jb = role == 2 ? w - nvec : (role == 1 ? w - MQ : w), dir = role == 1 ? 1 : 0;
+    if (d.skip_done && d.done[b]) return;
+    const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
+    cplx* img = sc_img[wv];
+    const int C = mf.C;
+    double pre[NT], pim[NT];
+    {
+        const cplx* V0 = role == 2 ? d.U0 : (dir ? d.W : d.Psi0);
+        const int ncol = role == 2 ? d.n : d.m;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            const int row = 16 * I + lc, col = 4 * jb + lk;
+            cplx v = cmake(0.0, 0.0);
+            if (row < d.n && col < ncol) v = V0[row * ncol + col];
+            pre[I] = v.x; pim[I] = v.y;
+        }
+    }
+    cplx* out = (dir ? mf.BndA : mf.BndF) + (size_t)b * C * NT * MQ * 64;
+    auto store = [&](int c) {
+        if (role == 2) return;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) out[(((size_t)c * NT + I) * MQ + jb) * 64 + lane] = cmake(pre[I], pim[I]);
+    };
+    struct Frag { cplx f[NT][QQS]; };
+    const double sg = dir ? -1.0 : 1.0;                                             // adjoint: conj fragD(P) IS the strip operand of P^dagger
+    auto load_frag = [&](int c, Frag& fr) {
+        const cplx* F = (dir ? mf.PfD : mf.PfT) + ((size_t)b * C + c) * QFR;
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int q = 0; q < QQS; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];
+    };
+    auto product = [&](const Frag& fr) {
+#pragma unroll
+        for (int I = 0; I < NT; ++I) img[lk * LDP + 16 * I + lc] = cmake(pre[I], pim[I]);
+        wave_lds_fence();
+        double a[NT], bq[NT], cq[NT];
+#pragma unroll
+        for (int I = 0; I < NT; ++I) { a[I] = 0.0; bq[I] = 0.0; cq[I] = 0.0; }
+#pragma unroll
+        for (int kb = 0; kb < QQS; ++kb) {
+            const cplx v = img[li4 * LDP + 4 * kb + lk];                            // X[4 kb + lk][4 jb + li4]
+#pragma unroll
+            for (int I = 0; I < NT; ++I) {
+                const double br = fr.f[I][kb].x, bi = sg * fr.f[I][kb].y, bs = br + bi;
+                a[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, br, a[I], 0, 0, 0);
+                bq[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, bi, bq[I], 0, 0, 0);
+                cq[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x + v.y, bs, cq[I], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < NT; ++I) { pre[I] = a[I] - bq[I]; pim[I] = cq[I] - a[I] - bq[I]; }
+        wave_lds_fence();                                                           // the image is rewritten by the next product
+    };
+    // forward: c = 0 .. C-2 (result -> chunk c + 1; final_state: .. C-1); adjoint: c = C-1 .. 1 (result -> chunk c - 1); step s uses chunk cs(s)
+    auto cs = [&](int s) { return dir ? C - 1 - s : s; };
+    const int nst = role == 2 ? C : C - 1;
+    store(dir ? C - 1 : 0);
+    if (nst >= 1) {
+        Frag f0, f1;
+        load_frag(cs(0), f0);
+        int s = 0;
+        for (; s + 2 <= nst; s += 2) {
+            load_frag(cs(s + 1), f1); asm volatile("" ::: "memory"); product(f0); store(dir ? cs(s) - 1 : cs(s) + 1);
+            load_frag(cs(min(s + 2, nst - 1)), f0); asm volatile("" ::: "memory"); product(f1); store(dir ? cs(s + 1) - 1 : cs(s + 1) + 1);
+        }
+        if (s < nst) { product(f0); store(dir ? cs(s) - 1 : cs(s) + 1); }
+    }
+    if (role == 2) {
+        cplx* Xf = d.Xfinal + (size_t)b * d.n * d.n;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            const int row = 16 * I + lc, col = 4 * jb + lk;
+            if (row < d.n && col < d.n) Xf[row * d.n + col] = cmake(pre[I], pim[I]);
+        }
     }
 }
 

@@ -5,7 +5,21 @@
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.latency) { qoc_mfma_latency_sweeps(mf, d, s); return; }       // (final_state only when read back: qoc_mfma_final_state)
     const int items = d.B * mf.C + d.B * mf.NT;
-    if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    if (mf.BndF) {
+        // chunk boundaries once per seed (forward, and the z-free adjoint ones when the backward sweep takes them), then the sweep
+        const int MQ = mf.mq <= 2 ? 2 : 4, waves = d.B * ((mf.BndA ? 2 : 1) * MQ + 4 * mf.NT);     // + the column blocks of final_state
+        if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_bnd_scan<2>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, mf.BndA ? 1 : 0);
+        else hipLaunchKernelGGL(k_mfma_bnd_scan<3>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, mf.BndA ? 1 : 0);
+        const int sw = d.B * mf.C;                                                // sweep items only: final_state comes from the scan
+        if (mf.NT == 2) {
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_forward2<2, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+        } else {
+            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+            else hipLaunchKernelGGL((k_mfma_forward2<3, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+        }
+    }
+    else if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 2 && mf.variant != 1) {
         // 4x4x4 sweep; like the backward choice this must not depend on the batch size (bit-identical seeds across shardings)
         if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);

@@ -37,6 +37,8 @@ struct QocMfma {
     bool store_T = true;      // false: NT = 2 sweeps on the 4x4x4 kernels, which gather K^T operands from KfD
     cplx* PfD = nullptr;      // [B][C] fragD(P_c)
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
+    cplx* BndF = nullptr;     // [B][C][NT * MQ][64] chunk-start vectors Psi (sweep register layout), k_mfma_bnd_scan; null: the sweeps walk the chunk products
+    cplx* BndA = nullptr;     // [B][C][NT * MQ][64] z-free costates at the chunk ends (no state regulariser); null: the backward sweep walks
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
     cplx* Goff = nullptr;     // [B][NG] the same for whole groups of chunks (latency mode with a state regulariser)
     cplx* LamD = nullptr;     // NT > 2: [B][steps][16 NT rows][16 columns] costates for the slice-parallel gradient kernel

@@ -12,9 +12,9 @@ from quantum_optimal_control.core import hip_engine  # noqa: E402
 if __name__ == '__main__':
     c, Hs, U0, V, W, dt = bench.build_problem()
     print('%6s %14s %14s %14s %14s' % ('seeds', 'AUTO', 'MFMA latency', 'GEMM route', 'MFMA batch'))
-    for seeds in (1, 2, 4, 8, 10, 12, 14, 16, 20, 24, 32):
+    for seeds in (1, 2, 4, 8, 12, 16, 20, 24, 32, 48, 64):
         row = []
-        for path, variant in ((0, 0), (2, 5), (4, 0), (2, 4)):
+        for path, variant in ((0, 0), (2, 5), (4, 0), (2, 0)):
             e = hip_engine.HipEngine(Hs, U0, V, W, c['maxA'], dt, c['total_time'], bench.SLICES, bench.TAYLOR[0], bench.TAYLOR[1], reg_coeffs={},
                                      n_seeds=seeds, path=path, variant=variant)
             e.set_base(bench.seed_bases(0, seeds))
