@@ -45,9 +45,14 @@ def import_reference():
     from lib2to3.main import main as two_to_three
     with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
         two_to_three('lib2to3.fixes', ['-w', '-n', os.path.join(pkg, 'core', 'system_parameters.py')])
+    # the reference package has the same top-level name as this repo's drop-in package (which tests/golden/cases.py imports its recipes
+    # from): forget ours, or the import below would silently resolve to THIS repo's modules
+    for name in [m for m in sys.modules if m == 'quantum_optimal_control' or m.startswith('quantum_optimal_control.')]:
+        del sys.modules[name]
     sys.path.insert(0, scratch)
     gf = importlib.import_module('quantum_optimal_control.helper_functions.grape_functions')
     sp = importlib.import_module('quantum_optimal_control.core.system_parameters')
+    assert gf.__file__.startswith(scratch) and sp.__file__.startswith(scratch), 'not the reference: %s %s' % (gf.__file__, sp.__file__)
     return gf, sp, scratch
 
 
