@@ -76,7 +76,10 @@ typedef struct qoc_config {
                                  * row-strip-major products whose result rewrites the left-operand image in place (n <= 32, Taylor
                                  * order >= 3; auto for n <= 32 batches since round 3); 2..8 (and auto) run the n <= 32 sweeps on
                                  * v_mfma_f64_4x4x4 as well */
-    int32_t reserved[6];
+    int32_t plan_seeds;         /* 0, or the batch size AUTO plans for instead of n_seeds: path, kernel family, chunk count and split
+                                 * factors are derived from it, so that a restart evolves bit-identically whether it runs in one engine
+                                 * of `plan_seeds` control sets or in a shard of it (GrapeSharded passes restarts / GPUs of the node) */
+    int32_t reserved[5];
 } qoc_config;
 
 /* Adam loop hyper-parameters == Convergence (core/convergence.py:16-49). */

@@ -27,6 +27,7 @@ __device__ __forceinline__ void cfma_conj(cplx& acc, cplx a, cplx b) {
 // Everything a kernel needs, passed by value (kernarg segment -> SGPRs).
 struct QocDev {
     int n, k, steps, m, T, s, B;
+    int Bplan;           // the batch size AUTO decisions are taken for (qoc_config.plan_seeds, else B): never an array extent
     int state_transfer;
     double dt;
     // regularisers (coefficients already divided by steps, regularization_functions.py:16,22,32,...)

@@ -379,6 +379,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const int n = cfg->n, k = cfg->k, steps = cfg->steps, m = cfg->m, B = cfg->n_seeds;
     d.n = n; d.k = k; d.steps = steps; d.m = m; d.T = cfg->taylor_terms; d.s = cfg->state_transfer ? 0 : cfg->scaling;
     d.B = B; d.state_transfer = cfg->state_transfer; d.dt = cfg->dt;
+    d.Bplan = cfg->plan_seeds > 0 ? cfg->plan_seeds : B;
     const double inv_steps = 1.0 / (double)steps;
     d.has_amp = cfg->has_amplitude; d.a_amp = cfg->c_amplitude * inv_steps;
     d.has_env = cfg->has_envelope; d.a_env = cfg->c_envelope * inv_steps;
@@ -479,11 +480,14 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    the MFMA path is ahead from 32 seeds on (4.96 vs 5.14 ms at 32, 9.16 vs 10.05 at 64, 17.4 vs 19.8 at 128 seeds of n = 64 x 500
     //    slices, since the row-tile gradient kernel); with more controls, or fewer seeds, the GEMM path (k = 6: 4.55 vs 4.69 ms at
     //    64 seeds x 200 slices; k = 8: level).
-    const bool nt4_batch = n > 48 && k <= 4 && B >= 32;
-    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && B < 8) || (n > 16 && n <= 32 && B <= 8 && m <= 8 && steps >= 100));
+    // every batch-size-dependent choice below is taken for Bp = qoc_config.plan_seeds (else the local batch): a shard of a restart
+    // batch then runs the same path, kernels and chunking as the whole batch would
+    const int Bp = d.Bplan;
+    const bool nt4_batch = n > 48 && k <= 4 && Bp >= 32;
+    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= 8 && m <= 8 && steps >= 100));
     const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
-    bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && B >= ST_DIRECT_FROM));
+    bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && Bp >= ST_DIRECT_FROM));
     if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
     // a handful of control sets of an n <= 32 unitary problem (the reference's own use is ONE per Grape() call): the latency mode of
@@ -496,13 +500,13 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // With a state regulariser (forbidden levels, speed_up) the backward half is the affine recursion of the batch kernels on the
     // latency mode's chunks, with two-level boundaries (QocMfma::lat_sources): one C2 trajectory with dwdt + forbidden levels 0.189 ms
     // against 0.290 (GEMM route) and 0.72 (batch kernels); ahead up to ~4096 seed-slices (tools/c2_forbidden_single.py).
-    const long long lat_work = (long long)B * steps;
+    const long long lat_work = (long long)Bp * steps;
     const bool lat_src = d.n_forb > 0 || d.has_speed;
     const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
-                              (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && B <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
-                                : n > 32 ? (lat_work <= 16384 && B <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
-                                       : (lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && B <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
-                               (B == 1 && steps <= 8192));
+                              (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && Bp <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
+                                : n > 32 ? (lat_work <= 16384 && Bp <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
+                                       : (lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && Bp <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
+                               (Bp == 1 && steps <= 8192));
     if (path == QOC_PATH_AUTO)
         path = latency_auto ? QOC_PATH_MFMA
                             : (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));

@@ -305,7 +305,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
     // unitary chains get their chunk boundaries in log depth (k_gemm_scan_nodes), so a latency-bound launch (few (seed, chunk)
     // workgroups) prefers chunks half as long: C2 single trajectory 0.214 (S = 16) -> 0.198 ms (S = 8); 0.195 at S = 4
-    if (gm.persistent && !d.state_transfer && !direct && L > 1 && (size_t)d.B * ((d.steps + (1 << L) - 1) >> L) <= 64) --L;
+    if (gm.persistent && !d.state_transfer && !direct && L > 1 && (size_t)d.Bplan * ((d.steps + (1 << L) - 1) >> L) <= 64) --L;
     gm.L = L; gm.S = 1 << L;
     gm.NC = (d.steps + gm.S - 1) / gm.S;
     gm.SP = gm.NC * gm.S;
@@ -384,10 +384,14 @@ static inline bool qoc_gemm_lds_opt_in() {
            hipFuncSetAttribute((const void*)k_gemm_scan_nodes<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_scan_lds(64)) == hipSuccess &&
            hipFuncSetAttribute((const void*)k_zgemm_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_zgemm_wg_lds()) == hipSuccess;
 }
+// planned / local batch of the engine whose launches are being enqueued by this host thread (set by the qoc_gemm_* entry points): the
+// split factor and the kernel family change the association of the sums, so they follow the PLANNED batch (QocDev::Bplan)
+static thread_local double qoc_gemm_plan_scale = 1.0;
 // picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small
 static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
-    const size_t tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
-    const unsigned blocks = (unsigned)tiles;
+    const size_t real_tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
+    const unsigned blocks = (unsigned)real_tiles;
+    const size_t tiles = (size_t)((double)real_tiles * qoc_gemm_plan_scale + 0.5);
     int sk = 1;
     if (tiles * 2 <= 2048 && (g.Kdim / 2) % 8 == 0) sk = 2;
     if (tiles * 4 <= 2048 && (g.Kdim / 4) % 8 == 0) sk = 4;
@@ -409,7 +413,7 @@ static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipSt
         else qoc_gemm_launch_sk<true, 0, 1>(g, blocks, s);
     } else if (sk == 1 && (g.tiles_m & 1) == 0 && (g.tiles_n & 3) == 0 && (g.Kdim % ZW_KC) == 0 && g.Kdim >= 128 && tiles >= 8 * 1024) {
         // large plain products: workgroup tiles of 64 x 128 on the 4x4x4 MFMA form
-        hipLaunchKernelGGL(k_zgemm_wg, dim3((unsigned)(tiles / 8)), dim3(256), qoc_zgemm_wg_lds(), s, g);
+        hipLaunchKernelGGL(k_zgemm_wg, dim3((unsigned)(real_tiles / 8)), dim3(256), qoc_zgemm_wg_lds(), s, g);
     } else {
         if (sk == 8) qoc_gemm_launch_sk<false, 0, 8>(g, blocks, s);
         else if (sk == 4) qoc_gemm_launch_sk<false, 0, 4>(g, blocks, s);
@@ -452,6 +456,7 @@ static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s) {
 
 // K_t for all (seed, slice): the dominant part of the path (bracketed by the profiling events of the engine)
 static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    qoc_gemm_plan_scale = (double)d.Bplan / (double)d.B;
     const int N = gm.N;
     const size_t NN = (size_t)N * N, BS = (size_t)d.B * gm.SP;
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
@@ -527,6 +532,7 @@ static inline ChainArgs qoc_gemm_direct_backward_args(const QocGemm& gm, const Q
 static inline bool qoc_gemm_zfree_backward(const QocGemm& gm, const QocDev& d) { return gm.direct && !(d.n_forb > 0 || d.has_speed) && d.steps >= 2; }
 
 static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    qoc_gemm_plan_scale = (double)d.Bplan / (double)d.B;
     const int N = gm.N, xw = d.state_transfer ? 0 : N, ld = xw + QOC_TW, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
@@ -654,6 +660,7 @@ static inline void qoc_gemm_bwd_sweep(QocGemm& gm, const QocDev& d, hipStream_t 
 }
 
 static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    qoc_gemm_plan_scale = (double)d.Bplan / (double)d.B;
     const int N = gm.N, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const bool need_src = d.n_forb > 0 || d.has_speed;

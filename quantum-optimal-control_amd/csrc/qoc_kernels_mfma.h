@@ -63,7 +63,7 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
     if (mf.NT > 2) return mf.variant == 1 ? 1 : (mf.variant == 2 ? 2 : 7);
     // AUTO, NT = 2: the in-place kernel whatever the batch (few (seed, chunk) items only occur with pinned chunk counts -- AUTO gives
     // small batches to the latency mode --, and a kernel that does not depend on the local batch keeps a restart bit-identical under any sharding)
-    int v = mf.variant > 0 ? mf.variant : (mf.NT == 2 ? ((d.T >= 3 || d.B * mf.C >= 512) ? 8 : 1) : 1);
+    int v = mf.variant > 0 ? mf.variant : (mf.NT == 2 ? ((d.T >= 3 || d.Bplan * mf.C >= 512) ? 8 : 1) : 1);
     if (v == 7) v = 4;                                                  // the row-block kernel is an NT = 3 / 4 kernel
     if (v == 8 && (d.T < 3 || mf.NT != 2)) v = 4;                      // the in-place kernel needs at least one Horner product (T >= 3)
     if (v == 4 && (d.T < 2 || mf.NT != 2)) v = 3;                      // the streamed kernel starts from the product A * A

@@ -18,7 +18,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         // Fewer than 32 seeds (NT = 2): chunks down to 8 slices keep all SIMDs busy -- 16 seeds: 0.50 ms per iteration with 63 chunks against
         // 0.62 with 32; 20 seeds: 0.52 (50 chunks) against 0.63; 24 seeds: 0.58 (42) against 0.64 -- the longer boundary recursion of the
         // sweeps costs less than the idle SIMDs of the exponential kernel.
-        C = NT == 2 ? 1024 / d.B : (1024 + d.B - 1) / d.B;
+        C = NT == 2 ? 1024 / d.Bplan : (1024 + d.Bplan - 1) / d.Bplan;          // (the PLANNED batch: a shard of it chunks like the whole)
         if (C > (NT == 2 ? 64 : 32)) C = NT == 2 ? 64 : 32;
     }
     // latency mode (variant 5; AUTO for a handful of seeds, qoc_mfma_latency_ok): one wave per SLICE for the exponentials, short

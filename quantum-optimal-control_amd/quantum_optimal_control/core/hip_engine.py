@@ -26,7 +26,7 @@ class QocConfig(C.Structure):
                 ('c_d2wdt2', C.c_double), ('c_speed_up', C.c_double), ('c_bandpass', C.c_double),
                 ('band_lo', C.c_int32), ('band_hi', C.c_int32), ('n_forbidden', C.c_int32),
                 ('forbid_dressed', C.c_int32), ('device', C.c_int32), ('path', C.c_int32), ('chunks', C.c_int32),
-                ('variant', C.c_int32), ('reserved', C.c_int32 * 6)]
+                ('variant', C.c_int32), ('plan_seeds', C.c_int32), ('reserved', C.c_int32 * 5)]
 
 
 class QocAdamParams(C.Structure):
@@ -156,6 +156,13 @@ def comm_unique_id():
     return buf.raw
 
 
+def plan_seeds_for(total_restarts):
+    """The batch size AUTO should plan for when `total_restarts` control sets may be sharded over the GPUs of this node: what a
+    full-node run gives each GPU.  It depends on the node, not on how many ranks a launch uses, so a restart evolves bit-identically
+    under any rank count (and a full-node run keeps every GPU's 1024 SIMDs busy)."""
+    return max(1, -(-int(total_restarts) // max(1, device_count())))
+
+
 def comm_probe(device=0):
     """Local preconditions of QocComm (librccl loadable, device usable); raises QocError with the reason.  No collective."""
     _check(load_library().qoc_comm_probe(int(device)))
@@ -215,7 +222,7 @@ class HipEngine(object):
     """Device-resident GRAPE problem: constants in HBM, n_seeds control sets, one HIP stream."""
 
     def __init__(self, Hs, U0, V, W, maxA, dt, total_time, steps, taylor_terms, scaling, state_transfer=False,
-                 reg_coeffs=None, one_minus_gauss=None, Vs=None, n_seeds=1, device=0, path=PATH_AUTO, chunks=0, variant=0):
+                 reg_coeffs=None, one_minus_gauss=None, Vs=None, n_seeds=1, device=0, path=PATH_AUTO, chunks=0, variant=0, plan_seeds=0):
         lib = load_library()
         self._lib = lib
         self._h = C.c_void_p()
@@ -246,6 +253,7 @@ class HipEngine(object):
         use_vs = Vs is not None and cfg.n_forbidden > 0
         cfg.forbid_dressed = int(use_vs)
         cfg.device, cfg.path, cfg.chunks, cfg.variant = int(device), int(path), int(chunks), int(variant)
+        cfg.plan_seeds = int(plan_seeds)       # 0: plan for n_seeds; > 0: the batch AUTO plans for (sharded restarts: see plan_seeds_for)
         omg = None
         if one_minus_gauss is not None:
             omg = np.ascontiguousarray(np.asarray(one_minus_gauss, dtype=np.float64))

@@ -26,7 +26,8 @@ if __name__ == '__main__':
     np.random.seed(c['np_seed'])
     with contextlib.redirect_stdout(io.StringIO()):
         uks1, Uf1 = Grape(convergence=conv, method='Adam', restarts=6, **grape_kwargs(c))
-    assert np.allclose(uks, uks1, atol=1e-9) and np.allclose(Uf, Uf1, atol=1e-9), (rank, np.max(np.abs(uks - uks1)))
+    # bit for bit: both runs plan their kernels for the same batch (qoc_config.plan_seeds), whatever the rank count
+    assert np.array_equal(uks, uks1) and np.array_equal(Uf, Uf1), (rank, np.max(np.abs(uks - uks1)))
     print('OK sharded rank %d' % rank, flush=True)
     dist.barrier()
     dist.destroy_process_group()
