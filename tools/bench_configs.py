@@ -23,7 +23,13 @@ def run(name, c, n_seeds, iters, path=0, variant=0, chunks=0):
     rng = np.random.default_rng(0)
     eng.set_base(rng.normal(0, 1 / np.sqrt(sp.steps), (n_seeds, sp.k, sp.steps)))
     p = eng.adam_params(max_iterations=10 ** 9, conv_target=-1.0, min_grad=-1.0)
+    # warm up for >= 0.3 s and time >= 0.5 s: a launch-bound run of a few iterations right after the engine was created can come out 2-3x
+    # slow (GPU still at its idle clocks; the 17.76 ms line of profiles/r02_secondary_configs.txt was such a run)
+    t0 = time.perf_counter()
     eng.iterate(p, 2); eng.sync()
+    per = max((time.perf_counter() - t0) / 2, 1e-5)
+    eng.iterate(p, max(1, min(2000, int(0.3 / per)))); eng.sync()
+    iters = max(iters, min(5000, int(0.5 / per)))
     t0 = time.perf_counter()
     eng.iterate(p, iters); eng.sync()
     el = time.perf_counter() - t0
