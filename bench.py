@@ -37,7 +37,7 @@ import numpy as np  # noqa: E402
 N, K_OPS, SLICES, M, TAYLOR = 32, 4, 500, 8, (5, 3)
 SEEDS_PER_GPU = 64
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X public fp64 matrix (= vector) peak; MI355X_MICROARCH.md lists no fp64 row
-PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 
 
 def build_problem():
@@ -250,6 +250,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-single', action='store_true', help='skip the one-trajectory latency measurement')
     ap.add_argument('--groups', type=int, default=1, help='split the seeds of this GPU over G engines/streams')
+    ap.add_argument('--prewarm', type=int, default=100, help='untimed iterations BEFORE the W warm-up steps: a GPU that was idle takes tens of '
+                                                               'milliseconds to reach its working clocks, more than W = 5 steps of 1.2 ms last')
     ap.add_argument('--reference-ops-worker', default=None, help=argparse.SUPPRESS)   # internal: one process of the all-core B-faithful CPU leg
     args = ap.parse_args()
     if args.reference_ops_worker:
@@ -307,6 +309,10 @@ def main():
         if transport is not None:
             transport.barrier()
 
+    iterate(max(0, args.prewarm))          # clocks up; restarted below, so that exactly warmup + steps iterations lie behind the reported state
+    sync()
+    for g in range(G):
+        engs[g].set_base(seed_bases(shard.first + gsh[g].first, gsh[g].count))
     iterate(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -400,7 +406,7 @@ def main():
                        'transport_fallback': bool(comm is not None and comm.library.startswith('files')),
                        'rccl_error': getattr(comm, 'fallback_reason', None) if comm is not None else None,
                        'parallelism': 'seed-sharded x%d, one all-gather of final fidelities, no collective inside the iterations' % world},
-            'per_seed_iterations_per_s': args.steps / elapsed,
+            'per_seed_iterations_per_s': args.steps / elapsed, 'prewarm_steps': max(0, args.prewarm),
             'single_trajectory': single,
             'best_fidelity': float(np.max(fidelity)),
             'roofline': roof,

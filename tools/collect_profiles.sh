@@ -6,10 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/collect
 mkdir -p $O
 cd $R
-python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 # kernel table of EXACTLY the driver command (its dominant-kernel average must reproduce roofline.avg_launch_ms)
-rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench.py > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench.py --steps 20 --warmup 5 > $O/bench_under_rocprof.json 2>/dev/null
 cd $R
 python tools/rocpd_kernel_stats.py $(ls $O/prof_bench/*/*_results.db | head -1) > $O/prof_bench.txt 2>&1
 rm -rf $O/prof_bench
