@@ -11,7 +11,7 @@ import pytest
 
 from oracle import grape_oracle as go
 from tests.golden import cases
-from tests.helpers import grape_kwargs, oracle_system
+from tests.helpers import grape_kwargs, load_golden, oracle_system
 
 pytestmark = pytest.mark.gpu
 
@@ -803,3 +803,28 @@ def test_plan_seeds_makes_a_shard_bit_identical_to_the_whole_batch():
     unplanned = run(guesses[pick], 0)
     assert unplanned[3] != 16                              # latency mode: other chunking, other association ...
     np.testing.assert_allclose(unplanned[0], small[0], atol=1e-9)          # ... same mathematics
+
+
+@pytest.mark.parametrize('name', ['c1', 'small_auto_U0', 'dressed_forbidden', 'state_small', 'c3_small', 'unitary_allreg', 'state_transfer_allreg', 'c2_n8'])
+@pytest.mark.parametrize('path', [0, 1], ids=['auto', 'generic'])
+def test_hip_against_the_reference_graph_vectors(name, path):
+    """The HIP engine straight against tests/golden/graph_*.npz -- numbers the reference's OWN graph code produced (lib2to3 copy of
+    core/tensorflow_state.py + core/regularization_functions.py run on a TF1 stand-in, tests/golden/make_graph_golden.py), no oracle in
+    between: loss, reg_loss, unitary_scale, grad_squared, gradient, final_state, inter_vecs, and the variable after one Adam step."""
+    from tests.golden.make_graph_golden import graph_cases
+    c = graph_cases()[name]
+    fx = load_golden('graph_%s.npz' % name)
+    sp = oracle_system(c)                                   # inputs only (a1-a5 are pinned bit-exactly by sysparams_*.npz)
+    eng = make_engine(sp, n_seeds=1, path=path)
+    eng.set_base(fx['base0'][None])
+    r = eng.evaluate()
+    for key in ('loss', 'reg_loss', 'unitary_scale', 'grad_squared'):
+        assert abs(r[key][0] - float(fx[key])) <= S_RTOL * max(1.0, abs(float(fx[key]))), (key, r[key][0], float(fx[key]))
+    gmax = np.max(np.abs(fx['grad_pack']))
+    assert np.max(np.abs(r['grad'][0] - fx['grad_pack'])) <= G_RTOL * max(gmax, 1e-3)
+    np.testing.assert_allclose(eng.get_inter_vecs()[0], fx['inter_vecs'], rtol=0, atol=U_ATOL * max(1, np.max(np.abs(fx['inter_vecs']))))
+    if not sp.state_transfer:
+        np.testing.assert_allclose(eng.get_final_unitary()[0], fx['final_state'], rtol=0, atol=U_ATOL)
+    eng.adam_step(float(fx['adam_lr']))
+    np.testing.assert_allclose(eng.get_base()[0], fx['base_after_adam'], rtol=0, atol=1e-12)
+    eng.close()
