@@ -33,6 +33,11 @@
 
 #define ILDS (16 * NT + 5)        // image row stride (complex elements): conflict-free strip stores and block reads (as chunk4s)
 
+#ifndef QOC_INPLACE_PIPE
+#define QOC_INPLACE_PIPE 0        // 1: combine of group ib - 1 after the first block step of group ib (two accumulator sets) instead of at the group
+                                  // boundary -- measured SLOWER, 0.815 against 0.800 ms per launch: the boundary batch does not wait for the pipe (its
+                                  // first instructions need the oldest results), and a batch between two MFMAs of a running group costs more issue slots
+#endif
 #ifndef QOC_LAP
 #define QOC_LAP(ph)
 #define QOC_LAP_INIT
@@ -78,9 +83,14 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
         ring.v[st & 3] = base[4 * kb * ILDS + 4 * ib];
         ring.s[st & 3] = bases[4 * kb * ILDS + 4 * ib];
     };
+    // (QOC_INPLACE_PIPE = 1: the combine of group ib - 1 runs after the first block step of group ib, on the other accumulator set)
+    double acc[2][3][NT];
     for_each([&](auto ibc) {
         constexpr int ib = decltype(ibc)::value, pib = (ib + QS - 1) % QS;      // pending strip: the previous group's (the previous product's last)
-        double a[NT], b[NT], c[NT];
+        constexpr int off = (QOC_INPLACE_PIPE && ib > 0) ? 1 : 0;               // its stores follow the (deferred) combine
+        double (&a)[NT] = acc[ib & 1][0];
+        double (&b)[NT] = acc[ib & 1][1];
+        double (&c)[NT] = acc[ib & 1][2];
         constexpr bool preset = decltype(init(ibc, a, c))::value;
         init(ibc, a, c);
         __builtin_amdgcn_sched_barrier(0);
@@ -89,9 +99,10 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
             const int st = ib * QS + kb;
             fetch(st + RA);
             fence();
-            if (kb < 2 * NT) {                                          // one store of the pending strip per block step
-                if ((kb & 1) == 0) wbase[16 * (kb >> 1) * ILDS + 4 * pib] = ring.pri[kb >> 1];
-                else wbases[16 * (kb >> 1) * ILDS + 4 * pib] = ring.psu[kb >> 1];
+            if (kb >= off && kb < off + 2 * NT) {                       // one store of the pending strip per block step
+                const int q = kb - off;
+                if ((q & 1) == 0) wbase[16 * (q >> 1) * ILDS + 4 * pib] = ring.pri[q >> 1];
+                else wbases[16 * (q >> 1) * ILDS + 4 * pib] = ring.psu[q >> 1];
                 fence();
             }
             const cplx v = ring.v[st & 3];
@@ -106,6 +117,13 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
                     a[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.x, P.re[J][kb], a[J], 0, 0, 0);
                     b[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(v.y, P.im[J][kb], b[J], 0, 0, 0);
                     c[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(vs, P.su[J][kb], c[J], 0, 0, 0);
+                }
+            }
+            if constexpr (QOC_INPLACE_PIPE && ib > 0) {
+                if (kb == 0) {                                          // the previous group's VALU batch, under no dependence on the pipe
+                    __builtin_amdgcn_sched_barrier(0);
+                    epi(std::integral_constant<int, ib - 1>{}, acc[(ib - 1) & 1][0], acc[(ib - 1) & 1][1], acc[(ib - 1) & 1][2], ring.pri, ring.psu);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if constexpr (RELOAD_IN) {
@@ -126,9 +144,11 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
             }
         }
         // the group's VALU batch stays a batch: a lone wave's VALU instructions cost MFMA issue slots wherever they stand, least in a group
-        __builtin_amdgcn_sched_barrier(0);
-        epi(ibc, a, b, c, ring.pri, ring.psu);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!QOC_INPLACE_PIPE || ib == QS - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            epi(ibc, a, b, c, ring.pri, ring.psu);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }, std::make_integer_sequence<int, QS>{});
 }
 
