@@ -57,11 +57,14 @@ template <class F, int... I>
 __device__ __forceinline__ void for_each(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 
 // strip (J, ib) of the matrix in the image -> the three planes of a set (strip layout = the store pattern: conflict-free)
-template <int NT>
+// PAIR: re and im by one ds_read_b128 (conflict-free with this stride; they then share a 128-bit register tuple); else two ds_read_b64 (2-way
+// bank conflicts, but the planes are separate registers: the imaginary plane of A_t must be free to die after the first product)
+template <int NT, bool PAIR>
 __device__ __forceinline__ void load_strip(const cplx* img, const double* imgs, int lane, Set<NT>& S, int J, int ib) {
     const int o = (16 * J + (lane & 15)) * ILDS + 4 * ib + (lane >> 4);
-    const double* p = (const double*)(img + o);
-    S.re[J][ib] = p[0]; S.im[J][ib] = p[1]; S.su[J][ib] = imgs[o];
+    if constexpr (PAIR) { const cplx v = img[o]; S.re[J][ib] = v.x; S.im[J][ib] = v.y; }
+    else { const double* p = (const double*)(img + o); S.re[J][ib] = p[0]; S.im[J][ib] = p[1]; }
+    S.su[J][ib] = imgs[o];
 }
 
 // One product acc = (image) * P, row strip by row strip.
@@ -130,7 +133,7 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
                 if (ib == 0 && kb == 2 * NT) {                          // the previous product's last strip is in the image now
                     fence();
 #pragma unroll
-                    for (int J = 0; J < NT; ++J) load_strip<NT>(img, imgs, lane, P, J, QS - 1);
+                    for (int J = 0; J < NT; ++J) load_strip<NT, true>(img, imgs, lane, P, J, QS - 1);
                     fence();
                 }
             }
@@ -138,7 +141,7 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
                 if (ib == QS - 1 && kb < QS - 1) {                      // strip kb has multiplied for the last time: the new matrix's strip kb takes its registers
                     fence();
 #pragma unroll
-                    for (int J = 0; J < NT; ++J) load_strip<NT>(img, imgs, lane, P, J, kb);
+                    for (int J = 0; J < NT; ++J) load_strip<NT, true>(img, imgs, lane, P, J, kb);
                     fence();
                 }
             }
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
 #pragma unroll
             for (int J = 0; J < NT; ++J) {
 #pragma unroll
-                for (int ib = 0; ib < QS - 1; ++ib) load_strip<NT>(img, imgs, lane, SA, J, ib);
+                for (int ib = 0; ib < QS - 1; ++ib) load_strip<NT, false>(img, imgs, lane, SA, J, ib);
                 SA.re[J][QS - 1] = ring.pri[J].x; SA.im[J][QS - 1] = ring.pri[J].y; SA.su[J][QS - 1] = ring.psu[J];
             }
             fence();
