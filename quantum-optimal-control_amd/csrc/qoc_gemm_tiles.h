@@ -173,15 +173,28 @@ __global__ void __launch_bounds__(64 * SK) k_zgemm32(GemmArgs g) {
 // multiplies, written to LDS between two LDS-only barriers.  In the loop a wave reads its 4x4 blocks of A (broadcast over the
 // four block lanes) through a 3-slot ring two steps ahead and the 4-row strips of B of the next k-block while this one
 // multiplies; __builtin_amdgcn_sched_barrier pins that order (left alone hipcc sinks the reads next to their use).
+// The kernel lives in its own translation unit (qoc_gemm_wg.hip, compiled WITHOUT -amdgpu-mfma-vgpr-form: its 96 accumulators belong in
+// AGPRs, where they cost nothing until the epilogue; the rest of the GEMM path gains from the VGPR form); other units see the two host entries.
+void qoc_zgemm_wg_launch(const struct GemmArgs& g, unsigned blocks, hipStream_t s);
+bool qoc_zgemm_wg_opt_in();
 #define ZW_KC 16           // depth of a k-chunk (32, filling the 160 KB of LDS, was slower: C5 281 vs 271 ms)
 #define ZW_LDA (ZW_KC + 4) // + 4: the 16 (row, k) addresses of a block read fall into distinct banks
-struct ZwB { cplx v[4]; double s[4]; };
-__global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
+static inline size_t qoc_zgemm_wg_lds() { return (size_t)2 * (64 * ZW_LDA + ZW_KC * 128) * (sizeof(cplx) + sizeof(double)); }   // 159744 B of the 160 KB
+#ifdef QOC_ZGEMM_WG_TU
+#ifndef ZW_WAVES
+#define ZW_WAVES 8         // waves per workgroup: 8 = two per SIMD, a 32 x 32 wave tile each (48 accumulators); 4 = one per SIMD, 32 x 64 (96)
+#endif
+// Two waves per SIMD (round 3): with one, the matrix pipe was busy 60 % of the cycles -- a lone wave's s_waitcnt / barrier time (23 % of its
+// cycles, SQ_WAIT_ANY) and its ~90 VALU instructions per chunk are all exposed; a partner wave's MFMAs fill them.
+template <int NJ> struct ZwB { cplx v[NJ]; double s[NJ]; };
+__global__ void __launch_bounds__(64 * ZW_WAVES, 1) k_zgemm_wg(GemmArgs g) {
+    constexpr int NW = ZW_WAVES, NTHR = 64 * NW, NJ = NW == 8 ? 2 : 4;        // NJ = 16-column strips of a wave tile
     extern __shared__ __attribute__((aligned(16))) char zw_lds[];
-    cplx* Ai = (cplx*)zw_lds;                        // [64][ZW_LDA]
-    cplx* Bi = Ai + 64 * ZW_LDA;                     // [ZW_KC][128]
-    double* As = (double*)(Bi + ZW_KC * 128);        // [64][ZW_LDA]
-    double* Bs = As + 64 * ZW_LDA;                   // [ZW_KC][128]
+    // LDS: two image sets (double buffer), each A [64][ZW_LDA] + B [ZW_KC][128]: the complex parts of both sets, then their re + im sums
+    cplx* Ai = (cplx*)zw_lds;                        // set 0: [64][ZW_LDA]
+    cplx* Bi = Ai + 64 * ZW_LDA;                     //        [ZW_KC][128]
+    double* As = (double*)(Ai + 2 * (64 * ZW_LDA + ZW_KC * 128));        // sums of set 0: [64][ZW_LDA]
+    double* Bs = As + 64 * ZW_LDA;                   //                   [ZW_KC][128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tm2 = g.tiles_m >> 1, tn2 = g.tiles_n >> 2, tiles = tm2 * tn2;
@@ -196,18 +209,18 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
     const cplx* __restrict__ A = g.A + (size_t)bhi * g.sA2 + (size_t)blo * g.sA;
     const cplx* __restrict__ Bm = g.Bm + (size_t)bhi * g.sB2 + (size_t)blo * g.sB;
     const int lr = lane & 15, lk = lane >> 4, li4 = lane & 3;
-    const int r0w = 32 * (wv & 1), c0w = 64 * (wv >> 1);
+    const int r0w = 32 * (wv & 1), c0w = 16 * NJ * (wv >> 1);
     // staging roles, lane-contiguous in global memory AND in LDS (a first mapping with 4 / 8 consecutive elements per thread
-    // put every ds_write on 4 bank groups): element e of a thread is flat index e*256 + tid of the chunk,
+    // put every ds_write on 4 bank groups): element e of a thread is flat index e * NTHR + tid of the chunk,
     // A chunk 64 rows x KC k -> (row = idx / KC, k = idx % KC), B chunk KC k x 128 columns -> (k = idx / 128, column = idx % 128)
-    constexpr int KC = ZW_KC, NSA = 64 * KC / 256, NSB = KC * 128 / 256, RPE = 256 / KC;   // elements per thread, A rows per e
+    constexpr int KC = ZW_KC, NSA = 64 * KC / NTHR, NSB = KC * 128 / NTHR, RPE = NTHR / KC, KPE = NTHR / 128;   // elements per thread; A rows / B k-rows per e
     const cplx* Ag = A + (size_t)(r0 + tid / KC) * g.lda + (tid % KC);            // + e * RPE rows
-    const cplx* Bg = Bm + (size_t)(tid >> 7) * g.ldb + c0 + (tid & 127);          // + e * 2 k-rows
-    double t1[8][4], t2[8][4], t3[8][4];
+    const cplx* Bg = Bm + (size_t)(tid >> 7) * g.ldb + c0 + (tid & 127);          // + e * KPE k-rows
+    double t1[8][NJ], t2[8][NJ], t3[8][NJ];
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
-        for (int J = 0; J < 4; ++J) { t1[ib][J] = 0.0; t2[ib][J] = 0.0; t3[ib][J] = 0.0; }
+        for (int J = 0; J < NJ; ++J) { t1[ib][J] = 0.0; t2[ib][J] = 0.0; t3[ib][J] = 0.0; }
     const int nch = g.Kdim / KC;
     cplx sa[NSA], sb[NSB];
     auto stage_fetch = [&](int ch) {
@@ -215,59 +228,76 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < NSA; ++e) sa[e] = Ag[(size_t)(RPE * e) * g.lda + KC * ch];
 #pragma unroll
-        for (int e = 0; e < NSB; ++e) sb[e] = Bg[(size_t)(KC * ch + 2 * e) * g.ldb];
+        for (int e = 0; e < NSB; ++e) sb[e] = Bg[(size_t)(KC * ch + KPE * e) * g.ldb];
         __builtin_amdgcn_sched_barrier(0);
-    };
-    auto stage_store = [&]() {
-#pragma unroll
-        for (int e = 0; e < NSA; ++e) { const int o = (RPE * e + tid / KC) * ZW_LDA + (tid % KC); Ai[o] = sa[e]; As[o] = sa[e].x + sa[e].y; }
-#pragma unroll
-        for (int e = 0; e < NSB; ++e) { const int o = (2 * e + (tid >> 7)) * 128 + (tid & 127); Bi[o] = sb[e]; Bs[o] = sb[e].x + sb[e].y; }
     };
     const cplx* arow = Ai + (r0w + li4) * ZW_LDA + lk;          // + (4 ib) * ZW_LDA + 4 kb
     const double* asrow = As + (r0w + li4) * ZW_LDA + lk;
     const cplx* bcol = Bi + lk * 128 + c0w + lr;                // + (4 kb) * 128 + 16 J
     const double* bscol = Bs + lk * 128 + c0w + lr;
-    auto load_b = [&](ZwB& b, int kb) {
-#pragma unroll
-        for (int J = 0; J < 4; ++J) { b.v[J] = bcol[(4 * kb) * 128 + 16 * J]; b.s[J] = bscol[(4 * kb) * 128 + 16 * J]; }
+    // Two image sets: while chunk ch multiplies out of set ch & 1, the staged registers of chunk ch + 1 go to the other set ONE LDS store at a
+    // time under the first half of its MFMAs, the fetch of chunk ch + 2 is issued at half time into the registers just stored, and ONE
+    // barrier per chunk separates "everybody has read set ch & 1 and written the other" from the next chunk.
+    constexpr int SET = 64 * ZW_LDA + ZW_KC * 128;            // elements of one image set (complex part; the sums follow the two complex sets)
+    cplx* const Ai0 = Ai; double* const As0 = (double*)(Ai + 2 * SET);
+    auto store_one = [&](int q, int set) {                      // q = 0 .. 2 (NSA + NSB) - 1: one LDS store of the staged chunk
+        cplx* ai = Ai0 + (size_t)set * SET; cplx* bi = ai + 64 * ZW_LDA;
+        double* as = As0 + (size_t)set * SET; double* bs = as + 64 * ZW_LDA;
+        const int e = q >> 1;
+        if (e < NSA) { const int o = (RPE * e + tid / KC) * ZW_LDA + (tid % KC); if (q & 1) as[o] = sa[e].x + sa[e].y; else ai[o] = sa[e]; }
+        else { const int f = e - NSA, o = (KPE * f + (tid >> 7)) * 128 + (tid & 127); if (q & 1) bs[o] = sb[f].x + sb[f].y; else bi[o] = sb[f]; }
     };
+    constexpr int NQ = 2 * (NSA + NSB), NSTEP = 2 * KC;        // the stores of a chunk over the first 16 of its 32 block steps
     stage_fetch(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) store_one(q, 0);
+    stage_fetch(1);
+    lds_barrier();
     for (int ch = 0; ch < nch; ++ch) {
-        stage_store();
-        lds_barrier();
-        stage_fetch(ch + 1);                                    // in flight while this chunk multiplies
+        const int set = ch & 1;
+        const cplx* arow_s = arow + (size_t)set * SET;
+        const double* asrow_s = (const double*)((const char*)asrow + (size_t)set * SET * sizeof(double));
+        const cplx* bcol_s = bcol + (size_t)set * SET;
+        const double* bscol_s = (const double*)((const char*)bscol + (size_t)set * SET * sizeof(double));
         // KC/4 x 8 block steps (kb, ib) of the chunk; A blocks through a 3-slot ring two steps ahead, B strips one k-block ahead
         cplx av[3]; double as[3];
-        auto load_a = [&](int st, int slot) { const int kb = st >> 3, ib = st & 7; av[slot] = arow[(4 * ib) * ZW_LDA + 4 * kb]; as[slot] = asrow[(4 * ib) * ZW_LDA + 4 * kb]; };
-        ZwB b0, b1;
-        load_b(b0, 0);
+        auto load_a = [&](int st, int slot) { const int kb = st >> 3, ib = st & 7; av[slot] = arow_s[(4 * ib) * ZW_LDA + 4 * kb]; as[slot] = asrow_s[(4 * ib) * ZW_LDA + 4 * kb]; };
+        auto load_bs = [&](ZwB<NJ>& b, int kb) {
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) { b.v[J] = bcol_s[(4 * kb) * 128 + 16 * J]; b.s[J] = bscol_s[(4 * kb) * 128 + 16 * J]; }
+        };
+        ZwB<NJ> b0, b1;
+        load_bs(b0, 0);
         load_a(0, 0);
         load_a(1, 1);
 #pragma unroll
-        for (int st = 0; st < 2 * KC; ++st) {
+        for (int st = 0; st < NSTEP; ++st) {
             const int kb = st >> 3, ib = st & 7;
-            if (st + 2 < 2 * KC) load_a(st + 2, (st + 2) % 3);
-            if (ib == 0 && kb + 1 < KC / 4) load_b((kb & 1) ? b0 : b1, kb + 1);
+            if (st + 2 < NSTEP) load_a(st + 2, (st + 2) % 3);
+            if (ib == 0 && kb + 1 < KC / 4) load_bs((kb & 1) ? b0 : b1, kb + 1);
+            // chunk ch + 1 -> the other set, spread over the first half of the steps (clamped chunks beyond the last one are stored too: harmless)
+#pragma unroll
+            for (int q = (st * NQ) / (NSTEP / 2); q < ((st + 1) * NQ) / (NSTEP / 2) && q < NQ; ++q) store_one(q, set ^ 1);
+            if (st == NSTEP / 2) stage_fetch(ch + 2);          // the staged registers are free again
             __builtin_amdgcn_sched_barrier(0);
-            const ZwB& b = (kb & 1) ? b1 : b0;
+            const ZwB<NJ>& b = (kb & 1) ? b1 : b0;
             const cplx a = av[st % 3];
             const double asum = as[st % 3];
 #pragma unroll
-            for (int J = 0; J < 4; ++J) {
+            for (int J = 0; J < NJ; ++J) {
                 t1[ib][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, b.v[J].x, t1[ib][J], 0, 0, 0);
                 t2[ib][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, b.v[J].y, t2[ib][J], 0, 0, 0);
                 t3[ib][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(asum, b.s[J], t3[ib][J], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        lds_barrier();                                          // every wave is done reading this chunk's images
+        lds_barrier();                                          // set ch & 1 has been read by every wave, the other set is complete
     }
     // D strip (ib, J): lane 16 i + c16 <-> (row = r0 + r0w + 4 ib + i, col = c0 + c0w + 16 J + c16)
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
-        for (int J = 0; J < 4; ++J) {
+        for (int J = 0; J < NJ; ++J) {
             const int row = r0 + r0w + 4 * ib + lk, col = c0 + c0w + 16 * J + lr;
             const double vre = t1[ib][J] - t2[ib][J], vim = t3[ib][J] - t1[ib][J] - t2[ib][J];
             cplx v = cmake(g.alpha * vre, g.alpha * vim);
@@ -280,4 +310,4 @@ __global__ void __launch_bounds__(256, 1) k_zgemm_wg(GemmArgs g) {
             if (g.CT) g.CT[(size_t)bt * g.sCT + (size_t)col * g.ldct + row] = v;
         }
 }
-static inline size_t qoc_zgemm_wg_lds() { return (size_t)(64 * ZW_LDA + ZW_KC * 128) * (sizeof(cplx) + sizeof(double)); }
+#endif  // QOC_ZGEMM_WG_TU

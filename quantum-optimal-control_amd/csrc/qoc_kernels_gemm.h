@@ -382,7 +382,7 @@ static inline bool qoc_gemm_lds_opt_in() {
     return qoc_gemm_lds_opt_in_sk<false, 0>() && qoc_gemm_lds_opt_in_sk<false, 1>() && qoc_gemm_lds_opt_in_sk<false, 2>() && qoc_gemm_lds_opt_in_sk<true, 0>() &&
            hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx)) == hipSuccess &&
            hipFuncSetAttribute((const void*)k_gemm_scan_nodes<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_scan_lds(64)) == hipSuccess &&
-           hipFuncSetAttribute((const void*)k_zgemm_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_zgemm_wg_lds()) == hipSuccess;
+           qoc_zgemm_wg_opt_in();
 }
 // planned / local batch of the engine whose launches are being enqueued by this host thread (set by the qoc_gemm_* entry points): the
 // split factor and the kernel family change the association of the sums, so they follow the PLANNED batch (QocDev::Bplan)
@@ -413,7 +413,7 @@ static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipSt
         else qoc_gemm_launch_sk<true, 0, 1>(g, blocks, s);
     } else if (sk == 1 && (g.tiles_m & 1) == 0 && (g.tiles_n & 3) == 0 && (g.Kdim % ZW_KC) == 0 && g.Kdim >= 128 && tiles >= 8 * 1024) {
         // large plain products: workgroup tiles of 64 x 128 on the 4x4x4 MFMA form
-        hipLaunchKernelGGL(k_zgemm_wg, dim3((unsigned)(real_tiles / 8)), dim3(256), qoc_zgemm_wg_lds(), s, g);
+        qoc_zgemm_wg_launch(g, (unsigned)(real_tiles / 8), s);
     } else {
         if (sk == 8) qoc_gemm_launch_sk<false, 0, 8>(g, blocks, s);
         else if (sk == 4) qoc_gemm_launch_sk<false, 0, 4>(g, blocks, s);
