@@ -52,7 +52,7 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
           dressed_info=None, maxA=None, use_gpu=True, sparse_H=True, sparse_U=False, sparse_K=False, draw=None,
           initial_guess=None, show_plots=True, unitary_error=1e-4, method='Adam', state_transfer=False,
           no_scaling=False, freq_unit='GHz', file_name=None, save=True, data_path=None, Taylor_terms=None,
-          use_inter_vecs=True, restarts=1, _first_seed=0, _device=0, _return_session=False, _total_restarts=None):
+          use_inter_vecs=True, restarts=1, plan_seeds=None, _first_seed=0, _device=0, _return_session=False):
     """Reference signature (main_grape/grape.py:19) plus one optional extension: ``restarts=B`` optimises B control sets at
     once on the GPU -- the first is the reference's own initial guess (same NumPy RNG draw / ``initial_guess``), the others
     are independent N(0, 1/sqrt(steps)) restarts -- and returns the (uks, U_final) of the best final fidelity."""
@@ -89,11 +89,11 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
                                 maxAmp, draw, initial_guess, show_plots, unitary_error, state_transfer, no_scaling,
                                 reg_coeffs, save, file_path, Taylor_terms, use_gpu, use_inter_vecs, sparse_H, sparse_U,
                                 sparse_K)
-    # the engine plans (path, kernels, chunking) for the share a full-node run gives one GPU of ALL the restarts of this call, not for
-    # the restarts that happen to live in this process: a restart then evolves bit-identically under any rank count
-    from quantum_optimal_control.core import hip_engine
-    plan = hip_engine.plan_seeds_for(max(1, int(restarts)) if _total_restarts is None else int(_total_restarts))
-    tfs = HipState(sys_para, n_seeds=max(1, int(restarts)), device=_device, first_seed=_first_seed, plan_seeds=plan)   # constants -> HBM
+    # plan_seeds (extension): the batch size the engine plans its path / kernels / chunking for instead of `restarts` (None: its own batch,
+    # the fastest choice for this process).  GrapeSharded passes hip_engine.plan_seeds_for(all restarts), so that a restart evolves
+    # bit-identically under any rank count; Grape(restarts=R, plan_seeds=hip_engine.plan_seeds_for(R)) reproduces a sharded run in one process.
+    tfs = HipState(sys_para, n_seeds=max(1, int(restarts)), device=_device, first_seed=_first_seed,
+                   plan_seeds=0 if plan_seeds is None else int(plan_seeds))   # constants -> HBM
     graph = tfs.build_graph()
     conv = Convergence(sys_para, time_unit, convergence)
     try:
@@ -124,8 +124,10 @@ def GrapeSharded(*args, restarts=8, dist=None, comm=None, **kwargs):
     = a single process.  Every rank optimises its own restarts on its own GPU -- no data-path collective --, the best final
     losses are all-gathered once, and the winner's (uks, U_final) is broadcast, so every rank returns the same pair.
     Global restart g starts from the same point whatever the number of ranks (restart 0 = the reference's own draw), and every engine plans
-    its kernels for the same batch (`hip_engine.plan_seeds_for(restarts)`), so the result is BIT-identical to `Grape(restarts=restarts)` in one
-    process -- tests/sharded_script.py checks array_equal."""
+    its kernels for the same batch (`plan_seeds`, default `hip_engine.plan_seeds_for(restarts)` = restarts / GPUs of the node: what a full-node
+    launch gives each GPU), so the result is BIT-identical under any rank count and to `Grape(restarts=restarts, plan_seeds=<the same>)` in one
+    process -- tests/sharded_script.py checks array_equal.  (A launch on far fewer GPUs than the node has runs kernels planned for a smaller
+    batch than it holds; pass plan_seeds to choose.)"""
     from quantum_optimal_control.parallel_seeds import SeedShard
     if comm is not None:
         world, rank = comm.world, comm.rank
@@ -140,7 +142,9 @@ def GrapeSharded(*args, restarts=8, dist=None, comm=None, **kwargs):
     device = int(kwargs.pop('device', default_device))
     if rank != 0:
         kwargs['save'] = False                                       # only rank 0 may write the run log
-    out = Grape(*args, restarts=shard.count, _first_seed=shard.first, _device=device, _return_session=True, _total_restarts=int(restarts), **kwargs)
+    from quantum_optimal_control.core import hip_engine
+    kwargs.setdefault('plan_seeds', hip_engine.plan_seeds_for(int(restarts)))
+    out = Grape(*args, restarts=shard.count, _first_seed=shard.first, _device=device, _return_session=True, **kwargs)
     if world == 1:
         return None if out is None else out[:2]
     # one value per RANK (its best restart): gather, pick the winner, broadcast its pulse and unitary.  A rank whose run was
