@@ -3,6 +3,7 @@ scipy.optimize.minimize driven by the CPU oracle, (b) the reference's float32 ar
 gradient against a derivation that shares no code with the oracle."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,8 @@ from oracle import grape_oracle as go
 from tests import independent_gradient as ig
 from tests.golden import cases
 from tests.helpers import grape_kwargs, oracle_system
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_fp32_reference_arithmetic_at_full_c2_size():
@@ -108,3 +111,37 @@ def test_scipy_drivers_follow_the_oracle_driven_optimiser(method):
     assert calls['n'] >= 10
     np.testing.assert_allclose(uks, uks_o, rtol=0, atol=1e-8 * np.max(np.abs(uks_o)))
     np.testing.assert_allclose(Uf, r_o['U_final'], rtol=0, atol=1e-8)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/quantum_optimal_control'), reason='needs the reference tree (build container only)')
+def test_committed_fixtures_are_what_the_reference_code_produces(tmp_path):
+    """Integrity of tests/golden/: re-run both generators against /root/reference in a scratch copy of tests/golden/ and compare every array with
+    the committed file -- sysparams_* / helpers (the reference's NumPy code) bit for bit, graph_* (its graph code on the TF1 stand-in) to 1e-14
+    (torch reductions may reassociate between runs of different thread counts)."""
+    import shutil
+    import subprocess
+    import sys
+    golden = os.path.join(ROOT, 'tests', 'golden')
+    work = tmp_path / 'repo'
+    (work / 'tests').mkdir(parents=True)
+    shutil.copytree(golden, work / 'tests' / 'golden')
+    for f in ('__init__.py', 'helpers.py'):
+        shutil.copy(os.path.join(ROOT, 'tests', f), work / 'tests' / f)
+    os.symlink(os.path.join(ROOT, 'quantum-optimal-control_amd'), work / 'quantum-optimal-control_amd')
+    os.symlink(os.path.join(ROOT, 'oracle'), work / 'oracle')
+    for script in ('make_golden.py', 'make_graph_golden.py'):
+        r = subprocess.run([sys.executable, str(work / 'tests' / 'golden' / script)], capture_output=True, text=True, timeout=900, cwd=str(work))
+        assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    checked = 0
+    for name in sorted(os.listdir(golden)):
+        if not name.endswith('.npz') or name.startswith('c2_bench'):
+            continue
+        old, new = np.load(os.path.join(golden, name)), np.load(work / 'tests' / 'golden' / name)
+        assert sorted(old.files) == sorted(new.files), name
+        for k in old.files:
+            if name.startswith('graph_') and old[k].dtype.kind in 'fc':
+                np.testing.assert_allclose(new[k], old[k], rtol=0, atol=1e-14 * max(1.0, float(np.max(np.abs(old[k])))), err_msg='%s:%s' % (name, k))
+            else:
+                assert np.array_equal(old[k], new[k]), (name, k)
+            checked += 1
+    assert checked > 200
