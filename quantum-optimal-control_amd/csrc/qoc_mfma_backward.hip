@@ -60,6 +60,18 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         return true;
     };
     if (!up(&mf.HfD, hd) || !up(&mf.HfT, ht) || !up(&mf.U0fD, u0)) { msg = "MFMA path: constant upload failed"; return -3; }
+    {
+        // k_mfma_expm_inplace evaluates the Taylor polynomial in the scaled variable S = sigma A with sigma^T = 1/T!: the polynomial is then
+        // monic, its Horner start X = S + c I costs nothing but the diagonal, and sigma / 2^s is folded into a scaled copy of the Hamiltonians
+        const int T = d.T < 1 ? 1 : (d.T > 22 ? 22 : d.T);
+        mf.psigma = std::pow(mf.invfact[T], 1.0 / (double)T);
+        for (int j = 0; j < 24; ++j) mf.pcoef[j] = mf.invfact[j] * std::pow(mf.psigma, -(double)j);
+        mf.pcoef[T] = 1.0;
+        const double sc = mf.psigma / (double)(1 << d.s);
+        std::vector<cplx> hs(hd);
+        for (auto& v : hs) { v.x *= sc; v.y *= sc; }
+        if (!up(&mf.HsD, hs)) { msg = "MFMA path: constant upload failed"; return -3; }
+    }
     // the large buffers are carved out of ONE allocation (placement of separate hipMallocs after earlier engines of the process
     // were freed was worth a factor 2 on the GEMM path)
     std::vector<std::pair<cplx**, size_t>> wanted;

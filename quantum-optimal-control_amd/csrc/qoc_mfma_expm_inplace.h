@@ -50,7 +50,7 @@ template <int NT> struct Set { double re[NT][4 * NT], im[NT][4 * NT], su[NT][4 *
 // left blocks in flight (RA = 3 steps ahead, NS % 4 == 0) + the result strip of the last completed group, whose four LDS stores are
 // issued one per block step under the NEXT group's MFMAs (issued together at the group boundary they occupy the wave's LDS queue for ~200
 // cycles and the block reads behind them arrive late)
-template <int NT> struct Ring { cplx v[4]; double s[4]; cplx pri[NT]; double psu[NT]; };
+template <int NT> struct Ring { cplx v[4]; double s[4]; cplx pri[NT]; double psu[NT]; double ppl[3][NT]; };   // ppl: a pending strip as planes (PLANES products)
 
 __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
 template <class F, int... I>
@@ -74,7 +74,9 @@ __device__ __forceinline__ void load_strip(const cplx* img, const double* imgs, 
 // RELOAD_IN: this product's strip QS - 1 is such a read-back still to be issued (its stores are this product's first four).
 // The ring holds the blocks of steps st .. st + RA - 1 on entry and those of the NEXT product's first steps on exit (every product
 // of this kernel reads its left operand from the same image, whose rows 0 .. are complete long before the previous product ends).
-template <int NT, bool RELOAD_IN, bool RELOAD_OUT, class Init, class Epi>
+// PLANES: the epilogue hands the image strip over as three planes (ring.ppl: re, im, re + im) that are stored by three ds_write_b64 each --
+// for results that ARE registers of another matrix (X = S + c I: no VALU instruction to pair re with im); the last strip is paired for the next product.
+template <int NT, bool RELOAD_IN, bool RELOAD_OUT, bool PLANES, class Init, class Epi>
 __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<NT>& ring, Set<NT>& P, Init&& init, Epi&& epi) {
     constexpr int QS = 4 * NT, NS = QS * QS, RA = 3;
     const cplx* base = img + (lane >> 4) * ILDS + (lane & 3);
@@ -102,7 +104,14 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
             const int st = ib * QS + kb;
             fetch(st + RA);
             fence();
-            if (kb >= off && kb < off + 2 * NT) {                       // one store of the pending strip per block step
+            if (PLANES && ib > 0) {                                     // this product's own strips: three plane stores per column block
+                if (kb >= off && kb < off + 3 * NT) {
+                    const int q = kb - off, J = q / 3, w = q % 3;
+                    if (w < 2) ((double*)(wbase + 16 * J * ILDS + 4 * pib))[w] = ring.ppl[w][J];
+                    else wbases[16 * J * ILDS + 4 * pib] = ring.ppl[2][J];
+                    fence();
+                }
+            } else if (kb >= off && kb < off + 2 * NT) {                // one store of the pending strip per block step
                 const int q = kb - off;
                 if ((q & 1) == 0) wbase[16 * (q >> 1) * ILDS + 4 * pib] = ring.pri[q >> 1];
                 else wbases[16 * (q >> 1) * ILDS + 4 * pib] = ring.psu[q >> 1];
@@ -125,7 +134,8 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
             if constexpr (QOC_INPLACE_PIPE && ib > 0) {
                 if (kb == 0) {                                          // the previous group's VALU batch, under no dependence on the pipe
                     __builtin_amdgcn_sched_barrier(0);
-                    epi(std::integral_constant<int, ib - 1>{}, acc[(ib - 1) & 1][0], acc[(ib - 1) & 1][1], acc[(ib - 1) & 1][2], ring.pri, ring.psu);
+                    static_assert(!PLANES || !QOC_INPLACE_PIPE, "plane epilogues with the deferred combine are not wired up");
+                    if constexpr (!PLANES) epi(std::integral_constant<int, ib - 1>{}, acc[(ib - 1) & 1][0], acc[(ib - 1) & 1][1], acc[(ib - 1) & 1][2], ring.pri, ring.psu);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -149,7 +159,13 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
         // the group's VALU batch stays a batch: a lone wave's VALU instructions cost MFMA issue slots wherever they stand, least in a group
         if constexpr (!QOC_INPLACE_PIPE || ib == QS - 1) {
             __builtin_amdgcn_sched_barrier(0);
-            epi(ibc, a, b, c, ring.pri, ring.psu);
+            if constexpr (PLANES) {
+                epi(ibc, a, b, c, ring.ppl[0], ring.ppl[1], ring.ppl[2]);
+                if constexpr (ib == QS - 1) {                           // the next product stores pairs
+#pragma unroll
+                    for (int J = 0; J < NT; ++J) { ring.pri[J] = cmake(ring.ppl[0][J], ring.ppl[1][J]); ring.psu[J] = ring.ppl[2][J]; }
+                }
+            } else epi(ibc, a, b, c, ring.pri, ring.psu);
             __builtin_amdgcn_sched_barrier(0);
         }
     }, std::make_integer_sequence<int, QS>{});
@@ -162,8 +178,8 @@ __device__ __forceinline__ cplx* frag_at(cplx* F, int f) { return F + (f & ~3) *
 
 }  // namespace qoc_inplace
 
-// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient)
-template <int KC>
+// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient); EVEN = even Taylor order
+template <int KC, bool EVEN>
 __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma mf) {
     using namespace qoc_inplace;
     constexpr int NT = 2, QS = 4 * NT;
@@ -175,16 +191,15 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
     if (d.skip_done && d.done[b]) return;
     QOC_LAP_INIT
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps);
-    const double inv_scale = 1.0 / (double)(1 << d.s);
     const int dlt = (lane & 15) - (lane >> 4);
     double idv[4];                                    // identity pattern of a diagonal tile: strip r of the tile holds the diagonal where dlt == 4 r
 #pragma unroll
     for (int r = 0; r < 4; ++r) idv[r] = dlt == 4 * r ? 1.0 : 0.0;
     const int mm = d.T >> 1;
-    const bool even = (d.T & 1) == 0;
+    constexpr bool even = EVEN;
     const int nH = even ? mm - 1 : mm;                // Horner products over A2 (tensorflow_state.py:37-41 in Paterson-Stockmeyer form); >= 1 here (T >= 3)
-    const double p_c0 = even ? mf.invfact[2 * mm - 2] : mf.invfact[2 * mm], p_c1 = even ? mf.invfact[2 * mm - 1] : mf.invfact[2 * mm + 1];
-    const double p_cT = even ? mf.invfact[d.T] : 0.0;
+    // the polynomial in the scaled variable S = sigma A_t is monic (QocMfma::pcoef): its Horner start is S + c0 I (odd order) or S^2 + c1 S + c0 I
+    const double p_c0 = even ? mf.pcoef[2 * mm - 2] : mf.pcoef[2 * mm], p_c1 = even ? mf.pcoef[2 * mm - 1] : 1.0;
 
     Set<NT> SA, SB, R;
     Ring<NT> ring;
@@ -198,16 +213,16 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
         for (int ib = 0; ib < QS; ++ib) { R.re[J][ib] = diag(J, ib); R.im[J][ib] = 0.0; R.su[J][ib] = diag(J, ib); }
 
     const cplx* hk[KC + 1];
-    hk[0] = mf.HfD;
+    hk[0] = mf.HsD;                                   // Hamiltonian images already scaled by sigma / 2^s
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk) hk[kk + 1] = mf.HfD + (size_t)(kk < d.k ? kk + 1 : 0) * QFR;
+    for (int kk = 0; kk < KC; ++kk) hk[kk + 1] = mf.HsD + (size_t)(kk < d.k ? kk + 1 : 0) * QFR;
     auto coeffs = [&](int t, double (&ck)[KC]) {
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) ck[kk] = kk < d.k ? d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale : 0.0;
+        for (int kk = 0; kk < KC; ++kk) ck[kk] = kk < d.k ? d.u[((size_t)b * d.k + kk) * d.steps + t] : 0.0;
     };
-    // strip (J, ib) of A_t = (H0' + sum_k u_k H_k') / 2^s from the staged Hamiltonian strips
+    // strip (J, ib) of S_t = sigma (H0' + sum_k u_k H_k') / 2^s from the staged (scaled) Hamiltonian strips
     auto assemble = [&](const cplx (&h)[KC + 1], const double (&ck)[KC], double& re, double& im) {
-        re = h[0].x * inv_scale; im = h[0].y * inv_scale;
+        re = h[0].x; im = h[0].y;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) { re = fma(ck[kk], h[kk + 1].x, re); im = fma(ck[kk], h[kk + 1].y, im); }
     };
@@ -247,25 +262,32 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
 
     for (int t = t0; t < t1; ++t) {
         cplx* Kout = mf.KfD + kitem(mf, d.steps, b, t);
-        // ---- A2 = A * A -> SB;  X0 = c0 I + c1 A + cT A2 -> image (left operand of the first Horner product) ---------------------------
-        product<NT, false, false>(img, imgs, lane, ring, SA, no_init,
-                                  [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
+        // ---- S2 = S * S -> SB;  Horner start X = S + c0 I (odd order: the strips of S with a shifted diagonal -- planes, no pairing) or
+        //      S2 + c1 S + c0 I (even order) -> image (left operand of the first Horner product) ---------------------------------------------
+        product<NT, false, false, true>(img, imgs, lane, ring, SA, no_init,
+                                        [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], double (&ore)[NT], double (&oim)[NT], double (&osu)[NT]) {
             constexpr int ib = decltype(ibc)::value;
 #pragma unroll
             for (int J = 0; J < NT; ++J) {
                 double re, im, su;
                 combine(a[J], bq[J], cq[J], re, im, su);
                 SB.re[J][ib] = re; SB.im[J][ib] = im; SB.su[J][ib] = su;
-                const double xr = fma(p_cT, re, fma(p_c1, SA.re[J][ib], p_c0 * diag(J, ib)));
-                const double xi = fma(p_cT, im, p_c1 * SA.im[J][ib]);
-                ori[J] = cmake(xr, xi); osu[J] = xr + xi;
+                if constexpr (even) {
+                    ore[J] = re + fma(p_c1, SA.re[J][ib], p_c0 * diag(J, ib));
+                    oim[J] = fma(p_c1, SA.im[J][ib], im);
+                    osu[J] = ore[J] + oim[J];
+                } else if ((ib >> 2) == J) {
+                    ore[J] = fma(p_c0, diag(J, ib), SA.re[J][ib]); oim[J] = SA.im[J][ib]; osu[J] = fma(p_c0, diag(J, ib), SA.su[J][ib]);
+                } else {
+                    ore[J] = SA.re[J][ib]; oim[J] = SA.im[J][ib]; osu[J] = SA.su[J][ib];
+                }
             }
         });
         QOC_LAP(1)
         // ---- Horner over A2 with the factors commuted: X <- X * A2 + (d0 I + d1 A); the last one is followed by a product that takes its
         //      right operand from the image (squaring) or needs none (s = 0: the result is K_t) ------------------------------------------------
         for (int i = nH - 1; i >= 0; --i) {
-            const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
+            const double d0 = mf.pcoef[2 * i], d1 = mf.pcoef[2 * i + 1];
             auto init = [&](auto ibc, double (&a)[NT], double (&cq)[NT]) {
                 constexpr int ib = decltype(ibc)::value;
 #pragma unroll
@@ -286,14 +308,14 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
                     if (kout) frag_at(Kout, J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane] = ori[J];
                 }
             };
-            if (i > 0) product<NT, false, false>(img, imgs, lane, ring, SB, init, epi);
-            else product<NT, false, true>(img, imgs, lane, ring, SB, init, epi);
+            if (i > 0) product<NT, false, false, false>(img, imgs, lane, ring, SB, init, epi);
+            else product<NT, false, true, false>(img, imgs, lane, ring, SB, init, epi);
         }
         QOC_LAP(2)
         // ---- squarings: X <- X * X; the right operand is read back from the image into SB strip by strip ---------------------------------
         for (int sq = 0; sq < d.s; ++sq) {
             const bool kout = sq == d.s - 1;
-            product<NT, true, true>(img, imgs, lane, ring, SB, no_init,
+            product<NT, true, true, false>(img, imgs, lane, ring, SB, no_init,
                                     [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
                 constexpr int ib = decltype(ibc)::value;
 #pragma unroll
@@ -319,7 +341,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
                     for (int kk = 0; kk <= KC; ++kk) h[J][kk] = frag_at(hk[kk], J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane];
             };
             stage(0);
-            product<NT, false, false>(img, imgs, lane, ring, R, no_init,
+            product<NT, false, false, false>(img, imgs, lane, ring, R, no_init,
                                       [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
                 constexpr int ib = decltype(ibc)::value;
 #pragma unroll

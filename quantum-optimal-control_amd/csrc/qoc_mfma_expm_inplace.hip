@@ -5,6 +5,7 @@
 
 void qoc_mfma_launch_expm_inplace(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const dim3 grid(d.B * mf.C), block(64);
-    if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_inplace<4>, grid, block, 0, s, d, mf);
-    else hipLaunchKernelGGL(k_mfma_expm_inplace<8>, grid, block, 0, s, d, mf);
+    const bool even = (d.T & 1) == 0;
+    if (d.k <= 4) { if (even) hipLaunchKernelGGL((k_mfma_expm_inplace<4, true>), grid, block, 0, s, d, mf); else hipLaunchKernelGGL((k_mfma_expm_inplace<4, false>), grid, block, 0, s, d, mf); }
+    else { if (even) hipLaunchKernelGGL((k_mfma_expm_inplace<8, true>), grid, block, 0, s, d, mf); else hipLaunchKernelGGL((k_mfma_expm_inplace<8, false>), grid, block, 0, s, d, mf); }
 }

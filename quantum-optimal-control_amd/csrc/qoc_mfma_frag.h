@@ -29,6 +29,9 @@ struct QocMfma {
     int NT = 2;               // 16x16 tiles per matrix dimension (1: n <= 16, 2: n <= 32)
     int FR = 1024;            // complex elements per fragD matrix = 256 NT^2
     double invfact[24];       // 1/j!
+    double pcoef[24];         // in-place exponential kernel: coefficients of the MONIC polynomial in S = sigma A, pcoef[j] = sigma^-j / j!, sigma = (1/T!)^(1/T)
+    double psigma = 1.0;      //   sigma
+    cplx* HsD = nullptr;      // [k+1] fragD(-i dt H) * sigma / 2^s: the same kernel assembles S_t = sigma A_t straight from these
     cplx* HfD = nullptr;      // [k+1] fragD(-i dt H), zero padded
     cplx* HfT = nullptr;      // [k+1] fragD((-i dt H)^T)
     cplx* U0fD = nullptr;     // fragD(U0), zero padded
