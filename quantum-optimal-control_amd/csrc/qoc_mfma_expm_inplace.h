@@ -178,8 +178,9 @@ __device__ __forceinline__ cplx* frag_at(cplx* F, int f) { return F + (f & ~3) *
 
 }  // namespace qoc_inplace
 
-// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient); EVEN = even Taylor order
-template <int KC, bool EVEN>
+// KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient); EVEN = even Taylor order; S0 = no
+// squaring (the last Horner product completes K_t and stores it: a run-time test there splits every Horner product into a basic block per group)
+template <int KC, bool EVEN, bool S0>
 __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma mf) {
     using namespace qoc_inplace;
     constexpr int NT = 2, QS = 4 * NT;
@@ -297,7 +298,6 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
                 }
                 return std::true_type{};
             };
-            const bool kout = i == 0 && d.s == 0;
             auto epi = [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
                 constexpr int ib = decltype(ibc)::value;
 #pragma unroll
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
                     double re, im, su;
                     combine(a[J], bq[J], cq[J], re, im, su);
                     ori[J] = cmake(re, im); osu[J] = su;
-                    if (kout) frag_at(Kout, J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane] = ori[J];
+                    if constexpr (S0) { if (i == 0) frag_at(Kout, J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane] = ori[J]; }
                 }
             };
             if (i > 0) product<NT, false, false, false>(img, imgs, lane, ring, SB, init, epi);

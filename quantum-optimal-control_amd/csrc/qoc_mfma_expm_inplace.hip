@@ -5,7 +5,9 @@
 
 void qoc_mfma_launch_expm_inplace(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const dim3 grid(d.B * mf.C), block(64);
-    const bool even = (d.T & 1) == 0;
-    if (d.k <= 4) { if (even) hipLaunchKernelGGL((k_mfma_expm_inplace<4, true>), grid, block, 0, s, d, mf); else hipLaunchKernelGGL((k_mfma_expm_inplace<4, false>), grid, block, 0, s, d, mf); }
-    else { if (even) hipLaunchKernelGGL((k_mfma_expm_inplace<8, true>), grid, block, 0, s, d, mf); else hipLaunchKernelGGL((k_mfma_expm_inplace<8, false>), grid, block, 0, s, d, mf); }
+    const bool even = (d.T & 1) == 0, s0 = d.s == 0;
+#define QOC_IP(KCv, EVv, S0v) hipLaunchKernelGGL((k_mfma_expm_inplace<KCv, EVv, S0v>), grid, block, 0, s, d, mf)
+    if (d.k <= 4) { if (even) { if (s0) QOC_IP(4, true, true); else QOC_IP(4, true, false); } else { if (s0) QOC_IP(4, false, true); else QOC_IP(4, false, false); } }
+    else { if (even) { if (s0) QOC_IP(8, true, true); else QOC_IP(8, true, false); } else { if (s0) QOC_IP(8, false, true); else QOC_IP(8, false, false); } }
+#undef QOC_IP
 }

@@ -51,7 +51,7 @@ int main() {
     for (int rep = 0; rep < 5; ++rep) {
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof zero));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_mfma_expm_inplace<4, false>), dim3(B * C), dim3(64), 0, 0, d, mf);
+        hipLaunchKernelGGL((k_mfma_expm_inplace<4, false, false>), dim3(B * C), dim3(64), 0, 0, d, mf);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
