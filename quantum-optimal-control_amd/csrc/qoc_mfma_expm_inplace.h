@@ -21,7 +21,12 @@
 //  * Commuting operands.  Every matrix of the polynomial is a polynomial in A_t, so the Horner step X <- A2 X + B_i is taken as
 //    X <- X A2 + B_i: the changing factor is the LEFT operand (image, in place), the fixed A2 the right one (registers).  B_i =
 //    d0 I + d1 A enters through the accumulators' initial values (a0 = B_i.re, c0 = B_i.re + B_i.im: 2 instead of 3 VALU per strip).
-//  * Registers: SA = A_t as three planes (re, im, re + im; im dies after the first product), SB = A2, then the squarings' right
+//  * MONIC polynomial.  The kernel works with S_t = sigma A_t, sigma^T = 1 / T!: in S the Taylor polynomial sum_j pcoef[j] S^j (pcoef[j] =
+//    sigma^-j / j!) is monic, so its Horner start is S + c I (odd order) -- the image of S that is already in LDS with a shifted diagonal: no
+//    arithmetic but on the diagonal tiles, and the strips go back as planes (nothing pairs re with im) -- or S^2 + c1 S + c0 I (even order); the
+//    scale has dissolved when the last Horner product finishes (lambda_i = sigma^2i, lambda_0 = 1).  sigma / 2^s sits in a scaled copy of the
+//    Hamiltonian images (QocMfma::HsD), so the assembly of S_t is k fused multiply-adds per entry and nothing else.
+//  * Registers: SA = S_t as three planes (re, im, re + im; im dies after the first product), SB = A2, then the squarings' right
 //    operand, then R' = K_t R (copied to R after the product); the running chunk product R is touched once per slice and is what
 //    the register allocator parks in AGPRs (MFMA reads B operands from there).  K_t goes to HBM strip by strip from the epilogue of
 //    the product that completes it; A_{t+1} is assembled strip by strip under the chunk product, written to the image rows that
