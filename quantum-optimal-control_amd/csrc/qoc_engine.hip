@@ -234,7 +234,7 @@ static inline void launch_loss(const QocDev& d, hipStream_t s) {
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     QocDev d = e->d;
     d.skip_done = ap.mode == 1 ? 1 : 0;      // qoc_eval / explicit steps always evaluate every seed
-    d.uscale_in_loss = (e->path == QOC_PATH_MFMA && !e->mf.latency) ? 1 : 0;
+    d.uscale_in_loss = (e->path == QOC_PATH_MFMA && !e->mf.latency && !e->mf.updown) ? 1 : 0;
     const int total = d.B * d.k * d.steps;
     int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
     if (cgrid > 2048) cgrid = 2048;
@@ -296,15 +296,17 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     }
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
-    e->final_stale = e->path == QOC_PATH_MFMA && e->mf.latency;      // final_state / unitary_scale are formed when read back
-    e->inter_stale = e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast);   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
+    e->final_stale = e->path == QOC_PATH_MFMA && (e->mf.latency || e->mf.updown);      // final_state / unitary_scale are formed when read back
+    e->inter_stale = (e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast))   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
+                     || (e->path == QOC_PATH_MFMA && e->mf.updown);                  // (k_mfma_downup stores no Psi_t either)
     return QOC_OK;
 }
 
 // latency mode of the MFMA path: final_state and unitary_scale of the last evaluation, formed on demand
 static int refresh_final(qoc_engine* e) {
     if (!e->final_stale) return QOC_OK;
-    qoc_mfma_final_state(e->mf, e->d, e->stream);
+    if (e->mf.latency) qoc_mfma_final_state(e->mf, e->d, e->stream);
+    else qoc_mfma_final_state_batch(e->mf, e->d, e->stream);
     HIP_TRY(hipGetLastError());
     e->final_stale = false;
     return QOC_OK;

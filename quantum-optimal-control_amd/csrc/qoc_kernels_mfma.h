@@ -86,6 +86,7 @@ void qoc_mfma_launch_expm_inplace(QocMfma& mf, const QocDev& d, hipStream_t s); 
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s);    // qoc_mfma_forward.hip
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_backward.hip
 void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip: latency mode, on read-back
+void qoc_mfma_final_state_batch(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_forward.hip: k_mfma_downup batches, on read-back
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s);      // qoc_mfma_forward.hip: latency mode, on read-back
 int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg);    // qoc_mfma_latency.hip
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s);    //   forward + z-free adjoint sweep in one launch (lat_sources: forward only, then d.inter unpacked)

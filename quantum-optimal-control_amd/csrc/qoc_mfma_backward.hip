@@ -2,6 +2,7 @@
 // launcher, and the path set-up (it reserves LDS for these kernels).
 #include "qoc_kernels_mfma.h"
 #include "qoc_mfma_backward.h"
+#include "qoc_mfma_downup.h"
 
 int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
                                  std::vector<void*>& allocs, std::string& msg) {
@@ -10,6 +11,10 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     const int NT = (mf.variant == 5 && d.n <= 32) ? 2 : d.n <= 16 ? 1 : (d.n <= 32 ? 2 : ((d.n <= 48 && !(mf.variant == 5 && d.k > 4)) ? 3 : 4));
     const int FR = 256 * NT * NT;
     mf.NT = NT; mf.FR = FR;
+    // both sweeps in one kernel, a wave per half chunk (k_mfma_downup; needs the z-free chunk boundaries of the scan: bnd_adj below, and
+    // m <= 8: its exchange buffers and images share the LDS with the control images)
+    mf.updown = NT == 2 && mf.variant != 1 && mf.variant != 5 && d.k <= 5 && d.m <= 8 && !(d.n_forb > 0 || d.has_speed) &&
+                !(getenv("QOC_UPDOWN") && atoi(getenv("QOC_UPDOWN")) == 0);
     int C = chunks_req;
     if (C <= 0) {
         // NT = 2: the default exponential kernel is ONE wave of 444 VGPRs per (seed, chunk), i.e. at most one resident wave per
@@ -88,11 +93,13 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         mf.grad_lds = (size_t)((d.k + 3) & ~3) * NT * 256 * sizeof(cplx);
         if (!al((cplx**)&mf.gpart, ((size_t)NT * d.B * d.k * d.steps + 1) / 2)) { msg = "MFMA path: out of device memory"; return -3; }
     }
+    if (mf.updown && !al(&mf.LamL, (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     if (mf.lat_sources && !al(&mf.Goff, (size_t)d.B * mf.NG * 4 * NT * 64)) { msg = "MFMA path: out of device memory"; return -3; }
     // chunk boundaries once per seed (k_mfma_bnd_scan) for the 4x4x4 batch sweeps; the adjoint ones only where k_mfma_backward3 takes them
     // (NT = 2, k <= 5, no state regulariser: the costate is then linear in the overlap)
     const bool bnd = (NT == 2 || NT == 3) && mf.variant != 1 && !mf.latency;
     const bool bnd_adj = bnd && NT == 2 && d.k <= 5 && !(d.n_forb > 0 || d.has_speed);
+    mf.updown = mf.updown && bnd_adj;
     const size_t nbnd = (size_t)d.B * C * NT * (mf.mq <= 2 ? 2 : 4) * 64;
     if ((bnd && !al(&mf.BndF, nbnd)) || (bnd_adj && !al(&mf.BndA, nbnd))) { msg = "MFMA path: out of device memory"; return -3; }
     // forbidden levels / speed_up on the thin affine sweeps of qoc_mfma_latency.h; dressed levels (up to 4 of them) take their sources from Fd
@@ -151,6 +158,17 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         if (hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess ||
             hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.bwd_lds3) != hipSuccess) {
             msg = "MFMA path: cannot reserve LDS for the two-level backward kernel";
+            return -2;
+        }
+    }
+    if (NT == 2 && mf.updown) {
+        const int kc = d.k == 5 ? 5 : 4, mqv = mf.mq <= 2 ? 2 : 4;
+        mf.du_lds = (size_t)kc * FR * sizeof(cplx) + (size_t)8 * 4 * mqv * F2_LDP * sizeof(cplx) + (size_t)4 * 2 * NT * mqv * 64 * sizeof(cplx) +
+                    (size_t)8 * 4 * kc * sizeof(double) + 8 * sizeof(int);          // control images, wave images, exchange buffers, row partials, flags
+        const void* k4 = d.k == 5 ? (mf.mq <= 2 ? (const void*)k_mfma_downup<2, 5> : (const void*)k_mfma_downup<2, 5>)
+                                  : (mf.mq <= 2 ? (const void*)k_mfma_downup<2, 4> : (const void*)k_mfma_downup<2, 4>);
+        if (hipFuncSetAttribute(k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.du_lds) != hipSuccess) {
+            msg = "MFMA path: cannot reserve LDS for the fused sweep kernel";
             return -2;
         }
     }
@@ -222,7 +240,12 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
                                else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
 #define QOC_B3B(MQv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, false, 5, 3>), g3, b3, mf.bwd_lds3, s, d, mf); \
                           else hipLaunchKernelGGL((k_mfma_backward3<MQv, false, 4, 3>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
-            if (mf.BndA && !src) { if (mf.mq <= 2) QOC_B3B(2); else QOC_B3B(4); }
+            if (mf.updown && !src) {
+                const dim3 gd((items + 3) / 4), bd(512);                  // 4 items per workgroup, a wave per half chunk
+                if (d.k == 5) hipLaunchKernelGGL((k_mfma_downup<2, 5>), gd, bd, mf.du_lds, s, d, mf);
+                else hipLaunchKernelGGL((k_mfma_downup<2, 4>), gd, bd, mf.du_lds, s, d, mf);
+            }
+            else if (mf.BndA && !src) { if (mf.mq <= 2) QOC_B3B(2); else QOC_B3B(4); }
             else if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
             else { if (src) QOC_B3(4, true); else QOC_B3(4, false); }
 #undef QOC_B3B

@@ -231,21 +231,26 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
 // that chain was C sequential 32 x 32 products on v_mfma_f64_16x16x4 by two waves per seed -- ~5 us per chunk, the critical path of the
 // launch from ~32 chunks on (63 chunks: 405 us of which the sweep itself needs ~90).
 template <int NT>
-__global__ void __launch_bounds__(256) k_mfma_bnd_scan(QocDev d, QocMfma mf, int MQ, int adjoint_too) {
+__global__ void __launch_bounds__(256) k_mfma_bnd_scan(QocDev d, QocMfma mf, int MQ, int flags, const cplx* __restrict__ PT, const cplx* __restrict__ PD, int C) {
+    // flags: 1 = adjoint boundaries too, 2 = Psi_N = P_{C-1} BndF[C-1] -> d.inter[steps] (the loss needs it before k_mfma_downup runs),
+    //        4 = ONLY final_state (on read-back), 8 = no final_state (k_mfma_downup batches form it when it is read back: its 8 waves per
+    //        seed were 2/3 of this kernel's reads -- every wave of a seed reads every chunk product: 64 seeds x 32 chunks x 12 waves x 16 KB
+    //        = 403 MB, 48 us)
+    const int adjoint_too = flags & 1, psi_final = flags & 2;
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx sc_img[4][4 * LDP];               // per wave: image[column j % 4][row]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nvec = (adjoint_too ? 2 : 1) * MQ, per_seed = nvec + 4 * NT;           // roles: Psi blocks, (costate blocks,) column blocks of U0
+    const int nvec = (adjoint_too ? 2 : 1) * MQ;                                     // roles: Psi blocks, (costate blocks,) column blocks of U0
+    const int per_seed = (flags & 4) ? 4 * NT : ((flags & 8) ? nvec : nvec + 4 * NT);
     const int item = blockIdx.x * 4 + wv;
     if (item >= d.B * per_seed) return;
-    const int b = item / per_seed, w = item - b * per_seed;
+    const int b = item / per_seed, w = item - b * per_seed + ((flags & 4) ? nvec : 0);
     const int role = w < MQ ? 0 : (w < nvec ? 1 : 2), jb = role == 2 ? w - nvec : (role == 1 ? w - MQ : w), dir = role == 1 ? 1 : 0;
     if (d.skip_done && d.done[b]) return;
     const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
     cplx* img = sc_img[wv];
-    const int C = mf.C;
-    double pre[NT], pim[NT];
+    double pre[NT], pim[NT];                                                        // (PT / PD / C: the chunk products, or the products of groups of chunks)
     {
         const cplx* V0 = role == 2 ? d.U0 : (dir ? d.W : d.Psi0);
         const int ncol = role == 2 ? d.n : d.m;
@@ -259,14 +264,14 @@ __global__ void __launch_bounds__(256) k_mfma_bnd_scan(QocDev d, QocMfma mf, int
     }
     cplx* out = (dir ? mf.BndA : mf.BndF) + (size_t)b * C * NT * MQ * 64;
     auto store = [&](int c) {
-        if (role == 2) return;
+        if (role == 2 || c >= C) return;
 #pragma unroll
         for (int I = 0; I < NT; ++I) out[(((size_t)c * NT + I) * MQ + jb) * 64 + lane] = cmake(pre[I], pim[I]);
     };
     struct Frag { cplx f[NT][QQS]; };
     const double sg = dir ? -1.0 : 1.0;                                             // adjoint: conj fragD(P) IS the strip operand of P^dagger
     auto load_frag = [&](int c, Frag& fr) {
-        const cplx* F = (dir ? mf.PfD : mf.PfT) + ((size_t)b * C + c) * QFR;
+        const cplx* F = (dir ? PD : PT) + ((size_t)b * C + c) * QFR;
 #pragma unroll
         for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -279,9 +284,13 @@ __global__ void __launch_bounds__(256) k_mfma_bnd_scan(QocDev d, QocMfma mf, int
         double a[NT], bq[NT], cq[NT];
 #pragma unroll
         for (int I = 0; I < NT; ++I) { a[I] = 0.0; bq[I] = 0.0; cq[I] = 0.0; }
+        cplx vv[QQS];                                                               // all block reads first: the wave is alone on its SIMD, and a
+#pragma unroll                                                                      // read issued next to its use exposes the LDS latency QQS times per step
+        for (int kb = 0; kb < QQS; ++kb) vv[kb] = img[li4 * LDP + 4 * kb + lk];     // X[4 kb + lk][4 jb + li4]
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int kb = 0; kb < QQS; ++kb) {
-            const cplx v = img[li4 * LDP + 4 * kb + lk];                            // X[4 kb + lk][4 jb + li4]
+            const cplx v = vv[kb];
 #pragma unroll
             for (int I = 0; I < NT; ++I) {
                 const double br = fr.f[I][kb].x, bi = sg * fr.f[I][kb].y, bs = br + bi;
@@ -296,17 +305,28 @@ __global__ void __launch_bounds__(256) k_mfma_bnd_scan(QocDev d, QocMfma mf, int
     };
     // forward: c = 0 .. C-2 (result -> chunk c + 1; final_state: .. C-1); adjoint: c = C-1 .. 1 (result -> chunk c - 1); step s uses chunk cs(s)
     auto cs = [&](int s) { return dir ? C - 1 - s : s; };
-    const int nst = role == 2 ? C : C - 1;
+    const int nst = (role == 2 || (role == 0 && psi_final)) ? C : C - 1;
     store(dir ? C - 1 : 0);
     if (nst >= 1) {
-        Frag f0, f1;
-        load_frag(cs(0), f0);
+        // two chunk products in flight ahead of the one that multiplies
+        Frag f0, f1, f2;
+        load_frag(cs(0), f0); load_frag(cs(min(1, nst - 1)), f1);
+        asm volatile("" ::: "memory");
+        auto one = [&](Frag& cur, Frag& nxt, int s) {
+            load_frag(cs(min(s + 2, nst - 1)), nxt); asm volatile("" ::: "memory"); product(cur); store(dir ? cs(s) - 1 : cs(s) + 1);
+        };
         int s = 0;
-        for (; s + 2 <= nst; s += 2) {
-            load_frag(cs(s + 1), f1); asm volatile("" ::: "memory"); product(f0); store(dir ? cs(s) - 1 : cs(s) + 1);
-            load_frag(cs(min(s + 2, nst - 1)), f0); asm volatile("" ::: "memory"); product(f1); store(dir ? cs(s + 1) - 1 : cs(s + 1) + 1);
+        for (; s + 3 <= nst; s += 3) { one(f0, f2, s); one(f1, f0, s + 1); one(f2, f1, s + 2); }
+        if (s < nst) { one(f0, f2, s); ++s; }
+        if (s < nst) { one(f1, f0, s); ++s; }
+    }
+    if (role == 0 && psi_final) {
+        cplx* out = d.inter + ((size_t)b * (d.steps + 1) + d.steps) * d.n * d.m;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            const int row = 16 * I + lc, col = 4 * jb + lk;
+            if (row < d.n && col < d.m) out[row * d.m + col] = cmake(pre[I], pim[I]);
         }
-        if (s < nst) { product(f0); store(dir ? cs(s) - 1 : cs(s) + 1); }
     }
     if (role == 2) {
         cplx* Xf = d.Xfinal + (size_t)b * d.n * d.n;

@@ -7,11 +7,14 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const int items = d.B * mf.C + d.B * mf.NT;
     if (mf.BndF) {
         // chunk boundaries once per seed (forward, and the z-free adjoint ones when the backward sweep takes them), then the sweep
-        const int MQ = mf.mq <= 2 ? 2 : 4, waves = d.B * ((mf.BndA ? 2 : 1) * MQ + 4 * mf.NT);     // + the column blocks of final_state
-        if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_bnd_scan<2>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, mf.BndA ? 1 : 0);
-        else hipLaunchKernelGGL(k_mfma_bnd_scan<3>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, mf.BndA ? 1 : 0);
+        const int MQ = mf.mq <= 2 ? 2 : 4, waves = d.B * ((mf.BndA ? 2 : 1) * MQ + (mf.updown ? 0 : 4 * mf.NT));     // + the column blocks of final_state
+        const int flags = (mf.BndA ? 1 : 0) | (mf.updown ? 2 | 8 : 0);
+        if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_bnd_scan<2>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, flags, (const cplx*)mf.PfT, (const cplx*)mf.PfD, mf.C);
+        else hipLaunchKernelGGL(k_mfma_bnd_scan<3>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, flags, (const cplx*)mf.PfT, (const cplx*)mf.PfD, mf.C);
         const int sw = d.B * mf.C;                                                // sweep items only: final_state comes from the scan
-        if (mf.NT == 2) {
+        if (mf.updown) {
+            // the forward sweep runs inside k_mfma_downup (after the adjoint one); Psi_N for the loss came from the scan
+        } else if (mf.NT == 2) {
             if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
             else hipLaunchKernelGGL((k_mfma_forward2<2, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
         } else {
@@ -32,9 +35,24 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    if (!d.uscale_in_loss) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
+    if (!d.uscale_in_loss && !mf.updown) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
+}
+
+// k_mfma_downup batches: final_state = P_{C-1} ... P_0 U0 and unitary_scale of the last evaluation, when they are read back
+void qoc_mfma_final_state_batch(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    QocDev dd = d;
+    dd.skip_done = 0;                                                     // every seed's last evaluation is still in PfT
+    const int MQ = mf.mq <= 2 ? 2 : 4, waves = d.B * 4 * mf.NT;
+    hipLaunchKernelGGL(k_mfma_bnd_scan<2>, dim3((waves + 3) / 4), dim3(256), 0, s, dd, mf, MQ, (mf.BndA ? 1 : 0) | 4, (const cplx*)mf.PfT, (const cplx*)mf.PfD, mf.C);
+    hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, dd);
 }
 
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s) {
+    if (mf.updown) {                                                              // k_mfma_downup keeps no Psi_t: the forward sweep, now
+        const int sw = d.B * mf.C;
+        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+        else hipLaunchKernelGGL((k_mfma_forward2<2, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+        return;
+    }
     hipLaunchKernelGGL(k_mfma_unpack_inter, dim3(512), dim3(256), 0, s, d, mf, mf.mq <= 2 ? 2 : 4);
 }

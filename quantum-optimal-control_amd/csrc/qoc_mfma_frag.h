@@ -42,6 +42,8 @@ struct QocMfma {
     cplx* PfT = nullptr;      // [B][C] fragD(P_c^T)
     cplx* BndF = nullptr;     // [B][C][NT * MQ][64] chunk-start vectors Psi (sweep register layout), k_mfma_bnd_scan; null: the sweeps walk the chunk products
     cplx* BndA = nullptr;     // [B][C][NT * MQ][64] z-free costates at the chunk ends (no state regulariser); null: the backward sweep walks
+    bool updown = false;      // both sweeps in one kernel, adjoint first (k_mfma_downup): NT = 2, k <= 5, no state regulariser; Psi_t is not stored (LamL holds the costates)
+    size_t du_lds = 0;
     cplx* Aoff = nullptr;     // [B][C] affine offsets a_c of the backward recursion (D-layout column block, 512 cplx)
     cplx* Goff = nullptr;     // [B][NG] the same for whole groups of chunks (latency mode with a state regulariser)
     cplx* LamD = nullptr;     // NT > 2: [B][steps][16 NT rows][16 columns] costates for the slice-parallel gradient kernel

@@ -1,6 +1,7 @@
 """Oracle parity at the EXACT configuration bench.py times ("Next round" 1).
 
-bench.py resolves C2 x 64 seeds per GPU to path = MFMA, the in-place-image exponential kernel and 16 chunks of 32 slices; the other
+bench.py resolves C2 x 64 seeds per GPU to path = MFMA, the in-place-image exponential kernel, 16 chunks of 32 slices and the one-wave
+sweep kernel k_mfma_downup; the other
 full-size tests use 2 seeds (63 chunks of 8) or compare HIP batches with each other.  Here the 64-seed batch itself is compared with
 the oracle (core/tensorflow_state.py:204-242,323-356; core/run_session.py:47-69) for seeds {0, 31, 63}: one evaluation (loss, U_final,
 gradient) and three iterations of the device loop.  The expected values are committed fixtures (tests/golden/make_bench_golden.py),

@@ -1,0 +1,83 @@
+// updown_cache_probe.hip -- does a second pass over a chunk of K, taken right after the first one in the opposite direction, come out of a
+// cache?  (forward + adjoint sweep in one kernel.)  The K trajectory of the bench is 64 seeds x 500 slices x 16 KB = 524 MB;
+// a (seed, chunk) item of S slices is S x 16 KB.  One wave per item streams its slices up (mode 0), up and back down (mode 1), or up twice
+// (mode 2); a writer kernel fills the buffer first (as the exponential kernel does in the iteration).  Output: time and GB/s per mode for
+// several chunk lengths and occupancies (dynamic LDS limits the workgroups per CU).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// the writer: as the exponential kernel, one wave per item writes its S slices in time order, all items at once (so what was written LAST --
+// what a write-back cache still holds -- is the late slices of every item, not the end of the buffer)
+__global__ void __launch_bounds__(64) k_fill(d2* p, int S) {
+    d2* base = p + (size_t)blockIdx.x * S * 1024;
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) base[(size_t)s * 1024 + q * 64 + threadIdx.x] = (d2){(double)(s + q), 1.0};
+        __builtin_amdgcn_s_sleep(100);
+    }
+}
+
+__device__ __forceinline__ void slice_sum(const d2* __restrict__ F, int lane, d2 (&acc)[4]) {
+    d2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = F[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q & 3] += v[q];
+}
+
+__global__ void __launch_bounds__(256) k_probe(const d2* __restrict__ K, double* out, int items, int S, int mode) {
+    extern __shared__ char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    d2 acc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int item = blockIdx.x * 4 + wv; item < items; item += gridDim.x * 4) {
+        const d2* base = K + (size_t)item * S * 1024;
+        if (mode >= 3) {                                                // 3: down only, 4: down and back up
+            for (int s = S - 1; s >= 0; --s) slice_sum(base + (size_t)s * 1024, lane, acc);
+            if (mode == 4) for (int s = 0; s < S; ++s) slice_sum(base + (size_t)s * 1024, lane, acc);
+            continue;
+        }
+        for (int s = 0; s < S; ++s) slice_sum(base + (size_t)s * 1024, lane, acc);
+        if (mode == 1) for (int s = S - 1; s >= 0; --s) slice_sum(base + (size_t)s * 1024, lane, acc);
+        if (mode == 2) for (int s = 0; s < S; ++s) slice_sum(base + (size_t)s * 1024, lane, acc);
+    }
+    const d2 t = acc[0] + acc[1] + acc[2] + acc[3];
+    if (t.x == -1.0) out[threadIdx.x] = t.y;
+    if (smem[0] == 77 && t.y == -2.0) out[0] = 1.0;
+}
+
+int main() {
+    const size_t total_slices = 64 * 500, n = total_slices * 1024;
+    d2* K; double* out;
+    CHECK(hipMalloc((void**)&K, n * sizeof(d2)));
+    CHECK(hipMalloc((void**)&out, 4096));
+    CHECK(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int Ss[] = {4, 8, 16, 32};
+    const int ldss[] = {0, 40 * 1024, 80 * 1024, 160 * 1024};          // workgroups per CU: 8 (register limit of the probe), 4, 2, 1
+    printf("K = %.0f MB; one wave per item, 4 waves per workgroup; persistent grid of 256 x (workgroups per CU)\n", n * 16 / 1e6);
+    printf("%4s %6s %6s | %9s %9s %9s %9s %9s (us)\n", "S", "wg/CU", "items", "up", "updown", "upup", "down", "downup");
+    for (int S : Ss)
+        for (int li = 0; li < 4; ++li) {
+            const int items = (int)(total_slices / S), per_cu = li == 0 ? 8 : (li == 1 ? 4 : (li == 2 ? 2 : 1));
+            float us[5];
+            for (int mode = 0; mode < 5; ++mode) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    hipLaunchKernelGGL(k_fill, dim3(items), dim3(64), 0, 0, K, S);
+                    CHECK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_probe, dim3(256 * per_cu), dim3(256), ldss[li], 0, K, out, items, S, mode);
+                    CHECK(hipEventRecord(e1));
+                    CHECK(hipEventSynchronize(e1));
+                    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                }
+                us[mode] = best * 1e3f;
+            }
+            printf("%4d %6d %6d | %9.1f %9.1f %9.1f %9.1f %9.1f\n", S, per_cu, items, us[0], us[1], us[2], us[3], us[4]);
+        }
+    return 0;
+}
