@@ -11,11 +11,16 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // the writer: as the exponential kernel, one wave per item writes its S slices in time order, all items at once (so what was written LAST --
 // what a write-back cache still holds -- is the late slices of every item, not the end of the buffer)
-__global__ void __launch_bounds__(64) k_fill(d2* p, int S) {
+__global__ void __launch_bounds__(64) k_fill(d2* p, int S, int nt) {
     d2* base = p + (size_t)blockIdx.x * S * 1024;
     for (int s = 0; s < S; ++s) {
+        if (nt) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) base[(size_t)s * 1024 + q * 64 + threadIdx.x] = (d2){(double)(s + q), 1.0};
+            for (int q = 0; q < 16; ++q) __builtin_nontemporal_store((d2){(double)(s + q), 1.0}, &base[(size_t)s * 1024 + q * 64 + threadIdx.x]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) base[(size_t)s * 1024 + q * 64 + threadIdx.x] = (d2){(double)(s + q), 1.0};
+        }
         __builtin_amdgcn_s_sleep(100);
     }
 }
@@ -34,6 +39,26 @@ __global__ void __launch_bounds__(256) k_probe(const d2* __restrict__ K, double*
     d2 acc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     for (int item = blockIdx.x * 4 + wv; item < items; item += gridDim.x * 4) {
         const d2* base = K + (size_t)item * S * 1024;
+        if (mode == 5 || mode == 6) {                                   // up, the loads of DEPTH slices in flight (5: two, 6: three)
+            d2 v0[16], v1[16], v2[16];
+            auto ld = [&](d2 (&v)[16], int s) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = base[(size_t)(s < S ? s : S - 1) * 1024 + q * 64 + lane];
+                asm volatile("" ::: "memory");
+            };
+            auto use = [&](d2 (&v)[16]) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q & 3] += v[q];
+            };
+            if (mode == 5) {
+                ld(v0, 0);
+                for (int s = 0; s < S; s += 2) { ld(v1, s + 1); use(v0); ld(v0, s + 2); use(v1); }
+            } else {
+                ld(v0, 0); ld(v1, 1);
+                for (int s = 0; s < S; s += 3) { ld(v2, s + 2); use(v0); ld(v0, s + 3); use(v1); ld(v1, s + 4); use(v2); }
+            }
+            continue;
+        }
         if (mode >= 3) {                                                // 3: down only, 4: down and back up
             for (int s = S - 1; s >= 0; --s) slice_sum(base + (size_t)s * 1024, lane, acc);
             if (mode == 4) for (int s = 0; s < S; ++s) slice_sum(base + (size_t)s * 1024, lane, acc);
@@ -48,7 +73,7 @@ __global__ void __launch_bounds__(256) k_probe(const d2* __restrict__ K, double*
     if (smem[0] == 77 && t.y == -2.0) out[0] = 1.0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const size_t total_slices = 64 * 500, n = total_slices * 1024;
     d2* K; double* out;
     CHECK(hipMalloc((void**)&K, n * sizeof(d2)));
@@ -56,18 +81,20 @@ int main() {
     CHECK(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int nt = argc > 1 ? atoi(argv[1]) : 0;                        // 1: the writer uses non-temporal stores
+    printf("writer stores: %s\n", nt ? "non-temporal" : "plain");
     const int Ss[] = {4, 8, 16, 32};
     const int ldss[] = {0, 40 * 1024, 80 * 1024, 160 * 1024};          // workgroups per CU: 8 (register limit of the probe), 4, 2, 1
     printf("K = %.0f MB; one wave per item, 4 waves per workgroup; persistent grid of 256 x (workgroups per CU)\n", n * 16 / 1e6);
-    printf("%4s %6s %6s | %9s %9s %9s %9s %9s (us)\n", "S", "wg/CU", "items", "up", "updown", "upup", "down", "downup");
+    printf("%4s %6s %6s | %9s %9s %9s %9s %9s %9s %9s (us)\n", "S", "wg/CU", "items", "up", "updown", "upup", "down", "downup", "up 2 deep", "up 3 deep");
     for (int S : Ss)
         for (int li = 0; li < 4; ++li) {
             const int items = (int)(total_slices / S), per_cu = li == 0 ? 8 : (li == 1 ? 4 : (li == 2 ? 2 : 1));
-            float us[5];
-            for (int mode = 0; mode < 5; ++mode) {
+            float us[7];
+            for (int mode = 0; mode < 7; ++mode) {
                 float best = 1e9f;
                 for (int rep = 0; rep < 4; ++rep) {
-                    hipLaunchKernelGGL(k_fill, dim3(items), dim3(64), 0, 0, K, S);
+                    hipLaunchKernelGGL(k_fill, dim3(items), dim3(64), 0, 0, K, S, nt);
                     CHECK(hipEventRecord(e0));
                     hipLaunchKernelGGL(k_probe, dim3(256 * per_cu), dim3(256), ldss[li], 0, K, out, items, S, mode);
                     CHECK(hipEventRecord(e1));
@@ -77,7 +104,7 @@ int main() {
                 }
                 us[mode] = best * 1e3f;
             }
-            printf("%4d %6d %6d | %9.1f %9.1f %9.1f %9.1f %9.1f\n", S, per_cu, items, us[0], us[1], us[2], us[3], us[4]);
+            printf("%4d %6d %6d | %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f\n", S, per_cu, items, us[0], us[1], us[2], us[3], us[4], us[5], us[6]);
         }
     return 0;
 }
