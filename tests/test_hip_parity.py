@@ -88,6 +88,28 @@ def test_mfma_path_parity(chunks, variant):
     _mfma_path_parity(chunks, variant, 0)
 
 
+@pytest.mark.parametrize('chunks', [0, 3, 40])
+def test_separate_sweep_kernels_behind_the_fused_one(chunks, monkeypatch):
+    """NT = 2 batches without a state regulariser run both sweeps in k_mfma_downup; QOC_UPDOWN=0 (read when the engine is created) keeps the
+    separate kernels k_mfma_forward2<BND> + k_mfma_backward3<MODE 3> for A/B runs: same oracle, and the two agree with each other."""
+    c = cases.case_c2(n=32, k=4, steps=40, m=8, taylor=(5, 3), seed=0)
+    sp = oracle_system(c)
+    rng = np.random.default_rng(11)
+    bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2]
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('QOC_UPDOWN', flag)
+        eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=8)
+        eng.set_base(np.stack(bases))
+        check_eval(eng, sp, bases)
+        out[flag] = (eng.evaluate(), eng.get_inter_vecs(), eng.get_final_unitary())
+        eng.close()
+    gmax = np.max(np.abs(out['0'][0]['grad']))
+    assert np.max(np.abs(out['1'][0]['grad'] - out['0'][0]['grad'])) <= 1e-13 * gmax
+    np.testing.assert_allclose(out['1'][1], out['0'][1], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(out['1'][2], out['0'][2], rtol=0, atol=1e-14)
+
+
 @pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6, 7, 8], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd', 'mfma4_row_blocks',
                                                                  'mfma4_inplace_image'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
