@@ -252,7 +252,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         if (!(skip & 4)) qoc_mfma_launch_forward(e->mf, d, e->stream);
         if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
         if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
-        if (!(skip & 8) && (!e->mf.latency || (e->mf.lat_sources && !e->mf.lat_src_fast))) launch_loss(d, e->stream);   // latency mode: inside the backward kernel
+        if (!(skip & 8) && !e->mf.updown && (!e->mf.latency || (e->mf.lat_sources && !e->mf.lat_src_fast))) launch_loss(d, e->stream);   // latency mode / k_mfma_downup: inside the backward kernel
         if (!(skip & 16)) {
             if (fused_tail) qoc_mfma_latency_gradient(e->mf, d, &ap, e->stream);
             else qoc_mfma_launch_backward(e->mf, d, e->stream);
