@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
     cplx* imgS = imgT + (size_t)NB * QNP * QLDS;                         // [NB][NT * QQS * 64] right operand: strip (J, kb), lane
     constexpr int TSZ = QNP * QLDS, SSZ = NT * QQS * 64;
     const int lane = threadIdx.x & 63;
+    const unsigned ulane = threadIdx.x & 63u;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // row strips NT w .. NT w + NT - 1
     const int per = SLICE ? d.steps : mf.C;
     const int b = blockIdx.x / per, c = blockIdx.x - b * per;
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
     QOC_LAP_INIT
     const int t0 = SLICE ? c : c * mf.L, t1 = SLICE ? c + 1 : min(t0 + mf.L, d.steps);
     const double inv_scale = 1.0 / (double)(1 << d.s);
-    const int dlt = (lane & 15) - (lane >> 4);
+    int dlt = (lane & 15) - (lane >> 4);
     // identity: element (row 4 ib + lk, column 16 J + lc) with ib = NT w + r is diagonal iff 4 ib - 16 J == lc - lk
     auto diag = [&](int r, int J) { return (4 * (NT * w + r) - 16 * J == dlt) ? 1.0 : 0.0; };
     const int mm = d.T >> 1;
@@ -111,19 +112,28 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
 #pragma unroll
         for (int J = 0; J < NT; ++J) { R.re[r][J] = diag(r, J); R.im[r][J] = 0.0; }
     for (int t = t0; t < t1; ++t) {
+        asm volatile("" : "+v"(dlt));            // (the diagonal masks are compares, not nine doubles hoisted out of the loop and spilled)
         // ---- A_t, own row strips, one column block at a time (NT (KC + 1) strips of the Hamiltonian stack in flight) ------------------
         double ck[KC];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) ck[kk] = kk < d.k ? d.u[((size_t)b * d.k + kk) * d.steps + t] * inv_scale : 0.0;
         Rows A, X;
+        unsigned hoff[NT][NT];
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int r = 0; r < NT; ++r) { hoff[J][r] = ((unsigned)(J * QQS + NT * w + r) * 64u + ulane) * (unsigned)sizeof(cplx); asm volatile("" : "+v"(hoff[J][r])); }
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
             cplx hst[KC + 1][NT];
 #pragma unroll
             for (int kk = 0; kk <= KC; ++kk) {
-                const cplx* H = mf.HfD + (size_t)(kk <= d.k ? kk : 0) * QFR + (J * QQS + NT * w) * 64 + lane;
+                // a scalar base per matrix + a 32-bit byte offset per (column block, strip) that hipcc cannot see through: with the lane
+                // folded into the pointer it hoists one 64-bit VGPR pair per (matrix, column block, strip) out of the slice loop and spills
+                // them (236 B of scratch, every reload followed by s_waitcnt vmcnt(0): the loads of the assembly went out one at a time)
+                const char* H = (const char*)(mf.HfD + (size_t)(kk <= d.k ? kk : 0) * QFR);
 #pragma unroll
-                for (int r = 0; r < NT; ++r) hst[kk][r] = H[r * 64];
+                for (int r = 0; r < NT; ++r) hst[kk][r] = *(const cplx*)(H + hoff[J][r]);
             }
 #pragma unroll
             for (int r = 0; r < NT; ++r) {
