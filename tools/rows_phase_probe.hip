@@ -16,11 +16,14 @@ __device__ unsigned long long g_phase[QOC_NPH];
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 int main() {
-    constexpr int NT = 3;
+#ifndef ROWS_NT
+#define ROWS_NT 3
+#endif
+    constexpr int NT = ROWS_NT;
     const int B = 64, steps = 500, k = 4, C = 16, L = 32, FR = 256 * NT * NT;
     QocDev d;
     memset(&d, 0, sizeof d);
-    d.n = 48; d.k = k; d.steps = steps; d.m = 8; d.T = 5; d.s = 3; d.B = B;
+    d.n = 16 * NT; d.k = k; d.steps = steps; d.m = 8; d.T = 5; d.s = 3; d.B = B;
     QocMfma mf;
     mf.C = C; mf.L = L; mf.NT = NT; mf.FR = FR; mf.store_T = false;
     { double f = 1.0; for (int j = 0; j < 24; ++j) { if (j > 0) f *= (double)j; mf.invfact[j] = 1.0 / f; } }
@@ -55,14 +58,14 @@ int main() {
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    printf("k_mfma_expm_rows<3, 4>, %zu B of LDS per workgroup: %.3f ms per launch (with the clock hooks)\n", lds, best);
+    printf("k_mfma_expm_rows<%d, 4>, n = %d, %zu B of LDS per workgroup: %.3f ms per launch (with the clock hooks)\n", NT, 16 * NT, lds, best);
     unsigned long long hp[QOC_NPH];
     CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_phase), sizeof hp));
-    const char* names[QOC_NPH] = {"assembly of A_t", "publishes (LDS stores + barriers)", "products (324 MFMAs each)", "epilogues, K_t store", "P_c out"};
+    const char* names[QOC_NPH] = {"assembly of A_t", "publishes (LDS stores + barriers)", "products", "epilogues, K_t store", "P_c out"};
     double tot = 0;
     for (int i = 0; i < QOC_NPH; ++i) tot += (double)hp[i];
     const double wgs = B * C, slices = (double)L;
     for (int i = 0; i < QOC_NPH; ++i) printf("%-36s %6.1f %%   %9.0f ticks per slice (wave 0)\n", names[i], 100.0 * hp[i] / tot, hp[i] / wgs / slices);
-    printf("ticks per slice total %.0f; 7 products of 324 MFMAs x 17 cycles = %d pipe cycles per wave\n", tot / wgs / slices, 7 * 324 * 17);
+    printf("ticks per slice total %.0f; 7 products of %d MFMAs x 17 cycles = %d pipe cycles per wave\n", tot / wgs / slices, 36 * NT * NT, 7 * 36 * NT * NT * 17);
     return 0;
 }
