@@ -160,14 +160,62 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) lo[(16 * I + lc) * 16 + 4 * jb + lk] = cmake(zre[I][jb], zim[I][jb]);
     };
+    // Undressed forbidden levels and speed_up need only Psi_t at this lane's own entries and one scalar per slice: fetched UNCONDITIONALLY (clamped
+    // indices, masked afterwards) together with the next K_t -- source_at()'s conditional loads are waited for on the spot with vmcnt(0), which
+    // drained the K prefetch in every slice (as in k_mfma_backward3, source_fast).  Dressed levels keep source_at().
+    const bool fast_src = need_src && !d.forbid_dressed;
+    struct SrcIn { cplx own[2][MQ]; cplx zt; };
+    double wrow[2] = {0.0, 0.0};                                         // sum of 2 a_f over the forbidden levels equal to this lane's rows (loop invariant)
+    cplx wown[2][MQ];
+    const double speed_coef = (need_src && d.has_speed) ? -d.a_speed * d.su_resid[b] * 2.0 / ((double)d.m * (double)d.m) : 0.0;
+    if (fast_src) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            for (int f = 0; f < d.n_forb; ++f) wrow[I] += (16 * I + lc == d.forb_state[f]) ? 2.0 * d.forb_a[f] : 0.0;
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) wown[I][jb] = d.W[min(16 * I + lc, d.n - 1) * d.m + min(4 * jb + lk, d.m - 1)];
+        }
+    }
+    auto fetch_src = [&](SrcIn& si, int t) {
+        const cplx* psi = d.inter + ((size_t)b * (d.steps + 1) + max(t, 1)) * d.n * d.m;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) si.own[I][jb] = psi[min(16 * I + lc, d.n - 1) * d.m + min(4 * jb + lk, d.m - 1)];
+        si.zt = *(d.has_speed ? d.ztau + (size_t)b * (d.steps + 1) + max(t, 1) : d.zfin + b);
+    };
+    auto apply_src = [&](const SrcIn& si, int t) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int jb = 0; jb < MQ; ++jb) {
+                const cplx phi = si.own[I][jb];
+                const double w = wrow[I] * (phi.x * phi.x + phi.y * phi.y);
+                cplx sv = cscale(phi, w);
+                const cplx zw = cscale(cmul(si.zt, wown[I][jb]), speed_coef);
+                sv.x += d.has_speed ? zw.x : 0.0; sv.y += d.has_speed ? zw.y : 0.0;
+                const bool ok = t > 0 && 16 * I + lc < d.n && 4 * jb + lk < d.m;
+                sre[I][jb] = ok ? sv.x : 0.0; sim[I][jb] = ok ? sv.y : 0.0;
+            }
+    };
     auto src_or_zero = [&](int t) { if (need_src && t > 0) source(max(t, 1)); else zero_src(); };
     load_frag(Kb + (size_t)(len - 1) * mf.FR, A);
     int i = 0;                                                           // step i handles slice t = t1 - 1 - i
+    if (fast_src) {
+        SrcIn s0, s1;
+        fetch_src(s0, t1 - 1);
+        for (; i + 2 <= len; i += 2) {
+            fetch_src(s1, t1 - 2 - i); load_frag(Kb + (size_t)(len - 2 - i) * mf.FR, A1); asm volatile("" ::: "memory"); store_lam(t1 - 1 - i); apply_src(s0, t1 - 1 - i); step(A);
+            fetch_src(s0, t1 - 3 - i); load_frag(Kb + (size_t)max(len - 3 - i, 0) * mf.FR, A); asm volatile("" ::: "memory"); store_lam(t1 - 2 - i); apply_src(s1, t1 - 2 - i); step(A1);
+        }
+        if (i < len) { store_lam(t1 - 1 - i); apply_src(s0, t1 - 1 - i); step(A); }
+    } else {
     for (; i + 2 <= len; i += 2) {
         src_or_zero(t1 - 1 - i); load_frag(Kb + (size_t)(len - 2 - i) * mf.FR, A1); asm volatile("" ::: "memory"); store_lam(t1 - 1 - i); step(A);
         src_or_zero(t1 - 2 - i); load_frag(Kb + (size_t)max(len - 3 - i, 0) * mf.FR, A); asm volatile("" ::: "memory"); store_lam(t1 - 2 - i); step(A1);
     }
     if (i < len) { src_or_zero(t1 - 1 - i); store_lam(t1 - 1 - i); step(A); }
+    }
     if (FULL) return;
     cplx* out = mf.Aoff + ((size_t)b * mf.C + c) * (QQS * 64);             // D-layout 16x16x4 column block 0
 #pragma unroll
