@@ -110,6 +110,22 @@ def test_separate_sweep_kernels_behind_the_fused_one(chunks, monkeypatch):
     np.testing.assert_allclose(out['1'][2], out['0'][2], rtol=0, atol=1e-14)
 
 
+@pytest.mark.parametrize('n,k,steps,m,chunks,seeds', [(17, 3, 33, 5, 8, 5), (32, 5, 33, 8, 33, 3), (24, 1, 7, 1, 2, 6), (9, 2, 64, 3, 0, 7)],
+                         ids=['ragged_chunks_5_seeds', 'one_slice_chunks_k5', 'odd_halves_m1', 'auto_chunks_7_seeds'])
+def test_fused_sweep_kernel_edge_shapes(n, k, steps, m, chunks, seeds):
+    """k_mfma_downup: a last chunk shorter than the others, chunks of ONE slice (the second half of the pair is empty), odd chunk lengths (halves of
+    different size), seed counts that do not fill the last workgroup, partial column blocks, five control images."""
+    c = cases.case_c2(n=n, k=k, steps=steps, m=m, taylor=(5, 2), seed=60 + n)
+    sp = oracle_system(c)
+    rng = np.random.default_rng(n)
+    bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) for _ in range(seeds - 1)]
+    eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=8)
+    assert eng.path == 2
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
+
+
 @pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6, 7, 8], ids=['mfma16', 'mfma4_two_waves', 'mfma4_one_wave', 'mfma4_streamed_image', 'latency_mode', 'mfma4_pair_two_per_simd', 'mfma4_row_blocks',
                                                                  'mfma4_inplace_image'])
 @pytest.mark.parametrize('variant', ['plain', 'sources', 'small_n', 'dressed', 'n40_nt3', 'n48_k4_sources_nt3', 'n64_nt4', 'n18_T2_s1', 'n32_T3_s0',
