@@ -289,6 +289,30 @@ def test_mfma_and_generic_paths_agree_in_the_loop():
     np.testing.assert_allclose(out[0][2]['loss'], out[1][2]['loss'], atol=1e-12)
 
 
+def test_batch_kernels_with_seeds_that_stop_at_different_iterations():
+    """Device loop on the MFMA batch kernels (fused sweeps, read-backs formed on demand) with a stop rule that ends the seeds one by one: a finished
+    seed is skipped by every kernel from then on, and what is read back for it afterwards -- pulses, final unitary, inter_vecs, scalars -- is its
+    LAST evaluation, exactly as on the generic path."""
+    c = cases.case_c2(n=12, k=2, steps=24, m=4, taylor=(5, 2), seed=3)
+    sp = oracle_system(c)
+    rng = np.random.default_rng(8)
+    bases = np.stack([sp.base0 * s + 0.3 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) for s in (1.0, 0.2, 2.5, -1.0, 0.6, 1.7)])
+    conv = dict(rate=0.05, max_iterations=60, learning_rate_decay=100, conv_target=0.6, min_grad=1e-25)      # the oracle stops after 60, 60, 10, 60, 24, 8 iterations
+    out = []
+    for path, variant in ((1, 0), (2, 8)):
+        eng = make_engine(sp, n_seeds=len(bases), path=path, variant=variant)
+        eng.set_base(bases)
+        its = eng.run_adam(eng.adam_params(poll_every=4, **conv))
+        out.append((list(its), eng.get_base(), eng.get_uks(evaluated=True), eng.get_final_unitary(), eng.get_inter_vecs(), eng.scalars()))
+        eng.close()
+    assert out[0][0] == out[1][0] and len(set(out[0][0])) > 2, out[0][0]          # the seeds really stop at different iterations
+    for q in (1, 2, 3, 4):
+        np.testing.assert_allclose(out[0][q], out[1][q], rtol=0, atol=1e-10)
+    for key in ('loss', 'unitary_scale', 'grad_squared'):
+        np.testing.assert_allclose(out[0][5][key], out[1][5][key], rtol=0, atol=1e-10)
+    assert list(out[0][5]['done']) == list(out[1][5]['done'])
+
+
 def test_adam_loop_parity_and_stop_rules():
     """Device-resident loop == run_session.start_adam_optimizer (iteration counting, LR schedule, TF1 Adam)."""
     sp = oracle_system(cases.case_c1())
