@@ -480,12 +480,13 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    on (1.11 vs 1.50 ms at 8, 1.70 vs 2.72 at 16, 5.27 vs 9.88 ms at 64 seeds of n = 48; the GEMM path pads to N = 64), ties at
     //    4 (1.00 vs 0.95) and loses below (0.96 vs 0.62 ms at 2); 48 < n <= 64 (NT = 4; tools/n64_batch_sweep.py): with k <= 4 controls
     //    the MFMA path is ahead from 32 seeds on (4.96 vs 5.14 ms at 32, 9.16 vs 10.05 at 64, 17.4 vs 19.8 at 128 seeds of n = 64 x 500
-    //    slices, since the row-tile gradient kernel); with more controls, or fewer seeds, the GEMM path (k = 6: 4.55 vs 4.69 ms at
-    //    64 seeds x 200 slices; k = 8: level).
+    //    slices, since the row-tile gradient kernel); with more controls the GEMM path up to 64 seeds, the MFMA path beyond (round 3, after
+    //    k_mfma_expm_rows lost its scratch: k = 6 x 200 slices 4.33 vs 4.35 ms at 64 seeds, 7.86 vs 8.47 at 128; k = 8 x 1000 slices 20.05 vs
+    //    20.54 at 64, 38.7 vs 40.7 at 128; at 32 seeds the GEMM path: 2.31 vs 2.59, 10.4 vs 10.7).
     // every batch-size-dependent choice below is taken for Bp = qoc_config.plan_seeds (else the local batch): a shard of a restart
     // batch then runs the same path, kernels and chunking as the whole batch would
     const int Bp = d.Bplan;
-    const bool nt4_batch = n > 48 && k <= 4 && Bp >= 32;
+    const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= 32) || Bp >= 64);
     const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= 8 && m <= 8 && steps >= 100));
     const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
