@@ -58,6 +58,8 @@ struct QocDev {
     // per-evaluation intermediates
     double* w;           // [B][k][steps] sin(base)
     double* u;           // [B][k][steps] maxA*w
+    double* w2;          // the same for the NEXT evaluation, written by the Adam tail of this one (null: k_controls forms them); the engine swaps
+    double* u2;          //   the pairs between iterations, so that u / w stay "the controls of the last evaluation" until the next one starts
     double* dLdu;        // [B][k][steps]
     double* grad;        // [B][k][steps] d reg_loss / d base
     cplx* inter;         // [B][steps+1][n][m]

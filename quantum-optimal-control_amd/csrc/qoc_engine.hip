@@ -67,6 +67,7 @@ struct qoc_engine {
     QocGemm gm;
     bool evaluated = false;
     int skip_mask = 0;          // QOC_DEBUG_SKIP (timing experiments only): 1 controls, 2 exponentials, 4 forward, 8 loss, 16 backward, 32 finish
+    bool controls_ready = false;                     // u2 / w2 hold maxA sin(base) of the CURRENT variable (written by the Adam tail or by qoc_get_uks)
     bool final_stale = false, inter_stale = false;   // MFMA latency mode: Xfinal / uscale not yet formed for the last evaluation
     double* step_lr = nullptr;  // [B] per-seed learning rates of qoc_adam_step
     // profiling of the dominant kernel
@@ -232,7 +233,14 @@ static inline void launch_loss(const QocDev& d, hipStream_t s) {
 }
 
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
+    // the slice kernel of the n <= 32 latency mode forms its own controls; everybody else reads u / w: from k_controls, or -- when the Adam tail of
+    // the previous iteration (or qoc_get_uks) has left them in u2 / w2 -- by swapping the two pairs (one launch less per iteration)
+    const bool own_controls = e->path == QOC_PATH_MFMA && e->mf.latency && e->mf.NT == 2;
+    const bool swap_in = e->controls_ready && !own_controls && !(e->skip_mask & 1);
+    if (swap_in) { std::swap(e->d.u, e->d.u2); std::swap(e->d.w, e->d.w2); }
+    e->controls_ready = false;
     QocDev d = e->d;
+    if (own_controls) { d.u2 = nullptr; d.w2 = nullptr; }
     d.skip_done = ap.mode == 1 ? 1 : 0;      // qoc_eval / explicit steps always evaluate every seed
     d.uscale_in_loss = (e->path == QOC_PATH_MFMA && !e->mf.latency && !e->mf.updown) ? 1 : 0;
     const int total = d.B * d.k * d.steps;
@@ -244,7 +252,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     // (with the local pulse regularisers too -- amplitude, envelope, dwdt, d2wdt2; the bandpass DFT keeps its own launch)
     const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && (!e->mf.lat_sources || e->mf.lat_src_fast) && !d.has_band && !(skip & (16 | 32));
     // (latency mode of the MFMA path: the slice kernel of the exponentials forms its own controls)
-    if (!(skip & 1) && !(e->path == QOC_PATH_MFMA && e->mf.latency && e->mf.NT == 2)) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
+    if (!(skip & 1) && !own_controls && !swap_in) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {
         TRY(prof_begin(e));
         if (!(skip & 2)) qoc_mfma_launch_expm(e->mf, d, e->stream);
@@ -296,6 +304,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     }
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
+    e->controls_ready = ap.mode != 0 && !own_controls && !(skip & (16 | 32));       // the Adam tail ran: u2 / w2 belong to the moved variable
     e->final_stale = e->path == QOC_PATH_MFMA && (e->mf.latency || e->mf.updown);      // final_state / unitary_scale are formed when read back
     e->inter_stale = (e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast))   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
                      || (e->path == QOC_PATH_MFMA && e->mf.updown);                  // (k_mfma_downup stores no Psi_t either)
@@ -438,7 +447,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
 #define ALLOC(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     ALLOC(d.base, B * ks); ALLOC(d.adam_m, B * ks); ALLOC(d.adam_v, B * ks);
     ALLOC(d.adam_t, (size_t)B); ALLOC(d.iters, (size_t)B); ALLOC(d.done, (size_t)B);
-    ALLOC(d.w, B * ks); ALLOC(d.u, B * ks); ALLOC(d.dLdu, B * ks); ALLOC(d.grad, B * ks);
+    ALLOC(d.w, B * ks); ALLOC(d.u, B * ks); ALLOC(d.w2, B * ks); ALLOC(d.u2, B * ks); ALLOC(d.dLdu, B * ks); ALLOC(d.grad, B * ks);
     ALLOC(d.inter, (size_t)B * (steps + 1) * nm);
     ALLOC(d.Xfinal, (size_t)B * nn);
     ALLOC(d.ztau, (size_t)B * (steps + 1));
@@ -590,6 +599,7 @@ int qoc_set_base(qoc_handle e, const double* base) {
     HIP_TRY(hipMemsetAsync(d.done, 0, d.B * sizeof(int), e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->evaluated = false;
+    e->controls_ready = false;
     return QOC_OK;
 }
 
@@ -690,10 +700,16 @@ int qoc_get_uks(qoc_handle e, double* uks) {
     const int total = d.B * d.k * d.steps;
     int cgrid = (total + QOC_BLOCK - 1) / QOC_BLOCK;
     if (cgrid > 2048) cgrid = 2048;
-    hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
-    HIP_TRY(hipGetLastError());
+    // (into u2 / w2: u / w keep the controls of the last evaluation for qoc_get_uks_evaluated and the regularisers' read-backs)
+    if (!e->controls_ready) {
+        QocDev dd = d;
+        dd.u = d.u2; dd.w = d.w2;
+        hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, dd);
+        HIP_TRY(hipGetLastError());
+        e->controls_ready = true;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(uks, d.u, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(uks, d.u2, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
     return QOC_OK;
 }
 

@@ -150,11 +150,17 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     }
     if (ap.mode == 0) return;
 
+    // controls of the next evaluation (u2 / w2; the engine swaps them in instead of launching k_controls): a seed that does not move keeps its own
+    auto keep_controls = [&]() {
+        if (!d.u2) return;
+        for (int o = threadIdx.x; o < ks; o += blockDim.x) { d.w2[(size_t)b * ks + o] = w[o]; d.u2[(size_t)b * ks + o] = d.u[(size_t)b * ks + o]; }
+    };
     if (ap.mode == 1) {                                                          // run_session.py:56-66
-        if (was_done) return;
+        if (was_done) { keep_controls(); return; }
         const bool end = (loss < ap.conv_target) || (g2 < ap.min_grad) || (it0 >= ap.max_iterations);
         if (end) {
             if (threadIdx.x == 0) d.done[b] = 1;
+            keep_controls();
             return;
         }
         if (threadIdx.x == 0) d.iters[b] = it0 + 1;                              // update_and_save :92
@@ -169,7 +175,9 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
                 const double mm = b1 * m_r[e] + (1.0 - b1) * g;
                 const double vv = b2 * v_r[e] + (1.0 - b2) * g * g;
                 am[o] = mm; av[o] = vv;
-                base[o] = b_r[e] - lr_t * mm / (sqrt(vv) + eps);
+                const double bn = b_r[e] - lr_t * mm / (sqrt(vv) + eps);
+                base[o] = bn;
+                if (d.u2) { const double wn = sin(bn); d.w2[(size_t)b * ks + o] = wn; d.u2[(size_t)b * ks + o] = d.maxA[o / steps] * wn; }   // = k_controls
             }
         }
     } else {
@@ -178,7 +186,9 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
             const double mm = b1 * am[o] + (1.0 - b1) * g;
             const double vv = b2 * av[o] + (1.0 - b2) * g * g;
             am[o] = mm; av[o] = vv;
-            base[o] -= lr_t * mm / (sqrt(vv) + eps);
+            const double bn = base[o] - lr_t * mm / (sqrt(vv) + eps);
+            base[o] = bn;
+            if (d.u2) { const double wn = sin(bn); d.w2[(size_t)b * ks + o] = wn; d.u2[(size_t)b * ks + o] = d.maxA[o / steps] * wn; }
         }
     }
     if (threadIdx.x == 0) d.adam_t[b] = tstep;

@@ -313,6 +313,35 @@ def test_batch_kernels_with_seeds_that_stop_at_different_iterations():
     assert list(out[0][5]['done']) == list(out[1][5]['done'])
 
 
+@pytest.mark.parametrize('path', [1, 2, 4], ids=['generic', 'mfma', 'gemm'])
+def test_current_and_evaluated_pulses_do_not_disturb_each_other(path):
+    """qoc_get_uks = maxA sin(base) of the CURRENT variable, qoc_get_uks_evaluated = the pulses the LAST evaluation ran on; inside the Adam loop they
+    differ by one step.  Reading one must not change the other (the current ones are formed in the buffers of the next evaluation), whatever
+    the order, and the loop must continue as if nobody had looked."""
+    c = cases.case_c2(n=10, k=2, steps=16, m=3, taylor=(5, 1), seed=9)
+    sp = oracle_system(c)
+    bases = np.stack([sp.base0, -0.5 * sp.base0])
+    conv = dict(rate=0.05, max_iterations=10 ** 6, learning_rate_decay=100, conv_target=-1.0, min_grad=-1.0)
+    ref = make_engine(sp, n_seeds=2, path=path)
+    ref.set_base(bases)
+    ref.iterate(ref.adam_params(**conv), 7)
+    eng = make_engine(sp, n_seeds=2, path=path)
+    eng.set_base(bases)
+    p = eng.adam_params(**conv)
+    eng.iterate(p, 4)
+    cur = eng.get_uks()
+    ev = eng.get_uks(evaluated=True)
+    base = eng.get_base()
+    np.testing.assert_allclose(cur, sp.maxA[None, :, None] * np.sin(base), rtol=0, atol=1e-15)
+    assert np.max(np.abs(cur - ev)) > 1e-6                                      # one Adam step apart
+    np.testing.assert_array_equal(eng.get_uks(evaluated=True), ev)              # ... and still there after the other read
+    np.testing.assert_array_equal(eng.get_uks(), cur)
+    eng.iterate(p, 3)
+    np.testing.assert_array_equal(eng.get_base(), ref.get_base())               # the reads changed nothing
+    np.testing.assert_array_equal(eng.get_uks(evaluated=True), ref.get_uks(evaluated=True))
+    eng.close(); ref.close()
+
+
 def test_adam_loop_parity_and_stop_rules():
     """Device-resident loop == run_session.start_adam_optimizer (iteration counting, LR schedule, TF1 Adam)."""
     sp = oracle_system(cases.case_c1())
