@@ -12,7 +12,13 @@ fp64 (the shim computes the reference's float32 tensors in float64 on purpose).
 A stand-in for TensorFlow does not make this "the reference run here" (DESIGN.md section 2 keeps saying "parity unpinned by the
 reference's runtime"); it removes the human restatement of loop bounds, slices and signs between the reference text and the oracle.
 
-Run:  python tests/golden/make_graph_golden.py        (needs /root/reference; writes tests/golden/graph_*.npz)
+Round 4 adds (a) the BASELINE sizes themselves -- graph_c2_full_s0 / _s63.npz: C2 (n=32, k=4, 500 slices, m=8, (T,s)=(5,3)) from the control sets of
+bench.py's restart seeds 0 and 63; graph_c3_full.npz: C3 (n=64, k=6, 1000 slices, state transfer, dwdt + forbidden levels) -- so that the GPU tests
+of those configurations compare with the reference's text directly, not with the oracle; (b) `--fp32`: the same text with `tf.float32` = torch.float32
+(QOC_TF1_SHIM_FP32=1, tests/golden/tf1_shim.py), i.e. at the reference's own precision -> graph32_*.npz, the tier-2 statement of SURVEY.md 8c.
+
+Run:  python tests/golden/make_graph_golden.py          (needs /root/reference; writes tests/golden/graph_*.npz)
+      python tests/golden/make_graph_golden.py --fp32   (writes tests/golden/graph32_*.npz)
 """
 import contextlib
 import importlib
@@ -49,6 +55,24 @@ def graph_cases():
     out['state_transfer_allreg'] = c
     out['c2_n8'] = cases.case_c2(n=8, k=3, steps=20, m=4, taylor=(5, 3), seed=12)
     return out
+
+
+def full_size_cases():
+    """The BASELINE configurations at their full sizes.  `base0` replaces SystemParameters.ops_weight_base (an INPUT of the graph code:
+    tensorflow_state.py:176 reads it) where the bench's own restart seeds are wanted; `keep_inter` = store every time point."""
+    import bench
+    from tests.golden import cases
+    out = {}
+    for seed, keep in ((0, True), (63, False)):
+        c = cases.case_c2(n=bench.N, k=bench.K_OPS, steps=bench.SLICES, m=bench.M, taylor=bench.TAYLOR, seed=0)
+        c['base0'] = bench.seed_bases(seed, 1)[0]; c['keep_inter'] = keep
+        out['c2_full_s%d' % seed] = c
+    c = cases.case_c3(); c['keep_inter'] = True            # base0: the reference's own draw under np.random.seed(np_seed)
+    out['c3_full'] = c
+    return out
+
+
+FP32_CASES = ('c1', 'c2_n8', 'unitary_allreg', 'state_transfer_allreg', 'dressed_forbidden', 'c2_full_s0', 'c3_full')
 
 
 def import_reference_graph():
@@ -114,35 +138,47 @@ def r2c_cols(M, n):
     return M[:n] + 1j * M[n:]
 
 
-def run_case(mods, tf, name, c):
+def run_case(mods, tf, name, c, prefix='graph'):
     tf.reset()
     with contextlib.redirect_stdout(io.StringIO()):
         S = system_parameters(mods, c)
+        if c.get('base0') is not None:
+            assert np.shape(S.ops_weight_base) == np.shape(c['base0'])
+            S.ops_weight_base = np.array(c['base0'])
         tfs = mods['core.tensorflow_state'].TensorflowState(S)
         tfs.build_graph()
     n, steps = S.state_num, S.steps
-    g = lambda t: t.detach().numpy().copy()               # noqa: E731
+    g = lambda t: t.detach().numpy().astype(np.float64)   # noqa: E731  (a copy; fp32 runs are stored widened)
     out = dict(base0=g(tfs.ops_weight_base), loss=float(tfs.loss), reg_loss=float(tfs.reg_loss), unitary_scale=float(tfs.unitary_scale),
                grad_squared=float(tfs.grad_squared), grad_pack=g(tfs.grad_pack)[0], exp_terms=S.exp_terms, scaling=S.scaling)
     packed = g(tfs.inter_vecs_packed)                       # (2n, steps + 1, m)
     out['inter_vecs'] = np.transpose(r2c_cols(packed, n), (1, 0, 2))       # [steps + 1][n][m]
+    if not c.get('keep_inter', True) or prefix != 'graph':
+        out['inter_vecs'] = out['inter_vecs'][[0, steps // 2, steps]]      # first, middle and last time point only
     if not c['state_transfer']:
         F = g(tfs.final_state)
         out['final_state'] = F[:n, :n] + 1j * F[n:, :n]     # analysis.py:18-24 (RtoCMat)
     tfs.optimizer.run(ADAM_LR)                              # session.run([optimizer], {learning_rate: lr})   run_session.py:69
     out['base_after_adam'] = g(tfs.ops_weight_base)
     out['adam_lr'] = ADAM_LR
-    np.savez_compressed(os.path.join(HERE, 'graph_%s.npz' % name), **out)
-    print('  graph_%s: loss %.12f reg_loss %.12f |grad| %.3e (T, s) = (%d, %d)' % (name, out['loss'], out['reg_loss'], np.max(np.abs(out['grad_pack'])),
+    np.savez_compressed(os.path.join(HERE, '%s_%s.npz' % (prefix, name)), **out)
+    print('  %s_%s: loss' % (prefix, name) + '  %.12f reg_loss %.12f |grad| %.3e (T, s) = (%d, %d)' % (out['loss'], out['reg_loss'], np.max(np.abs(out['grad_pack'])),
                                                                                  S.exp_terms, S.scaling))
 
 
 if __name__ == '__main__':
+    fp32 = '--fp32' in sys.argv[1:]
+    if fp32:
+        os.environ['QOC_TF1_SHIM_FP32'] = '1'               # read by the shim when the scratch copy imports it as `tensorflow`
     todo = graph_cases()                                    # recipes first: they come from THIS repo's package of the same name
+    todo.update(full_size_cases())
+    if fp32:
+        todo = {name: todo[name] for name in FP32_CASES}
     mods, tf, scratch = import_reference_graph()
+    assert tf.FP32 == fp32
     try:
-        print('reference graph code imported from scratch copy', scratch)
+        print('reference graph code imported from scratch copy', scratch, '(float32 tensors)' if fp32 else '(float32 held in float64)')
         for name, c in todo.items():
-            run_case(mods, tf, name, c)
+            run_case(mods, tf, name, c, prefix='graph32' if fp32 else 'graph')
     finally:
         shutil.rmtree(scratch, ignore_errors=True)

@@ -9,19 +9,23 @@ a torch.autograd.Function whose backward is the reference's own grad_func, and `
 
 What this buys: the loop bounds, slices, signs and op order of a6-a14 in the golden vectors are the REFERENCE's, not a human restatement.
 What it does not: it is a stand-in for TensorFlow, so by the letter of the rules the oracle stays "parity unpinned by the reference's own
-runtime" (DESIGN.md section 2 says so).  `float32` is mapped to torch.float64 on purpose: the fixtures check the oracle's algebra at fp64;
-the fp32 round-off of the real reference is bounded separately (tests/test_oracle_graph.py).
+runtime" (DESIGN.md section 2 says so).  `float32` is mapped to torch.float64 by default: those fixtures (graph_*.npz) check the algebra at
+fp64.  With QOC_TF1_SHIM_FP32=1 in the environment at import `float32` IS torch.float32 (and complex64 torch.complex64): the reference's text
+then runs at the reference's OWN precision, and the fixtures graph32_*.npz made that way bound the distance between the fp64 engine and what
+the real reference computes (tier 2 of SURVEY.md 8c).
 Nothing of this file or of the reference travels to the GPU box; only the numeric outputs do (tests/golden/graph_*.npz).
 """
 import contextlib
+import os
 import types
 
 import numpy as np
 import torch
 
-float32 = torch.float64            # see the module docstring
+FP32 = os.environ.get('QOC_TF1_SHIM_FP32', '0') == '1'
+float32 = torch.float32 if FP32 else torch.float64            # see the module docstring
 float64 = torch.float64
-complex64 = torch.complex128
+complex64 = torch.complex64 if FP32 else torch.complex128
 int32 = torch.int64
 
 _VARIABLES = []                    # (tensor, trainable) in creation order

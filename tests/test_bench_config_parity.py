@@ -80,3 +80,31 @@ def test_single_control_set_with_regularisers_against_the_oracle():
     eng.set_base(base)
     compare_three_iterations(eng, g, [0])
     eng.close()
+
+
+def test_bench_batch_configuration_against_the_reference_text():
+    """The 64-seed bench engine against tests/golden/graph_c2_full_s{0,63}.npz: the reference's own graph text (core/tensorflow_state.py:204-242,
+    323-356 on the TF1 stand-in, tests/golden/make_graph_golden.py) evaluated on the control sets of restart seeds 0 and 63 -- the oracle is
+    not in between.  One evaluation and the reference's one optimiser step (run_session.py:69)."""
+    fx = {s: load_golden('graph_c2_full_s%d.npz' % s) for s in (0, 63)}
+    eng = bench_engine(bench.SEEDS_PER_GPU)
+    assert (eng.path, eng.chunks) == (2, 16)
+    bases = bench.seed_bases(0, bench.SEEDS_PER_GPU)
+    for s in fx:
+        np.testing.assert_array_equal(bases[s], fx[s]['base0'])
+    eng.set_base(bases)
+    r = eng.evaluate()
+    Uf, inter = eng.get_final_unitary(), eng.get_inter_vecs()
+    for s, f in fx.items():
+        for key in ('loss', 'reg_loss', 'grad_squared', 'unitary_scale'):
+            assert abs(r[key][s] - float(f[key])) <= L_ATOL * max(1.0, abs(float(f[key]))), (key, s, r[key][s], float(f[key]))
+        gmax = np.max(np.abs(f['grad_pack']))
+        assert np.max(np.abs(r['grad'][s] - f['grad_pack'])) <= G_RTOL * gmax
+        np.testing.assert_allclose(Uf[s], f['final_state'], rtol=0, atol=U_ATOL)
+        iv = inter[s] if f['inter_vecs'].shape[0] == bench.SLICES + 1 else inter[s][[0, bench.SLICES // 2, bench.SLICES]]
+        np.testing.assert_allclose(iv, f['inter_vecs'], rtol=0, atol=U_ATOL)
+    eng.adam_step(float(fx[0]['adam_lr']))
+    base = eng.get_base()
+    for s, f in fx.items():
+        np.testing.assert_allclose(base[s], f['base_after_adam'], rtol=0, atol=1e-9)
+    eng.close()

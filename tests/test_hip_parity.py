@@ -919,3 +919,64 @@ def test_hip_against_the_reference_graph_vectors(name, path):
     eng.adam_step(float(fx['adam_lr']))
     np.testing.assert_allclose(eng.get_base()[0], fx['base_after_adam'], rtol=0, atol=1e-12)
     eng.close()
+
+
+def _reference_text_case(name):
+    from tests.test_oracle_golden import graph_case
+    c = graph_case(name)
+    sp = oracle_system(c)
+    if c.get('base0') is not None:
+        sp.base0 = np.array(c['base0'])
+    return c, sp
+
+
+FULL_ROUTES = [('c2_full_s0', 0, 0, 0, 2), ('c2_full_s0', 2, 4, 0, 2), ('c2_full_s0', 2, 8, 16, 2), ('c2_full_s0', 4, 0, 0, 4), ('c2_full_s63', 0, 0, 0, 2),
+               ('c3_full', 0, 0, 0, 4), ('c3_full', 4, 0, 1, 4), ('c3_full', 3, 0, 0, 3)]
+
+
+@pytest.mark.parametrize('name,path,variant,chunks,expect', FULL_ROUTES,
+                         ids=['c2_auto_latency_mode', 'c2_mfma_batch_kernels', 'c2_mfma_inplace_16_chunks', 'c2_gemm', 'c2_seed63_auto',
+                              'c3_auto_propagator', 'c3_direct', 'c3_fused'])
+def test_hip_against_the_reference_text_at_baseline_sizes(name, path, variant, chunks, expect):
+    """BASELINE configs 2 and 3 at FULL size against tests/golden/graph_c2_full_s*.npz / graph_c3_full.npz: what the reference's own
+    core/tensorflow_state.py:204-261,323-356 + regularization_functions.py text computes for these inputs (make_graph_golden.py, TF1 stand-in,
+    float32 tensors held in float64) -- no oracle between the HIP engine and the reference's text.  Full-size tolerances:
+    scalars 1e-11, gradient 1e-10 max|g|, vectors / U_final 1e-11."""
+    c, sp = _reference_text_case(name)
+    fx = load_golden('graph_%s.npz' % name)
+    eng = make_engine(sp, n_seeds=1, path=path, chunks=chunks, variant=variant)
+    assert eng.path == expect
+    eng.set_base(fx['base0'][None])
+    r = eng.evaluate()
+    for key in ('loss', 'reg_loss', 'unitary_scale', 'grad_squared'):
+        assert abs(r[key][0] - float(fx[key])) <= 1e-11 * max(1.0, abs(float(fx[key]))), (key, r[key][0], float(fx[key]))
+    gmax = np.max(np.abs(fx['grad_pack']))
+    assert np.max(np.abs(r['grad'][0] - fx['grad_pack'])) <= 1e-10 * gmax, (np.max(np.abs(r['grad'][0] - fx['grad_pack'])), gmax)
+    inter = eng.get_inter_vecs()[0]
+    if fx['inter_vecs'].shape[0] != inter.shape[0]:
+        inter = inter[[0, sp.steps // 2, sp.steps]]
+    np.testing.assert_allclose(inter, fx['inter_vecs'], rtol=0, atol=1e-11)
+    if not sp.state_transfer:
+        np.testing.assert_allclose(eng.get_final_unitary()[0], fx['final_state'], rtol=0, atol=1e-11)
+    eng.adam_step(float(fx['adam_lr']))                    # the reference's session.run([optimizer]) once, run_session.py:69
+    np.testing.assert_allclose(eng.get_base()[0], fx['base_after_adam'], rtol=0, atol=1e-9)     # conditioning: tests/test_oracle_golden.py
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['c1', 'c2_n8', 'unitary_allreg', 'state_transfer_allreg', 'dressed_forbidden', 'c2_full_s0', 'c3_full'])
+def test_hip_within_float32_roundoff_of_the_reference_text_at_its_own_precision(name):
+    """Tier 2 of SURVEY.md 8c: tests/golden/graph32_*.npz is the reference's text run with float32 tensors (the precision the real reference
+    computes in); the fp64 engine sits within accumulated float32 round-off of it -- bounds and their measurement in tests/test_oracle_golden.py."""
+    from tests.test_oracle_golden import assert_tier2
+    c, sp = _reference_text_case(name)
+    fx = load_golden('graph32_%s.npz' % name)
+    eng = make_engine(sp, n_seeds=1)
+    eng.set_base(sp.base0[None])
+    r = eng.evaluate()
+    o = {key: r[key][0] for key in ('loss', 'reg_loss', 'unitary_scale', 'grad_squared', 'grad')}
+    inter = eng.get_inter_vecs()[0]
+    o['inter_vecs'] = inter if fx['inter_vecs'].shape[0] == inter.shape[0] else inter[[0, sp.steps // 2, sp.steps]]
+    if not sp.state_transfer:
+        o['U_final'] = eng.get_final_unitary()[0]
+    assert_tier2(o, fx, sp.state_transfer)
+    eng.close()
