@@ -205,7 +205,7 @@ def spawn_ranks(n):
     s.close()
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', QOC_BENCH_SELF_SPAWNED='1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -233,6 +233,13 @@ class _GlooTransport(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return t.numpy()
 
+    def all_gather(self, values):
+        import torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64).reshape(-1))
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return np.stack([o.numpy() for o in out])
+
     def close(self):
         self.dist.barrier()
         self.dist.destroy_process_group()
@@ -252,6 +259,11 @@ def main():
     ap.add_argument('--groups', type=int, default=1, help='split the seeds of this GPU over G engines/streams')
     ap.add_argument('--prewarm', type=int, default=100, help='untimed iterations BEFORE the W warm-up steps: a GPU that was idle takes tens of '
                                                                'milliseconds to reach its working clocks, more than W = 5 steps of 1.2 ms last')
+    ap.add_argument('--require-rccl', dest='require_rccl', action='store_true', default=None,
+                    help='N > 1: an RCCL start-up failure on any rank ends the run with a non-zero exit code instead of a file-transport line '
+                         '(the default under a launcher, i.e. in the driver form `python -m torch.distributed.run ... bench.py --gpus N`)')
+    ap.add_argument('--allow-file-transport', dest='require_rccl', action='store_false',
+                    help='N > 1: let the ranks fall back to the file transport when RCCL cannot start (the line then carries transport_fallback: true)')
     ap.add_argument('--reference-ops-worker', default=None, help=argparse.SUPPRESS)   # internal: one process of the all-core B-faithful CPU leg
     args = ap.parse_args()
     if args.reference_ops_worker:
@@ -261,6 +273,8 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC, before the HIP runtime starts (also done by load_library)
     from quantum_optimal_control import parallel_seeds
     from quantum_optimal_control.core import hip_engine
     from quantum_optimal_control.parallel_seeds import SeedShard
@@ -269,14 +283,26 @@ def main():
     if world != max(1, args.gpus):
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     backend = os.environ.get('QOC_BENCH_BACKEND', 'rccl')
+    # LOCAL_RANK -> HIP device: torch.distributed.run leaves all GPUs of the node visible to every rank (device = LOCAL_RANK); a launcher that
+    # narrowed the view to one device per rank (HIP_VISIBLE_DEVICES) gives device 0
+    device = parallel_seeds.device_for_rank(local_rank, hip_engine.device_count())
     if os.environ.get('QOC_BENCH_SAME_DEVICE') == '1':      # test hook: N ranks on ONE GPU (with the gloo transport)
-        local_rank = 0
+        device = 0
+    local_rank = device
     comm = gloo = None
     if world > 1:
         if backend == 'gloo':
             gloo = _GlooTransport(rank, world)
         else:
-            comm = parallel_seeds.open_comm(rank=rank, world=world, device=local_rank)
+            # a launcher started the ranks (the driver's form): RCCL or nothing, unless --allow-file-transport / QOC_TRANSPORT=file say otherwise
+            require = args.require_rccl
+            if require is None:
+                require = os.environ.get('QOC_BENCH_SELF_SPAWNED') != '1' and os.environ.get('QOC_TRANSPORT', 'rccl') != 'file'
+            try:
+                comm = parallel_seeds.open_comm(rank=rank, world=world, device=device, require_rccl=bool(require))
+            except parallel_seeds.RcclRequired as exc:
+                sys.stderr.write('bench.py: rank %d: %s\n' % (rank, exc))
+                sys.exit(3)
     transport = comm if comm is not None else gloo
 
     c, Hs, U0, V, W, dt = build_problem()
@@ -334,6 +360,14 @@ def main():
     assert int(np.sum(sc['done'])) == 0 and np.all(sc['iterations'] == args.warmup + args.steps), \
         'a seed stopped early: timed work would be incomplete'
     assert np.array_equal(fidelity[shard.first:shard.first + shard.count], 1.0 - sc['loss']), 'gathered row != local losses'
+    # who ran where and how long: one row per rank (elapsed ms, HIP device index, compute units, device name as 48 bytes)
+    info = hip_engine.device_info(device)
+    name_bytes = np.frombuffer(info['name'].encode()[:48].ljust(48, b' '), dtype=np.uint8).astype(np.float64)
+    row = np.concatenate([[elapsed * 1e3, float(device), float(info['compute_units'])], name_bytes])
+    rows = transport.all_gather(row) if transport is not None else row[None]
+    per_rank = [{'rank': r, 'ms_total': float(rows[r][0]), 'ms_per_step': float(rows[r][0]) / args.steps, 'device': int(rows[r][1]),
+                 'compute_units': int(rows[r][2]), 'device_name': bytes(rows[r][3:].astype(np.uint8)).decode(errors='replace').strip()}
+                for r in range(world)]
     if transport is not None:
         elapsed = float(transport.all_reduce_max([elapsed])[0])
 
@@ -399,7 +433,9 @@ def main():
             'config': {'workload': 'C2 3-transmon-size unitary gate: n=32 k=4 steps=500 m=8 Taylor(T,s)=(5,3), '
                                    '%d independent control seeds per GPU (aggregate over seeds), reg_coeffs={}' % B,
                        'seeds_per_gpu': B, 'total_seeds': total_seeds, 'path': eng.path, 'chunks': eng.chunks,
-                       'stream_groups': G, 'ranks_seen': world, 'fidelities_gathered': int(fidelity.shape[0]),
+                       'stream_groups': G, 'ranks_seen': len(per_rank), 'fidelities_gathered': int(fidelity.shape[0]),
+                       'comm_library': (comm.library if comm is not None else None), 'per_rank': per_rank,
+                       'devices_distinct': len(set(q['device'] for q in per_rank)),
                        'transport': (comm.library if comm.library.startswith('files') else 'rccl (%s)' % comm.library) if comm is not None
                        else ('gloo (test hook)' if gloo is not None else 'single process'),
                        # an RCCL run that fell back to files must not look like an RCCL result: both keys say so explicitly

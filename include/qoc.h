@@ -193,6 +193,9 @@ int qoc_comm_barrier(qoc_comm_handle c);
 /* ---- introspection ---------------------------------------------------------------------------------------------*/
 int qoc_path_in_use(qoc_handle h);        /* the QOC_PATH_* the engine resolved AUTO to */
 int qoc_chunks_in_use(qoc_handle h);
+/* One line of key=value pairs naming what AUTO resolved to (path, kernel family of the exponentials, chunk count, sweep kernels / route):
+ * no counterpart in the reference (TensorFlow places its ops itself); the dispatch test tests/test_auto_plan.py reads it. */
+int qoc_plan_describe(qoc_handle h, char* buf, int32_t len);
 int qoc_device_count(void);
 int qoc_device_info(int32_t device, char* name, int32_t name_len, int32_t* compute_units, int64_t* hbm_bytes);
 const char* qoc_last_error(void);

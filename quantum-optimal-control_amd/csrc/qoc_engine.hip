@@ -359,6 +359,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
                const double* maxA, const double* one_minus_gauss, const int32_t* forbidden_states,
                const double* forbidden_coeffs, const double* Vs, qoc_handle* out) {
     if (!cfg || !Hs || !V || !W || !maxA || !out) return fail(QOC_ERR_INVALID, "qoc_create: null argument");
+    if (cfg->plan_seeds < 0) return fail(QOC_ERR_INVALID, "qoc_create: plan_seeds = %d (0 = plan for n_seeds, > 0 = the batch AUTO plans for)", cfg->plan_seeds);
     if (cfg->n < 1 || cfg->k < 1 || cfg->steps < 1 || cfg->m < 1 || cfg->n_seeds < 1)
         return fail(QOC_ERR_INVALID, "qoc_create: n, k, steps, m, n_seeds must be >= 1");
     if (cfg->taylor_terms < 1 || cfg->scaling < 0 || cfg->scaling > 30)
@@ -494,12 +495,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    20.54 at 64, 38.7 vs 40.7 at 128; at 32 seeds the GEMM path: 2.31 vs 2.59, 10.4 vs 10.7).
     // every batch-size-dependent choice below is taken for Bp = qoc_config.plan_seeds (else the local batch): a shard of a restart
     // batch then runs the same path, kernels and chunking as the whole batch would
-    const int Bp = d.Bplan;
-    const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= 32) || Bp >= 64);
-    const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= 8 && m <= 8 && steps >= 100));
     const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
-    bool gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && Bp >= ST_DIRECT_FROM));
     if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
     // a handful of control sets of an n <= 32 unitary problem (the reference's own use is ONE per Grape() call): the latency mode of
@@ -512,16 +509,36 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // With a state regulariser (forbidden levels, speed_up) the backward half is the affine recursion of the batch kernels on the
     // latency mode's chunks, with two-level boundaries (QocMfma::lat_sources): one C2 trajectory with dwdt + forbidden levels 0.189 ms
     // against 0.290 (GEMM route) and 0.72 (batch kernels); ahead up to ~4096 seed-slices (tools/c2_forbidden_single.py).
-    const long long lat_work = (long long)Bp * steps;
     const bool lat_src = d.n_forb > 0 || d.has_speed;
-    const bool latency_auto = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
+    struct AutoPlan { int path; bool latency; bool gemm_direct; };
+    // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by row)
+    auto plan_for = [&](int Bp) -> AutoPlan {
+        const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= 32) || Bp >= 64);
+        const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= 8 && m <= 8 && steps >= 100));
+        const long long lat_work = (long long)Bp * steps;
+        const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
                               (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && Bp <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
                                 : n > 32 ? (lat_work <= 16384 && Bp <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
                                        : (lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && Bp <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
                                (Bp == 1 && steps <= 8192));
-    if (path == QOC_PATH_AUTO)
-        path = latency_auto ? QOC_PATH_MFMA
-                            : (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
+        AutoPlan p;
+        p.latency = latency;
+        p.gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && Bp >= ST_DIRECT_FROM));
+        p.path = cfg->path != QOC_PATH_AUTO ? cfg->path
+                 : latency ? QOC_PATH_MFMA : (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
+        return p;
+    };
+    const AutoPlan plan = plan_for(d.Bplan);
+    const bool latency_auto = plan.latency, gemm_direct = plan.gemm_direct;
+    path = plan.path;
+    if (d.Bplan < B) {
+        // a plan for FEWER control sets than the engine holds is legal (a rank that holds several shards of a planned batch keeps bit-identity
+        // with them) but can cost a factor: say so once when it changes what AUTO would have picked for the resident batch
+        const AutoPlan own = plan_for(B);
+        if (own.path != plan.path || own.latency != plan.latency || own.gemm_direct != plan.gemm_direct)
+            fprintf(stderr, "libqoc_hip: note: plan_seeds = %d < n_seeds = %d changes the AUTO plan (path %d%s instead of %d%s): kernels tuned for the smaller batch run on the larger one\n",
+                    d.Bplan, B, plan.path, plan.latency ? " latency mode" : "", own.path, own.latency ? " latency mode" : "");
+    }
     if (path == QOC_PATH_MFMA && !mfma_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 64, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
@@ -531,10 +548,12 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
+#ifdef QOC_DEBUG     // timing experiments only (tools/skip_timing.py builds its own library with -DQOC_DEBUG): never in the product library
     if (const char* sk = getenv("QOC_DEBUG_SKIP")) {                          // wall-clock attribution of one kernel group (results are garbage)
         e->skip_mask = atoi(sk);
         if (e->skip_mask) fprintf(stderr, "libqoc_hip: WARNING: QOC_DEBUG_SKIP=%d is set -- kernel groups are skipped or repeated, every result of this engine is garbage (timing experiments only)\n", e->skip_mask);
     }
+#endif
     if (path == QOC_PATH_MFMA) {
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;
@@ -782,6 +801,30 @@ int qoc_time_iterations(qoc_handle e, const qoc_adam_params* p, int32_t iters, d
 
 int qoc_path_in_use(qoc_handle e) { return e ? e->path : QOC_ERR_INVALID; }
 int qoc_chunks_in_use(qoc_handle e) { return e ? e->chunks : QOC_ERR_INVALID; }
+
+// What AUTO resolved to, as one line of key=value pairs (tests/test_auto_plan.py pins the dispatch table of DESIGN.md section 4 with it):
+//   MFMA path:  path=mfma nt=<tiles> expm=<exponential kernel 1..8> chunks=<C> sweeps=<downup|split|row_tile_gradient|latency|latency_sources|one_wave>
+//   GEMM path:  path=gemm route=<unitary|propagator|direct> chunks=<NC> slices_per_chunk=<S> chains=<persistent|launches>
+//   others:     path=generic | path=st_fused
+int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
+    if (!e || !buf || len < 1) return fail(QOC_ERR_INVALID, "qoc_plan_describe: null handle or buffer");
+    char tmp[256];
+    if (e->path == QOC_PATH_MFMA) {
+        const QocMfma& mf = e->mf;
+        const bool split = (mf.NT > 2 || (mf.NT == 2 && e->d.k >= 6)) && mf.variant != 1;
+        const char* sweeps = mf.latency ? (mf.lat_sources ? "latency_sources" : "latency")
+                             : mf.updown ? "downup" : (split ? (mf.grad_rt ? "row_tile_gradient" : "split") : (mf.variant == 1 || mf.NT == 1 || mf.NT == 4 ? "one_wave" : "pair"));
+        snprintf(tmp, sizeof tmp, "path=mfma nt=%d expm=%d chunks=%d sweeps=%s", mf.NT, qoc_mfma_expm_variant(mf, e->d), mf.C, sweeps);
+    } else if (e->path == QOC_PATH_GEMM) {
+        const QocGemm& g = e->gm;
+        snprintf(tmp, sizeof tmp, "path=gemm route=%s chunks=%d slices_per_chunk=%d chains=%s", g.direct ? "direct" : (e->d.state_transfer ? "propagator" : "unitary"),
+                 g.NC, g.S, g.persistent ? "persistent" : "launches");
+    } else {
+        snprintf(tmp, sizeof tmp, "path=%s", e->path == QOC_PATH_ST_FUSED ? "st_fused" : "generic");
+    }
+    snprintf(buf, (size_t)len, "%s", tmp);
+    return QOC_OK;
+}
 
 }  // extern "C"
 

@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
 struct QocGemm {
     int N = 0, S = 1, L = 0, NC = 1, SP = 1;
     int MV = 0, ldW = 0;      // persistent mode: vector slots (1/2/4/8) and row stride of the time-major wide buffers
+    double plan_scale = 1.0;  // planned / local batch (QocDev::Bplan / B): split-K factors and kernel families are chosen for the planned batch
     bool direct = false;      // state transfer as Taylor mat-vec chains on the assembled generators (one chunk, no propagators)
     bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
     cplx* HsP = nullptr;      // [k+1][N][N]
@@ -298,6 +299,7 @@ static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
 static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, bool direct, std::vector<void*>& allocs, std::string& msg) {
     const int N = ((d.n + 31) / 32) * 32;
     gm.N = N;
+    gm.plan_scale = (double)d.Bplan / (double)d.B;
     gm.persistent = N <= 64 && d.m <= 8;
     gm.MV = d.m <= 1 ? 1 : (d.m <= 2 ? 2 : (d.m <= 4 ? 4 : 8));
     gm.direct = direct && d.state_transfer && gm.persistent;
@@ -384,14 +386,12 @@ static inline bool qoc_gemm_lds_opt_in() {
            hipFuncSetAttribute((const void*)k_gemm_scan_nodes<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_scan_lds(64)) == hipSuccess &&
            qoc_zgemm_wg_opt_in();
 }
-// planned / local batch of the engine whose launches are being enqueued by this host thread (set by the qoc_gemm_* entry points): the
-// split factor and the kernel family change the association of the sums, so they follow the PLANNED batch (QocDev::Bplan)
-static thread_local double qoc_gemm_plan_scale = 1.0;
-// picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small
-static inline void qoc_gemm_launch(bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
+// picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small.  The split factor and the kernel
+// family change the association of the sums, so they follow the PLANNED batch: QocGemm::plan_scale = planned / local batch (qoc_gemm_setup)
+static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
     const size_t real_tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
     const unsigned blocks = (unsigned)real_tiles;
-    const size_t tiles = (size_t)((double)real_tiles * qoc_gemm_plan_scale + 0.5);
+    const size_t tiles = (size_t)((double)real_tiles * gm.plan_scale + 0.5);
     int sk = 1;
     if (tiles * 2 <= 2048 && (g.Kdim / 2) % 8 == 0) sk = 2;
     if (tiles * 4 <= 2048 && (g.Kdim / 4) % 8 == 0) sk = 4;
@@ -449,14 +449,13 @@ static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s) {
         g.batch = (int)((size_t)d.B * (gm.SP >> l));
         const bool want_t = gm.persistent && !gm.direct && l == gm.L;        // chunk products also transposed, for the backward boundary chain
         g.CT = want_t ? gm.PcT : nullptr; g.sCT = (long long)NN; g.ldct = N;
-        qoc_gemm_launch(false, 0, g, s);
+        qoc_gemm_launch(gm, false, 0, g, s);
         prev = out;
     }
 }
 
 // K_t for all (seed, slice): the dominant part of the path (bracketed by the profiling events of the engine)
 static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
-    qoc_gemm_plan_scale = (double)d.Bplan / (double)d.B;
     const int N = gm.N;
     const size_t NN = (size_t)N * N, BS = (size_t)d.B * gm.SP;
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
@@ -490,14 +489,14 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     cplx* oth = (products % 2 == 0) ? gm.P : gm.K;
     if (deg >= 2) {
         g.A = gm.A; g.Bm = gm.A; g.C = gm.A2; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
-        qoc_gemm_launch(false, 0, g, s);                         // A2 = A*A
+        qoc_gemm_launch(gm, false, 0, g, s);                         // A2 = A*A
         if (even) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, gm.A2, cur, BS * NN, N,
                                      invf[2 * mm - 2], invf[2 * mm - 1], invf[deg]);
         else hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N,
                                 invf[2 * mm], invf[2 * mm + 1], 0.0);
         for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {    // S <- c_{2i} I + c_{2i+1} A + A2*S
             g.A = gm.A2; g.Bm = cur; g.C = oth; g.E = gm.A; g.alpha = 1.0; g.beta = invf[2 * i + 1]; g.gamma = invf[2 * i];
-            qoc_gemm_launch(false, 0, g, s);
+            qoc_gemm_launch(gm, false, 0, g, s);
             cplx* t = cur; cur = oth; oth = t;
         }
     } else {
@@ -506,7 +505,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     }
     for (int sq = 0; sq < nsq; ++sq) {                       // M <- M M                    tensorflow_state.py:43-44
         g.A = cur; g.Bm = cur; g.C = oth; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
-        qoc_gemm_launch(false, 0, g, s);
+        qoc_gemm_launch(gm, false, 0, g, s);
         cplx* t = cur; cur = oth; oth = t;
     }
     (void)cur;                                               // == gm.K by construction
@@ -532,7 +531,6 @@ static inline ChainArgs qoc_gemm_direct_backward_args(const QocGemm& gm, const Q
 static inline bool qoc_gemm_zfree_backward(const QocGemm& gm, const QocDev& d) { return gm.direct && !(d.n_forb > 0 || d.has_speed) && d.steps >= 2; }
 
 static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s) {
-    qoc_gemm_plan_scale = (double)d.Bplan / (double)d.B;
     const int N = gm.N, xw = d.state_transfer ? 0 : N, ld = xw + QOC_TW, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
@@ -580,7 +578,7 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
             const int pairs = cnt / 2, nxt = (cnt + 1) / 2;
             r.A = lvl + NN; r.Bm = lvl; r.C = out; r.sA = r.sB = 2 * (long long)NN; r.sC = (long long)NN;
             r.inner = pairs; r.sA2 = r.sB2 = (long long)cnt * NN; r.sC2 = (long long)nxt * NN; r.batch = d.B * pairs;
-            qoc_gemm_launch(false, 0, r, s);
+            qoc_gemm_launch(gm, false, 0, r, s);
             if (cnt & 1)
                 hipLaunchKernelGGL(k_gemm_copy_mats, dim3(gemm_grid((size_t)d.B * NN)), dim3(256), 0, s, out + (size_t)pairs * NN,
                                    (long long)nxt * NN, lvl + (size_t)(cnt - 1) * NN, (long long)cnt * NN, d.B, (int)NN);
@@ -592,7 +590,7 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         memset(&r, 0, sizeof r);
         r.A = lvl; r.sA = (long long)NN; r.lda = N; r.Bm = gm.Y0; r.C = gm.Y1; r.ldb = r.ldc = ld; r.sB = r.sC = (long long)N * ld;
         r.Kdim = N; r.tiles_m = N / 32; r.tiles_n = ld / 32; r.batch = d.B; r.alpha = 1.0;
-        qoc_gemm_launch(false, 0, r, s);
+        qoc_gemm_launch(gm, false, 0, r, s);
         hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(N > 64 ? 1024 : 256), 0, s, d, gm.Y1, N);
         // chunk-start vectors Psibnd[c] = P_{c-1} ... P_0 Psi0, c = 1 .. NC-1: one workgroup per (seed, chunk), <= log2(NC) nodes
         ScanArgs a = sc;
@@ -609,7 +607,7 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
     const size_t yslot = (size_t)d.B * N * ld;
     for (int c = 0; c < (gm.persistent ? 0 : NC); ++c) {
         g.A = Pc + (size_t)c * NN; g.Bm = gm.Y0 + (size_t)c * yslot; g.C = gm.Y0 + (size_t)(c + 1) * yslot;
-        qoc_gemm_launch(false, 0, g, s);
+        qoc_gemm_launch(gm, false, 0, g, s);
     }
     if (!gm.persistent && NC > 1)
         hipLaunchKernelGGL(k_gemm_take_bnd_all, dim3(gemm_grid((size_t)d.B * (NC - 1) * thin)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
@@ -636,7 +634,7 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
         if (j == 0) { h.Bm = gm.Psibnd; h.sB = (long long)thin; }
         else { h.Bm = gm.interP + (size_t)(j - 1) * thin; h.sB = (long long)thin * S; }
         h.C = gm.interP + (size_t)j * thin;
-        qoc_gemm_launch(false, 0, h, s);
+        qoc_gemm_launch(gm, false, 0, h, s);
     }
     hipLaunchKernelGGL(k_gemm_unpad_inter, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.SP);
 }
@@ -655,12 +653,11 @@ static inline void qoc_gemm_bwd_sweep(QocGemm& gm, const QocDev& d, hipStream_t 
         g.E = need_src ? gm.SrcP + (size_t)j * thin : nullptr;
         if (j > 0) { g.C = gm.LamP + (size_t)(j - 1) * thin; g.sC = (long long)thin * S; }
         else { g.C = first_out; g.sC = (long long)thin; }
-        qoc_gemm_launch(true, 0, g, s);
+        qoc_gemm_launch(gm, true, 0, g, s);
     }
 }
 
 static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s) {
-    qoc_gemm_plan_scale = (double)d.Bplan / (double)d.B;
     const int N = gm.N, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const bool need_src = d.n_forb > 0 || d.has_speed;
@@ -720,7 +717,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     for (int c = NC - 1; c >= 1; --c) {
         g.A = Pc + (size_t)c * NN; g.Bm = gm.Ebnd + (size_t)c * thin; g.C = gm.Ebnd + (size_t)(c - 1) * thin;
         g.E = need_src ? gm.Aoff + (size_t)c * thin : nullptr;
-        qoc_gemm_launch(true, 0, g, s);
+        qoc_gemm_launch(gm, true, 0, g, s);
     }
     hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)gm.Ebnd, N, S, NC);
     qoc_gemm_bwd_sweep(gm, d, s, need_src, nullptr);
@@ -738,7 +735,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         h.A = gm.HsP + NN; h.inner = d.k; h.sA = (long long)NN; h.sA2 = 0;
         h.sB = h.sL = 0; h.sB2 = h.sL2 = (long long)N * gm.ldW;
         h.batch = d.B * d.k;
-        qoc_gemm_launch(false, 2, h, s);
+        qoc_gemm_launch(gm, false, 2, h, s);
         hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, tm, gm.ldW, gm.MV);
         return;
     }
@@ -755,7 +752,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
             h.A = gm.HsP + (size_t)(kk + 1) * NN;
             h.partial = gm.partial + (size_t)b * d.steps * h.partial_stride;
             h.partial_offset = kk * (N / 32);
-            qoc_gemm_launch(false, 1, h, s);
+            qoc_gemm_launch(gm, false, 1, h, s);
         }
     }
     hipLaunchKernelGGL(k_gemm_grad_reduce, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, N / 32);

@@ -58,6 +58,7 @@ _SIGNATURES = {
     'qoc_time_iterations': (C.c_int, [C.c_void_p, C.POINTER(QocAdamParams), C.c_int32, _DP]),
     'qoc_path_in_use': (C.c_int, [C.c_void_p]),
     'qoc_chunks_in_use': (C.c_int, [C.c_void_p]),
+    'qoc_plan_describe': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     'qoc_comm_unique_id': (C.c_int, [C.c_void_p]),
     'qoc_comm_probe': (C.c_int, [C.c_int32]),
     'qoc_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -86,6 +87,10 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError('libqoc_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
                           'g.build()"` (hipcc --offload-arch=gfx950); there is no CPU fallback.' % LIB_PATH)
+    # one process per GPU under a launcher: RCCL shares device memory between the ranks through dmabuf IPC handles, the only kind this host
+    # driver supports, and the HIP runtime reads the switch when it starts -- i.e. possibly at the first call into the library loaded here
+    if int(os.environ.get('WORLD_SIZE', '1') or 1) > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
@@ -93,6 +98,10 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def library_loaded():
+    return _lib is not None
 
 
 class QocError(RuntimeError):
@@ -265,6 +274,9 @@ class HipEngine(object):
                               None if Vsa is None else _dp(Vsa.view(np.float64)), C.byref(self._h)))
         self.path = lib.qoc_path_in_use(self._h)
         self.chunks = lib.qoc_chunks_in_use(self._h)
+        buf = C.create_string_buffer(256)
+        _check(lib.qoc_plan_describe(self._h, buf, 256))
+        self.plan = dict(kv.split('=', 1) for kv in buf.value.decode().split())
 
     # -- lifetime ---------------------------------------------------------------------------------------------
     def close(self):

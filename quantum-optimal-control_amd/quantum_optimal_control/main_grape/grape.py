@@ -123,11 +123,13 @@ def GrapeSharded(*args, restarts=8, dist=None, comm=None, **kwargs):
     launcher's RANK/LOCAL_RANK/WORLD_SIZE) or `dist` = an initialised `torch.distributed` module (gloo in the CPU tests); neither
     = a single process.  Every rank optimises its own restarts on its own GPU -- no data-path collective --, the best final
     losses are all-gathered once, and the winner's (uks, U_final) is broadcast, so every rank returns the same pair.
-    Global restart g starts from the same point whatever the number of ranks (restart 0 = the reference's own draw), and every engine plans
-    its kernels for the same batch (`plan_seeds`, default `hip_engine.plan_seeds_for(restarts)` = restarts / GPUs of the node: what a full-node
-    launch gives each GPU), so the result is BIT-identical under any rank count and to `Grape(restarts=restarts, plan_seeds=<the same>)` in one
-    process -- tests/sharded_script.py checks array_equal.  (A launch on far fewer GPUs than the node has runs kernels planned for a smaller
-    batch than it holds; pass plan_seeds to choose.)"""
+    Global restart g starts from the same point whatever the number of ranks (restart 0 = the reference's own draw), and every engine of the
+    launch plans its kernels for the same batch: `plan_seeds`, default = the LARGEST shard of this launch, ceil(restarts / ranks) -- identical on all
+    ranks, and never smaller than what an engine holds, so AUTO picks what is fastest for the launch at hand.  Bit-identity ACROSS launches with
+    different rank counts is opt-in: pass the same `plan_seeds` to each of them (`hip_engine.plan_seeds_for(restarts)` = restarts / GPUs of the
+    node is the natural choice) -- the result is then bit for bit that of `Grape(restarts=restarts, plan_seeds=<the same>)` in one process
+    (tests/sharded_script.py checks array_equal); an engine that holds more control sets than it plans for says so on stderr when that changes
+    the kernels it runs."""
     from quantum_optimal_control.parallel_seeds import SeedShard
     if comm is not None:
         world, rank = comm.world, comm.rank
@@ -142,8 +144,7 @@ def GrapeSharded(*args, restarts=8, dist=None, comm=None, **kwargs):
     device = int(kwargs.pop('device', default_device))
     if rank != 0:
         kwargs['save'] = False                                       # only rank 0 may write the run log
-    from quantum_optimal_control.core import hip_engine
-    kwargs.setdefault('plan_seeds', hip_engine.plan_seeds_for(int(restarts)))
+    kwargs.setdefault('plan_seeds', max(shard.counts))
     out = Grape(*args, restarts=shard.count, _first_seed=shard.first, _device=device, _return_session=True, **kwargs)
     if world == 1:
         return None if out is None else out[:2]

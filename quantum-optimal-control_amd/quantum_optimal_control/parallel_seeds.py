@@ -24,6 +24,33 @@ def launch_env():
             int(os.environ.get('WORLD_SIZE', '1')))
 
 
+def launch_key():
+    """What the ranks of ONE launch share and no other launch does: master port + the launcher's PID (the ranks of one
+    torch.distributed.run / bench.py launch are siblings: os.getppid() is the same number on all of them) + the launcher's start time in
+    clock ticks (/proc/<pid>/stat field 22: a recycled PID of a crashed earlier launch gives another key, so its left-over files are
+    never read as fresh exchanges)."""
+    ppid = os.getppid()
+    start = '0'
+    try:
+        with open('/proc/%d/stat' % ppid) as f:
+            start = f.read().rsplit(')', 1)[1].split()[19]
+    except (OSError, IndexError):
+        pass
+    return '%s_%d_%s' % (os.environ.get('MASTER_PORT', '0'), ppid, start)
+
+
+def device_for_rank(local_rank, visible_devices):
+    """HIP device index of a rank: LOCAL_RANK when the rank sees all GPUs of the node (torch.distributed.run exports no
+    HIP_VISIBLE_DEVICES: every rank sees 8 devices and must pick its own), device 0 when the launcher already narrowed the rank's view to ONE
+    device (HIP_VISIBLE_DEVICES=<local rank>), LOCAL_RANK modulo the count otherwise (more ranks than visible GPUs share them round-robin)."""
+    local_rank, visible_devices = int(local_rank), int(visible_devices)
+    if visible_devices <= 0:
+        raise RuntimeError('no HIP device visible to local rank %d' % local_rank)
+    if visible_devices == 1:
+        return 0
+    return local_rank % visible_devices
+
+
 def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=300.0):
     """Hand `make_payload()` (bytes, evaluated on rank 0 only) to every rank of a one-node job through a file.
 
@@ -33,7 +60,7 @@ def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=300.
     if world == 1:
         return make_payload()
     if key is None:
-        key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+        key = launch_key()
     directory = directory or os.environ.get('QOC_RDZV_DIR', '/tmp')
     path = os.path.join(directory, 'qoc_rdzv_%d_%s' % (os.getuid(), key))
     if rank == 0:
@@ -62,7 +89,7 @@ def rendezvous_cleanup(rank, world, key=None, directory=None):
     if world == 1 or rank != 0:
         return
     if key is None:
-        key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+        key = launch_key()
     directory = directory or os.environ.get('QOC_RDZV_DIR', '/tmp')
     try:
         os.remove(os.path.join(directory, 'qoc_rdzv_%d_%s' % (os.getuid(), key)))
@@ -75,13 +102,15 @@ _OPEN_CALLS = 0          # open_comm calls of this process: every call of one la
 
 
 def _private_dir(path):
-    """Directory only this user can write (0700), created if missing; a directory somebody else planted is refused."""
+    """Directory only this user can write (0700), created if missing; anything somebody else planted under the (predictable) name is refused --
+    lstat, not stat: a symbolic link to a private directory of this user would pass an ownership check that follows it, and close() removes files there."""
+    import stat
     try:
-        os.makedirs(path, mode=0o700)
+        os.mkdir(path, 0o700)
     except FileExistsError:
         pass
-    st = os.stat(path)
-    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+    st = os.lstat(path)
+    if stat.S_ISLNK(st.st_mode) or not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
         raise PermissionError('%s exists and is not a private directory of uid %d' % (path, os.getuid()))
 
 
@@ -153,24 +182,33 @@ class FileComm(object):
         if self._dir is None:
             return
         self.barrier()
-        # a rank says goodbye only after it has read the last exchange; whoever sees every goodbye is the last one out and
-        # takes the directory with it (two ranks may both see them all: removals that find nothing are fine)
+        # a rank says goodbye only after it has read the last exchange; whoever sees every goodbye is the last one out: it removes the files of
+        # THIS transport -- <seq>_<rank>.npy and bye_<rank> of the ranks of this communicator, nothing else that may sit in the directory -- and
+        # the then empty directory (two ranks may both see all goodbyes: removals that find nothing are fine; rmdir fails on foreign files)
+        import re
         open(os.path.join(self._dir, 'bye_%d' % self.rank), 'wb').close()
         try:
-            names = os.listdir(self._dir)
-            if sum(1 for x in names if x.startswith('bye_')) == self.world:
-                for x in names:
-                    try:
-                        os.remove(os.path.join(self._dir, x))
-                    except OSError:
-                        pass
+            byes = ['bye_%d' % r for r in range(self.world)]
+            if all(os.path.exists(os.path.join(self._dir, x)) for x in byes):
+                mine = re.compile(r'^(\d+_(\d+)\.npy(\.tmp)?|bye_(\d+))$')
+                for x in os.listdir(self._dir):
+                    hit = mine.match(x)
+                    if hit and int(hit.group(2) or hit.group(4)) < self.world:
+                        try:
+                            os.remove(os.path.join(self._dir, x))
+                        except OSError:
+                            pass
                 os.rmdir(self._dir)
         except OSError:
             pass
         self._dir = None
 
 
-def open_comm(rank=None, world=None, device=None, key=None):
+class RcclRequired(RuntimeError):
+    """open_comm(require_rccl=True) / QOC_REQUIRE_RCCL=1: some rank could not use RCCL and a file-transport line must not stand in for it."""
+
+
+def open_comm(rank=None, world=None, device=None, key=None, require_rccl=None, call_index=None):
     """Communicator for this rank (None for a single process): RCCL behind the C ABI (hip_engine.QocComm), or -- when some rank
     cannot use RCCL, or QOC_TRANSPORT=file -- the file transport above (FileComm, same interface), with a warning on stderr and
     `comm.fallback_reason` set.  Collective: every rank of the launch calls it.
@@ -179,11 +217,25 @@ def open_comm(rank=None, world=None, device=None, key=None):
       1. every rank checks its LOCAL preconditions (librccl loadable, device usable: hip_engine.comm_probe) -- no collective;
       2. the ranks agree on the outcome through the file transport; one failure sends everybody to it;
       3. rank 0 creates the RCCL id and hands it out through the same transport; every rank enters ncclCommInitRank;
-      4. the ranks agree again (the initialisation itself may fail on some rank: IPC handles, device binding)."""
+      4. the ranks agree again (the initialisation itself may fail on some rank: IPC handles, device binding).
+
+    require_rccl (default: QOC_REQUIRE_RCCL=1 in the environment): no fallback -- every rank raises RcclRequired with the reason (the verdict is
+    collective, so nobody is left waiting).  A first run on a new multi-GPU node should fail loudly on an xGMI / RCCL problem.
+    call_index: which open_comm call of the launch this is (each gets its own exchange directory); default = a per-process counter, which
+    assumes every rank has called open_comm equally often -- pass it (or QOC_COMM_CALL) when that is not so.
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, the only kind this host driver supports) must be in the environment BEFORE the HIP runtime
+    starts: hip_engine.load_library() sets it for multi-rank launches (WORLD_SIZE > 1); a process that loaded the library earlier without
+    it is told so here."""
     global _OPEN_CALLS
+    import sys
     from quantum_optimal_control.core import hip_engine
-    # the host driver shares device memory between processes through dmabuf only: RCCL's hipIpcGetMemHandle needs this before HIP starts
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if require_rccl is None:
+        require_rccl = os.environ.get('QOC_REQUIRE_RCCL', '0') == '1'
+    if 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ:
+        if hip_engine.library_loaded():
+            sys.stderr.write('quantum_optimal_control.parallel_seeds: WARNING: libqoc_hip was loaded before HSA_ENABLE_IPC_MODE_LEGACY=0 was set; '
+                             'if the HIP runtime has already started, RCCL cannot exchange IPC handles (export it before the first engine call)\n')
+        os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
     erank, elocal, eworld = launch_env()
     rank = erank if rank is None else rank
     world = eworld if world is None else world
@@ -191,16 +243,24 @@ def open_comm(rank=None, world=None, device=None, key=None):
     if world == 1:
         return None
     if key is None:
-        key = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
-    call, _OPEN_CALLS = _OPEN_CALLS, _OPEN_CALLS + 1
-    files = FileComm(rank, world, '%s_c%d' % (key, call))
+        key = launch_key()
+    if call_index is None:
+        call_index = os.environ.get('QOC_COMM_CALL')
+    if call_index is None:
+        call_index, _OPEN_CALLS = _OPEN_CALLS, _OPEN_CALLS + 1
+    files = FileComm(rank, world, '%s_c%d' % (key, int(call_index)))
     files.fallback_reason = None
 
     def fall_back(reason):
+        if require_rccl:
+            try:
+                files.close()
+            except Exception:
+                pass
+            raise RcclRequired('RCCL is required (require_rccl / QOC_REQUIRE_RCCL=1) and is not usable: %s' % reason)
         files.library = 'files (host): ' + reason
         files.fallback_reason = reason
         if rank == 0 and os.environ.get('QOC_TRANSPORT', 'rccl') != 'file':
-            import sys
             sys.stderr.write('quantum_optimal_control.parallel_seeds: WARNING: RCCL is NOT in use, the ranks exchange their results '
                              'through files (%s)\n' % reason)
         return files

@@ -1,0 +1,198 @@
+"""AUTO's dispatch table, row by row, on both sides of every threshold ("Next round" 2).
+
+`qoc_create` (csrc/qoc_engine.hip, `plan_for`) picks path, kernel family, chunk count and sweep kernels from the problem shape and the
+batch; the thresholds are measured numbers.  A threshold edit must not silently route a shape to a kernel no test runs, so this file
+  (1) restates the table of DESIGN.md section 4 as ordered RULES in Python (`expected_plan`), independent of the C++ text,
+  (2) walks batch sizes {1, 2, 4, 5, 8, 9, 16, 17, 31, 32, 63, 64, 111, 112} x n in {16, 17, 32, 33, 48, 49, 64} x k in {4, 5, 6, 8} x
+      {no state regulariser, forbidden level} in unitary mode (pulse lengths chosen so that seeds x slices falls on either side of the
+      latency-mode limits 4096 / 4608 / 16384), and the state-transfer routes either side of 48 / 112 control sets,
+  (3) creates the AUTO engine for each (1032 unitary rows), asserts the plan it reports (`qoc_plan_describe`) is the expected one, and -- for the
+      smallest and the largest batch that resolve to each distinct plan of a shape, i.e. on both sides of every threshold that changes the
+      kernels -- checks the first and the last control set of the batch against the CPU oracle (reference: core/tensorflow_state.py:25-65,
+      204-261, 323-356).
+"""
+import numpy as np
+import pytest
+
+from tests.golden import cases
+from tests.helpers import oracle_system
+from tests.test_hip_parity import check_eval
+
+pytestmark = pytest.mark.gpu
+
+LAT_WORK, LAT_WORK_SRC, LAT_WORK_NT3, LAT_WORK_NT4 = 4608, 4096, 16384, 4096      # seeds x slices up to which the latency mode is taken
+FORBID = lambda n: {'dwdt': 0.1, 'forbidden_coeff_list': [3.0], 'states_forbidden_list': [n - 1]}      # noqa: E731
+
+
+def ceil_div(a, b):
+    return -(-a // b)
+
+
+def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, hermitian=True):
+    """DESIGN.md section 4, the AUTO table, as ordered rules -> the dict HipEngine.plan reports."""
+    if state_transfer:
+        # rows "state transfer ...": GEMM path; direct route for large batches (n <= 32: from 112 control sets, n <= 64: from 48) and for
+        # non-Hermitian generators; the propagator route otherwise; m > 8 or n > 64 cannot run direct
+        direct_ok = n <= 64 and m <= 8
+        if m > 32 or not (hermitian or direct_ok):
+            return {'path': 'st_fused' if (n <= 64 and m <= 4 and k <= 8) else 'generic'}
+        direct = direct_ok and (not hermitian or B >= (112 if n <= 32 else 48))
+        return {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
+    mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= T <= 22
+    if not mfma_ok:
+        return {'path': 'gemm', 'route': 'unitary'} if m <= 32 else {'path': 'generic'}
+    work = B * steps
+    # row "latency mode": one or a few control sets
+    if T >= 2 and steps >= 64:
+        if n > 48 or (n > 32 and k > 4):
+            lat = work <= LAT_WORK_NT4 and B <= 4
+        elif n > 32:
+            lat = work <= LAT_WORK_NT3 and B <= 8
+        else:
+            lat = work <= (LAT_WORK_SRC if state_reg else LAT_WORK) and B <= (16 if n > 16 else (2 if state_reg else 4))
+        lat = lat or (B == 1 and steps <= 8192)
+    else:
+        lat = False
+    if lat:
+        nt = 2 if n <= 32 else (3 if (n <= 48 and k <= 4) else 4)
+        L = ceil_div(steps, ceil_div(steps, 8))
+        return {'path': 'mfma', 'nt': nt, 'expm': 5, 'chunks': ceil_div(steps, L), 'sweeps': 'latency_sources' if state_reg else 'latency'}
+    # rows "GEMM": 48 < n <= 64 below the NT = 4 batch sizes; 32 < n <= 48 with fewer than 8 control sets; 16 < n <= 32 with <= 8 control sets
+    nt4_batch = n > 48 and ((k <= 4 and B >= 32) or B >= 64)
+    if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < 8) or (16 < n <= 32 and B <= 8 and m <= 8 and steps >= 100):
+        return {'path': 'gemm', 'route': 'unitary', 'chains': 'persistent' if m <= 8 else 'launches'}
+    # rows "MFMA batch kernels"
+    nt = 1 if n <= 16 else 2 if n <= 32 else 3 if n <= 48 else 4
+    C = min(1024 // B if nt == 2 else ceil_div(1024, B), 64 if nt == 2 else 32)
+    C = max(1, min(C, steps))
+    C = ceil_div(steps, ceil_div(steps, C))
+    if nt == 2:
+        expm = 8 if T >= 3 else ((4 if T == 2 else 3) if B * C >= 512 else 1)
+        sweeps = 'row_tile_gradient' if k >= 6 else ('downup' if (m <= 8 and not state_reg) else 'pair')
+    elif nt == 1:
+        expm, sweeps = 1, 'one_wave'
+    else:
+        expm, sweeps = 7, 'row_tile_gradient'
+    return {'path': 'mfma', 'nt': nt, 'expm': expm, 'chunks': C, 'sweeps': sweeps}
+
+
+def unitary_rows():
+    rows = []
+    for n in (16, 17, 32, 33, 48, 49, 64):
+        for k in (4, 5, 6, 8):
+            for reg in (False, True):
+                for B in (1, 2, 4, 5, 8, 9, 16, 17, 31, 32, 63, 64, 111, 112):
+                    # every (n, k, regulariser, batch) once at 130 slices; the (k = 4 / k = 5) columns also at the pulse lengths that put
+                    # seeds x slices on either side of the latency mode's limit for this class of n
+                    lens = {130}
+                    if k in (4, 5):
+                        limit = (LAT_WORK_NT4 if (n > 48 or (n > 32 and k > 4)) else LAT_WORK_NT3 if n > 32 else (LAT_WORK_SRC if reg else LAT_WORK))
+                        if 2 <= B <= 16 and 64 <= limit // B <= 1200:
+                            lens |= {limit // B, limit // B + 1}
+                    if B >= 63 and (n > 32 or k >= 6):
+                        lens = {70}                       # large batches of the large shapes: short pulses keep the oracle side cheap
+                    for steps in sorted(lens):
+                        rows.append((n, k, reg, B, steps))
+    # Taylor orders below the in-place kernel's range, and an order-1 problem the latency mode cannot take
+    extra = [(32, 4, False, 64, 130, 2), (32, 4, False, 3, 130, 2), (32, 4, False, 64, 130, 1), (32, 4, False, 1, 130, 1), (20, 3, False, 40, 96, 2)]
+    return rows, extra
+
+
+def _problem(n, k, steps, m, T, s, reg, seed):
+    c = cases.case_c2(n=n, k=k, steps=steps, m=m, taylor=(T, s), seed=seed)
+    c['total_time'] = 20.0 * steps / 500.0                # short pulses: a well-conditioned gradient at every size
+    if reg:
+        c['reg_coeffs'] = FORBID(n)
+    return c
+
+
+def _run(c, B, expect, seed, check=True):
+    from quantum_optimal_control.core import hip_engine
+    sp = oracle_system(c)
+    eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
+                               state_transfer=sp.state_transfer, reg_coeffs=sp.reg_coeffs, one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=B)
+    try:
+        got = {key: (int(v) if v.lstrip('-').isdigit() else v) for key, v in eng.plan.items()}
+        for key, want in expect.items():
+            assert got.get(key) == want, (key, want, got)
+        if not check:
+            return
+        rng = np.random.default_rng(seed)
+        bases = rng.normal(0, 1 / np.sqrt(sp.steps), (B, sp.k, sp.steps))
+        eng.set_base(bases)
+        picked = sorted({0, B - 1})
+
+        class TwoOf(object):                               # check_eval walks `bases`: hand it the first and the last control set only
+            def __init__(self, eng):
+                self.eng = eng
+
+            def evaluate(self):
+                r = self.eng.evaluate()
+                return {key: np.asarray(v)[picked] for key, v in r.items()}
+
+            def get_inter_vecs(self):
+                return self.eng.get_inter_vecs()[picked]
+
+            def get_final_unitary(self):
+                return self.eng.get_final_unitary()[picked]
+        check_eval(TwoOf(eng), sp, [bases[b] for b in picked])
+    finally:
+        eng.close()
+
+
+ROWS, EXTRA = unitary_rows()
+
+
+@pytest.mark.parametrize('n', [16, 17, 32, 33, 48, 49, 64])
+@pytest.mark.parametrize('k', [4, 5, 6, 8])
+def test_auto_plan_unitary_rows(n, k):
+    m = 8
+    mine = [r for r in ROWS if (r[0], r[1]) == (n, k)]
+    assert len(mine) >= 28
+    # oracle parity at the smallest and the largest batch of every distinct (regulariser, plan-without-chunk-count) group of this shape
+    groups = {}
+    for i, (_, _, reg, B, steps) in enumerate(mine):
+        plan = expected_plan(n, k, m, steps, 5, B, state_reg=reg)
+        sig = (reg,) + tuple(sorted((key, v) for key, v in plan.items() if key != 'chunks'))
+        groups.setdefault(sig, []).append((B, steps, i))
+    checked = set()
+    for rows in groups.values():
+        checked.add(min(rows)[2])
+        checked.add(max(rows)[2])
+    for i, (_, _, reg, B, steps) in enumerate(mine):
+        expect = expected_plan(n, k, m, steps, 5, B, state_reg=reg)
+        _run(_problem(n, k, steps, m, 5, 2, reg, seed=100 + n), B, expect, seed=B, check=i in checked)
+
+
+@pytest.mark.parametrize('n,k,reg,B,steps,T', EXTRA, ids=['T2_batch', 'T2_latency', 'T1_batch', 'T1_single_no_latency', 'n20_T2_small_launch'])
+def test_auto_plan_low_taylor_orders(n, k, reg, B, steps, T):
+    expect = expected_plan(n, k, 8, steps, T, B, state_reg=reg)
+    _run(_problem(n, k, steps, 8, T, 2, reg, seed=7), B, expect, seed=B)
+
+
+def test_auto_plan_wide_and_odd_shapes():
+    """m beyond the fused sweep (m > 8), beyond the MFMA path (m > 16), and beyond every fast path (m > 32)."""
+    for (n, k, m, B, steps) in ((32, 4, 13, 64, 130), (32, 4, 16, 20, 130), (40, 3, 20, 16, 96), (36, 2, 34, 3, 40)):
+        expect = expected_plan(n, k, m, steps, 5, B)
+        _run(_problem(n, k, steps, m, 5, 2, False, seed=3), B, expect, seed=B)
+
+
+ST_ROWS = [(64, 6, 1, 47, True), (64, 6, 1, 48, True), (33, 4, 2, 47, True), (33, 4, 2, 48, True), (32, 4, 1, 111, True), (32, 4, 1, 112, True),
+           (16, 3, 4, 111, True), (16, 3, 4, 112, True), (64, 6, 1, 3, False), (20, 3, 2, 1, False), (24, 3, 12, 4, True), (70, 3, 2, 50, True)]
+
+
+@pytest.mark.parametrize('n,k,m,B,hermitian', ST_ROWS, ids=['n%d_m%d_B%d_%s' % (r[0], r[2], r[3], 'herm' if r[4] else 'nonherm') for r in ST_ROWS])
+def test_auto_plan_state_transfer_rows(n, k, m, B, hermitian):
+    steps = 100
+    c = cases.case_c3(n=n, k=k, steps=steps, taylor=(8, 0), seed=5)
+    c['total_time'] = 4.0
+    rng = np.random.default_rng(n + m)
+    if m > 1:
+        def vecs():
+            Q, _ = np.linalg.qr(rng.normal(size=(n, m)) + 1j * rng.normal(size=(n, m)))
+            return [Q[:, j] for j in range(m)]
+        c['states_concerned_list'], c['U'] = vecs(), vecs()
+    if not hermitian:
+        c['H0'] = c['H0'] + 0.05j * np.diag(np.arange(n) / n)          # a lossy drift: the generators are no longer anti-Hermitian
+    expect = expected_plan(n, k, m, steps, 8, B, state_transfer=True, hermitian=hermitian)
+    _run(c, B, expect, seed=B)

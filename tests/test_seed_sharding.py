@@ -334,3 +334,129 @@ def test_bench_gpus8_rank_bookkeeping_on_one_gpu():
     assert j['n_gpus'] == 8 and cfg['ranks_seen'] == 8 and cfg['fidelities_gathered'] == 512 and cfg['total_seeds'] == 512
     assert cfg['transport'].startswith('files') and cfg['transport_fallback'] is True and cfg['rccl_error'] == 'QOC_TRANSPORT=file'
     assert cfg['chunks'] == 16 and cfg['path'] == 2                      # every rank runs the single-GPU bench configuration
+
+
+# ---- round 4: 8-GPU readiness -------------------------------------------------------------------------------
+def _require_rccl_worker(rank, world, key, directory, out):
+    """open_comm(require_rccl=True) with a communicator whose ncclCommInitRank fails on rank 1: EVERY rank must raise (exit code 3 here, as
+    bench.py does), not drop to the file transport."""
+    os.environ['QOC_RDZV_DIR'] = directory
+    os.environ.pop('QOC_TRANSPORT', None)
+    from quantum_optimal_control import parallel_seeds
+    from quantum_optimal_control.core import hip_engine
+
+    class FakeComm(object):
+        library = 'fake rccl'
+
+        def __init__(self, uid, world_, rank_, device):
+            if rank_ == 1:
+                raise hip_engine.QocError('ncclCommInitRank: unhandled system error')
+
+        def close(self):
+            pass
+
+    hip_engine.comm_probe = lambda device: None
+    hip_engine.comm_unique_id = lambda: bytes(range(hip_engine.COMM_ID_BYTES))
+    hip_engine.QocComm = FakeComm
+    try:
+        parallel_seeds.open_comm(rank=rank, world=world, device=0, key=key, require_rccl=True)
+    except parallel_seeds.RcclRequired as exc:
+        out.put((rank, str(exc)))
+        sys.exit(3)
+    out.put((rank, 'no exception'))
+
+
+def test_require_rccl_turns_a_forced_rccl_failure_into_a_nonzero_exit_on_every_rank(tmp_path):
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_require_rccl_worker, args=(r, 2, 'req_%d' % os.getpid(), str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 3
+    for r in range(2):
+        assert 'RCCL is required' in got[r] and 'rank(s) [1]' in got[r], got[r]
+    assert os.listdir(str(tmp_path)) == []                   # and the agreement files are gone
+
+
+def test_local_rank_to_device_mapping():
+    """torch.distributed.run exports no HIP_VISIBLE_DEVICES: every rank sees all 8 GPUs and takes device = LOCAL_RANK; a launcher that narrowed
+    each rank's view to one device gives device 0; more ranks than devices go round-robin."""
+    from quantum_optimal_control.parallel_seeds import device_for_rank
+    assert [device_for_rank(r, 8) for r in range(8)] == list(range(8))
+    assert [device_for_rank(r, 1) for r in range(8)] == [0] * 8
+    assert [device_for_rank(r, 4) for r in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
+    with pytest.raises(RuntimeError, match='no HIP device'):
+        device_for_rank(0, 0)
+
+
+def test_file_transport_refuses_a_planted_symlink_and_keys_differ_between_launches(tmp_path):
+    from quantum_optimal_control import parallel_seeds
+    victim = tmp_path / 'victim'
+    victim.mkdir(mode=0o700)
+    (victim / 'precious').write_text('x')
+    link = tmp_path / ('qoc_fc_%d_planted' % os.getuid())
+    os.symlink(str(victim), str(link))
+    with pytest.raises(PermissionError, match='not a private directory'):
+        parallel_seeds.FileComm(0, 2, 'planted', directory=str(tmp_path))
+    assert (victim / 'precious').exists()
+    # the default key carries the launcher's pid AND its start time: a recycled pid of a crashed launch does not collide
+    port, pid, start = parallel_seeds.launch_key().split('_')
+    assert int(pid) == os.getppid() and int(start) > 0
+    # close() removes only what the communicator wrote
+    comm = parallel_seeds.FileComm(0, 1, 'solo', directory=str(tmp_path))
+    foreign = os.path.join(comm._dir, 'somebody_elses_file')
+    open(foreign, 'w').close()
+    comm.barrier()
+    comm.close()
+    assert os.path.exists(foreign)
+
+
+def test_grape_sharded_plans_for_the_largest_shard_of_its_launch(monkeypatch):
+    """the default plan of GrapeSharded is ceil(restarts / ranks) of the launch at hand -- never smaller than the batch an
+    engine holds -- not restarts / GPUs of the node."""
+    from quantum_optimal_control.main_grape import grape as G
+    seen = {}
+
+    def fake_grape(*a, **kw):
+        seen.update(kw)
+        return None
+    monkeypatch.setattr(G, 'Grape', fake_grape)
+
+    class FakeComm(object):
+        world, rank, device = 2, 1, 1
+
+        def all_gather(self, values):                      # an interrupted run on every rank: GrapeSharded returns None after the gather
+            return np.full((2, len(values)), np.inf)
+    assert G.GrapeSharded(None, None, None, None, 1.0, 4, [0], restarts=65, comm=FakeComm()) is None
+    assert seen['plan_seeds'] == 33 and seen['restarts'] == 32 and seen['_first_seed'] == 33 and seen['_device'] == 1
+    G.GrapeSharded(None, None, None, None, 1.0, 4, [0], restarts=64)
+    assert seen['plan_seeds'] == 64 and seen['restarts'] == 64
+    G.GrapeSharded(None, None, None, None, 1.0, 4, [0], restarts=64, plan_seeds=8)
+    assert seen['plan_seeds'] == 8
+
+
+@pytest.mark.gpu
+def test_bench_driver_form_fails_when_rccl_cannot_start():
+    """The driver's N > 1 form (torch.distributed.run) requires RCCL by default: with the RCCL library made unloadable both ranks exit non-zero
+    and no JSON line is printed; --allow-file-transport brings the flagged fallback line back."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', QOC_RCCL_LIBRARY='/nonexistent/librccl.so', QOC_BENCH_SAME_DEVICE='1')
+    for k in ('QOC_TRANSPORT', 'QOC_BENCH_BACKEND', 'QOC_REQUIRE_RCCL'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29561',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--seeds-per-gpu', '8', '--no-cpu-baseline', '--no-single']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode != 0, r.stdout[-1500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert 'RCCL is required' in r.stderr
+    r = subprocess.run(cmd + ['--allow-file-transport'], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    cfg = j['config']
+    assert cfg['transport_fallback'] is True and cfg['ranks_seen'] == 2 and len(cfg['per_rank']) == 2
+    assert all(q['device'] == 0 and q['ms_total'] > 0 and q['device_name'] for q in cfg['per_rank'])

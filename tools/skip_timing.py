@@ -1,4 +1,6 @@
-"""Wall-clock attribution for one trajectory: iteration time with one kernel group left out (QOC_DEBUG_SKIP)."""
+"""Wall-clock attribution for one trajectory: iteration time with one kernel group left out (QOC_DEBUG_SKIP).
+Needs a library built with the hook compiled in: `QOC_DEBUG_BUILD=1 python -c "import __graft_entry__ as g; g.build(force=True)"` (the product
+library does not read QOC_DEBUG_SKIP since round 4)."""
 import os, subprocess, sys
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 code = r'''
