@@ -117,7 +117,7 @@ def test_scipy_drivers_follow_the_oracle_driven_optimiser(method):
 def test_committed_fixtures_are_what_the_reference_code_produces(tmp_path):
     """Integrity of tests/golden/: re-run both generators against /root/reference in a scratch copy of tests/golden/ and compare every array with
     the committed file -- sysparams_* / helpers (the reference's NumPy code) bit for bit, graph_* (its graph code on the TF1 stand-in) to 1e-14
-    (torch reductions may reassociate between runs of different thread counts)."""
+    (torch reductions may reassociate between runs of different thread counts; the float32 set graph32_* to 1e-5 for the same reason)."""
     import shutil
     import subprocess
     import sys
@@ -127,10 +127,11 @@ def test_committed_fixtures_are_what_the_reference_code_produces(tmp_path):
     shutil.copytree(golden, work / 'tests' / 'golden')
     for f in ('__init__.py', 'helpers.py'):
         shutil.copy(os.path.join(ROOT, 'tests', f), work / 'tests' / f)
+    shutil.copy(os.path.join(ROOT, 'bench.py'), work / 'bench.py')          # the full-size C2 cases take bench.py's problem and restart seeds
     os.symlink(os.path.join(ROOT, 'quantum-optimal-control_amd'), work / 'quantum-optimal-control_amd')
     os.symlink(os.path.join(ROOT, 'oracle'), work / 'oracle')
-    for script in ('make_golden.py', 'make_graph_golden.py'):
-        r = subprocess.run([sys.executable, str(work / 'tests' / 'golden' / script)], capture_output=True, text=True, timeout=900, cwd=str(work))
+    for script in (['make_golden.py'], ['make_graph_golden.py'], ['make_graph_golden.py', '--fp32']):
+        r = subprocess.run([sys.executable, str(work / 'tests' / 'golden' / script[0])] + script[1:], capture_output=True, text=True, timeout=900, cwd=str(work))
         assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     checked = 0
     for name in sorted(os.listdir(golden)):
@@ -139,8 +140,11 @@ def test_committed_fixtures_are_what_the_reference_code_produces(tmp_path):
         old, new = np.load(os.path.join(golden, name)), np.load(work / 'tests' / 'golden' / name)
         assert sorted(old.files) == sorted(new.files), name
         for k in old.files:
-            if name.startswith('graph_') and old[k].dtype.kind in 'fc':
-                np.testing.assert_allclose(new[k], old[k], rtol=0, atol=1e-14 * max(1.0, float(np.max(np.abs(old[k])))), err_msg='%s:%s' % (name, k))
+            if name.startswith('graph32_') and k == 'base_after_adam':
+                continue                                   # float32 sign flips of the first Adam step (tests/test_oracle_golden.py)
+            if name.startswith('graph') and old[k].dtype.kind in 'fc':
+                tol = 1e-5 if name.startswith('graph32_') else 1e-14        # float32 runs: reductions reassociate at float32 round-off
+                np.testing.assert_allclose(new[k], old[k], rtol=0, atol=tol * max(1.0, float(np.max(np.abs(old[k])))), err_msg='%s:%s' % (name, k))
             else:
                 assert np.array_equal(old[k], new[k]), (name, k)
             checked += 1
