@@ -37,15 +37,16 @@ static int load(std::string& err) {
     std::lock_guard<std::mutex> lock(g_api_mu);
     if (g_api.lib) return 0;
     std::vector<std::string> candidates;
-    if (const char* forced = getenv("QOC_RCCL_LIBRARY")) candidates.push_back(forced);
+    const char* forced = getenv("QOC_RCCL_LIBRARY");       // an override is exclusive: no silent fall-through to another librccl
+    if (forced) candidates.push_back(forced);
     Dl_info info;
-    if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {       // the ROCm tree of OUR HIP runtime
+    if (!forced && dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {       // the ROCm tree of OUR HIP runtime
         std::string dir(info.dli_fname);
         // A process that imported PyTorch BEFORE this library has resolved our libamdhip64.so.7 to PyTorch's private copy (same
         // soname), and PyTorch's private librccl faults when driven from outside torch (observed: SIGSEGV in ncclGetUniqueId).
         // Refuse instead of crashing: the RCCL transport belongs to torch-free processes (bench.py, GrapeSharded(comm=...));
         // a torch process passes dist= and uses torch.distributed.
-        if (dir.find("/torch/lib/") != std::string::npos && !getenv("QOC_RCCL_LIBRARY")) {
+        if (dir.find("/torch/lib/") != std::string::npos) {
             err = "this process runs on PyTorch's private HIP runtime (" + dir + "): import quantum_optimal_control before torch, or "
                   "use the torch.distributed transport (dist=), or set QOC_RCCL_LIBRARY";
             return -1;
@@ -56,12 +57,18 @@ static int load(std::string& err) {
             candidates.push_back(dir.substr(0, slash) + "/librccl.so");
         }
     }
-    candidates.push_back("/opt/rocm/lib/librccl.so.1");
-    candidates.push_back("librccl.so.1");
+    if (!forced) {
+        candidates.push_back("/opt/rocm/lib/librccl.so.1");
+        candidates.push_back("librccl.so.1");
+    }
     std::string tried;
     for (const std::string& c : candidates) {
         void* h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!h) { tried += c + " (" + (dlerror() ? dlerror() : "?") + "); "; continue; }
+        if (!h) {
+            const char* why = dlerror();               // ONE call: dlerror() clears the message it returns
+            tried += c + " (" + (why ? why : "?") + "); ";
+            continue;
+        }
         Api a;
         a.lib = h;
         a.where = c;

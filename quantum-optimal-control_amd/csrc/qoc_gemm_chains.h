@@ -60,10 +60,11 @@ __device__ __forceinline__ void chain_butterfly(cplx (&acc)[MVT], int q) {
 // a reduce-scatter butterfly over the LG lanes (DPP), after which lane c holds the finished values x = base + s, s < SPLB, of its row
 // group in (row, slot)-major order; addend, LDS write and output store are done by the owner of each value.  LG trades LDS reads of the
 // vector (CC per thread) against butterfly levels (log2 LG): see FwdMap below for the choice per N.
-template <int N, int MV, int LG>
+template <int N, int MV, int LG, int NTHR = 256>
 struct BlockMap {
     // LG lanes share a group of R rows; a thread owns R x CC entries: rows R*g + rr, columns c + LG*cc
-    static constexpr int R = N * LG / 256, CC = N / LG, EL = R * CC, V = R * MV;
+    static constexpr int R = N * LG / NTHR, CC = N / LG, EL = R * CC, V = R * MV;
+    static constexpr int THREADS = NTHR;
     static constexpr int NSLB = V < LG ? V : LG, SPLB = V / NSLB;
     int g, c, base;
     __device__ __forceinline__ BlockMap(int tid) : g(tid / LG), c(tid % LG), base(((tid % LG) / (LG / NSLB)) * SPLB) {}
@@ -89,12 +90,30 @@ struct BlockMap {
 #pragma unroll
                 for (int jv = 0; jv < MV; ++jv) vv[cc][jv] = v[(c + LG * cc) * MV + jv];
             __builtin_amdgcn_sched_barrier(0);
+#ifdef QOC_CHAIN_SPLIT_ACC
+            // two partial sums per value (even / odd column blocks): twice as many independent FMA chains for a wave that is alone on its SIMD
+            cplx acc1[V];
+#pragma unroll
+            for (int x = 0; x < V; ++x) acc1[x] = cmake(0.0, 0.0);
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int jv = 0; jv < MV; ++jv) {
+                        cplx& t = (cc & 1) ? acc1[rr * MV + jv] : acc[rr * MV + jv];
+                        if (CONJ) cfma_conj(t, ku[rr * CC + cc], vv[cc][jv]); else cfma(t, ku[rr * CC + cc], vv[cc][jv]);
+                    }
+#pragma unroll
+            for (int x = 0; x < V; ++x) acc[x] = cadd(acc[x], acc1[x]);
+#else
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc)
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
                     for (int jv = 0; jv < MV; ++jv) { if (CONJ) cfma_conj(acc[rr * MV + jv], ku[rr * CC + cc], vv[cc][jv]); else cfma(acc[rr * MV + jv], ku[rr * CC + cc], vv[cc][jv]); }
+#endif
         } else {
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc) {
@@ -122,6 +141,16 @@ template <int N, int MV> struct FwdMap { using type = BlockMap<N, MV, 16>; };
 template <int MV> struct FwdMap<32, MV> { using type = BlockMap<32, MV, 8>; };
 template <> struct FwdMap<64, 1> { using type = BlockMap<64, 1, QOC_CHAIN_LG64>; };
 template <> struct FwdMap<64, 2> { using type = BlockMap<64, 2, QOC_CHAIN_LG64>; };
+// the Taylor chains of the direct state-transfer route (k_gemm_taylor_chain): thread count and lane-group width at N = 64, one or two vectors
+#ifndef QOC_TAYLOR_THREADS64
+#define QOC_TAYLOR_THREADS64 256
+#endif
+#ifndef QOC_TAYLOR_LG64
+#define QOC_TAYLOR_LG64 QOC_CHAIN_LG64
+#endif
+template <int N, int MV> struct TaylorMap { using type = typename FwdMap<N, MV>::type; };
+template <> struct TaylorMap<64, 1> { using type = BlockMap<64, 1, QOC_TAYLOR_LG64, QOC_TAYLOR_THREADS64>; };
+template <> struct TaylorMap<64, 2> { using type = BlockMap<64, 2, QOC_TAYLOR_LG64, QOC_TAYLOR_THREADS64>; };
 
 // y <- K_j y + E_j (CONJ: conj(K_j) y + E_j) with the mapping FwdMap picks for N.  Pipeline: K_j / E_j of the next two steps
 // are in flight in three register stages used round-robin by a 3x unrolled branch-free loop; y lives in LDS (double buffer)
@@ -212,8 +241,8 @@ __global__ void __launch_bounds__(256) k_gemm_chain_fwd(ChainArgs a) {
 // in the overlap z, so the backward chain starts from -(2/m^2) W and runs BESIDE the forward chain (k_gemm_scale_lam applies z
 // afterwards) -- the batched direct route is two latency-bound chains of 1000 x (T-1) dependent mat-vecs, on 64 of the 256 CUs each.
 template <int N, int MV>
-__global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a0, ChainArgs a1, int nb0) {
-    using BM = typename FwdMap<N, MV>::type;
+__global__ void __launch_bounds__((TaylorMap<N, MV>::type::THREADS)) k_gemm_taylor_chain(ChainArgs a0, ChainArgs a1, int nb0) {
+    using BM = typename TaylorMap<N, MV>::type;
     constexpr int EL = BM::EL, SPL = BM::SPLB, V = BM::V;
     __shared__ __attribute__((aligned(16))) cplx y[2][N * MV];
     __shared__ double tinv[64];                                            // 1 / ii!  (a division per term sat on the chain: ~14 fp64 instructions)
@@ -310,10 +339,10 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain(ChainArgs a0, ChainAr
 template <int N>
 static inline void qoc_taylor_chain_launch_n(const ChainArgs& a0, const ChainArgs& a1, int nb0, int blocks, hipStream_t s) {
     const int mv = a0.m <= 1 ? 1 : (a0.m <= 2 ? 2 : (a0.m <= 4 ? 4 : 8));
-    if (mv == 1) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 1>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
-    else if (mv == 2) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 2>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
-    else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
-    else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(256), 0, s, a0, a1, nb0);
+    if (mv == 1) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 1>), dim3(blocks), dim3(TaylorMap<N, 1>::type::THREADS), 0, s, a0, a1, nb0);
+    else if (mv == 2) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 2>), dim3(blocks), dim3(TaylorMap<N, 2>::type::THREADS), 0, s, a0, a1, nb0);
+    else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(TaylorMap<N, 4>::type::THREADS), 0, s, a0, a1, nb0);
+    else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(TaylorMap<N, 8>::type::THREADS), 0, s, a0, a1, nb0);
 }
 static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s) {
     if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
