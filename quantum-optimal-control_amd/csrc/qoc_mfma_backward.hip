@@ -4,6 +4,15 @@
 #include "qoc_mfma_backward.h"
 #include "qoc_mfma_downup.h"
 
+// k_mfma_downup for this problem: 4 or 5 control images in LDS, active 4-row strips of the padded propagators = ceil(n / 4)
+static const void* qoc_downup_kernel(const QocDev& d) {
+    const int qa = d.n > 28 ? 8 : (d.n > 24 ? 7 : (d.n > 20 ? 6 : 5));
+#define QOC_DU(KCv) (qa == 8 ? (const void*)k_mfma_downup<2, KCv, 8> : qa == 7 ? (const void*)k_mfma_downup<2, KCv, 7> : \
+                     qa == 6 ? (const void*)k_mfma_downup<2, KCv, 6> : (const void*)k_mfma_downup<2, KCv, 5>)
+    return d.k == 5 ? QOC_DU(5) : QOC_DU(4);
+#undef QOC_DU
+}
+
 int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
                                  std::vector<void*>& allocs, std::string& msg) {
     // (latency mode: NT = 2 kernels only -- a smaller problem is padded to 32: one trajectory of n = 16 runs 0.083 ms like n = 17, not 0.20)
@@ -126,6 +135,8 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         // column groups beyond m are never written by the sweeps and must read as zero in the gradient kernel
         const size_t xl = (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64 * sizeof(cplx);
         if (mf.PsiL && (hipMemset(mf.PsiL, 0, xl) != hipSuccess || hipMemset(mf.LamL, 0, xl) != hipSuccess)) { msg = "MFMA path: clearing PsiL / LamL failed"; return -2; }
+        // k_mfma_expm_inplace never writes the all-zero 4-row strips of a padded propagator (rows >= 4 ceil(n / 4)): they read as zero from here on
+        if (NT == 2 && d.n <= 28 && hipMemset(mf.KfD, 0, nk * sizeof(cplx)) != hipSuccess) { msg = "MFMA path: clearing the propagator buffer failed"; return -2; }
     }
     const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);
@@ -165,9 +176,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         const int kc = d.k == 5 ? 5 : 4, mqv = mf.mq <= 2 ? 2 : 4;
         mf.du_lds = (size_t)kc * FR * sizeof(cplx) + (size_t)8 * 4 * mqv * F2_LDP * sizeof(cplx) + (size_t)4 * 2 * NT * mqv * 64 * sizeof(cplx) +
                     (size_t)8 * 4 * kc * sizeof(double) + 8 * sizeof(int);          // control images, wave images, exchange buffers, row partials, flags
-        const void* k4 = d.k == 5 ? (mf.mq <= 2 ? (const void*)k_mfma_downup<2, 5> : (const void*)k_mfma_downup<2, 5>)
-                                  : (mf.mq <= 2 ? (const void*)k_mfma_downup<2, 4> : (const void*)k_mfma_downup<2, 4>);
-        if (hipFuncSetAttribute(k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.du_lds) != hipSuccess) {
+        if (hipFuncSetAttribute(qoc_downup_kernel(d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf.du_lds) != hipSuccess) {
             msg = "MFMA path: cannot reserve LDS for the fused sweep kernel";
             return -2;
         }
@@ -242,8 +251,8 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
                           else hipLaunchKernelGGL((k_mfma_backward3<MQv, false, 4, 3>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
             if (mf.updown && !src) {
                 const dim3 gd((items + 3) / 4), bd(512);                  // 4 items per workgroup, a wave per half chunk
-                if (d.k == 5) hipLaunchKernelGGL((k_mfma_downup<2, 5>), gd, bd, mf.du_lds, s, d, mf);
-                else hipLaunchKernelGGL((k_mfma_downup<2, 4>), gd, bd, mf.du_lds, s, d, mf);
+                void* kargs[] = {(void*)&d, (void*)&mf};
+                (void)hipLaunchKernel(qoc_downup_kernel(d), gd, bd, kargs, mf.du_lds, s);
             }
             else if (mf.BndA && !src) { if (mf.mq <= 2) QOC_B3B(2); else QOC_B3B(4); }
             else if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }

@@ -81,15 +81,21 @@ __device__ __forceinline__ void load_strip(const cplx* img, const double* imgs, 
 // of this kernel reads its left operand from the same image, whose rows 0 .. are complete long before the previous product ends).
 // PLANES: the epilogue hands the image strip over as three planes (ring.ppl: re, im, re + im) that are stored by three ds_write_b64 each --
 // for results that ARE registers of another matrix (X = S + c I: no VALU instruction to pair re with im); the last strip is paired for the next product.
-template <int NT, bool RELOAD_IN, bool RELOAD_OUT, bool PLANES, class Init, class Epi>
+// QA = ACTIVE 4-row strips per matrix dimension (ceil(n / 4), 5 .. 4 NT): a problem padded to 16 NT has all-zero rows and columns beyond 4 QA, and
+// neither the groups that would complete those rows nor the block steps over those inner indices run -- (QA / 8)^2 of the MFMAs of the padded product
+// at NT = 2.  The ring of left blocks is indexed by step & 3, so a product is NSP = NS rounded up to a multiple of 4 steps long: the steps NS .. NSP - 1
+// are virtual (they exist only as positions of the ring; nothing is fetched for them and nothing multiplies).
+template <int NT, int QA, bool RELOAD_IN, bool RELOAD_OUT, bool PLANES, class Init, class Epi>
 __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<NT>& ring, Set<NT>& P, Init&& init, Epi&& epi) {
-    constexpr int QS = 4 * NT, NS = QS * QS, RA = 3;
+    constexpr int QS = QA, NS = QS * QS, NSP = (NS + 3) & ~3, RA = 3;
+    static_assert(QA >= 5 && QA <= 4 * NT, "active strips: the stores of a pending strip and the read-backs need five block steps per group");
     const cplx* base = img + (lane >> 4) * ILDS + (lane & 3);
     const double* bases = imgs + (lane >> 4) * ILDS + (lane & 3);
     cplx* wbase = img + (lane & 15) * ILDS + (lane >> 4);           // strip (J, ib) -> wbase[16 J ILDS + 4 ib]
     double* wbases = imgs + (lane & 15) * ILDS + (lane >> 4);
     auto fetch = [&](int st) {
-        const int s2 = st % NS, ib = s2 / QS, kb = s2 % QS;
+        const int s2 = st % NSP, ib = s2 / QS, kb = s2 % QS;
+        if (s2 >= NS) return;                                           // a virtual step
         ring.v[st & 3] = base[4 * kb * ILDS + 4 * ib];
         ring.s[st & 3] = bases[4 * kb * ILDS + 4 * ib];
     };
@@ -110,8 +116,9 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
             fetch(st + RA);
             fence();
             if (PLANES && ib > 0) {                                     // this product's own strips: three plane stores per column block
-                if (kb >= off && kb < off + 3 * NT) {
-                    const int q = kb - off, J = q / 3, w = q % 3;
+#pragma unroll
+                for (int q = kb - off; q >= 0 && q < 3 * NT; q += QS) {     // (one per block step; with fewer steps than stores the first steps take two)
+                    const int J = q / 3, w = q % 3;
                     if (w < 2) ((double*)(wbase + 16 * J * ILDS + 4 * pib))[w] = ring.ppl[w][J];
                     else wbases[16 * J * ILDS + 4 * pib] = ring.ppl[2][J];
                     fence();
@@ -145,7 +152,8 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
                 }
             }
             if constexpr (RELOAD_IN) {
-                if (ib == 0 && kb == 2 * NT) {                          // the previous product's last strip is in the image now
+                // (issued behind the step of the strip's last store; with five steps per group the strip multiplies in step 4 already: one step earlier)
+                if (ib == 0 && kb == (QS > 2 * NT + 1 ? 2 * NT : 2 * NT - 1)) {   // the previous product's last strip is in the image now
                     fence();
 #pragma unroll
                     for (int J = 0; J < NT; ++J) load_strip<NT, true>(img, imgs, lane, P, J, QS - 1);
@@ -174,6 +182,8 @@ __device__ __forceinline__ void product(cplx* img, double* imgs, int lane, Ring<
             __builtin_amdgcn_sched_barrier(0);
         }
     }, std::make_integer_sequence<int, QS>{});
+#pragma unroll
+    for (int st = NS; st < NSP; ++st) { fetch(st + RA); fence(); }      // the virtual steps: only their look-ahead happens
 }
 
 // fragment f of a fragD matrix at uniform address F: scalar base (whole 4 KB groups of fragments) + immediate + 32-bit lane offset, so that
@@ -185,7 +195,9 @@ __device__ __forceinline__ cplx* frag_at(cplx* F, int f) { return F + (f & ~3) *
 
 // KC = controls handled by the pipelined assembly (k <= KC; surplus controls carry a zero coefficient); EVEN = even Taylor order; S0 = no
 // squaring (the last Horner product completes K_t and stores it: a run-time test there splits every Horner product into a basic block per group)
-template <int KC, bool EVEN, bool S0>
+// QA = active 4-row strips, ceil(n / 4) (see product()): the strips QA .. 7 of K_t are never written (the buffer is cleared once at set-up: zero rows
+// and columns, which is what the sweeps need of a padded propagator), those of the chunk product keep the identity they start from.
+template <int KC, bool EVEN, bool S0, int QA = 8>
 __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma mf) {
     using namespace qoc_inplace;
     constexpr int NT = 2, QS = 4 * NT;
@@ -242,14 +254,14 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
 #pragma unroll
         for (int J = 0; J < NT; ++J)
 #pragma unroll
-            for (int ib = 0; ib < QS; ++ib) {
+            for (int ib = 0; ib < QA; ++ib) {
                 cplx h[KC + 1];
 #pragma unroll
                 for (int kk = 0; kk <= KC; ++kk) h[kk] = frag_at(hk[kk], J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane];
                 double re, im;
                 assemble(h, ck, re, im);
                 SA.re[J][ib] = re; SA.im[J][ib] = im; SA.su[J][ib] = re + im;
-                if (ib == QS - 1) { ring.pri[J] = cmake(re, im); ring.psu[J] = re + im; }      // the last strip is the first product's pending one
+                if (ib == QA - 1) { ring.pri[J] = cmake(re, im); ring.psu[J] = re + im; }      // the last strip is the first product's pending one
                 else {
                     const int o = (16 * J + (lane & 15)) * ILDS + 4 * ib + (lane >> 4);
                     img[o] = cmake(re, im); imgs[o] = re + im;
@@ -270,7 +282,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
         cplx* Kout = mf.KfD + kitem(mf, d.steps, b, t);
         // ---- S2 = S * S -> SB;  Horner start X = S + c0 I (odd order: the strips of S with a shifted diagonal -- planes, no pairing) or
         //      S2 + c1 S + c0 I (even order) -> image (left operand of the first Horner product) ---------------------------------------------
-        product<NT, false, false, true>(img, imgs, lane, ring, SA, no_init,
+        product<NT, QA, false, false, true>(img, imgs, lane, ring, SA, no_init,
                                         [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], double (&ore)[NT], double (&oim)[NT], double (&osu)[NT]) {
             constexpr int ib = decltype(ibc)::value;
 #pragma unroll
@@ -313,14 +325,14 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
                     if constexpr (S0) { if (i == 0) frag_at(Kout, J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane] = ori[J]; }
                 }
             };
-            if (i > 0) product<NT, false, false, false>(img, imgs, lane, ring, SB, init, epi);
-            else product<NT, false, true, false>(img, imgs, lane, ring, SB, init, epi);
+            if (i > 0) product<NT, QA, false, false, false>(img, imgs, lane, ring, SB, init, epi);
+            else product<NT, QA, false, true, false>(img, imgs, lane, ring, SB, init, epi);
         }
         QOC_LAP(2)
         // ---- squarings: X <- X * X; the right operand is read back from the image into SB strip by strip ---------------------------------
         for (int sq = 0; sq < d.s; ++sq) {
             const bool kout = sq == d.s - 1;
-            product<NT, true, true, false>(img, imgs, lane, ring, SB, no_init,
+            product<NT, QA, true, true, false>(img, imgs, lane, ring, SB, no_init,
                                     [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
                 constexpr int ib = decltype(ibc)::value;
 #pragma unroll
@@ -346,7 +358,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
                     for (int kk = 0; kk <= KC; ++kk) h[J][kk] = frag_at(hk[kk], J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane];
             };
             stage(0);
-            product<NT, false, false, false>(img, imgs, lane, ring, R, no_init,
+            product<NT, QA, false, false, false>(img, imgs, lane, ring, R, no_init,
                                       [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
                 constexpr int ib = decltype(ibc)::value;
 #pragma unroll
@@ -355,19 +367,22 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
                     assemble(h[J], ck, re, im);
                     ori[J] = cmake(re, im); osu[J] = re + im;
                 }
-                if constexpr (ib + 1 < QS) stage(ib + 1);
+                if constexpr (ib + 1 < QA) stage(ib + 1);
 #pragma unroll
                 for (int J = 0; J < NT; ++J) combine(a[J], bq[J], cq[J], SB.re[J][ib], SB.im[J][ib], SB.su[J][ib]);
             });
             QOC_LAP(4)
-            R = SB;
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+#pragma unroll
+                for (int ib = 0; ib < QA; ++ib) { R.re[J][ib] = SB.re[J][ib]; R.im[J][ib] = SB.im[J][ib]; R.su[J][ib] = SB.su[J][ib]; }   // (strips beyond QA stay the identity)
             // right operand of the next A * A: read back from the image; the last strip is still pending, i.e. in registers
             fence();
 #pragma unroll
             for (int J = 0; J < NT; ++J) {
 #pragma unroll
-                for (int ib = 0; ib < QS - 1; ++ib) load_strip<NT, false>(img, imgs, lane, SA, J, ib);
-                SA.re[J][QS - 1] = ring.pri[J].x; SA.im[J][QS - 1] = ring.pri[J].y; SA.su[J][QS - 1] = ring.psu[J];
+                for (int ib = 0; ib < QA - 1; ++ib) load_strip<NT, false>(img, imgs, lane, SA, J, ib);
+                SA.re[J][QA - 1] = ring.pri[J].x; SA.im[J][QA - 1] = ring.pri[J].y; SA.su[J][QA - 1] = ring.psu[J];
             }
             fence();
             QOC_LAP(5)
