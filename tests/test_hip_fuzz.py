@@ -56,14 +56,19 @@ def random_problem(seed):
 @pytest.mark.parametrize('seed', range(128))
 def test_random_problem_all_paths(seed):
     from quantum_optimal_control.core import hip_engine
-    c, B, rng = random_problem(seed)
-    sp = oracle_system(c)
     import oracle.grape_oracle as go
-    if not np.isfinite(go.evaluate(sp, sp.base0)['unitary_scale']) or abs(go.evaluate(sp, sp.base0)['unitary_scale']) > 1e6:
-        pytest.skip('ill-conditioned draw: the truncated series blows up, relative parity is meaningless')
+    for attempt in range(16):
+        # an ill-conditioned draw (the truncated series blows up: relative parity is meaningless) is re-drawn, not skipped
+        c, B, rng = random_problem(seed + 1000 * attempt)
+        sp = oracle_system(c)
+        us = go.evaluate(sp, sp.base0)['unitary_scale']
+        if np.isfinite(us) and abs(us) <= 1e6:
+            break
+    else:
+        raise AssertionError('no well-conditioned draw in 16 attempts from seed %d' % seed)
     bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 * (i + 1) for i in range(B - 1)]
     tried = 0
-    for path, chunks, kernel in ((0, 0, 0), (1, 0, 0), (2, 0, 1), (2, 3, 2), (2, 2, 3), (2, 5, 4), (2, 0, 5), (2, 4, 5), (2, 3, 6), (3, 0, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0)):
+    for path, chunks, kernel in ((0, 0, 0), (1, 0, 0), (2, 0, 1), (2, 3, 2), (2, 2, 3), (2, 5, 4), (2, 0, 5), (2, 4, 5), (2, 3, 6), (2, 3, 7), (2, 4, 8), (3, 0, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0)):
         try:
             eng = make_engine(sp, n_seeds=B, path=path, chunks=chunks, variant=kernel)
         except hip_engine.QocError:
