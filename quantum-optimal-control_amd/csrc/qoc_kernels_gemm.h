@@ -249,6 +249,45 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
     }
 }
 
+// ---- gradients of large problems (N > 64, m <= 8) as ONE wide product per seed ----------------------------------------------------------
+// The per-slice thin tiles [t][N][32] of Psi_t / Lambda_t carry m <= 8 useful columns of 32: k batched launches of 2000 padded thin products
+// with a dot epilogue ran at ~21 TFLOP/s of mostly padding (C5: 12.7 ms of 215).  Re-packed time-major -- wide[row][t * 8 + col], the layout
+// the persistent chains of N <= 64 write directly -- the products of ALL controls are one batched N x N x (8 steps) GEMM on k_zgemm_wg, and
+// dL/du_{k,t} = Re sum conj(Lambda_t) (H_k' Psi_t) (tensorflow_state.py:61-63) is a column-block dot of its result.
+#define QOC_WIDE_MV 8
+__global__ void __launch_bounds__(256) k_gemm_to_wide(QocDev d, const cplx* __restrict__ thinP, const cplx* __restrict__ thinL,
+                                                      cplx* __restrict__ wideP, cplx* __restrict__ wideL, int N, int W) {
+    const size_t total = (size_t)d.steps * N * QOC_WIDE_MV;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(o % QOC_WIDE_MV);
+        const size_t tr = o / QOC_WIDE_MV;
+        const int row = (int)(tr % N), t = (int)(tr / N);
+        const size_t src = ((size_t)t * N + row) * QOC_TW + col, dst = (size_t)row * W + (size_t)t * QOC_WIDE_MV + col;
+        wideP[dst] = thinP[src];
+        wideL[dst] = thinL[src];
+    }
+}
+// one wave per (control, slice): rows lane, lane + 64, ...; the 8 columns of a slice are one 128-byte line of a row
+__global__ void __launch_bounds__(256) k_gemm_dot_wide(QocDev d, int b, const cplx* __restrict__ wideC, const cplx* __restrict__ wideL, int N, int W) {
+    const int lane = threadIdx.x & 63;
+    const size_t item = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (item >= (size_t)d.k * d.steps) return;
+    const int kk = (int)(item / d.steps), t = (int)(item - (size_t)kk * d.steps);
+    const cplx* C = wideC + (size_t)kk * N * W + (size_t)t * QOC_WIDE_MV;
+    const cplx* L = wideL + (size_t)t * QOC_WIDE_MV;
+    double acc = 0.0;
+    for (int row = lane; row < N; row += 64) {
+#pragma unroll
+        for (int col = 0; col < QOC_WIDE_MV; ++col) {
+            const cplx c = C[(size_t)row * W + col], l = L[(size_t)row * W + col];
+            acc = fma(l.x, c.x, acc); acc = fma(l.y, c.y, acc);                          // Re conj(l) c
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = acc;
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 // Time is cut into NC chunks of S = 2^L slices (padded with identity slices to SP = NC*S).  A pairwise product tree over
 // the K_t gives the chunk products at the batched-GEMM rate; the sequential part of each chain shrinks from `steps`
@@ -274,6 +313,8 @@ struct QocGemm {
     cplx* zthin = nullptr;    // [N][32] zeros
     cplx *Psibnd = nullptr, *Ebnd = nullptr, *Aoff = nullptr;        // [B][NC][N][32] chunk-start Psi, chunk-end Lambda, affine offsets
     double* partial = nullptr; // [B*steps][k][N/32]
+    int wideW = 0;            // > 0: gradients of an N > 64 problem through ONE wide product per seed (k_gemm_to_wide, k_zgemm_wg, k_gemm_dot_wide)
+    cplx *wideP = nullptr, *wideL = nullptr, *wideC = nullptr;   // [N][wideW], [N][wideW], [k][N][wideW]
 };
 
 // Unitary mode: any n.  State transfer: psi <- P(B_t) psi is the same chain with K_t = sum_{j<T} B_t^j/j! (no squaring);
@@ -346,6 +387,11 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
               al((void**)&gm.zthin, thin * sizeof(cplx)) &&
               al((void**)&gm.partial, (size_t)d.B * d.k * (N / 32) * (gm.persistent ? (size_t)gm.ldW : (size_t)d.steps) * sizeof(double));
     if (ok && need_src) ok = al((void**)&gm.SrcP, BSP * thin * sizeof(cplx));
+    // wide gradient products: large matrices with few vectors (row tiles in pairs and column tiles in fours: what k_zgemm_wg takes)
+    gm.wideW = (!gm.persistent && N >= 128 && (N / 32) % 2 == 0 && d.m <= QOC_WIDE_MV) ? (int)((((size_t)d.steps * QOC_WIDE_MV + 127) / 128) * 128) : 0;
+    if (ok && gm.wideW > 0)
+        ok = al((void**)&gm.wideP, (size_t)N * gm.wideW * sizeof(cplx)) && al((void**)&gm.wideL, (size_t)N * gm.wideW * sizeof(cplx)) &&
+             al((void**)&gm.wideC, (size_t)d.k * N * gm.wideW * sizeof(cplx));
     {
         size_t total = 0;
         for (auto& w : wanted) total += w.second;
@@ -366,6 +412,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
                   hipMemset(gm.Psibnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess &&
                   hipMemset(gm.Ebnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess &&
                   hipMemset(gm.Aoff, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess;
+    if (gm.wideW > 0) zeroed = zeroed && hipMemset(gm.wideP, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess &&
+                                         hipMemset(gm.wideL, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess;   // (the columns beyond 8 steps)
     if (!zeroed) { msg = "GEMM path: clearing the work buffers failed"; return -2; }
     return 0;
 }
@@ -737,6 +785,22 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         h.batch = d.B * d.k;
         qoc_gemm_launch(gm, false, 2, h, s);
         hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, tm, gm.ldW, gm.MV);
+        return;
+    }
+    if (gm.wideW > 0) {
+        const int W = gm.wideW;
+        GemmArgs h;
+        memset(&h, 0, sizeof h);
+        h.A = gm.HsP + NN; h.sA = (long long)NN; h.lda = N;                     // batch index = control
+        h.Bm = gm.wideP; h.sB = 0; h.ldb = W;
+        h.C = gm.wideC; h.sC = (long long)N * W; h.ldc = W;
+        h.Kdim = N; h.tiles_m = N / 32; h.tiles_n = W / 32; h.batch = d.k; h.alpha = 1.0;
+        for (int b = 0; b < d.B; ++b) {
+            hipLaunchKernelGGL(k_gemm_to_wide, dim3(gemm_grid((size_t)d.steps * N * QOC_WIDE_MV)), dim3(256), 0, s, d,
+                               (const cplx*)(gm.interP + (size_t)b * gm.SP * thin), (const cplx*)(gm.LamP + (size_t)b * gm.SP * thin), gm.wideP, gm.wideL, N, W);
+            qoc_gemm_launch(gm, false, 0, h, s);
+            hipLaunchKernelGGL(k_gemm_dot_wide, dim3((unsigned)(((size_t)d.k * d.steps + 3) / 4)), dim3(256), 0, s, d, b, (const cplx*)gm.wideC, (const cplx*)gm.wideL, N, W);
+        }
         return;
     }
     // gradients: for each control one batched product H_k' Psi_t contracted with conj(Lambda_t)   tensorflow_state.py:61-63
