@@ -5,18 +5,64 @@
 
 // ---- fused per-slice exponential for N <= 64 ---------------------------------------------------------------------------
 // One workgroup per (seed, slice): A_t is assembled into LDS, the Paterson-Stockmeyer Taylor polynomial and the squarings
-// run as MFMA products whose operands are read from two LDS-resident matrices (row stride N+1 elements: conflict-free for
-// both the left-operand pattern, 16 rows x 1 column, and the right-operand pattern, 1 row x 16 columns), accumulators and
+// run as MFMA products (4x4x4 form, lds_mm below) whose operands are read from two LDS-resident matrices (row stride N+1 elements), accumulators and
 // the per-wave block of A stay in registers, and only K_t is written to HBM.  The launch-per-product route streams three
 // B*SP*N*N buffers through HBM per product (7-11 products); this kernel writes one.
 // Wave w owns tile row I = w / (N/32) and the tile-column pair Jp = w % (N/32) (2 tiles of 16x16, sharing the left operand).
 #define QOC_GEMM_MAXT 48   // 1/j! tables of the GEMM path: Taylor orders up to 47
+#ifndef QOC_EXPM_LDPAD
+#define QOC_EXPM_LDPAD 1   // row stride of the LDS matrices = N + QOC_EXPM_LDPAD complex elements
+#endif
+#ifndef QOC_EXPM_MFMA4
+#define QOC_EXPM_MFMA4 0   // 1: products on v_mfma_f64_4x4x4 (measured SLOWER here: 8 waves per CU fetch 6 KB of operands per 24 MFMAs from LDS)
+#endif
 struct ExpmCoef { double c[QOC_GEMM_MAXT]; };
 
+// Products on v_mfma_f64_4x4x4_4b_f64 (round 4; the 16x16x4 instruction this kernel used before peaks at 48 TFLOP/s, the 4x4x4 form at 73):
+// a D / B register of the 4x4x4 form is a 4-row x 16-column strip with lane = 16 row + column -- exactly ONE register r of the 16 x 16 D tile
+// (row lk + 4 r, column lr) -- so the accumulators keep the D-tile layout of the rest of the kernel (component r of re[J] / im[J] = row strip r)
+// and only the operand fetch changes: per 4-deep block kb of the inner index the wave reads its four 4 x 4 left blocks (rows 16 I + 4 ib ..,
+// broadcast over the four lane groups of a block) and the two right strips of its tile-column pair, and issues 24 MFMAs (3-multiplication form).
 template <int N>
-__device__ __forceinline__ void lds_mm(const cplx* __restrict__ L, const cplx* __restrict__ R, int I, int Jp, int lane,
+__device__ __forceinline__ void lds_mm4(const cplx* __restrict__ L, const cplx* __restrict__ R, int I, int Jp, int lane,
                                        gd4 (&re)[2], gd4 (&im)[2]) {
-    constexpr int LD = N + 1;
+    constexpr int LD = N + QOC_EXPM_LDPAD;
+    double t1[2][4], t2[2][4], t3[2][4];
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) { t1[J][ib] = 0.0; t2[J][ib] = 0.0; t3[J][ib] = 0.0; }
+    const int lr = lane & 15, lk = lane >> 4, li = lane & 3;
+    const cplx* lp = L + (16 * I + li) * LD + lk;                 // block (ib, kb): lane 16 k + 4 b + i <-> L[16 I + 4 ib + i][4 kb + k]
+    const cplx* rp = R + lk * LD + 32 * Jp + lr;                  // strip (kb, J):  lane 16 k + c       <-> R[4 kb + k][32 Jp + 16 J + c]
+#pragma unroll 2
+    for (int kb = 0; kb < N / 4; ++kb) {
+        const cplx b0 = rp[4 * kb * LD], b1 = rp[4 * kb * LD + 16];
+        cplx a[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) a[ib] = lp[4 * ib * LD + 4 * kb];
+        const double bs0 = b0.x + b0.y, bs1 = b1.x + b1.y;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const double as = a[ib].x + a[ib].y;
+            t1[0][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ib].x, b0.x, t1[0][ib], 0, 0, 0);
+            t2[0][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ib].y, b0.y, t2[0][ib], 0, 0, 0);
+            t3[0][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(as, bs0, t3[0][ib], 0, 0, 0);
+            t1[1][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ib].x, b1.x, t1[1][ib], 0, 0, 0);
+            t2[1][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ib].y, b1.y, t2[1][ib], 0, 0, 0);
+            t3[1][ib] = __builtin_amdgcn_mfma_f64_4x4x4f64(as, bs1, t3[1][ib], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) { re[J][ib] = t1[J][ib] - t2[J][ib]; im[J][ib] = t3[J][ib] - t1[J][ib] - t2[J][ib]; }
+}
+
+template <int N>
+__device__ __forceinline__ void lds_mm16(const cplx* __restrict__ L, const cplx* __restrict__ R, int I, int Jp, int lane,
+                                         gd4 (&re)[2], gd4 (&im)[2]) {
+    constexpr int LD = N + QOC_EXPM_LDPAD;
     gd4 t1[2], t2[2], t3[2];
 #pragma unroll
     for (int J = 0; J < 2; ++J) { t1[J] = (gd4){0, 0, 0, 0}; t2[J] = (gd4){0, 0, 0, 0}; t3[J] = (gd4){0, 0, 0, 0}; }
@@ -34,11 +80,15 @@ __device__ __forceinline__ void lds_mm(const cplx* __restrict__ L, const cplx* _
 #pragma unroll
     for (int J = 0; J < 2; ++J) { re[J] = t1[J] - t2[J]; im[J] = t3[J] - t1[J] - t2[J]; }
 }
+template <int N>
+__device__ __forceinline__ void lds_mm(const cplx* __restrict__ L, const cplx* __restrict__ R, int I, int Jp, int lane, gd4 (&re)[2], gd4 (&im)[2]) {
+    if constexpr (QOC_EXPM_MFMA4) lds_mm4<N>(L, R, I, Jp, lane, re, im); else lds_mm16<N>(L, R, I, Jp, lane, re, im);
+}
 
 template <int N>
 __global__ void __launch_bounds__((N / 16) * (N / 16) * 32) k_gemm_expm_fused(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Kout,
                                                                                cplx* __restrict__ KTout, int SP, int deg, int nsq, ExpmCoef cf) {
-    constexpr int LD = N + 1, NT = (N / 16) * (N / 16) * 32, NN = N * N;
+    constexpr int LD = N + QOC_EXPM_LDPAD, NT = (N / 16) * (N / 16) * 32, NN = N * N;
     extern __shared__ __attribute__((aligned(16))) cplx ex_lds[];
     cplx* X = ex_lds;                   // A, then S / M
     cplx* Y = ex_lds + N * LD;          // A2

@@ -430,7 +430,7 @@ static inline bool qoc_gemm_lds_opt_in_sk() {
 }
 static inline bool qoc_gemm_lds_opt_in() {
     return qoc_gemm_lds_opt_in_sk<false, 0>() && qoc_gemm_lds_opt_in_sk<false, 1>() && qoc_gemm_lds_opt_in_sk<false, 2>() && qoc_gemm_lds_opt_in_sk<true, 0>() &&
-           hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 65 * (int)sizeof(cplx)) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 + QOC_EXPM_LDPAD) * (int)sizeof(cplx)) == hipSuccess &&
            hipFuncSetAttribute((const void*)k_gemm_scan_nodes<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_scan_lds(64)) == hipSuccess &&
            qoc_zgemm_wg_opt_in();
 }
@@ -515,7 +515,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     if (N <= 64) {
         ExpmCoef cf;
         { double f = 1.0; for (int j = 0; j < QOC_GEMM_MAXT; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
-        const size_t lds = 2 * (size_t)N * (N + 1) * sizeof(cplx);
+        const size_t lds = 2 * (size_t)N * (N + QOC_EXPM_LDPAD) * sizeof(cplx);
         if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
         else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
         qoc_gemm_tree(gm, d, s);
