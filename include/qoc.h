@@ -79,7 +79,15 @@ typedef struct qoc_config {
     int32_t plan_seeds;         /* 0, or the batch size AUTO plans for instead of n_seeds: path, kernel family, chunk count and split
                                  * factors are derived from it, so that a restart evolves bit-identically whether it runs in one engine
                                  * of `plan_seeds` control sets or in a shard of it (GrapeSharded passes restarts / GPUs of the node) */
-    int32_t reserved[5];
+    int32_t time_shards;        /* 0: off.  G >= 1: ONE large trajectory sharded along the TIME axis over G ranks (the
+                                 * alternative for config 5): rank r computes the propagators, sweeps and gradients of its run of time
+                                 * chunks; two collectives per iteration (all-gather of G rank products, all-reduce of the gradient
+                                 * array) on the engine's stream.  GEMM path, unitary mode, one control set, no state regulariser,
+                                 * n > 96, m <= 8 (csrc/qoc_gemm_ts.h); the reference has no counterpart (single device,
+                                 * main_grape/grape.py:106-109) */
+    int32_t time_rank;          /* this engine's rank 0 .. time_shards - 1 (give it its communicator: qoc_set_time_comm), or -1: all
+                                 * ranks emulated inside this one engine on one GPU (how the decomposition is tested) */
+    int32_t reserved[3];
 } qoc_config;
 
 /* Adam loop hyper-parameters == Convergence (core/convergence.py:16-49). */
@@ -189,6 +197,10 @@ int qoc_comm_all_gather_f64(qoc_comm_handle c, const double* send, int32_t count
 int qoc_comm_all_reduce_max_f64(qoc_comm_handle c, double* inout, int32_t count);
 int qoc_comm_broadcast_f64(qoc_comm_handle c, double* buf, int64_t count, int32_t root);
 int qoc_comm_barrier(qoc_comm_handle c);
+
+/* Time-sharded engines (qoc_config.time_shards >= 1, time_rank >= 0): the communicator whose ranks hold the other time shards; world and
+ * rank must equal time_shards / time_rank.  The engine's iterations then contain RCCL calls: every rank must enqueue the same iterations. */
+int qoc_set_time_comm(qoc_handle h, qoc_comm_handle c);
 
 /* ---- introspection ---------------------------------------------------------------------------------------------*/
 int qoc_path_in_use(qoc_handle h);        /* the QOC_PATH_* the engine resolved AUTO to */

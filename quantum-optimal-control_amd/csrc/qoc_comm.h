@@ -18,7 +18,7 @@ namespace qoc_rccl {
 typedef struct { char internal[128]; } UniqueId;
 typedef void* Comm;
 typedef int Result;                  // ncclSuccess = 0
-enum { kDouble = 8, kMax = 2 };
+enum { kDouble = 8, kSum = 0, kMax = 2 };
 struct Api {
     void* lib = nullptr;
     Result (*GetUniqueId)(UniqueId*) = nullptr;
@@ -111,6 +111,18 @@ static int comm_stage(qoc_comm* c, size_t doubles) {
     const size_t want = (doubles + 1023) & ~(size_t)1023;
     HIP_TRY(hipMalloc((void**)&c->stage, want * sizeof(double)));
     c->stage_doubles = want;
+    return QOC_OK;
+}
+
+// the two data-path collectives of a time-sharded engine (qoc_gemm_ts.h), device to device on the engine's stream, no host synchronisation
+int qoc_ts_all_gather(qoc_comm* c, void* buf, size_t doubles_per_rank, hipStream_t s) {
+    if (!c) return fail(QOC_ERR_INVALID, "time-sharded engine without a communicator (qoc_set_time_comm)");
+    RCCL_TRY(qoc_rccl::g_api.AllGather((const char*)buf + (size_t)c->rank * doubles_per_rank * sizeof(double), buf, doubles_per_rank, qoc_rccl::kDouble, c->comm, s));
+    return QOC_OK;
+}
+int qoc_ts_all_reduce_sum(qoc_comm* c, double* buf, size_t doubles, hipStream_t s) {
+    if (!c) return fail(QOC_ERR_INVALID, "time-sharded engine without a communicator (qoc_set_time_comm)");
+    RCCL_TRY(qoc_rccl::g_api.AllReduce(buf, buf, doubles, qoc_rccl::kDouble, qoc_rccl::kSum, c->comm, s));
     return QOC_OK;
 }
 
@@ -238,6 +250,15 @@ int qoc_comm_broadcast_f64(qoc_comm_handle c, double* buf_host, int64_t count, i
     RCCL_TRY(qoc_rccl::g_api.Broadcast(c->stage, c->stage, (size_t)count, qoc_rccl::kDouble, root, c->comm, c->stream));
     HIP_TRY(hipMemcpyAsync(buf_host, c->stage, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return QOC_OK;
+}
+
+int qoc_set_time_comm(qoc_handle e, qoc_comm_handle c) {
+    if (!e || !c) return fail(QOC_ERR_INVALID, "qoc_set_time_comm: null argument");
+    if (e->path != QOC_PATH_GEMM || e->gm.ts_G <= 0 || e->gm.ts_rank < 0) return fail(QOC_ERR_INVALID, "qoc_set_time_comm: the engine is not one rank of a time-sharded run");
+    if (c->world != e->gm.ts_G || c->rank != e->gm.ts_rank) return fail(QOC_ERR_INVALID, "qoc_set_time_comm: communicator rank %d of %d, engine rank %d of %d", c->rank, c->world, e->gm.ts_rank, e->gm.ts_G);
+    if (c->device != e->cfg.device) return fail(QOC_ERR_INVALID, "qoc_set_time_comm: engine on device %d, communicator on %d", e->cfg.device, c->device);
+    e->gm.ts_comm = c;
     return QOC_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "qoc_kernels_mfma.h"
 #include "qoc_kernels_st.h"
 #include "qoc_kernels_gemm.h"
+#include "qoc_gemm_ts.h"
 
 #ifndef QOC_LATENCY_MAX_WORK
 #define QOC_LATENCY_MAX_WORK 4608       // seeds x time slices up to which AUTO takes the latency mode (see latency_auto below): since the batch sweeps
@@ -266,12 +267,18 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
             else qoc_mfma_launch_backward(e->mf, d, e->stream);
         }
     } else if (e->path == QOC_PATH_GEMM) {
+        if (e->gm.ts_G > 0) {                                           // one trajectory sharded along the time axis (qoc_gemm_ts.h)
+            const int rc = qoc_gemm_ts_evaluate(e->gm, d, e->stream, [&]() { launch_loss(d, e->stream); }, [&]() { return prof_begin(e); }, [&]() { return prof_end(e); });
+            if (rc == 1) return fail(QOC_ERR_HIP, "time-sharded iteration: clearing the gradient array failed");
+            if (rc) return rc;                                          // (the message is the collective's / the profiler's)
+        } else {
         TRY(prof_begin(e));
         qoc_gemm_expm(e->gm, d, e->stream);
         TRY(prof_end(e));
         qoc_gemm_forward(e->gm, d, e->stream);
         launch_loss(d, e->stream);
         qoc_gemm_backward(e->gm, d, e->stream);
+        }
     } else if (!d.state_transfer) {
         TRY(prof_begin(e));
         hipLaunchKernelGGL(k_expm_generic, dim3(e->expm_grid), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->expm_scratch);
@@ -539,6 +546,11 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
             fprintf(stderr, "libqoc_hip: note: plan_seeds = %d < n_seeds = %d changes the AUTO plan (path %d%s instead of %d%s): kernels tuned for the smaller batch run on the larger one\n",
                     d.Bplan, B, plan.path, plan.latency ? " latency mode" : "", own.path, own.latency ? " latency mode" : "");
     }
+    if (cfg->time_shards >= 1) {
+        if (cfg->time_rank < -1 || cfg->time_rank >= cfg->time_shards) return bail(fail(QOC_ERR_INVALID, "qoc_create: time_rank %d of %d time shards", cfg->time_rank, cfg->time_shards));
+        if (cfg->path != QOC_PATH_AUTO && cfg->path != QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: time sharding runs on the GEMM path"));
+        path = QOC_PATH_GEMM;
+    }
     if (path == QOC_PATH_MFMA && !mfma_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 64, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
@@ -565,10 +577,17 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         e->chunks = e->mf.C;
     } else if (path == QOC_PATH_GEMM) {
         std::string msg;
+        if (cfg->time_shards >= 1) { e->gm.ts_G = cfg->time_shards; e->gm.ts_rank = cfg->time_rank; }
         rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, gemm_direct, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         if (!qoc_gemm_lds_opt_in()) return bail(fail(QOC_ERR_HIP, "qoc_create: cannot reserve LDS for the GEMM-path kernels"));
         e->chunks = e->gm.NC;
+        if (e->gm.ts_G > 0) {
+            std::string why;
+            if (!qoc_gemm_ts_supported(e->gm, d, e->gm.ts_G, why))
+                return bail(fail(QOC_ERR_INVALID, "qoc_create: time_shards = %d needs %s (n=%d m=%d chunks=%d)", e->gm.ts_G, why.c_str(), n, m, e->gm.NC));
+            qoc_gemm_ts_ranges(e->gm, e->gm.ts_G);
+        }
     } else if (!cfg->state_transfer) {
         ALLOC(e->K, (size_t)B * steps * nn);
         int grid = B * steps;
@@ -817,8 +836,9 @@ int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
         snprintf(tmp, sizeof tmp, "path=mfma nt=%d expm=%d chunks=%d sweeps=%s", mf.NT, qoc_mfma_expm_variant(mf, e->d), mf.C, sweeps);
     } else if (e->path == QOC_PATH_GEMM) {
         const QocGemm& g = e->gm;
-        snprintf(tmp, sizeof tmp, "path=gemm route=%s chunks=%d slices_per_chunk=%d chains=%s", g.direct ? "direct" : (e->d.state_transfer ? "propagator" : "unitary"),
-                 g.NC, g.S, g.persistent ? "persistent" : "launches");
+        int w = snprintf(tmp, sizeof tmp, "path=gemm route=%s chunks=%d slices_per_chunk=%d chains=%s", g.direct ? "direct" : (e->d.state_transfer ? "propagator" : "unitary"),
+                         g.NC, g.S, g.persistent ? "persistent" : "launches");
+        if (g.ts_G > 0) snprintf(tmp + w, sizeof tmp - w, " time_shards=%d time_rank=%d", g.ts_G, g.ts_rank);
     } else {
         snprintf(tmp, sizeof tmp, "path=%s", e->path == QOC_PATH_ST_FUSED ? "st_fused" : "generic");
     }

@@ -21,11 +21,14 @@
 
 // A_t = (H0' + sum_k u_k H_k') / 2^s for every (seed, slice), padded N x N           tensorflow_state.py:30-33
 // Slices are padded to SP = NC*S per seed; a padded slice gets A = 0, i.e. K = I exactly.
-__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq) {
+// (item_first, item_count): the (seed, slice) items this launch assembles -- all of them, or the slices of one rank of a time-sharded engine
+__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq,
+                                                        size_t item_first, size_t item_count) {
     const size_t NN = (size_t)N * N;
-    const size_t total = (size_t)d.B * SP * NN;
+    const size_t total = item_count * NN;
     const double inv = 1.0 / (double)(1 << sq);
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    for (size_t o0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o0 < total; o0 += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = o0 + item_first * NN;
         const size_t item = o / NN, e = o - item * NN;
         const int b = (int)(item / SP), t = (int)(item - (size_t)b * SP);
         cplx acc = cmake(0.0, 0.0);
@@ -43,15 +46,16 @@ __global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __r
 // The same with the k + 1 Hamiltonian entries of a thread held in registers over a run of (seed, slice) items (k <= 8, N*N a multiple of
 // 256): k_gemm_assemble re-reads them from L2 for every output entry -- (k + 1) x the written bytes through L2, 2.0 ms for the 4.2 GB of
 // C3 x 64 -- this one is bound by the HBM writes alone.  blockIdx.x = 256-entry column of the matrix, blockIdx.y = run of items.
-__global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq, int per) {
+__global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq, int per,
+                                                             size_t item_first, size_t item_count) {
     const size_t NN = (size_t)N * N;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     const double inv = 1.0 / (double)(1 << sq);
     cplx h[9];
 #pragma unroll
     for (int kk = 0; kk < 9; ++kk) h[kk] = kk <= d.k ? cscale(HsP[(size_t)kk * NN + e], inv) : cmake(0.0, 0.0);
-    const size_t items = (size_t)d.B * SP;
-    const size_t i0 = (size_t)blockIdx.y * per, i1 = i0 + per < items ? i0 + per : items;
+    const size_t items = item_first + item_count;
+    const size_t i0 = item_first + (size_t)blockIdx.y * per, i1 = i0 + per < items ? i0 + per : items;
     for (size_t item = i0; item < i1; ++item) {
         const int b = (int)(item / SP), t = (int)(item - (size_t)b * SP);
         cplx acc = cmake(0.0, 0.0);
@@ -256,8 +260,8 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
 // dL/du_{k,t} = Re sum conj(Lambda_t) (H_k' Psi_t) (tensorflow_state.py:61-63) is a column-block dot of its result.
 #define QOC_WIDE_MV 8
 __global__ void __launch_bounds__(256) k_gemm_to_wide(QocDev d, const cplx* __restrict__ thinP, const cplx* __restrict__ thinL,
-                                                      cplx* __restrict__ wideP, cplx* __restrict__ wideL, int N, int W) {
-    const size_t total = (size_t)d.steps * N * QOC_WIDE_MV;
+                                                      cplx* __restrict__ wideP, cplx* __restrict__ wideL, int N, int W, int count) {
+    const size_t total = (size_t)count * N * QOC_WIDE_MV;                                     // `count` slices from thinP / thinL on
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         const int col = (int)(o % QOC_WIDE_MV);
         const size_t tr = o / QOC_WIDE_MV;
@@ -268,11 +272,13 @@ __global__ void __launch_bounds__(256) k_gemm_to_wide(QocDev d, const cplx* __re
     }
 }
 // one wave per (control, slice): rows lane, lane + 64, ...; the 8 columns of a slice are one 128-byte line of a row
-__global__ void __launch_bounds__(256) k_gemm_dot_wide(QocDev d, int b, const cplx* __restrict__ wideC, const cplx* __restrict__ wideL, int N, int W) {
+// (column block ti of the wide buffers is slice t_first + ti: the whole pulse, or the slices of one rank of a time-sharded engine)
+__global__ void __launch_bounds__(256) k_gemm_dot_wide(QocDev d, int b, const cplx* __restrict__ wideC, const cplx* __restrict__ wideL, int N, int W,
+                                                       int t_first, int count) {
     const int lane = threadIdx.x & 63;
     const size_t item = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (item >= (size_t)d.k * d.steps) return;
-    const int kk = (int)(item / d.steps), t = (int)(item - (size_t)kk * d.steps);
+    if (item >= (size_t)d.k * count) return;
+    const int kk = (int)(item / count), t = (int)(item - (size_t)kk * count);
     const cplx* C = wideC + (size_t)kk * N * W + (size_t)t * QOC_WIDE_MV;
     const cplx* L = wideL + (size_t)t * QOC_WIDE_MV;
     double acc = 0.0;
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(256) k_gemm_dot_wide(QocDev d, int b, const cp
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) d.dLdu[((size_t)b * d.k + kk) * d.steps + t] = acc;
+    if (lane == 0) d.dLdu[((size_t)b * d.k + kk) * d.steps + t_first + t] = acc;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -315,6 +321,12 @@ struct QocGemm {
     double* partial = nullptr; // [B*steps][k][N/32]
     int wideW = 0;            // > 0: gradients of an N > 64 problem through ONE wide product per seed (k_gemm_to_wide, k_zgemm_wg, k_gemm_dot_wide)
     cplx *wideP = nullptr, *wideL = nullptr, *wideC = nullptr;   // [N][wideW], [N][wideW], [k][N][wideW]
+    // time-axis sharding of one trajectory (qoc_gemm_ts.h): G ranks own runs of chunks; ts_rank < 0 emulates all of them in this engine
+    int ts_G = 0, ts_rank = -1;
+    std::vector<int> ts_cb;                                       // chunk boundaries: rank r owns [ts_cb[r], ts_cb[r + 1])
+    cplx *ts_Rall = nullptr, *ts_Rtmp = nullptr;                  // [G][N][N] rank products (all-gathered in place), [2][N][N]
+    cplx *ts_Yr = nullptr, *ts_Er = nullptr;                      // [G + 1][N][N + 32]: [X | Psi] at the rank boundaries; [G + 1][N][32]: costates there
+    struct qoc_comm* ts_comm = nullptr;
 };
 
 // Unitary mode: any n.  State transfer: psi <- P(B_t) psi is the same chain with K_t = sum_{j<T} B_t^j/j! (no squaring);
@@ -392,6 +404,9 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     if (ok && gm.wideW > 0)
         ok = al((void**)&gm.wideP, (size_t)N * gm.wideW * sizeof(cplx)) && al((void**)&gm.wideL, (size_t)N * gm.wideW * sizeof(cplx)) &&
              al((void**)&gm.wideC, (size_t)d.k * N * gm.wideW * sizeof(cplx));
+    if (ok && gm.ts_G > 0)
+        ok = al((void**)&gm.ts_Rall, (size_t)gm.ts_G * NN * sizeof(cplx)) && al((void**)&gm.ts_Rtmp, 2 * NN * sizeof(cplx)) &&
+             al((void**)&gm.ts_Yr, (size_t)(gm.ts_G + 1) * N * (N + QOC_TW) * sizeof(cplx)) && al((void**)&gm.ts_Er, (size_t)(gm.ts_G + 1) * thin * sizeof(cplx));
     {
         size_t total = 0;
         for (auto& w : wanted) total += w.second;
@@ -471,30 +486,35 @@ static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const
 }
 
 static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
-static inline void qoc_gemm_assemble_launch(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int sq, hipStream_t s) {
-    const size_t NN = (size_t)N * N, items = (size_t)d.B * SP;
+static inline void qoc_gemm_assemble_launch(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int sq, hipStream_t s,
+                                            size_t item_first = 0, size_t item_count = 0) {
+    if (item_count == 0) item_count = (size_t)d.B * SP;
+    const size_t NN = (size_t)N * N, items = item_count;
     if (d.k <= 8 && NN % 256 == 0 && items >= 64) {
         const int gx = (int)(NN / 256);
         int per = (int)((items * gx + 8191) / 8192);                     // ~8192 workgroups
         if (per < 4) per = 4;
         const int gy = (int)((items + per - 1) / per);
-        if (gy <= 65535) { hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, per); return; }
+        if (gy <= 65535) { hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, per, item_first, item_count); return; }
     }
-    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(items * NN)), dim3(256), 0, s, d, HsP, Aout, N, SP, sq);
+    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(items * NN)), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, item_first, item_count);
 }
 
 // pairwise product tree: T_l[i] = T_{l-1}[2i+1] * T_{l-1}[2i]  (later slice on the left), T_0 = K
-static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s) {
+// (item_first, item_count): the chunk-aligned run of (seed, slice) items whose tree is built -- all of them by default
+static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s, size_t item_first = 0, size_t item_count = 0) {
     const int N = gm.N;
     const size_t NN = (size_t)N * N;
+    if (item_count == 0) item_count = (size_t)d.B * gm.SP;
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.lda = g.ldb = g.ldc = N; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.alpha = 1.0;
     const cplx* prev = gm.K;
     for (int l = 1; l <= gm.L; ++l) {
         cplx* out = gm.tree + gm.tree_off[l];
-        g.A = prev + NN; g.sA = 2 * (long long)NN; g.Bm = prev; g.sB = 2 * (long long)NN; g.C = out; g.sC = (long long)NN;
-        g.batch = (int)((size_t)d.B * (gm.SP >> l));
+        g.A = prev + ((item_first >> (l - 1)) + 1) * NN; g.sA = 2 * (long long)NN; g.Bm = prev + (item_first >> (l - 1)) * NN; g.sB = 2 * (long long)NN;
+        g.C = out + (item_first >> l) * NN; g.sC = (long long)NN;
+        g.batch = (int)(item_count >> l);
         const bool want_t = gm.persistent && !gm.direct && l == gm.L;        // chunk products also transposed, for the backward boundary chain
         g.CT = want_t ? gm.PcT : nullptr; g.sCT = (long long)NN; g.ldct = N;
         qoc_gemm_launch(gm, false, 0, g, s);
@@ -502,6 +522,7 @@ static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s) {
     }
 }
 
+static inline void qoc_gemm_expm_products(QocGemm& gm, const QocDev& d, hipStream_t s, size_t item_first, size_t item_count);
 // K_t for all (seed, slice): the dominant part of the path (bracketed by the profiling events of the engine)
 static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N;
@@ -521,9 +542,20 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         qoc_gemm_tree(gm, d, s);
         return;
     }
-    qoc_gemm_assemble_launch(d, gm.HsP, gm.A, N, gm.SP, nsq, s);
+    qoc_gemm_expm_products(gm, d, s, 0, BS);
+    qoc_gemm_tree(gm, d, s);
+}
+
+// N > 64: K_t of the items [item_first, item_first + item_count) by batched launches (all items, or the slices of one rank of a time-sharded engine)
+static inline void qoc_gemm_expm_products(QocGemm& gm, const QocDev& d, hipStream_t s, size_t item_first, size_t item_count) {
+    const int N = gm.N;
+    const size_t NN = (size_t)N * N, BS = item_count, off = item_first * NN;
+    const int deg = d.state_transfer ? d.T - 1 : d.T;
+    const int nsq = d.state_transfer ? 0 : d.s;
+    qoc_gemm_assemble_launch(d, gm.HsP, gm.A, N, gm.SP, nsq, s, item_first, item_count);
     // Taylor polynomial sum_{j<=T} A^j/j! (tensorflow_state.py:37-41) in Paterson-Stockmeyer form over A2 = A*A:
     // S = B_m ; S = B_i + A2*S with B_i = c_{2i} I + c_{2i+1} A  (T = 5: 3 products instead of 4); then s squarings.
+    cplx* const bufA = gm.A + off; cplx* const bufA2 = gm.A2 + off; cplx* const bufK = gm.K + off; cplx* const bufP = gm.P + off;
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.lda = g.ldb = g.ldc = g.lde = N; g.sA = g.sB = g.sC = g.sE = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.batch = (int)BS;
@@ -533,22 +565,22 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const bool even = (deg & 1) == 0;
     const int horner = deg >= 2 ? (even ? mm - 1 : mm) : 0;      // products after A2
     const int products = horner + nsq;                           // buffer flips until the result
-    cplx* cur = (products % 2 == 0) ? gm.K : gm.P;               // buffers alternate cur -> other on every product
-    cplx* oth = (products % 2 == 0) ? gm.P : gm.K;
+    cplx* cur = (products % 2 == 0) ? bufK : bufP;               // buffers alternate cur -> other on every product
+    cplx* oth = (products % 2 == 0) ? bufP : bufK;
     if (deg >= 2) {
-        g.A = gm.A; g.Bm = gm.A; g.C = gm.A2; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
+        g.A = bufA; g.Bm = bufA; g.C = bufA2; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
         qoc_gemm_launch(gm, false, 0, g, s);                         // A2 = A*A
-        if (even) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, gm.A2, cur, BS * NN, N,
+        if (even) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, bufA2, cur, BS * NN, N,
                                      invf[2 * mm - 2], invf[2 * mm - 1], invf[deg]);
-        else hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N,
+        else hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, (const cplx*)nullptr, cur, BS * NN, N,
                                 invf[2 * mm], invf[2 * mm + 1], 0.0);
         for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {    // S <- c_{2i} I + c_{2i+1} A + A2*S
-            g.A = gm.A2; g.Bm = cur; g.C = oth; g.E = gm.A; g.alpha = 1.0; g.beta = invf[2 * i + 1]; g.gamma = invf[2 * i];
+            g.A = bufA2; g.Bm = cur; g.C = oth; g.E = bufA; g.alpha = 1.0; g.beta = invf[2 * i + 1]; g.gamma = invf[2 * i];
             qoc_gemm_launch(gm, false, 0, g, s);
             cplx* t = cur; cur = oth; oth = t;
         }
     } else {
-        hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, gm.A, (const cplx*)nullptr, cur, BS * NN, N, 1.0,
+        hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, (const cplx*)nullptr, cur, BS * NN, N, 1.0,
                            deg >= 1 ? 1.0 : 0.0, 0.0);
     }
     for (int sq = 0; sq < nsq; ++sq) {                       // M <- M M                    tensorflow_state.py:43-44
@@ -556,8 +588,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         qoc_gemm_launch(gm, false, 0, g, s);
         cplx* t = cur; cur = oth; oth = t;
     }
-    (void)cur;                                               // == gm.K by construction
-    qoc_gemm_tree(gm, d, s);
+    (void)cur;                                               // == the K buffer by construction
 }
 
 static inline const cplx* qoc_gemm_chunk_products(const QocGemm& gm) { return gm.L > 0 ? gm.tree + gm.tree_off[gm.L] : gm.K; }
@@ -797,9 +828,9 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         h.Kdim = N; h.tiles_m = N / 32; h.tiles_n = W / 32; h.batch = d.k; h.alpha = 1.0;
         for (int b = 0; b < d.B; ++b) {
             hipLaunchKernelGGL(k_gemm_to_wide, dim3(gemm_grid((size_t)d.steps * N * QOC_WIDE_MV)), dim3(256), 0, s, d,
-                               (const cplx*)(gm.interP + (size_t)b * gm.SP * thin), (const cplx*)(gm.LamP + (size_t)b * gm.SP * thin), gm.wideP, gm.wideL, N, W);
+                               (const cplx*)(gm.interP + (size_t)b * gm.SP * thin), (const cplx*)(gm.LamP + (size_t)b * gm.SP * thin), gm.wideP, gm.wideL, N, W, d.steps);
             qoc_gemm_launch(gm, false, 0, h, s);
-            hipLaunchKernelGGL(k_gemm_dot_wide, dim3((unsigned)(((size_t)d.k * d.steps + 3) / 4)), dim3(256), 0, s, d, b, (const cplx*)gm.wideC, (const cplx*)gm.wideL, N, W);
+            hipLaunchKernelGGL(k_gemm_dot_wide, dim3((unsigned)(((size_t)d.k * d.steps + 3) / 4)), dim3(256), 0, s, d, b, (const cplx*)gm.wideC, (const cplx*)gm.wideL, N, W, 0, d.steps);
         }
         return;
     }

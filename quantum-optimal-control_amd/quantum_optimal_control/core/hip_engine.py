@@ -26,7 +26,7 @@ class QocConfig(C.Structure):
                 ('c_d2wdt2', C.c_double), ('c_speed_up', C.c_double), ('c_bandpass', C.c_double),
                 ('band_lo', C.c_int32), ('band_hi', C.c_int32), ('n_forbidden', C.c_int32),
                 ('forbid_dressed', C.c_int32), ('device', C.c_int32), ('path', C.c_int32), ('chunks', C.c_int32),
-                ('variant', C.c_int32), ('plan_seeds', C.c_int32), ('reserved', C.c_int32 * 5)]
+                ('variant', C.c_int32), ('plan_seeds', C.c_int32), ('time_shards', C.c_int32), ('time_rank', C.c_int32), ('reserved', C.c_int32 * 3)]
 
 
 class QocAdamParams(C.Structure):
@@ -59,6 +59,7 @@ _SIGNATURES = {
     'qoc_path_in_use': (C.c_int, [C.c_void_p]),
     'qoc_chunks_in_use': (C.c_int, [C.c_void_p]),
     'qoc_plan_describe': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    'qoc_set_time_comm': (C.c_int, [C.c_void_p, C.c_void_p]),
     'qoc_comm_unique_id': (C.c_int, [C.c_void_p]),
     'qoc_comm_probe': (C.c_int, [C.c_int32]),
     'qoc_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -231,7 +232,8 @@ class HipEngine(object):
     """Device-resident GRAPE problem: constants in HBM, n_seeds control sets, one HIP stream."""
 
     def __init__(self, Hs, U0, V, W, maxA, dt, total_time, steps, taylor_terms, scaling, state_transfer=False,
-                 reg_coeffs=None, one_minus_gauss=None, Vs=None, n_seeds=1, device=0, path=PATH_AUTO, chunks=0, variant=0, plan_seeds=0):
+                 reg_coeffs=None, one_minus_gauss=None, Vs=None, n_seeds=1, device=0, path=PATH_AUTO, chunks=0, variant=0, plan_seeds=0,
+                 time_shards=0, time_rank=-1, time_comm=None):
         lib = load_library()
         self._lib = lib
         self._h = C.c_void_p()
@@ -262,6 +264,7 @@ class HipEngine(object):
         use_vs = Vs is not None and cfg.n_forbidden > 0
         cfg.forbid_dressed = int(use_vs)
         cfg.device, cfg.path, cfg.chunks, cfg.variant = int(device), int(path), int(chunks), int(variant)
+        cfg.time_shards, cfg.time_rank = int(time_shards), int(time_rank)     # one trajectory sharded along the time axis (csrc/qoc_gemm_ts.h); -1: emulated in this engine
         cfg.plan_seeds = int(plan_seeds)       # 0: plan for n_seeds; > 0: the batch AUTO plans for (sharded restarts: see plan_seeds_for)
         omg = None
         if one_minus_gauss is not None:
@@ -277,6 +280,9 @@ class HipEngine(object):
         buf = C.create_string_buffer(256)
         _check(lib.qoc_plan_describe(self._h, buf, 256))
         self.plan = dict(kv.split('=', 1) for kv in buf.value.decode().split())
+        if time_comm is not None:
+            _check(lib.qoc_set_time_comm(self._h, time_comm._h))
+            self._time_comm = time_comm                # keep it alive as long as the engine
 
     # -- lifetime ---------------------------------------------------------------------------------------------
     def close(self):

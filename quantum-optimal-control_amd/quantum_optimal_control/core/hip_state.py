@@ -11,7 +11,7 @@ from quantum_optimal_control.core import hip_engine
 
 class HipState(object):
 
-    def __init__(self, sys_para, n_seeds=1, device=0, path=hip_engine.PATH_AUTO, chunks=0, first_seed=0, plan_seeds=0):
+    def __init__(self, sys_para, n_seeds=1, device=0, path=hip_engine.PATH_AUTO, chunks=0, first_seed=0, plan_seeds=0, time_comm=None):
         self.sys_para = sys_para
         self.n_seeds = n_seeds
         self.first_seed = first_seed      # global index of this engine's first restart (seed-sharded runs)
@@ -19,6 +19,7 @@ class HipState(object):
         self.path = path
         self.chunks = chunks
         self.plan_seeds = plan_seeds      # batch size AUTO plans for (0 = n_seeds): qoc_config.plan_seeds
+        self.time_comm = time_comm        # hip_engine.QocComm of a time-sharded run (one trajectory over the GPUs of a node), or None
         self.engine = None
 
     def build_graph(self):
@@ -39,7 +40,9 @@ class HipState(object):
             Hs, U0, V, W, sp.ops_max_amp, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
             state_transfer=sp.state_transfer, reg_coeffs=rc,
             one_minus_gauss=sp.one_minus_gauss if 'envelope' in rc else None, Vs=Vs,
-            n_seeds=self.n_seeds, device=self.device, path=self.path, chunks=self.chunks, plan_seeds=self.plan_seeds)
+            n_seeds=self.n_seeds, device=self.device, path=self.path, chunks=self.chunks, plan_seeds=self.plan_seeds,
+            time_shards=0 if self.time_comm is None else self.time_comm.world, time_rank=-1 if self.time_comm is None else self.time_comm.rank,
+            time_comm=self.time_comm)
         base = np.asarray(sp.ops_weight_base, dtype=np.float64)
         if base.ndim == 2 and (self.n_seeds > 1 or self.first_seed > 0):
             # global restart 0 = the reference's own starting point; restart g > 0 = the reproducible stream of index g,

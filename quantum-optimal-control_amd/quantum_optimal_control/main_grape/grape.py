@@ -52,7 +52,7 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
           dressed_info=None, maxA=None, use_gpu=True, sparse_H=True, sparse_U=False, sparse_K=False, draw=None,
           initial_guess=None, show_plots=True, unitary_error=1e-4, method='Adam', state_transfer=False,
           no_scaling=False, freq_unit='GHz', file_name=None, save=True, data_path=None, Taylor_terms=None,
-          use_inter_vecs=True, restarts=1, plan_seeds=None, _first_seed=0, _device=0, _return_session=False):
+          use_inter_vecs=True, restarts=1, plan_seeds=None, time_comm=None, _first_seed=0, _device=0, _return_session=False):
     """Reference signature (main_grape/grape.py:19) plus one optional extension: ``restarts=B`` optimises B control sets at
     once on the GPU -- the first is the reference's own initial guess (same NumPy RNG draw / ``initial_guess``), the others
     are independent N(0, 1/sqrt(steps)) restarts -- and returns the (uks, U_final) of the best final fidelity."""
@@ -92,8 +92,9 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
     # plan_seeds (extension): the batch size the engine plans its path / kernels / chunking for instead of `restarts` (None: its own batch,
     # the fastest choice for this process).  GrapeSharded passes hip_engine.plan_seeds_for(all restarts), so that a restart evolves
     # bit-identically under any rank count; Grape(restarts=R, plan_seeds=hip_engine.plan_seeds_for(R)) reproduces a sharded run in one process.
-    tfs = HipState(sys_para, n_seeds=max(1, int(restarts)), device=_device, first_seed=_first_seed,
-                   plan_seeds=0 if plan_seeds is None else int(plan_seeds))   # constants -> HBM
+    # time_comm (extension): a hip_engine.QocComm whose ranks share ONE large trajectory along the time axis (GrapeTimeSharded below)
+    tfs = HipState(sys_para, n_seeds=max(1, int(restarts)), device=_device if time_comm is None else time_comm.device, first_seed=_first_seed,
+                   plan_seeds=0 if plan_seeds is None else int(plan_seeds), time_comm=time_comm)   # constants -> HBM
     graph = tfs.build_graph()
     conv = Convergence(sys_para, time_unit, convergence)
     try:
@@ -115,6 +116,21 @@ def Grape(H0, Hops, Hnames, U, total_time, steps, states_concerned_list, converg
         return None
     finally:
         tfs.close()
+
+
+def GrapeTimeSharded(*args, comm=None, **kwargs):
+    """`Grape(...)` for ONE large control problem (hundreds of levels, thousands of slices: BASELINE config 5) on all GPUs of a node: the pulse is
+    cut along the TIME axis, rank r of `comm` (parallel_seeds.open_comm(): RCCL over xGMI behind the C ABI) forms the propagators, sweeps and
+    gradients of its run of time chunks, and two small collectives per iteration -- an all-gather of one n x n product per rank, an all-reduce of the
+    gradient array -- keep the ranks in lock step (csrc/qoc_gemm_ts.h).  Every rank runs the same optimiser on the whole pulse and returns
+    the same (uks, U_final); only rank 0 writes the run log.  comm = None: a plain Grape call.  Unitary mode, no forbidden-level / speed_up term,
+    n > 96, at most 8 states of interest; the reference has no counterpart (one device: main_grape/grape.py:106-109)."""
+    if comm is None:
+        return Grape(*args, **kwargs)
+    if comm.rank != 0:
+        kwargs['save'] = False
+        kwargs['show_plots'] = False
+    return Grape(*args, time_comm=comm, **kwargs)
 
 
 def GrapeSharded(*args, restarts=8, dist=None, comm=None, **kwargs):

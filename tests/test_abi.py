@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     from quantum_optimal_control.core import hip_engine
-    # 8 int32 + 2 double + 6 int32 + 6 double + 7 int32 + variant + plan_seeds + 5 reserved int32, natural alignment
+    # 8 int32 + 2 double + 6 int32 + 6 double + 7 int32 + variant + plan_seeds + time_shards + time_rank + 3 reserved int32, natural alignment
     assert ctypes.sizeof(hip_engine.QocConfig) == 8 * 4 + 2 * 8 + 6 * 4 + 6 * 8 + 14 * 4
     assert ctypes.sizeof(hip_engine.QocAdamParams) == 4 * 8 + 2 * 4
 
