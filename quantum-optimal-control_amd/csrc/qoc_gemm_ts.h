@@ -13,7 +13,7 @@
 // Two small collectives per iteration sit on the data path; everything else is the unsharded path on a sub-range of slices.
 //
 // time_rank = -1 EMULATES all G ranks inside one engine on one GPU (phases A, B, D, E looped over r, the exchanges are no-ops on the shared
-// buffers): the decomposition -- index ranges, rank products, the two chains over them -- is then testable against the oracle on a one-GPU box;
+// buffers): the decomposition -- index ranges, rank products, the two chains over them -- is then testable against the CPU restatement on a one-GPU box;
 // the real mode differs by the two RCCL calls only.  Scope: unitary mode, one control set, no state regulariser, N >= 128 with an even number
 // of row tiles, m <= 8 (the wide gradient product), G <= NC.  Every rank allocates the full-size buffers (C5: ~42 GB of 288).
 #pragma once
