@@ -29,6 +29,9 @@ struct GemmArgs {
     int inner; long long sA2, sB2, sC2, sL2;   // inner > 0: batch index bt -> (bt / inner, bt % inner); A, Bm, C, L offsets = hi*s?2 + lo*s?
     cplx* CT; long long sCT; int ldct;         // EPI = 0, optional: also store the transpose, CT[batch][col][row]
     int ldp;                                   // EPI = 2: per-COLUMN dots, partial[batch*stride + offset + tile_m*ldp + col]
+    // k_zgemm_wg only: the right operand is bt_c1 * Bm + bt_c0 * I (square Bm), formed while its chunks are staged -- the top block of a
+    // Paterson-Stockmeyer recursion then never exists in memory (no k_gemm_ps_init pass: one read and one write of every matrix saved)
+    int btrans; double bt_c0, bt_c1;
 };
 
 // SK wavefronts of a workgroup split the inner dimension of ONE tile (small-batch chain launches are latency-bound when
@@ -187,6 +190,7 @@ static inline size_t qoc_zgemm_wg_lds() { return (size_t)2 * (64 * ZW_LDA + ZW_K
 // Two waves per SIMD (round 3): with one, the matrix pipe was busy 60 % of the cycles -- a lone wave's s_waitcnt / barrier time (23 % of its
 // cycles, SQ_WAIT_ANY) and its ~90 VALU instructions per chunk are all exposed; a partner wave's MFMAs fill them.
 template <int NJ> struct ZwB { cplx v[NJ]; double s[NJ]; };
+template <bool BT>
 __global__ void __launch_bounds__(64 * ZW_WAVES, 1) k_zgemm_wg(GemmArgs g) {
     constexpr int NW = ZW_WAVES, NTHR = 64 * NW, NJ = NW == 8 ? 2 : 4;        // NJ = 16-column strips of a wave tile
     extern __shared__ __attribute__((aligned(16))) char zw_lds[];
@@ -223,8 +227,10 @@ __global__ void __launch_bounds__(64 * ZW_WAVES, 1) k_zgemm_wg(GemmArgs g) {
         for (int J = 0; J < NJ; ++J) { t1[ib][J] = 0.0; t2[ib][J] = 0.0; t3[ib][J] = 0.0; }
     const int nch = g.Kdim / KC;
     cplx sa[NSA], sb[NSB];
+    int staged_ch = 0;                                          // the chunk the staged registers hold (BT: the row index of a B element decides its diagonal term)
     auto stage_fetch = [&](int ch) {
         ch = min(ch, nch - 1);
+        staged_ch = ch;
 #pragma unroll
         for (int e = 0; e < NSA; ++e) sa[e] = Ag[(size_t)(RPE * e) * g.lda + KC * ch];
 #pragma unroll
@@ -245,7 +251,15 @@ __global__ void __launch_bounds__(64 * ZW_WAVES, 1) k_zgemm_wg(GemmArgs g) {
         double* as = As0 + (size_t)set * SET; double* bs = as + 64 * ZW_LDA;
         const int e = q >> 1;
         if (e < NSA) { const int o = (RPE * e + tid / KC) * ZW_LDA + (tid % KC); if (q & 1) as[o] = sa[e].x + sa[e].y; else ai[o] = sa[e]; }
-        else { const int f = e - NSA, o = (KPE * f + (tid >> 7)) * 128 + (tid & 127); if (q & 1) bs[o] = sb[f].x + sb[f].y; else bi[o] = sb[f]; }
+        else {
+            const int f = e - NSA, o = (KPE * f + (tid >> 7)) * 128 + (tid & 127);
+            cplx v = sb[f];
+            if constexpr (BT) {                                 // bt_c1 * B + bt_c0 * I
+                const bool dg = KC * staged_ch + KPE * f + (tid >> 7) == c0 + (tid & 127);
+                v.x = fma(g.bt_c1, v.x, dg ? g.bt_c0 : 0.0); v.y = g.bt_c1 * v.y;
+            }
+            if (q & 1) bs[o] = v.x + v.y; else bi[o] = v;
+        }
     };
     constexpr int NQ = 2 * (NSA + NSB), NSTEP = 2 * KC;        // the stores of a chunk over the first 16 of its 32 block steps
     stage_fetch(0);

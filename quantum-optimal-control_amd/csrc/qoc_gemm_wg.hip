@@ -4,8 +4,10 @@
 #include "qoc_gemm_tiles.h"
 
 void qoc_zgemm_wg_launch(const GemmArgs& g, unsigned blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_zgemm_wg, dim3(blocks), dim3(64 * ZW_WAVES), qoc_zgemm_wg_lds(), s, g);
+    if (g.btrans) hipLaunchKernelGGL(k_zgemm_wg<true>, dim3(blocks), dim3(64 * ZW_WAVES), qoc_zgemm_wg_lds(), s, g);
+    else hipLaunchKernelGGL(k_zgemm_wg<false>, dim3(blocks), dim3(64 * ZW_WAVES), qoc_zgemm_wg_lds(), s, g);
 }
 bool qoc_zgemm_wg_opt_in() {
-    return hipFuncSetAttribute((const void*)k_zgemm_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_zgemm_wg_lds()) == hipSuccess;
+    return hipFuncSetAttribute((const void*)k_zgemm_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_zgemm_wg_lds()) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k_zgemm_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_zgemm_wg_lds()) == hipSuccess;
 }

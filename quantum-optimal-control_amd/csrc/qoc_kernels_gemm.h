@@ -451,14 +451,24 @@ static inline bool qoc_gemm_lds_opt_in() {
 }
 // picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small.  The split factor and the kernel
 // family change the association of the sums, so they follow the PLANNED batch: QocGemm::plan_scale = planned / local batch (qoc_gemm_setup)
+#ifndef QOC_SK_TARGET
+#define QOC_SK_TARGET 2048     // waves a split-K launch aims at (~2 per SIMD)
+#endif
+// will this plain product run on k_zgemm_wg (the condition of the last-but-one branch below)?
+static inline bool qoc_gemm_takes_wg(const QocGemm& gm, const GemmArgs& g) {
+    const size_t real_tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
+    const size_t tiles = (size_t)((double)real_tiles * gm.plan_scale + 0.5);
+    const bool split = tiles * 2 <= QOC_SK_TARGET && (g.Kdim / 2) % 8 == 0;
+    return !split && (g.tiles_m & 1) == 0 && (g.tiles_n & 3) == 0 && (g.Kdim % ZW_KC) == 0 && g.Kdim >= 128 && tiles >= 8 * 1024;
+}
 static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
     const size_t real_tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
     const unsigned blocks = (unsigned)real_tiles;
     const size_t tiles = (size_t)((double)real_tiles * gm.plan_scale + 0.5);
     int sk = 1;
-    if (tiles * 2 <= 2048 && (g.Kdim / 2) % 8 == 0) sk = 2;
-    if (tiles * 4 <= 2048 && (g.Kdim / 4) % 8 == 0) sk = 4;
-    if (tiles * 8 <= 2048 && (g.Kdim / 8) % 8 == 0) sk = 8;
+    if (tiles * 2 <= QOC_SK_TARGET && (g.Kdim / 2) % 8 == 0) sk = 2;
+    if (tiles * 4 <= QOC_SK_TARGET && (g.Kdim / 4) % 8 == 0) sk = 4;
+    if (tiles * 8 <= QOC_SK_TARGET && (g.Kdim / 8) % 8 == 0) sk = 8;
     if (epi == 2) {
         if (sk == 8) qoc_gemm_launch_sk<false, 2, 8>(g, blocks, s);
         else if (sk == 4) qoc_gemm_launch_sk<false, 2, 4>(g, blocks, s);
@@ -570,13 +580,19 @@ static inline void qoc_gemm_expm_products(QocGemm& gm, const QocDev& d, hipStrea
     if (deg >= 2) {
         g.A = bufA; g.Bm = bufA; g.C = bufA2; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
         qoc_gemm_launch(gm, false, 0, g, s);                         // A2 = A*A
+        // odd order on the workgroup-tiled kernel: the top block S = c_{2m} I + c_{2m+1} A is formed from A while the first Horner product stages
+        // its right operand (GemmArgs::btrans) -- no k_gemm_ps_init pass (C5: 3.2 ms of reading and writing 8.4 GB each)
+        const bool top_in_flight = !even && mm >= 1 && qoc_gemm_takes_wg(gm, g);
         if (even) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, bufA2, cur, BS * NN, N,
                                      invf[2 * mm - 2], invf[2 * mm - 1], invf[deg]);
-        else hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, (const cplx*)nullptr, cur, BS * NN, N,
-                                invf[2 * mm], invf[2 * mm + 1], 0.0);
+        else if (!top_in_flight) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, (const cplx*)nullptr, cur, BS * NN, N,
+                                                    invf[2 * mm], invf[2 * mm + 1], 0.0);
         for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {    // S <- c_{2i} I + c_{2i+1} A + A2*S
             g.A = bufA2; g.Bm = cur; g.C = oth; g.E = bufA; g.alpha = 1.0; g.beta = invf[2 * i + 1]; g.gamma = invf[2 * i];
+            g.btrans = 0;
+            if (top_in_flight && i == mm - 1) { g.Bm = bufA; g.btrans = 1; g.bt_c0 = invf[2 * mm]; g.bt_c1 = invf[2 * mm + 1]; }
             qoc_gemm_launch(gm, false, 0, g, s);
+            g.btrans = 0;
             cplx* t = cur; cur = oth; oth = t;
         }
     } else {
