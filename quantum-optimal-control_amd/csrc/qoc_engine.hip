@@ -312,8 +312,9 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
     e->controls_ready = ap.mode != 0 && !own_controls && !(skip & (16 | 32));       // the Adam tail ran: u2 / w2 belong to the moved variable
-    e->final_stale = e->path == QOC_PATH_MFMA && (e->mf.latency || e->mf.updown);      // final_state / unitary_scale are formed when read back
-    e->inter_stale = (e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast))   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
+    e->final_stale = (e->path == QOC_PATH_MFMA && (e->mf.latency || e->mf.updown)) ||  // final_state / unitary_scale are formed when read back
+                     (e->path == QOC_PATH_GEMM && e->gm.ts_G <= 0 && qoc_gemm_lazy_final(e->gm, e->d));
+    e->inter_stale = (e->path == QOC_PATH_MFMA && e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast))   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
                      || (e->path == QOC_PATH_MFMA && e->mf.updown);                  // (k_mfma_downup stores no Psi_t either)
     return QOC_OK;
 }
@@ -321,7 +322,8 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
 // latency mode of the MFMA path: final_state and unitary_scale of the last evaluation, formed on demand
 static int refresh_final(qoc_engine* e) {
     if (!e->final_stale) return QOC_OK;
-    if (e->mf.latency) qoc_mfma_final_state(e->mf, e->d, e->stream);
+    if (e->path == QOC_PATH_GEMM) qoc_gemm_forward(e->gm, e->d, e->stream, true);      // the boundary chain once more, with X beside the vectors
+    else if (e->mf.latency) qoc_mfma_final_state(e->mf, e->d, e->stream);
     else qoc_mfma_final_state_batch(e->mf, e->d, e->stream);
     HIP_TRY(hipGetLastError());
     e->final_stale = false;

@@ -86,7 +86,8 @@ static inline void qoc_gemm_ts_expm(QocGemm& gm, const QocDev& d, int r, hipStre
     const int N = gm.N, S = gm.S;
     const size_t NN = (size_t)N * N;
     const int c0 = gm.ts_cb[r], c1 = gm.ts_cb[r + 1];
-    qoc_gemm_expm_products(gm, d, s, (size_t)c0 * S, (size_t)(c1 - c0) * S);
+    const size_t i0 = (size_t)c0 * S, i1 = min((size_t)c1 * S, (size_t)d.steps);   // (the padded slices of the last chunk keep the identity of set-up)
+    if (i1 > i0) qoc_gemm_expm_products(gm, d, s, i0, i1 - i0);
     qoc_gemm_tree(gm, d, s, (size_t)c0 * S, (size_t)(c1 - c0) * S);
     const cplx* Pc = qoc_gemm_chunk_products(gm);
     cplx* out = gm.ts_Rall + (size_t)r * NN;

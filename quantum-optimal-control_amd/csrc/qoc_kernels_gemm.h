@@ -294,6 +294,15 @@ __global__ void __launch_bounds__(256) k_gemm_dot_wide(QocDev d, int b, const cp
     if (lane == 0) d.dLdu[((size_t)b * d.k + kk) * d.steps + t_first + t] = acc;
 }
 
+// K[b][t] = I for the padded slices t = steps .. SP - 1 (set once: the launch-per-product route of ONE control set never computes them)
+__global__ void __launch_bounds__(256) k_gemm_pad_identity(cplx* __restrict__ K, int B, int N, int steps, int SP) {
+    const size_t NN = (size_t)N * N, per = (size_t)(SP - steps) * NN;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)B * per; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = o / per, r = o - b * per, t = steps + r / NN, e = r % NN;
+        K[(b * SP + t) * NN + e] = cmake(e / N == e % N ? 1.0 : 0.0, 0.0);
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 // Time is cut into NC chunks of S = 2^L slices (padded with identity slices to SP = NC*S).  A pairwise product tree over
 // the K_t gives the chunk products at the batched-GEMM rate; the sequential part of each chain shrinks from `steps`
@@ -430,6 +439,10 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     if (gm.wideW > 0) zeroed = zeroed && hipMemset(gm.wideP, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess &&
                                          hipMemset(gm.wideL, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess;   // (the columns beyond 8 steps)
     if (!zeroed) { msg = "GEMM path: clearing the work buffers failed"; return -2; }
+    if (poly && gm.SP > d.steps) {
+        hipLaunchKernelGGL(k_gemm_pad_identity, dim3(4096), dim3(256), 0, 0, gm.K, d.B, N, d.steps, gm.SP);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { msg = "GEMM path: the padded propagators could not be set"; return -2; }
+    }
     return 0;
 }
 
@@ -552,7 +565,8 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
         qoc_gemm_tree(gm, d, s);
         return;
     }
-    qoc_gemm_expm_products(gm, d, s, 0, BS);
+    // one control set: the padded slices (K = I exactly, written once by qoc_gemm_setup) are not computed -- C5: 16 of 2016 slices, 96 products
+    qoc_gemm_expm_products(gm, d, s, 0, d.B == 1 ? (size_t)d.steps : BS);
     qoc_gemm_tree(gm, d, s);
 }
 
@@ -625,8 +639,12 @@ static inline ChainArgs qoc_gemm_direct_backward_args(const QocGemm& gm, const Q
 // direct route without a state regulariser: backward chain beside the forward one (see qoc_gemm_forward)
 static inline bool qoc_gemm_zfree_backward(const QocGemm& gm, const QocDev& d) { return gm.direct && !(d.n_forb > 0 || d.has_speed) && d.steps >= 2; }
 
-static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s) {
-    const int N = gm.N, xw = d.state_transfer ? 0 : N, ld = xw + QOC_TW, S = gm.S, NC = gm.NC;
+// launch-per-step route in unitary mode: final_state / unitary_scale are formed when they are read back (qoc_gemm_final_state) -- inside the
+// iterations the boundary chain carries the m vectors only, not the N columns of X beside them (C5: 63 products of 512 x 544 columns per iteration)
+static inline bool qoc_gemm_lazy_final(const QocGemm& gm, const QocDev& d) { return !gm.persistent && !gm.direct && !d.state_transfer; }
+
+static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s, bool with_final = false) {
+    const int N = gm.N, xw = (d.state_transfer || (qoc_gemm_lazy_final(gm, d) && !with_final)) ? 0 : N, ld = xw + QOC_TW, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
     hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
@@ -706,7 +724,8 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s)
     }
     if (!gm.persistent && NC > 1)
         hipLaunchKernelGGL(k_gemm_take_bnd_all, dim3(gemm_grid((size_t)d.B * (NC - 1) * thin)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
-    if (!d.state_transfer && !gm.persistent) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(N > 64 ? 1024 : 256), 0, s, d, gm.Y0 + (size_t)NC * yslot, N);
+    if (xw > 0 && !gm.persistent) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(N > 64 ? 1024 : 256), 0, s, d, gm.Y0 + (size_t)NC * yslot, N);
+    if (with_final) return;                                    // read-back of final_state: the boundary chain with X beside the vectors was all that was asked for
     if (gm.persistent) {
         // every chunk swept by its own persistent workgroup: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}
         ChainArgs a;
