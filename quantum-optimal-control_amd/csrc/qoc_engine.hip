@@ -776,6 +776,7 @@ int qoc_get_final_unitary(qoc_handle e, double* Uf) {
 int qoc_get_inter_vecs(qoc_handle e, double* inter) {
     CHECK_H(e);
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_inter_vecs: nothing evaluated yet");
+    if (e->path == QOC_PATH_GEMM) TRY(qoc_gemm_ts_gather_inter(e->gm, e->d, e->stream));   // one rank of a time-sharded run: its own slices, summed over the ranks (a collective)
     if (e->inter_stale) {                                            // latency mode: the sweeps keep Psi_t in their own layout
         qoc_mfma_unpack_inter(e->mf, e->d, e->stream);
         HIP_TRY(hipGetLastError());

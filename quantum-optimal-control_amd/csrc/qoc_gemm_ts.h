@@ -67,6 +67,25 @@ __global__ void __launch_bounds__(256) k_ts_copy(cplx* __restrict__ dst, const c
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < count; o += (size_t)gridDim.x * blockDim.x) dst[o] = src[o];
 }
 
+// read-back of inter_vecs on one rank of a real run: every rank holds the time points of ITS slices (and all of them inter[0], inter[steps]);
+// what it does not own is cleared, then the ranks sum -- every time point has exactly one owner
+__global__ void __launch_bounds__(256) k_ts_clear_foreign(QocDev d, int t_first, int t_count, int keep_ends) {
+    const size_t nm = (size_t)d.n * d.m;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)(d.steps + 1) * nm; o += (size_t)gridDim.x * blockDim.x) {
+        const int tp = (int)(o / nm);                                  // time point: inter[tp], tp = t + 1 for slice t; 0 = the initial vectors
+        const bool ends = tp == 0 || tp == d.steps;
+        const bool mine = ends ? keep_ends != 0 : (tp - 1 >= t_first && tp - 1 < t_first + t_count);
+        if (!mine) d.inter[o] = cmake(0.0, 0.0);
+    }
+}
+static inline int qoc_gemm_ts_gather_inter(QocGemm& gm, const QocDev& d, hipStream_t s) {
+    if (gm.ts_G <= 0 || gm.ts_rank < 0) return 0;                      // (an emulating engine holds every slice)
+    const int c0 = gm.ts_cb[gm.ts_rank], c1 = gm.ts_cb[gm.ts_rank + 1];
+    const int t0 = c0 * gm.S, t1 = min(c1 * gm.S, d.steps);
+    hipLaunchKernelGGL(k_ts_clear_foreign, dim3(2048), dim3(256), 0, s, d, t0, t1 - t0, gm.ts_rank == 0 ? 1 : 0);
+    return qoc_ts_all_reduce_sum(gm.ts_comm, (double*)d.inter, (size_t)2 * (d.steps + 1) * d.n * d.m, s);
+}
+
 static inline bool qoc_gemm_ts_supported(const QocGemm& gm, const QocDev& d, int G, std::string& why) {
     if (d.state_transfer) { why = "unitary mode only"; return false; }
     if (d.B != 1) { why = "one control set (restart batches shard over seeds: parallel_seeds)"; return false; }
