@@ -72,6 +72,25 @@ def full_size_cases():
     return out
 
 
+def kernel_family_cases():
+    """One case per kernel family of the engine beyond n <= 32 / the BASELINE shapes (three time points of inter_vecs kept): the 48- and 64-wide
+    MFMA kernels, a padded size, three qutrits with six controls and forbidden levels (what the reference's transmon examples look like), and a
+    matrix size of the launch-per-product GEMM route (which the time-sharded engine runs on as well)."""
+    from tests.golden import cases
+    out = {}
+    out['fam_n40'] = cases.case_c2(n=40, k=3, steps=64, m=5, taylor=(5, 2), seed=31)
+    out['fam_n64'] = cases.case_c2(n=64, k=4, steps=64, m=8, taylor=(5, 3), seed=32)
+    out['fam_n20'] = cases.case_c2(n=20, k=4, steps=64, m=8, taylor=(5, 3), seed=33)
+    c = cases.case_c2(n=27, k=6, steps=80, m=8, taylor=(5, 3), seed=34)
+    c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [26, 25]}
+    out['fam_qutrits'] = c
+    out['fam_n100'] = cases.case_c2(n=100, k=3, steps=48, m=4, taylor=(5, 2), seed=35)
+    for c in out.values():
+        c['total_time'] = 20.0 * c['steps'] / 500.0
+        c['keep_inter'] = False
+    return out
+
+
 FP32_CASES = ('c1', 'c2_n8', 'unitary_allreg', 'state_transfer_allreg', 'dressed_forbidden', 'c2_full_s0', 'c3_full')
 
 
@@ -172,6 +191,7 @@ if __name__ == '__main__':
         os.environ['QOC_TF1_SHIM_FP32'] = '1'               # read by the shim when the scratch copy imports it as `tensorflow`
     todo = graph_cases()                                    # recipes first: they come from THIS repo's package of the same name
     todo.update(full_size_cases())
+    todo.update(kernel_family_cases())
     if fp32:
         todo = {name: todo[name] for name in FP32_CASES}
     mods, tf, scratch = import_reference_graph()

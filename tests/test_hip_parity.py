@@ -980,3 +980,35 @@ def test_hip_within_float32_roundoff_of_the_reference_text_at_its_own_precision(
         o['U_final'] = eng.get_final_unitary()[0]
     assert_tier2(o, fx, sp.state_transfer)
     eng.close()
+
+
+FAMILY_ROUTES = [('fam_n40', dict(), 1, 'latency'), ('fam_n40', dict(path=2), 8, 'row_tile_gradient'), ('fam_n40', dict(path=4), 2, 'unitary'),
+                 ('fam_n64', dict(), 1, 'latency'), ('fam_n64', dict(path=2), 4, 'row_tile_gradient'), ('fam_n64', dict(path=4), 3, 'unitary'),
+                 ('fam_n20', dict(), 1, 'latency'), ('fam_n20', dict(path=2, variant=8, chunks=4), 6, 'downup'), ('fam_n20', dict(path=4), 2, 'unitary'),
+                 ('fam_qutrits', dict(), 1, 'latency_sources'), ('fam_qutrits', dict(path=2, variant=8), 6, 'row_tile_gradient'), ('fam_qutrits', dict(path=4), 2, 'unitary'),
+                 ('fam_n100', dict(), 1, 'unitary'), ('fam_n100', dict(time_shards=3, time_rank=-1), 1, 'unitary')]
+
+
+@pytest.mark.parametrize('name,kw,B,expect', FAMILY_ROUTES, ids=['%s-%s-x%d' % (r[0], '_'.join('%s%s' % kv for kv in sorted(r[1].items())) or 'auto', r[2]) for r in FAMILY_ROUTES])
+def test_hip_against_the_reference_text_per_kernel_family(name, kw, B, expect):
+    """Every kernel family of the engine against numbers of the reference's own graph text (tests/golden/graph_fam_*.npz, make_graph_golden.py): the
+    48- and 64-wide MFMA kernels (latency mode and batch kernels), the active-strip kernels of a padded size, three qutrits with six controls and
+    forbidden levels, the launch-per-product GEMM route and the time-sharded engine on it -- control set 0 of the batch is the reference's own start."""
+    from quantum_optimal_control.core import hip_engine
+    c, sp = _reference_text_case(name)
+    fx = load_golden('graph_%s.npz' % name)
+    eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling, state_transfer=sp.state_transfer,
+                               reg_coeffs=sp.reg_coeffs, one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=B, **kw)
+    assert expect in (eng.plan.get('sweeps'), eng.plan.get('route')), eng.plan
+    bases = np.stack([fx['base0']] + [(0.5 + 0.25 * i) * fx['base0'] + 0.05 * i for i in range(1, B)])
+    eng.set_base(bases)
+    r = eng.evaluate()
+    for key in ('loss', 'reg_loss', 'unitary_scale', 'grad_squared'):
+        assert abs(r[key][0] - float(fx[key])) <= 1e-11 * max(1.0, abs(float(fx[key]))), (key, r[key][0], float(fx[key]))
+    gmax = np.max(np.abs(fx['grad_pack']))
+    assert np.max(np.abs(r['grad'][0] - fx['grad_pack'])) <= 1e-10 * gmax, (np.max(np.abs(r['grad'][0] - fx['grad_pack'])), gmax)
+    np.testing.assert_allclose(eng.get_inter_vecs()[0][[0, sp.steps // 2, sp.steps]], fx['inter_vecs'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(eng.get_final_unitary()[0], fx['final_state'], rtol=0, atol=1e-11)
+    eng.adam_step(float(fx['adam_lr']))
+    np.testing.assert_allclose(eng.get_base()[0], fx['base_after_adam'], rtol=0, atol=1e-9)
+    eng.close()

@@ -60,10 +60,14 @@ def test_guess_above_max_amp_raises():
 GRAPH_CASES = ['c1', 'small_auto_U0', 'dressed_forbidden', 'state_small', 'c3_small', 'unitary_allreg', 'state_transfer_allreg', 'c2_n8']
 # round 4: BASELINE configs 2 and 3 at their FULL sizes (C2 from the control sets of bench.py's restart seeds 0 and 63)
 FULL_CASES = ['c2_full_s0', 'c2_full_s63', 'c3_full']
+# one case per kernel family of the engine: 48- / 64-wide MFMA kernels, a padded size, three qutrits with six controls and forbidden levels, n = 100
+FAMILY_CASES = ['fam_n40', 'fam_n64', 'fam_n20', 'fam_qutrits', 'fam_n100']
 
 
 def graph_case(name):
-    from tests.golden.make_graph_golden import full_size_cases, graph_cases
+    from tests.golden.make_graph_golden import full_size_cases, graph_cases, kernel_family_cases
+    if name in FAMILY_CASES:
+        return kernel_family_cases()[name]
     return full_size_cases()[name] if name in FULL_CASES else graph_cases()[name]
 
 
@@ -73,7 +77,7 @@ def picked_time_points(inter, fx_inter):
     return inter if fx_inter.shape[0] == steps + 1 else inter[[0, steps // 2, steps]]
 
 
-@pytest.mark.parametrize('name', GRAPH_CASES + FULL_CASES)
+@pytest.mark.parametrize('name', GRAPH_CASES + FULL_CASES + FAMILY_CASES)
 def test_oracle_matches_the_reference_graph_code(name):
     c = graph_case(name)
     fx = load_golden('graph_%s.npz' % name)
