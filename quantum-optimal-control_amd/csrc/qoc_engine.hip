@@ -523,12 +523,23 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by row)
     auto plan_for = [&](int Bp) -> AutoPlan {
         const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= 32) || Bp >= 64);
-        const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= 8 && m <= 8 && steps >= 100));
+        // 16 < n <= 32 below the latency mode's reach (long pulses): the GEMM route up to a few control sets, fewer the smaller the active part of the padded
+        // matrices is (500 slices, GEMM route / MFMA batch kernels in ms: n = 32 x 6 0.290 / 0.315, x 8 0.340 / 0.318; n = 27 x 4 0.251 / 0.270, x 6 0.288 / 0.271;
+        // n = 20 x 2 0.185 / 0.196, x 4 0.249 / 0.196; with a forbidden level n = 32 x 8 0.436 / 0.473, n = 27 x 8 level, n = 20 x 6 0.373 / 0.360)
+        const int qa_g = (n + 3) / 4;
+        const int gemm_small = lat_src ? (qa_g <= 5 ? 5 : qa_g == 6 ? 6 : 8) : (qa_g <= 5 ? 2 : qa_g == 6 ? 3 : qa_g == 7 ? 5 : 7);
+        const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= 100));
         const long long lat_work = (long long)Bp * steps;
+        // 16 < n <= 32: the batch kernels work on the ACTIVE 4-row strips qa = ceil(n / 4) of the padded matrices since round 4 and take over earlier the
+        // smaller n is (tools/padded_latency_sweep.py, 500 slices: n = 20 / 24 / 27 / 32 level at ~5 / 6 / 7 / 8.5 control sets; with a forbidden
+        // level the latency mode stays ahead up to 8, at n = 20 up to 7): seeds x slices <= 512 qa, with a state regulariser min(4096, 768 qa)
+        const int qa = (n + 3) / 4 < 5 ? 5 : (n + 3) / 4;
+        const long long lat_limit = n <= 16 ? (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK)
+                                            : (lat_src ? std::min<long long>(QOC_LATENCY_MAX_WORK_SRC, 768LL * qa) : 512LL * qa);
         const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
                               (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && Bp <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
                                 : n > 32 ? (lat_work <= 16384 && Bp <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
-                                       : (lat_work <= (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK) && Bp <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
+                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
                                (Bp == 1 && steps <= 8192));
         AutoPlan p;
         p.latency = latency;

@@ -5,7 +5,7 @@ batch; the thresholds are measured numbers.  A threshold edit must not silently 
   (1) restates the table of DESIGN.md section 4 as ordered RULES in Python (`expected_plan`), independent of the C++ text,
   (2) walks batch sizes {1, 2, 4, 5, 8, 9, 16, 17, 31, 32, 63, 64, 111, 112} x n in {16, 17, 32, 33, 48, 49, 64} x k in {4, 5, 6, 8} x
       {no state regulariser, forbidden level} in unitary mode (pulse lengths chosen so that seeds x slices falls on either side of the
-      latency-mode limits 4096 / 4608 / 16384), and the state-transfer routes either side of 48 / 112 control sets,
+      latency-mode limits -- 4608 / 4096 for n <= 16, 512 ceil(n / 4) / min(4096, 768 ceil(n / 4)) for 16 < n <= 32, 16384, 4096 --), and the state-transfer routes either side of 48 / 112 control sets,
   (3) creates the AUTO engine for each (1032 unitary rows), asserts the plan it reports (`qoc_plan_describe`) is the expected one, and -- for the
       smallest and the largest batch that resolve to each distinct plan of a shape, i.e. on both sides of every threshold that changes the
       kernels -- checks the first and the last control set of the batch against the CPU oracle (reference: core/tensorflow_state.py:25-65,
@@ -20,7 +20,9 @@ from tests.test_hip_parity import check_eval
 
 pytestmark = pytest.mark.gpu
 
-LAT_WORK, LAT_WORK_SRC, LAT_WORK_NT3, LAT_WORK_NT4 = 4608, 4096, 16384, 4096      # seeds x slices up to which the latency mode is taken
+LAT_WORK, LAT_WORK_SRC, LAT_WORK_NT3, LAT_WORK_NT4 = 4608, 4096, 16384, 4096      # seeds x slices up to which the latency mode is taken (n <= 16; NT = 3; NT = 4)
+
+
 FORBID = lambda n: {'dwdt': 0.1, 'forbidden_coeff_list': [3.0], 'states_forbidden_list': [n - 1]}      # noqa: E731
 
 
@@ -28,6 +30,12 @@ def ceil_div(a, b):
     return -(-a // b)
 
 
+def lat_limit_nt2(n, state_reg):
+    """16 < n <= 32: the batch kernels work on the active 4-row strips qa = ceil(n / 4) and take over earlier the smaller n is."""
+    if n <= 16:
+        return LAT_WORK_SRC if state_reg else LAT_WORK
+    qa = max(5, ceil_div(n, 4))
+    return min(LAT_WORK_SRC, 768 * qa) if state_reg else 512 * qa
 def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, hermitian=True):
     """DESIGN.md section 4, the AUTO table, as ordered rules -> the dict HipEngine.plan reports."""
     if state_transfer:
@@ -49,7 +57,7 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         elif n > 32:
             lat = work <= LAT_WORK_NT3 and B <= 8
         else:
-            lat = work <= (LAT_WORK_SRC if state_reg else LAT_WORK) and B <= (16 if n > 16 else (2 if state_reg else 4))
+            lat = work <= lat_limit_nt2(n, state_reg) and B <= (16 if n > 16 else (2 if state_reg else 4))
         lat = lat or (B == 1 and steps <= 8192)
     else:
         lat = False
@@ -57,9 +65,12 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         nt = 2 if n <= 32 else (3 if (n <= 48 and k <= 4) else 4)
         L = ceil_div(steps, ceil_div(steps, 8))
         return {'path': 'mfma', 'nt': nt, 'expm': 5, 'chunks': ceil_div(steps, L), 'sweeps': 'latency_sources' if state_reg else 'latency'}
-    # rows "GEMM": 48 < n <= 64 below the NT = 4 batch sizes; 32 < n <= 48 with fewer than 8 control sets; 16 < n <= 32 with <= 8 control sets
+    # rows "GEMM": 48 < n <= 64 below the NT = 4 batch sizes; 32 < n <= 48 with fewer than 8 control sets; 16 < n <= 32 with a few control sets
+    # (2 / 3 / 5 / 7 for ceil(n / 4) = 5 / 6 / 7 / 8; 5 / 6 / 8 / 8 with a state regulariser)
     nt4_batch = n > 48 and ((k <= 4 and B >= 32) or B >= 64)
-    if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < 8) or (16 < n <= 32 and B <= 8 and m <= 8 and steps >= 100):
+    qa = ceil_div(n, 4)
+    gemm_small = ({5: 5, 6: 6}.get(qa, 8) if state_reg else {5: 2, 6: 3, 7: 5}.get(qa, 7)) if 16 < n <= 32 else 0
+    if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < 8) or (16 < n <= 32 and B <= gemm_small and m <= 8 and steps >= 100):
         return {'path': 'gemm', 'route': 'unitary', 'chains': 'persistent' if m <= 8 else 'launches'}
     # rows "MFMA batch kernels"
     nt = 1 if n <= 16 else 2 if n <= 32 else 3 if n <= 48 else 4
@@ -86,7 +97,7 @@ def unitary_rows():
                     # seeds x slices on either side of the latency mode's limit for this class of n
                     lens = {130}
                     if k in (4, 5):
-                        limit = (LAT_WORK_NT4 if (n > 48 or (n > 32 and k > 4)) else LAT_WORK_NT3 if n > 32 else (LAT_WORK_SRC if reg else LAT_WORK))
+                        limit = (LAT_WORK_NT4 if (n > 48 or (n > 32 and k > 4)) else LAT_WORK_NT3 if n > 32 else lat_limit_nt2(n, reg))
                         if 2 <= B <= 16 and 64 <= limit // B <= 1200:
                             lens |= {limit // B, limit // B + 1}
                     if B >= 63 and (n > 32 or k >= 6):
