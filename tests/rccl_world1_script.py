@@ -65,5 +65,20 @@ if __name__ == '__main__':
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=0, atol=1e-12)
     assert abs(res[1][1] - res[0][1]) < 1e-12
     np.testing.assert_allclose(res[1][3], res[0][3], rtol=0, atol=1e-12)      # inter_vecs: gathered over the (one) rank
+    # and through the Python entry point: GrapeTimeSharded(comm=...) = Grape(...) for a world of one
+    import contextlib
+    import io
+    from quantum_optimal_control.main_grape.grape import Grape, GrapeTimeSharded
+    cL = cases.case_c2(n=100, k=2, steps=32, m=4, taylor=(5, 2), seed=9)
+    kw = dict(H0=cL['H0'], Hops=cL['Hops'], Hnames=cL['Hnames'], U=cL['U'], total_time=cL['total_time'], steps=cL['steps'],
+              states_concerned_list=cL['states_concerned_list'], maxA=cL['maxA'], reg_coeffs={}, Taylor_terms=cL['Taylor_terms'], save=False, show_plots=False,
+              convergence={'rate': 0.02, 'update_step': 2, 'max_iterations': 3, 'conv_target': 1e-12, 'learning_rate_decay': 100})
+    outs = []
+    for fn, extra in ((Grape, {}), (GrapeTimeSharded, {'comm': comm})):
+        np.random.seed(cL['np_seed'])
+        with contextlib.redirect_stdout(io.StringIO()):
+            outs.append(fn(**kw, **extra))
+    np.testing.assert_allclose(np.asarray(outs[1][0]), np.asarray(outs[0][0]), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=0, atol=1e-11)
     comm.close()
     print('OK rccl world1 via', comm.library)
