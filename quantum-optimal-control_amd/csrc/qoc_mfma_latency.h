@@ -27,8 +27,11 @@
 // loads, the fetch that bounds a step -- and 3 QQS MFMAs; the left blocks need X over ALL rows, so the waves publish their 16 rows to
 // a double-buffered LDS image and meet at one barrier per step.  (With one wave carrying all row tiles, 16 NT^2 KB and 3 NT QQS MFMAs
 // per step, the launch was 18.5 instead of 13 us at C2, and at NT = 4 a 256-register matrix left no room for a prefetch.)
+// chunk_offsets (undressed forbidden levels only -- their sources are elementwise in this layout and need nothing but Psi): the forward
+// role goes back DOWN its chunk from a zero costate with the sources of the states it has just formed and leaves the chunk offset a_c (AoffL):
+// role 0 of k_mfma_sweep_src, one launch less (one C2 trajectory with dwdt + two forbidden levels: 0.126 -> 0.121 ms per iteration).
 template <int NT>
-__global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf) {
+__global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf, int chunk_offsets) {
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx img[2][4 * LDP];                 // image[buffer][column j][row] of the workgroup's 4 columns
     const int lane = threadIdx.x & 63;
@@ -42,7 +45,7 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf
     if (d.skip_done && d.done[b]) return;                                         // whole workgroup: no barrier yet
     const int t0 = c * mf.L, t1 = min(t0 + mf.L, d.steps), len = t1 - t0;
     const int lk = lane >> 4, lc = lane & 15, li4 = lane & 3;
-    const double sg = adj ? -1.0 : 1.0;
+    double sg = adj ? -1.0 : 1.0;
     double pre, pim;
     {
         const cplx* X0 = adj ? d.W : d.Psi0;
@@ -126,6 +129,7 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf
         i = min(i, len - 1);
         return Kb + (size_t)(adj ? len - 1 - i : i) * mf.FR;
     };
+    const double psr = pre, psi_ = pim;                                           // the chunk-start vector: the state the source of slice t0 is formed from
     Frag K0, K1;
     load_frag(k_ptr(0), K0);
     int i = 0;
@@ -134,6 +138,37 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_sweep_lat(QocDev d, QocMfma mf
         load_frag(k_ptr(i + 2), K0); asm volatile("" ::: "memory"); step(K1, i + 1);
     }
     if (i < len) step(K0, i);
+    if (adj || !chunk_offsets) return;
+    // ---- chunk offset a_c = sum over the chunk of (K_{t0}^dagger ... K_{t-1}^dagger) S_t: X <- K_t^dagger X + S_t from X = 0, t = t1 - 1 .. t0, with
+    //      S_t[row][col] = (sum of 2 a_f over the forbidden levels f == row) |psi|^2 psi, psi = the state BEFORE slice t (regularization_functions.py:71-95,
+    //      qoc_state_source.h) -- this lane's own entry of the vectors the sweep above has just stored (the chunk-start vector for t0)
+    {
+        const int row = 16 * I + lc, col = 4 * jq0 + lk;
+        const bool inside = row < d.n && col < d.m;
+        double wrow = 0.0;
+        for (int f = 0; f < d.n_forb; ++f) wrow += (row == d.forb_state[f]) ? 2.0 * d.forb_a[f] : 0.0;
+        const cplx* mine = XL + (size_t)(I * MQs + jq0) * 64 + lane;             // + t (NT MQs) 64: this lane's entry of Psi after slice t
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the stores of the sweep above (this very lane's) have reached memory
+        auto source = [&](int t) -> cplx {                                        // tau = t: the state before slice t; 0 at tau = 0
+            const cplx p = t > t0 ? mine[(size_t)(t - 1) * (NT * MQs) * 64] : cmake(psr, psi_);
+            const double pop = p.x * p.x + p.y * p.y;
+            return (t > 0 && inside) ? cscale(p, wrow * pop) : cmake(0.0, 0.0);
+        };
+        const cplx* Ka = mf.KfD + kitem(mf, d.steps, b, t0);
+        sg = -1.0;
+        pre = 0.0; pim = 0.0;
+        load_frag(Ka + (size_t)(len - 1) * mf.FR, K0);
+        for (int j = 0; j < len; ++j) {
+            const int t = t1 - 1 - j;
+            const cplx add = source(t);
+            if (j + 1 < len) load_frag(Ka + (size_t)(len - 2 - j) * mf.FR, K1);
+            asm volatile("" ::: "memory");
+            product(K0);
+            pre += add.x; pim += add.y;
+            if (j + 1 < len) K0 = K1;
+        }
+        mf.AoffL[((size_t)b * mf.C + c) * (NT * MQs * 64) + (size_t)(I * MQs + jq0) * 64 + lane] = cmake(pre, pim);
+    }
 }
 
 // Fidelity and state-regulariser values of the latency mode with sources, straight from the register-layout vectors (k_loss reads the API

@@ -23,14 +23,20 @@ int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
     return 0;
 }
 
+// the chunk offsets of the source recursion come out of the forward sweep itself when the sources need nothing but Psi (undressed forbidden levels, no speed_up)
+static inline bool qoc_lat_offsets_in_sweep(const QocMfma& mf, const QocDev& d) {
+    return mf.lat_src_fast && !mf.lat_dressed && !d.has_speed && d.n_forb > 0 && !(getenv("QOC_LAT_OFFSETS_IN_SWEEP") && atoi(getenv("QOC_LAT_OFFSETS_IN_SWEEP")) == 0);
+}
+
 // forward and z-free adjoint sweep side by side: 2 x (seed, chunk, group of 4 columns) workgroups of NT waves (one row tile each)
 void qoc_mfma_latency_sweeps(QocMfma& mf, const QocDev& d, hipStream_t s) {
     // (with a state regulariser only the forward half: the costate needs the sources, i.e. the forward states, first)
     // (state regularisers on the batch kernels' recursion: the forward half only; on the thin source sweeps both halves, Lambda0 is used)
     const dim3 g((mf.lat_sources && !mf.lat_src_fast ? 1 : 2) * d.B * mf.C * mf.mq);
-    if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(256), 0, s, d, mf);
-    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(192), 0, s, d, mf);
-    else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(128), 0, s, d, mf);
+    const int co = qoc_lat_offsets_in_sweep(mf, d) ? 1 : 0;           // undressed forbidden levels: the forward role also leaves the chunk offsets of the source recursion
+    if (mf.NT == 4) hipLaunchKernelGGL(k_mfma_sweep_lat<4>, g, dim3(256), 0, s, d, mf, co);
+    else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_sweep_lat<3>, g, dim3(192), 0, s, d, mf, co);
+    else hipLaunchKernelGGL(k_mfma_sweep_lat<2>, g, dim3(128), 0, s, d, mf, co);
     if (mf.lat_src_fast) {                                             // fidelity + state-regulariser values straight from PsiL (instead of unpack + k_loss)
         const dim3 gl(d.B * ((d.steps + 1 + 15) / 16));
 #define QOC_LOSS(NTv) do { if (mf.lat_dressed) hipLaunchKernelGGL((k_mfma_loss_lat<NTv, true>), gl, dim3(1024), 0, s, d, mf); \
@@ -47,7 +53,8 @@ void qoc_mfma_latency_gradient(QocMfma& mf, const QocDev& d, const QocAdamDev* a
     if (mf.lat_src_fast) {
         // the source part of the costate: chunk offsets, group offsets, then the sweep that stores the total costate (k_loss has run)
         const dim3 gc(d.B * mf.C * mf.mq), gg(d.B * mf.NG * mf.mq), bs(64 * mf.NT);
-#define QOC_SRC1(NTv, DRv) do { hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gc, bs, 0, s, d, mf, 0); hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gg, bs, 0, s, d, mf, 1); \
+        const bool have_offsets = qoc_lat_offsets_in_sweep(mf, d);     // (k_mfma_sweep_lat has left them)
+#define QOC_SRC1(NTv, DRv) do { if (!have_offsets) hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gc, bs, 0, s, d, mf, 0); hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gg, bs, 0, s, d, mf, 1); \
                           hipLaunchKernelGGL((k_mfma_sweep_src<NTv, DRv>), gc, bs, 0, s, d, mf, 2); } while (0)
 #define QOC_SRC(NTv) do { if (mf.lat_dressed) QOC_SRC1(NTv, true); else QOC_SRC1(NTv, false); } while (0)
         if (mf.NT == 4) QOC_SRC(4); else if (mf.NT == 3) QOC_SRC(3); else QOC_SRC(2);
