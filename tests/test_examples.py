@@ -32,3 +32,13 @@ def test_two_transmon_cz_example():
     with contextlib.redirect_stdout(io.StringIO()):
         f = two_transmon_cz.main(iterations=400, quiet=True)
     assert f > 0.999
+
+
+def test_three_transmon_cz_example():
+    """n = 27, six controls, 19 forbidden levels + dwdt: a batch of 16 restarts on the batch kernels (active strips 7 of 8, affine costate), and one
+    control set in the latency mode -- end to end through Grape(), checked by re-simulating the returned pulse with exact propagators."""
+    import three_transmon_cz
+    with contextlib.redirect_stdout(io.StringIO()):
+        f16 = three_transmon_cz.main(iterations=800, restarts=16, quiet=True)
+        f1 = three_transmon_cz.main(iterations=400, restarts=1, quiet=True)
+    assert f16 > 0.995 and f1 > 0.99
