@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets(QocDev d, QocMfma mf) 
 // left operand = 4x4 blocks of Z^T from a wave-private LDS image.  The source term has conditional loads (waited for on the
 // spot), so it is evaluated before the next K_t is fetched.  163 -> 124 us per launch at the regularised C2 x 64.  FULL = true: the same
 // sweep from the terminal costate through the chunk boundaries, storing Lambda_t for k_mfma_grad (k >= 6 controls).
-template <int MQ, bool FULL>
+// QA: active 4-row strips of the padded K (ceil(n / 4)): the all-zero strips beyond are neither loaded nor multiplied.
+template <int MQ, bool FULL, int QA = 8>
 __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf) {
     constexpr int NT = 2;
     __shared__ __attribute__((aligned(16))) cplx o2_img[4][16 * F2_LDP];          // per wave: image[column j][row]
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];        // K[4q + lk][16 I + lc]
+            for (int q = 0; q < QA; ++q) fr.f[I][q] = F[(I * QQS + q) * 64 + lane];        // K[4q + lk][16 I + lc]
     };
     double sre[2][MQ], sim[2][MQ];
     auto source = [&](int t) {
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) { a[I][jb] = 0.0; bq[I][jb] = 0.0; cq[I][jb] = 0.0; }
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
+        for (int kb = 0; kb < QA; ++kb) {
             cplx v[MQ];
 #pragma unroll
             for (int jb = 0; jb < MQ; ++jb) v[jb] = img[(4 * jb + li4) * F2_LDP + 4 * kb + lk];   // Z[4 kb + lk][4 jb + li4]
@@ -609,7 +610,8 @@ __global__ void __launch_bounds__(256) k_mfma_grad_sum(QocDev d, QocMfma mf, int
 // MODE 3 (batch kernels without a state regulariser, round 3): no boundary recursion at all -- the z-free costate at the end of the chunk
 // comes from k_mfma_bnd_scan (BndA) and is scaled by -(2/m^2) z here.  In MODE 0 every item ran C - 1 boundary steps on the chunk products
 // that all chunks of its seed read at the same time: 6.8 us per step against 2.0 us per slice, 100 of the kernel's 165 us at 16 chunks.
-template <int MQ, bool SRC, int KC = 4, int MODE = 0>
+// QA: active 4-row strips of the padded K / chunk products (ceil(n / 4)); the zero strips beyond are neither loaded nor multiplied.
+template <int MQ, bool SRC, int KC = 4, int MODE = 0, int QA = 8>
 __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     constexpr int NT = 2;                                                       // KC = control images in LDS: 4, or 5 (k = 5 still fits the 160 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -662,7 +664,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
     };
     auto load_frag = [&](const cplx* __restrict__ F, Frag& fr) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) fr.f[q] = F[(h * QQS + q) * 64 + lane];
+        for (int q = 0; q < QA; ++q) fr.f[q] = F[(h * QQS + q) * 64 + lane];
     };
     // (ore, oim) <- rows of tile h of M^dagger Lambda, M given by its fragD fragment, Lambda by the image `bf` of the pair
     auto dagger_product = [&](const Frag& fr, int bf, double (&nre)[MQ], double (&nim)[MQ]) {
@@ -670,7 +672,7 @@ __global__ void __launch_bounds__(512) k_mfma_backward3(QocDev d, QocMfma mf) {
 #pragma unroll
         for (int jb = 0; jb < MQ; ++jb) { a[jb] = 0.0; bq[jb] = 0.0; cq[jb] = 0.0; }
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
+        for (int kb = 0; kb < QA; ++kb) {
             const cplx* src = (kb < 4 ? pad_lo : pad_hi) + (size_t)bf * 16 * B2_LDP + 4 * (kb & 3) + lk;
             const double br = fr.f[kb].x, bi = -fr.f[kb].y, bs = br + bi;
 #pragma unroll

@@ -6,11 +6,24 @@
 
 // k_mfma_downup for this problem: 4 or 5 control images in LDS, active 4-row strips of the padded propagators = ceil(n / 4)
 static const void* qoc_downup_kernel(const QocDev& d) {
-    const int qa = d.n > 28 ? 8 : (d.n > 24 ? 7 : (d.n > 20 ? 6 : 5));
+    const int qa = qoc_active_strips(d.n);
 #define QOC_DU(KCv) (qa == 8 ? (const void*)k_mfma_downup<2, KCv, 8> : qa == 7 ? (const void*)k_mfma_downup<2, KCv, 7> : \
                      qa == 6 ? (const void*)k_mfma_downup<2, KCv, 6> : (const void*)k_mfma_downup<2, KCv, 5>)
     return d.k == 5 ? QOC_DU(5) : QOC_DU(4);
 #undef QOC_DU
+}
+
+// the batch sweep k_mfma_backward3<MODE 0>; with a state regulariser (the route that takes it by default) on the active strips of K
+static const void* qoc_backward3_kernel(const QocMfma& mf, const QocDev& d) {
+    const bool src = d.n_forb > 0 || d.has_speed;
+    const int qa = qoc_active_strips(d.n);
+#define QOC_B3S(MQv, KCv) (qa == 8 ? (const void*)k_mfma_backward3<MQv, true, KCv, 0, 8> : qa == 7 ? (const void*)k_mfma_backward3<MQv, true, KCv, 0, 7> : \
+                           qa == 6 ? (const void*)k_mfma_backward3<MQv, true, KCv, 0, 6> : (const void*)k_mfma_backward3<MQv, true, KCv, 0, 5>)
+#define QOC_B3K(MQv, KCv) (src ? QOC_B3S(MQv, KCv) : (const void*)k_mfma_backward3<MQv, false, KCv>)
+    if (d.k == 5) return mf.mq <= 2 ? QOC_B3K(2, 5) : QOC_B3K(4, 5);
+    return mf.mq <= 2 ? QOC_B3K(2, 4) : QOC_B3K(4, 4);
+#undef QOC_B3K
+#undef QOC_B3S
 }
 
 int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_host,
@@ -147,12 +160,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         const int kc = d.k == 5 ? 5 : 4;
         mf.bwd_lds3 = (size_t)kc * FR * sizeof(cplx) + (size_t)8 * 2 * 16 * B2_LDP * sizeof(cplx) + 4 * 2 * 2 * 4 * kc * sizeof(double);
     }
-    const bool b3src = d.n_forb > 0 || d.has_speed;
-    const void* b3k = nullptr;
-#define QOC_B3K(MQv, KCv) (b3src ? (const void*)k_mfma_backward3<MQv, true, KCv> : (const void*)k_mfma_backward3<MQv, false, KCv>)
-    if (d.k == 5) b3k = mf.mq <= 2 ? QOC_B3K(2, 5) : QOC_B3K(4, 5);
-    else b3k = mf.mq <= 2 ? QOC_B3K(2, 4) : QOC_B3K(4, 4);
-#undef QOC_B3K
+    const void* b3k = qoc_backward3_kernel(mf, d);
     if (mf.latency) {
         if (qoc_mfma_latency_setup(mf, d, msg) != 0) return -2;
         void* p = nullptr;
@@ -222,8 +230,10 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     if ((d.n_forb > 0 || d.has_speed) && mf.C > 1) {
         if (NT == 2 && mf.variant != 1) {
             const int wpg = mf.lat_sources ? 1 : 4;                      // latency mode: one sweep per workgroup, i.e. per CU
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, false>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, false>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf);
+#define QOC_O2(QAv) do { if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, false, QAv>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf); \
+                         else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, false, QAv>), dim3((items + wpg - 1) / wpg), dim3(64 * wpg), 0, s, d, mf); } while (0)
+            QOC_QA_SWITCH(qoc_active_strips(d.n), QOC_O2);
+#undef QOC_O2
         } else {
             hipLaunchKernelGGL(k_mfma_bwd_offsets<NT>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
         }
@@ -245,8 +255,6 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
                 return;
             }
             const dim3 g3((items + 3) / 4), b3(512);                     // 4 pairs of waves per workgroup
-#define QOC_B3(MQv, SRCv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 5>), g3, b3, mf.bwd_lds3, s, d, mf); \
-                               else hipLaunchKernelGGL((k_mfma_backward3<MQv, SRCv, 4>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
 #define QOC_B3B(MQv) do { if (d.k == 5) hipLaunchKernelGGL((k_mfma_backward3<MQv, false, 5, 3>), g3, b3, mf.bwd_lds3, s, d, mf); \
                           else hipLaunchKernelGGL((k_mfma_backward3<MQv, false, 4, 3>), g3, b3, mf.bwd_lds3, s, d, mf); } while (0)
             if (mf.updown && !src) {
@@ -255,17 +263,20 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
                 (void)hipLaunchKernel(qoc_downup_kernel(d), gd, bd, kargs, mf.du_lds, s);
             }
             else if (mf.BndA && !src) { if (mf.mq <= 2) QOC_B3B(2); else QOC_B3B(4); }
-            else if (mf.mq <= 2) { if (src) QOC_B3(2, true); else QOC_B3(2, false); }
-            else { if (src) QOC_B3(4, true); else QOC_B3(4, false); }
+            else {
+                void* kargs[] = {(void*)&d, (void*)&mf};
+                (void)hipLaunchKernel(qoc_backward3_kernel(mf, d), g3, b3, kargs, mf.bwd_lds3, s);
+            }
 #undef QOC_B3B
-#undef QOC_B3
             return;
         }
         {
             // k >= 6: the control images fit in LDS next to no sweep's pads; costate sweep + slice-parallel gradient kernel (4 images
             // per pass) instead of the row-split 16x16x4 sweep reading them from L2 (C2 x 64 with k = 8: 1.55 vs 1.71 ms per iteration)
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+#define QOC_O2F(QAv) do { if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_bwd_offsets2<2, true, QAv>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf); \
+                          else hipLaunchKernelGGL((k_mfma_bwd_offsets2<4, true, QAv>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf); } while (0)
+            QOC_QA_SWITCH(qoc_active_strips(d.n), QOC_O2F);
+#undef QOC_O2F
             const int slices = d.B * d.steps;
             int gg = (slices + 3) / 4; if (gg > 2048) gg = 2048;
             if (mf.grad_rt) {

@@ -7,7 +7,7 @@ void qoc_mfma_launch_expm_inplace(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const dim3 grid(d.B * mf.C), block(64);
     const bool even = (d.T & 1) == 0, s0 = d.s == 0;
     // active 4-row strips of the padded 32 x 32 matrices: ceil(n / 4) (17 <= n <= 32: 5 .. 8)
-    const int qa = d.n > 28 ? 8 : (d.n > 24 ? 7 : (d.n > 20 ? 6 : 5));
+    const int qa = qoc_active_strips(d.n);
 #define QOC_IP(KCv, EVv, S0v) do { if (qa == 8) hipLaunchKernelGGL((k_mfma_expm_inplace<KCv, EVv, S0v, 8>), grid, block, 0, s, d, mf); \
                                    else if (qa == 7) hipLaunchKernelGGL((k_mfma_expm_inplace<KCv, EVv, S0v, 7>), grid, block, 0, s, d, mf); \
                                    else if (qa == 6) hipLaunchKernelGGL((k_mfma_expm_inplace<KCv, EVv, S0v, 6>), grid, block, 0, s, d, mf); \

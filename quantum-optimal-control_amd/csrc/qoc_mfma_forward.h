@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
 // BND: the chunk-start vectors come from k_mfma_bnd_scan (BndF) instead of a walk over the chunk products before this chunk.  Every
 // chunk of a seed walked the SAME products at the same time -- an L2 hot spot that made a boundary step 5.8 us against 2.6 us for a
 // slice of the sweep itself, half of the kernel's critical path at 16 chunks (profiles/r03_chunks_kernel_table.txt).
-template <int NT, int MQ, bool BND = false>
+// QA: active 4-column groups of the padded K (ceil(n / 4); the columns beyond are zero): neither loaded nor multiplied.
+template <int NT, int MQ, bool BND = false, int QA = 4 * NT>
 __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
     constexpr int LDP = 16 * NT + 1;
     __shared__ __attribute__((aligned(16))) cplx f2_img[4][16 * LDP];             // per wave: image[column j][row]
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
 #pragma unroll
             for (int I = 0; I < NT; ++I)
 #pragma unroll
-                for (int q = 0; q < QQS; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
+                for (int q = 0; q < QA; ++q)  // K^T[4q + lk][16 I + lc] = K[16 I + lc][4q + lk] gathered from fragD(K): quads of lanes (lk) read 64 contiguous bytes
                     fr.f[I][q] = F[((q >> 2) * QQS + 4 * I + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * (q & 3) + lk];
         };
         // Psi <- M Psi with M^T given by its fragD fragment
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256) k_mfma_forward2(QocDev d, QocMfma mf) {
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) { a[I][jb] = 0.0; bq[I][jb] = 0.0; cq[I][jb] = 0.0; }
 #pragma unroll
-            for (int kb = 0; kb < QQS; ++kb) {
+            for (int kb = 0; kb < QA; ++kb) {
                 cplx v[MQ];
 #pragma unroll
                 for (int jb = 0; jb < MQ; ++jb) v[jb] = img[(4 * jb + li4) * LDP + 4 * kb + lk];   // Psi[4 kb + lk][4 jb + li4]

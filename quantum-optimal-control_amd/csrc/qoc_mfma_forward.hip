@@ -2,6 +2,14 @@
 #include "qoc_kernels_mfma.h"
 #include "qoc_mfma_forward.h"
 
+// the NT = 2 sweep from the chunk boundaries of the scan, on the active column groups of K
+static void qoc_launch_forward2_bnd(QocMfma& mf, const QocDev& d, int sw, hipStream_t s) {
+#define QOC_F2(QAv) do { if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2, true, QAv>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf); \
+                         else hipLaunchKernelGGL((k_mfma_forward2<2, 4, true, QAv>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf); } while (0)
+    QOC_QA_SWITCH(qoc_active_strips(d.n), QOC_F2);
+#undef QOC_F2
+}
+
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.latency) { qoc_mfma_latency_sweeps(mf, d, s); return; }       // (final_state only when read back: qoc_mfma_final_state)
     const int items = d.B * mf.C + d.B * mf.NT;
@@ -15,8 +23,7 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
         if (mf.updown) {
             // the forward sweep runs inside k_mfma_downup (after the adjoint one); Psi_N for the loss came from the scan
         } else if (mf.NT == 2) {
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_forward2<2, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+            qoc_launch_forward2_bnd(mf, d, sw, s);
         } else {
             if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
             else hipLaunchKernelGGL((k_mfma_forward2<3, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
@@ -50,8 +57,7 @@ void qoc_mfma_final_state_batch(QocMfma& mf, const QocDev& d, hipStream_t s) {
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s) {
     if (mf.updown) {                                                              // k_mfma_downup keeps no Psi_t: the forward sweep, now
         const int sw = d.B * mf.C;
-        if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<2, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
-        else hipLaunchKernelGGL((k_mfma_forward2<2, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+        qoc_launch_forward2_bnd(mf, d, sw, s);
         return;
     }
     hipLaunchKernelGGL(k_mfma_unpack_inter, dim3(512), dim3(256), 0, s, d, mf, mf.mq <= 2 ? 2 : 4);
