@@ -549,7 +549,7 @@ static inline void qoc_gemm_expm_products(QocGemm& gm, const QocDev& d, hipStrea
 // K_t for all (seed, slice): the dominant part of the path (bracketed by the profiling events of the engine)
 static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N;
-    const size_t NN = (size_t)N * N, BS = (size_t)d.B * gm.SP;
+    const size_t BS = (size_t)d.B * gm.SP;
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
     if (gm.direct) {                                             // the chains apply the Taylor series themselves
