@@ -149,7 +149,9 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         const size_t xl = (size_t)d.B * d.steps * NT * (mf.mq <= 2 ? 2 : 4) * 64 * sizeof(cplx);
         if (mf.PsiL && (hipMemset(mf.PsiL, 0, xl) != hipSuccess || hipMemset(mf.LamL, 0, xl) != hipSuccess)) { msg = "MFMA path: clearing PsiL / LamL failed"; return -2; }
         // k_mfma_expm_inplace never writes the all-zero 4-row strips of a padded propagator (rows >= 4 ceil(n / 4)): they read as zero from here on
-        if (NT == 2 && d.n <= 28 && hipMemset(mf.KfD, 0, nk * sizeof(cplx)) != hipSuccess) { msg = "MFMA path: clearing the propagator buffer failed"; return -2; }
+        if (NT == 2 && d.n <= 28 && (hipMemset(mf.KfD, 0, nk * sizeof(cplx)) != hipSuccess || (mf.KfT && hipMemset(mf.KfT, 0, nk * sizeof(cplx)) != hipSuccess))) {
+            msg = "MFMA path: clearing the propagator buffers failed"; return -2;
+        }
     }
     const size_t pads = (size_t)4 * 16 * (16 * NT + 1) * sizeof(cplx);
     const size_t hbytes = (size_t)d.k * FR * sizeof(cplx);

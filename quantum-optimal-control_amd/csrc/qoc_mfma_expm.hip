@@ -45,8 +45,11 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     }
     if (v == 5 && NT == 2) {
         // latency mode: K_t by two waves per slice, then the chunk products and the products of groups of G chunks
-        if (d.k <= 4) hipLaunchKernelGGL(k_mfma_expm_slice2<4>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);
-        else hipLaunchKernelGGL(k_mfma_expm_slice2<8>, dim3(d.B * d.steps), dim3(128), 0, s, d, mf);
+#define QOC_SL2(QAv) do { if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_slice2<4, QAv>), dim3(d.B * d.steps), dim3(128), 0, s, d, mf); \
+                          else hipLaunchKernelGGL((k_mfma_expm_slice2<8, QAv>), dim3(d.B * d.steps), dim3(128), 0, s, d, mf); } while (0)
+        { static const bool all8 = getenv("QOC_LAT_QA8") && atoi(getenv("QOC_LAT_QA8")) != 0;   // A/B: the padded problem in full
+          QOC_QA_SWITCH_LAT(all8 ? 8 : qoc_active_strips_lat(d.n), QOC_SL2); }
+#undef QOC_SL2
         // (k_mfma_chain_rows2: the columns of the right operand split over the waves of a workgroup -- 9.8 -> 8.5 us per launch at C2)
         hipLaunchKernelGGL(k_mfma_chain_rows2<2>, dim3(d.B * mf.C * 8), dim3(128), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
         hipLaunchKernelGGL(k_mfma_chain_rows2<2>, dim3(d.B * mf.NG * 8), dim3(128), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);

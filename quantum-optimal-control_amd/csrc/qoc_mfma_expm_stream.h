@@ -497,7 +497,9 @@ __global__ void __launch_bounds__(64 * NT) k_mfma_chain_rows2(QocDev d, QocMfma 
 // row half, two barriers per product) 27.1 us -- beyond two waves the kernel is bound by its ~4 us of cold first loads after the
 // kernel boundary and by the publish / barrier / fetch latency of each product, not by its MFMAs (device-side clocks: assembly 4.2 us,
 // first product 1.3 us, the other five 7.3-10 us, output 0.6 us in the four-wave variant).
-template <int KC>
+// QA = active 4-row strips of the padded problem (ceil(n / 4), 5 .. 8): the all-zero row strips beyond are neither assembled nor multiplied
+// nor stored (QA^2 of the 64 block steps of a product); KfD / KfT keep the zeros of set-up there.
+template <int KC, int QA = 8>
 __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) {
     constexpr int NT = 2;
     __shared__ __attribute__((aligned(16))) cplx img[2][QNP * QLDS];
@@ -524,7 +526,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
     for (int kk = 0; kk <= KC; ++kk) {
         const cplx* H = mf.HfD + (size_t)(kk <= d.k ? kk : 0) * QFR + (J * QQS) * 64 + lane;
 #pragma unroll
-        for (int ib = 0; ib < QQS; ++ib) hst[kk][ib] = H[ib * 64];
+        for (int ib = 0; ib < QA; ++ib) hst[kk][ib] = H[ib * 64];
     }
     double ck[KC], bs0[KC], ma[KC];
 #pragma unroll
@@ -540,9 +542,16 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
         if (kk < d.k && J == 0 && lane == 0) { const size_t ci = ((size_t)b * d.k + kk) * d.steps + t; d.w[ci] = wk; d.u[ci] = uk; }
         ck[kk] = kk < d.k ? uk * inv_scale : 0.0;
     }
+    if constexpr (QA < QQS) {                                           // rows >= 4 QA of both images read as zero (fragD(K^T) is gathered from them)
+#pragma unroll
+        for (int ib = QA; ib < QQS; ++ib) {
+            const int o = (16 * J + (lane & 15)) * QLDS + 4 * ib + (lane >> 4);
+            img[0][o] = cmake(0.0, 0.0); img[1][o] = cmake(0.0, 0.0); imgs[0][o] = 0.0; imgs[1][o] = 0.0;
+        }
+    }
     Col A, X;
 #pragma unroll
-    for (int ib = 0; ib < QQS; ++ib) {
+    for (int ib = 0; ib < QA; ++ib) {
         double re = hst[0][ib].x * inv_scale, im = hst[0][ib].y * inv_scale;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) { re = fma(ck[kk], hst[kk + 1][ib].x, re); im = fma(ck[kk], hst[kk + 1][ib].y, im); }
@@ -552,7 +561,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
     int cur = 0;
     auto publish = [&](const Col& m) {                                  // own strips of the next left operand -> image `cur`, then meet the partner
 #pragma unroll
-        for (int ib = 0; ib < QQS; ++ib) {
+        for (int ib = 0; ib < QA; ++ib) {
             const int o = (16 * J + (lane & 15)) * QLDS + 4 * ib + (lane >> 4);
             img[cur][o] = cmake(m.re[ib], m.im[ib]);
             imgs[cur][o] = m.su[ib];
@@ -564,10 +573,10 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
     auto product = [&](const Col& p) {                                  // acc = (image cur) * p; the other image is free for the next publish
         const cplx* base = img[cur] + (lane >> 4) * QLDS + (lane & 3);
         const double* bases = imgs[cur] + (lane >> 4) * QLDS + (lane & 3);
-        constexpr int NS = QQS * QQS, RA = 3, RS = RA + 1;
+        constexpr int NS = QA * QA, RA = 3, RS = RA + 1;
         cplx vb[RS]; double sb[RS];
         auto fetch = [&](int st, int slot) {
-            const int kb = st / QQS, ib = st % QQS;
+            const int kb = st / QA, ib = st % QA;
             vb[slot] = base[4 * kb * QLDS + 4 * ib];
             sb[slot] = bases[4 * kb * QLDS + 4 * ib];
         };
@@ -575,7 +584,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
         for (int st = 0; st < RA; ++st) fetch(st, st);
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
-            const int kb = st / QQS, ib = st % QQS;
+            const int kb = st / QA, ib = st % QA;
             if (st + RA < NS) fetch(st + RA, (st + RA) % RS);
             lds_order();
             const cplx v = vb[st % RS];
@@ -601,7 +610,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
     {
         Col A2;
 #pragma unroll
-        for (int ib = 0; ib < QQS; ++ib) {
+        for (int ib = 0; ib < QA; ++ib) {
             const double re = a[ib] - bq[ib], im = cq[ib] - a[ib] - bq[ib];
             A2.re[ib] = re; A2.im[ib] = im; A2.su[ib] = re + im;
             X.re[ib] = fma(p_cT, re, fma(p_c1, A.re[ib], p_c0 * diag(ib)));
@@ -616,7 +625,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
                 cur ^= 1;                                               // same image again
                 const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
 #pragma unroll
-                for (int ib = 0; ib < QQS; ++ib) {
+                for (int ib = 0; ib < QA; ++ib) {
                     X.re[ib] = (a[ib] - bq[ib]) + fma(d1, A.re[ib], d0 * diag(ib));
                     X.im[ib] = fma(d1, A.im[ib], cq[ib] - a[ib] - bq[ib]);
                     X.su[ib] = X.re[ib] + X.im[ib];
@@ -631,7 +640,7 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
         publish(X);
         product(X);
 #pragma unroll
-        for (int ib = 0; ib < QQS; ++ib) {
+        for (int ib = 0; ib < QA; ++ib) {
             const double re = a[ib] - bq[ib], im = cq[ib] - a[ib] - bq[ib];
             X.re[ib] = re; X.im[ib] = im; X.su[ib] = re + im;
         }
@@ -640,10 +649,10 @@ __global__ void __launch_bounds__(128) k_mfma_expm_slice2(QocDev d, QocMfma mf) 
     // ---- K_t out: fragD(K) from the registers, fragD(K^T) through the image ------------------------------------------------------------
     const size_t item = kitem(mf, d.steps, b, t);
 #pragma unroll
-    for (int ib = 0; ib < QQS; ++ib) mf.KfD[item + (J * QQS + ib) * 64 + lane] = cmake(X.re[ib], X.im[ib]);
+    for (int ib = 0; ib < QA; ++ib) mf.KfD[item + (J * QQS + ib) * 64 + lane] = cmake(X.re[ib], X.im[ib]);
     publish(X);
 #pragma unroll
-    for (int q = 0; q < QQS; ++q) mf.KfT[item + (J * QQS + q) * 64 + lane] = img[cur][(4 * q + (lane >> 4)) * QLDS + 16 * J + (lane & 15)];
+    for (int q = 0; q < QA; ++q) mf.KfT[item + (J * QQS + q) * 64 + lane] = img[cur][(4 * q + (lane >> 4)) * QLDS + 16 * J + (lane & 15)];
     QOC_LAP(4)
     QOC_LAP_DONE
 }

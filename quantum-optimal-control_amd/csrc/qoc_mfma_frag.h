@@ -18,6 +18,9 @@
 // NT = 2 kernels templated on the ACTIVE 4-row strips of the padded 32 x 32 matrices (rows / columns >= n are zero): ceil(n / 4), at least 5
 static inline int qoc_active_strips(int n) { return n > 28 ? 8 : (n > 24 ? 7 : (n > 20 ? 6 : 5)); }
 #define QOC_QA_SWITCH(qa, F) do { switch (qa) { case 5: F(5); break; case 6: F(6); break; case 7: F(7); break; default: F(8); break; } } while (0)
+// latency mode (a smaller problem is padded to 32 there as well): also 2 and 4 strips for n <= 8 / n <= 16
+static inline int qoc_active_strips_lat(int n) { return n > 16 ? qoc_active_strips(n) : (n > 8 ? 4 : 2); }
+#define QOC_QA_SWITCH_LAT(qa, F) do { switch (qa) { case 2: F(2); break; case 4: F(4); break; case 5: F(5); break; case 6: F(6); break; case 7: F(7); break; default: F(8); break; } } while (0)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define QMFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
