@@ -32,7 +32,8 @@ extern "C" {
 
 #define QOC_PATH_AUTO 0
 #define QOC_PATH_GENERIC 1     /* any n: workgroup-cooperative complex-fp64 products from HBM/L2 */
-#define QOC_PATH_MFMA 2        /* n <= 64, unitary mode: register-resident MFMA chain kernels (v_mfma_f64_4x4x4 / 16x16x4; AUTO for n <= 32 batches) */
+#define QOC_PATH_MFMA 2        /* n <= 64: register-resident MFMA chain kernels (v_mfma_f64_4x4x4 / 16x16x4; AUTO for n <= 32 batches); unitary mode, and state
+                                * transfer with exactly anti-Hermitian generators (K_t = sum_{j < T} A^j / j! + the same thin sweeps; AUTO up to n = 48) */
 #define QOC_PATH_ST_FUSED 3    /* state transfer, n <= 64, m <= 4: register-resident generator, LDS vectors */
 #define QOC_PATH_GEMM 4        /* any n, m <= 32, both modes: fused LDS exponentials + product tree + persistent thin chains (n <= 64),
                                 * batched tiled MFMA GEMM launches above; state transfer by propagators or, with chunks = 1, directly */

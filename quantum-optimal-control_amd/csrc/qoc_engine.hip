@@ -323,6 +323,10 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
 static int refresh_final(qoc_engine* e) {
     if (!e->final_stale) return QOC_OK;
     if (e->path == QOC_PATH_GEMM) qoc_gemm_forward(e->gm, e->d, e->stream, true);      // the boundary chain once more, with X beside the vectors
+    else if (e->d.state_transfer) {                                                    // no final_state; unitary_scale from Psi_N
+        if (e->inter_stale) { qoc_mfma_unpack_inter(e->mf, e->d, e->stream); e->inter_stale = false; }
+        qoc_mfma_uscale_state_transfer(e->d, e->stream);
+    }
     else if (e->mf.latency) qoc_mfma_final_state(e->mf, e->d, e->stream);
     else qoc_mfma_final_state_batch(e->mf, e->d, e->stream);
     HIP_TRY(hipGetLastError());
@@ -486,9 +490,9 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
 
     // ---- path selection -----------------------------------------------------------------------------------------
     int path = cfg->path;
-    const bool mfma_ok = qoc_mfma_supported(d);
-    const bool st_ok = st_fused_supported(d);
     const bool antiherm = cfg->state_transfer ? qoc_all_antihermitian((const cplx*)Hs, n, k + 1) : true;
+    const bool mfma_ok = qoc_mfma_supported(d) && antiherm;          // (state transfer: the propagator's adjoint is the reference's gradient only then)
+    const bool st_ok = st_fused_supported(d);
     const bool gemm_ok = qoc_gemm_supported(d, antiherm);
     // Measured with tools/path_sweep.py (profiles/r01_path_sweep.txt):
     //  * unitary, n <= 32: the register-resident MFMA chain kernels win on throughput (1.8 vs 2.3 ms per iteration of 64
@@ -521,14 +525,24 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const bool lat_src = d.n_forb > 0 || d.has_speed;
     struct AutoPlan { int path; bool latency; bool gemm_direct; };
     // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by row)
+    // State transfer on the MFMA path (round 4, tools/st_path_sweep.py -> profiles/r04_state_transfer_paths.txt; m = 1, T = 10, 500 slices, ms per iteration,
+    // GEMM path / MFMA batch kernels / latency mode): n = 32 x 1: 0.125 / 0.300 / 0.073, x 4: 0.159 / 0.304 / 0.143, x 16: 0.388 / 0.324, x 64: 1.30 / 0.99,
+    // x 256: 2.00 (direct Taylor chains) / 3.78; n = 16 x 1: 0.126 / 0.192 / 0.063, x 8: 0.219 / 0.209 / 0.203, x 64: 1.28 / 0.34, x 256: 1.94 / 1.16;
+    // n = 48 x 1: 0.245 / 0.72 / 0.120, x 8: 1.02 / 0.77 / 0.58, x 16: 1.87 / 1.11, x 64: 2.60 / 3.31 (with forbidden levels 4.85 / 4.00);
+    // n = 64 (C3: k = 6, 1000 slices) x 1: 0.417 / 3.0 / 0.449, x 64: 9.73 / 18.1 -- so: the unitary table for n <= 32 and for 32 < n <= 48 with k <= 4 (NT = 3),
+    // the latency mode of n <= 16 up to 8 control sets, the GEMM route for up to 8 control sets from 25 levels on, and the direct Taylor chains of the GEMM
+    // path for the large batches they win (n <= 32: from 112 control sets of more than 20 levels, 28 with a state regulariser; n > 32: from 48, 112).
+    const bool st = cfg->state_transfer != 0;
+    const bool mfma_auto = mfma_ok && (!st || n <= 32 || (n <= 48 && k <= 4));
     auto plan_for = [&](int Bp) -> AutoPlan {
         const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= 32) || Bp >= 64);
         // 16 < n <= 32 below the latency mode's reach (long pulses): the GEMM route up to a few control sets, fewer the smaller the active part of the padded
         // matrices is (500 slices, GEMM route / MFMA batch kernels in ms: n = 32 x 6 0.290 / 0.315, x 8 0.340 / 0.318; n = 27 x 4 0.251 / 0.270, x 6 0.288 / 0.271;
         // n = 20 x 2 0.185 / 0.196, x 4 0.249 / 0.196; with a forbidden level n = 32 x 8 0.436 / 0.473, n = 27 x 8 level, n = 20 x 6 0.373 / 0.360)
         const int qa_g = (n + 3) / 4;
-        const int gemm_small = lat_src ? (qa_g <= 5 ? 5 : qa_g == 6 ? 6 : 8) : (qa_g <= 5 ? 2 : qa_g == 6 ? 3 : qa_g == 7 ? 5 : 7);
-        const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= 100));
+        const int gemm_small = (st && qa_g >= 7) ? 8 : lat_src ? (qa_g <= 5 ? 5 : qa_g == 6 ? 6 : 8) : (qa_g <= 5 ? 2 : qa_g == 6 ? 3 : qa_g == 7 ? 5 : 7);
+        const bool st_big = st && direct_ok && cfg->chunks <= 1 && (n <= 32 ? (Bp >= 112 && n > (lat_src ? 28 : 20)) : Bp >= (lat_src ? 112 : 48));
+        const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= 100) || st_big);
         const long long lat_work = (long long)Bp * steps;
         // 16 < n <= 32: the batch kernels work on the ACTIVE 4-row strips qa = ceil(n / 4) of the padded matrices since round 4 and take over earlier the
         // smaller n is (tools/padded_latency_sweep.py, 500 slices: n = 20 / 24 / 27 / 32 level at ~5 / 6 / 7 / 8.5 control sets; with a forbidden
@@ -536,16 +550,16 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         const int qa = (n + 3) / 4 < 5 ? 5 : (n + 3) / 4;
         const long long lat_limit = n <= 16 ? (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK)
                                             : (lat_src ? std::min<long long>(QOC_LATENCY_MAX_WORK_SRC, 768LL * qa) : 512LL * qa);
-        const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_ok && qoc_mfma_latency_ok(d) && steps >= 64 &&
+        const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_auto && qoc_mfma_latency_ok(d) && steps >= 64 &&
                               (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && Bp <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
                                 : n > 32 ? (lat_work <= 16384 && Bp <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
-                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? 16 : (lat_src ? 2 : 4)))) ||
+                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? 16 : (st ? 8 : (lat_src ? 2 : 4))))) ||
                                (Bp == 1 && steps <= 8192));
         AutoPlan p;
         p.latency = latency;
         p.gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && Bp >= ST_DIRECT_FROM));
         p.path = cfg->path != QOC_PATH_AUTO ? cfg->path
-                 : latency ? QOC_PATH_MFMA : (mfma_ok && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
+                 : latency ? QOC_PATH_MFMA : (mfma_auto && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
         return p;
     };
     const AutoPlan plan = plan_for(d.Bplan);
@@ -565,7 +579,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         path = QOC_PATH_GEMM;
     }
     if (path == QOC_PATH_MFMA && !mfma_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs unitary mode, n <= 64, m <= 16, k <= 8 (n=%d m=%d k=%d)", n, m, k));
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs n <= 64, m <= 16, k <= 8, a Taylor degree of 1 .. 22 and, in state transfer, exactly anti-Hermitian generators (n=%d m=%d k=%d T=%d)", n, m, k, d.T));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_GEMM && !gemm_ok)
@@ -583,8 +597,9 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;
         if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
-            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs unitary mode, n <= 32 with k <= 8 (or, with at most 4 dressed forbidden levels, n <= 64), "
-                                              "taylor_terms >= 2 (n=%d k=%d T=%d)", n, k, d.T));
+            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs n <= 32 with k <= 8 (or, with at most 4 dressed forbidden levels, n <= 64), "
+                                              "a Taylor degree >= 2 (n=%d k=%d T=%d)", n, k, d.T));
+        d.T = qoc_mfma_degree(d);                    // state transfer: sum_{j < T} A^j / j! is the polynomial of degree T - 1 (no squarings: d.s = 0)
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         e->chunks = e->mf.C;

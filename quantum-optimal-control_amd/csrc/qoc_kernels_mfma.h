@@ -33,8 +33,13 @@
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 
+// State transfer (round 4): matvecexp (tensorflow_state.py:77-97) applies sum_{j < T} A^j / j! to the vectors, i.e. the propagator is the Taylor polynomial of
+// degree T - 1 without squarings; with exactly anti-Hermitian generators its adjoint is the polynomial of -A that the reference's gradient (:99-133) applies,
+// so the MFMA path runs state transfer as K_t of that degree + the same thin sweeps (the caller checks the generators: qoc_all_antihermitian).
+// qoc_create lowers QocDev::T to the degree before qoc_mfma_setup; these predicates see the caller's T.
+static inline int qoc_mfma_degree(const QocDev& d) { return d.state_transfer ? d.T - 1 : d.T; }
 static inline bool qoc_mfma_supported(const QocDev& d) {
-    return !d.state_transfer && d.n <= 64 && d.m <= 16 && d.k <= 8 && d.T >= 1 && d.T <= 22;
+    return d.n <= 64 && d.m <= 16 && d.k <= 8 && qoc_mfma_degree(d) >= 1 && qoc_mfma_degree(d) <= 22;
 }
 
 // host: fragD image of a zero-padded n x n matrix (transpose optionally) for NT tiles per dimension
@@ -75,8 +80,8 @@ static inline int qoc_mfma_expm_variant(const QocMfma& mf, const QocDev& d) {
 static inline bool qoc_mfma_latency_ok(const QocDev& d) {
     if (d.n > 32)    // NT = 3 / 4: at most 4 DRESSED forbidden levels (more need the batch kernels' affine recursion, NT = 2 only); 32 < n <= 48 with
                      // more than 4 controls runs the NT = 4 kernels on the padded problem (NT = 3 keeps four control images in LDS)
-        return !d.state_transfer && d.n <= 64 && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22 && !(d.n_forb > 4 && d.forbid_dressed);
-    return !d.state_transfer && d.m <= 16 && d.k <= 8 && d.T >= 2 && d.T <= 22;
+        return d.n <= 64 && d.m <= 16 && d.k <= 8 && qoc_mfma_degree(d) >= 2 && qoc_mfma_degree(d) <= 22 && !(d.n_forb > 4 && d.forbid_dressed);
+    return d.m <= 16 && d.k <= 8 && qoc_mfma_degree(d) >= 2 && qoc_mfma_degree(d) <= 22;
 }
 
 // host entry points (defined next to their kernels)
@@ -86,6 +91,7 @@ void qoc_mfma_launch_expm_inplace(QocMfma& mf, const QocDev& d, hipStream_t s); 
 void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s);    // qoc_mfma_forward.hip
 void qoc_mfma_launch_backward(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_backward.hip
 void qoc_mfma_final_state(QocMfma& mf, const QocDev& d, hipStream_t s);       // qoc_mfma_expm.hip: latency mode, on read-back
+void qoc_mfma_uscale_state_transfer(const QocDev& d, hipStream_t s);            // qoc_mfma_forward.hip: state transfer on those routes, on read-back
 void qoc_mfma_final_state_batch(QocMfma& mf, const QocDev& d, hipStream_t s);   // qoc_mfma_forward.hip: k_mfma_downup batches, on read-back
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s);      // qoc_mfma_forward.hip: latency mode, on read-back
 int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg);    // qoc_mfma_latency.hip

@@ -354,6 +354,16 @@ __global__ void __launch_bounds__(64) k_mfma_uscale(QocDev d) {
     if (lane == 0) d.uscale[b] = part / (double)n;
 }
 
+// state transfer: unitary_scale = (sum_{a,j} |Psi_N[a][j]|^2)^2 / m^2      tensorflow_state.py:335 (k_loss forms it on the routes that launch it)
+__global__ void __launch_bounds__(64) k_mfma_uscale_st(QocDev d) {
+    const int b = blockIdx.x, nm = d.n * d.m, lane = threadIdx.x;
+    const cplx* fin = d.inter + ((size_t)b * (d.steps + 1) + d.steps) * nm;
+    double nrm = 0.0;
+    for (int o = lane; o < nm; o += 64) { const cplx f = fin[o]; nrm += f.x * f.x + f.y * f.y; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+    if (lane == 0) d.uscale[b] = nrm * nrm / ((double)d.m * (double)d.m);
+}
 
 // latency mode: d.inter[b][t + 1] (API layout, analysis.py:60) from PsiL[b][t]; launched when the vectors are read back
 __global__ void __launch_bounds__(256) k_mfma_unpack_inter(QocDev d, QocMfma mf, int MQ) {

@@ -15,8 +15,9 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const int items = d.B * mf.C + d.B * mf.NT;
     if (mf.BndF) {
         // chunk boundaries once per seed (forward, and the z-free adjoint ones when the backward sweep takes them), then the sweep
-        const int MQ = mf.mq <= 2 ? 2 : 4, waves = d.B * ((mf.BndA ? 2 : 1) * MQ + (mf.updown ? 0 : 4 * mf.NT));     // + the column blocks of final_state
-        const int flags = (mf.BndA ? 1 : 0) | (mf.updown ? 2 | 8 : 0);
+        const bool no_final = mf.updown || d.state_transfer;            // (state transfer has no final_state: tensorflow_state.py:244-261)
+        const int MQ = mf.mq <= 2 ? 2 : 4, waves = d.B * ((mf.BndA ? 2 : 1) * MQ + (no_final ? 0 : 4 * mf.NT));     // + the column blocks of final_state
+        const int flags = (mf.BndA ? 1 : 0) | (mf.updown ? 2 : 0) | (no_final ? 8 : 0);
         if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_bnd_scan<2>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, flags, (const cplx*)mf.PfT, (const cplx*)mf.PfD, mf.C);
         else hipLaunchKernelGGL(k_mfma_bnd_scan<3>, dim3((waves + 3) / 4), dim3(256), 0, s, d, mf, MQ, flags, (const cplx*)mf.PfT, (const cplx*)mf.PfD, mf.C);
         const int sw = d.B * mf.C;                                                // sweep items only: final_state comes from the scan
@@ -42,7 +43,7 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    if (!d.uscale_in_loss && !mf.updown) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
+    if (!d.uscale_in_loss && !mf.updown && !d.state_transfer) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
 }
 
 // k_mfma_downup batches: final_state = P_{C-1} ... P_0 U0 and unitary_scale of the last evaluation, when they are read back
@@ -52,6 +53,13 @@ void qoc_mfma_final_state_batch(QocMfma& mf, const QocDev& d, hipStream_t s) {
     const int MQ = mf.mq <= 2 ? 2 : 4, waves = d.B * 4 * mf.NT;
     hipLaunchKernelGGL(k_mfma_bnd_scan<2>, dim3((waves + 3) / 4), dim3(256), 0, s, dd, mf, MQ, (mf.BndA ? 1 : 0) | 4, (const cplx*)mf.PfT, (const cplx*)mf.PfD, mf.C);
     hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, dd);
+}
+
+// state transfer: unitary_scale of the last evaluation from Psi_N = d.inter[steps] (the routes whose loss is formed inside a sweep kernel), on read-back
+void qoc_mfma_uscale_state_transfer(const QocDev& d, hipStream_t s) {
+    QocDev dd = d;
+    dd.skip_done = 0;
+    hipLaunchKernelGGL(k_mfma_uscale_st, dim3(d.B), dim3(64), 0, s, dd);
 }
 
 void qoc_mfma_unpack_inter(QocMfma& mf, const QocDev& d, hipStream_t s) {

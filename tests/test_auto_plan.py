@@ -38,26 +38,31 @@ def lat_limit_nt2(n, state_reg):
     return min(LAT_WORK_SRC, 768 * qa) if state_reg else 512 * qa
 def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, hermitian=True):
     """DESIGN.md section 4, the AUTO table, as ordered rules -> the dict HipEngine.plan reports."""
-    if state_transfer:
+    st = state_transfer
+    deg = T - 1 if st else T                              # matvecexp sums j < T: the propagator is the Taylor polynomial of degree T - 1
+    direct_ok = st and n <= 64 and m <= 8
+
+    def gemm_state_transfer():
         # rows "state transfer ...": GEMM path; direct route for large batches (n <= 32: from 112 control sets, n <= 64: from 48) and for
         # non-Hermitian generators; the propagator route otherwise; m > 8 or n > 64 cannot run direct
-        direct_ok = n <= 64 and m <= 8
         if m > 32 or not (hermitian or direct_ok):
             return {'path': 'st_fused' if (n <= 64 and m <= 4 and k <= 8) else 'generic'}
         direct = direct_ok and (not hermitian or B >= (112 if n <= 32 else 48))
         return {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
-    mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= T <= 22
+    mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= deg <= 22 and hermitian
+    if st and not (mfma_ok and (n <= 32 or (n <= 48 and k <= 4))):
+        return gemm_state_transfer()                      # row "state transfer, n > 48 (or 32 < n <= 48 with k > 4), or generators that are not anti-Hermitian"
     if not mfma_ok:
         return {'path': 'gemm', 'route': 'unitary'} if m <= 32 else {'path': 'generic'}
     work = B * steps
     # row "latency mode": one or a few control sets
-    if T >= 2 and steps >= 64:
+    if deg >= 2 and steps >= 64:
         if n > 48 or (n > 32 and k > 4):
             lat = work <= LAT_WORK_NT4 and B <= 4
         elif n > 32:
             lat = work <= LAT_WORK_NT3 and B <= 8
         else:
-            lat = work <= lat_limit_nt2(n, state_reg) and B <= (16 if n > 16 else (2 if state_reg else 4))
+            lat = work <= lat_limit_nt2(n, state_reg) and B <= (16 if n > 16 else (8 if st else (2 if state_reg else 4)))
         lat = lat or (B == 1 and steps <= 8192)
     else:
         lat = False
@@ -66,11 +71,17 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         L = ceil_div(steps, ceil_div(steps, 8))
         return {'path': 'mfma', 'nt': nt, 'expm': 5, 'chunks': ceil_div(steps, L), 'sweeps': 'latency_sources' if state_reg else 'latency'}
     # rows "GEMM": 48 < n <= 64 below the NT = 4 batch sizes; 32 < n <= 48 with fewer than 8 control sets; 16 < n <= 32 with a few control sets
-    # (2 / 3 / 5 / 7 for ceil(n / 4) = 5 / 6 / 7 / 8; 5 / 6 / 8 / 8 with a state regulariser)
+    # (2 / 3 / 5 / 7 for ceil(n / 4) = 5 / 6 / 7 / 8; 5 / 6 / 8 / 8 with a state regulariser; state transfer: 8 from 25 levels on); state transfer: the
+    # large batches that the direct Taylor chains win (n <= 32: from 112 control sets of more than 20 levels -- 28 with a state regulariser; n > 32: from 48 -- 112)
     nt4_batch = n > 48 and ((k <= 4 and B >= 32) or B >= 64)
     qa = ceil_div(n, 4)
     gemm_small = ({5: 5, 6: 6}.get(qa, 8) if state_reg else {5: 2, 6: 3, 7: 5}.get(qa, 7)) if 16 < n <= 32 else 0
-    if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < 8) or (16 < n <= 32 and B <= gemm_small and m <= 8 and steps >= 100):
+    if st and qa >= 7 and 16 < n <= 32:
+        gemm_small = 8
+    st_big = direct_ok and ((B >= 112 and n > (28 if state_reg else 20)) if n <= 32 else B >= (112 if state_reg else 48))
+    if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < 8) or (16 < n <= 32 and B <= gemm_small and m <= 8 and steps >= 100) or st_big:
+        if st:
+            return gemm_state_transfer()
         return {'path': 'gemm', 'route': 'unitary', 'chains': 'persistent' if m <= 8 else 'launches'}
     # rows "MFMA batch kernels"
     nt = 1 if n <= 16 else 2 if n <= 32 else 3 if n <= 48 else 4
@@ -78,7 +89,7 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
     C = max(1, min(C, steps))
     C = ceil_div(steps, ceil_div(steps, C))
     if nt == 2:
-        expm = 8 if T >= 3 else ((4 if T == 2 else 3) if B * C >= 512 else 1)
+        expm = 8 if deg >= 3 else ((4 if deg == 2 else 3) if B * C >= 512 else 1)
         sweeps = 'row_tile_gradient' if k >= 6 else ('downup' if (m <= 8 and not state_reg) else 'pair')
     elif nt == 1:
         expm, sweeps = 1, 'one_wave'
@@ -191,15 +202,24 @@ def test_auto_plan_wide_and_odd_shapes():
         _run(_problem(n, k, steps, m, 5, 2, False, seed=3), B, expect, seed=B)
 
 
-ST_ROWS = [(64, 6, 1, 47, True), (64, 6, 1, 48, True), (33, 4, 2, 47, True), (33, 4, 2, 48, True), (32, 4, 1, 111, True), (32, 4, 1, 112, True),
-           (16, 3, 4, 111, True), (16, 3, 4, 112, True), (64, 6, 1, 3, False), (20, 3, 2, 1, False), (24, 3, 12, 4, True), (70, 3, 2, 50, True)]
+# (n, k, m, control sets, anti-Hermitian generators, forbidden levels): the GEMM-path routes either side of 48 / 112 control sets, the shapes the MFMA path
+# takes since round 4 (n <= 32; 32 < n <= 48 with k <= 4) on both sides of ITS limits (latency mode up to 8 control sets at n <= 16, the GEMM route up to 8
+# from 25 levels on, the direct Taylor chains for large batches), lossy generators, wide and large problems
+ST_ROWS = [(64, 6, 1, 47, True, True), (64, 6, 1, 48, True, True), (64, 6, 1, 1, True, True), (33, 6, 2, 47, True, True), (33, 6, 2, 48, True, True),
+           (33, 4, 2, 47, True, False), (33, 4, 2, 48, True, False), (48, 4, 1, 1, True, True), (48, 4, 1, 8, True, True), (48, 4, 1, 9, True, True),
+           (48, 4, 1, 111, True, True), (48, 4, 1, 112, True, True),
+           (32, 4, 1, 1, True, True), (32, 4, 1, 16, True, False), (32, 4, 1, 17, True, False), (32, 4, 1, 64, True, True), (32, 4, 1, 111, True, True), (32, 4, 1, 112, True, True),
+           (28, 4, 1, 112, True, True), (28, 4, 1, 112, True, False), (20, 4, 1, 112, True, False), (21, 4, 1, 112, True, False), (21, 4, 1, 111, True, False),
+           (16, 3, 4, 8, True, True), (16, 3, 4, 9, True, True), (16, 3, 4, 111, True, True), (16, 3, 4, 112, True, True), (8, 2, 1, 64, True, False),
+           (64, 6, 1, 3, False, True), (20, 3, 2, 1, False, True), (24, 3, 12, 4, True, True), (70, 3, 2, 50, True, True)]
+ST_LONG = [(27, 4, 1, 8, 640, False), (27, 4, 1, 9, 640, False), (32, 4, 1, 8, 600, True), (24, 4, 1, 8, 600, False), (16, 4, 1, 8, 600, False)]      # beyond the latency mode's reach: the GEMM route / the batch kernels
 
 
-@pytest.mark.parametrize('n,k,m,B,hermitian', ST_ROWS, ids=['n%d_m%d_B%d_%s' % (r[0], r[2], r[3], 'herm' if r[4] else 'nonherm') for r in ST_ROWS])
-def test_auto_plan_state_transfer_rows(n, k, m, B, hermitian):
-    steps = 100
+def _st_problem(n, k, m, steps, hermitian, reg):
     c = cases.case_c3(n=n, k=k, steps=steps, taylor=(8, 0), seed=5)
-    c['total_time'] = 4.0
+    c['total_time'] = 4.0 * steps / 100.0
+    if not reg:
+        c['reg_coeffs'] = {'dwdt': 1e-3}
     rng = np.random.default_rng(n + m)
     if m > 1:
         def vecs():
@@ -208,5 +228,17 @@ def test_auto_plan_state_transfer_rows(n, k, m, B, hermitian):
         c['states_concerned_list'], c['U'] = vecs(), vecs()
     if not hermitian:
         c['H0'] = c['H0'] + 0.05j * np.diag(np.arange(n) / n)          # a lossy drift: the generators are no longer anti-Hermitian
-    expect = expected_plan(n, k, m, steps, 8, B, state_transfer=True, hermitian=hermitian)
-    _run(c, B, expect, seed=B)
+    return c
+
+
+@pytest.mark.parametrize('n,k,m,B,hermitian,reg', ST_ROWS, ids=['n%d_k%d_m%d_B%d_%s%s' % (r[0], r[1], r[2], r[3], 'herm' if r[4] else 'nonherm', '_forb' if r[5] else '') for r in ST_ROWS])
+def test_auto_plan_state_transfer_rows(n, k, m, B, hermitian, reg):
+    steps = 100
+    expect = expected_plan(n, k, m, steps, 8, B, state_transfer=True, state_reg=reg, hermitian=hermitian)
+    _run(_st_problem(n, k, m, steps, hermitian, reg), B, expect, seed=B)
+
+
+@pytest.mark.parametrize('n,k,m,B,steps,reg', ST_LONG, ids=['n%d_B%d_%d%s' % (r[0], r[3], r[4], '_forb' if r[5] else '') for r in ST_LONG])
+def test_auto_plan_state_transfer_long_pulses(n, k, m, B, steps, reg):
+    expect = expected_plan(n, k, m, steps, 8, B, state_transfer=True, state_reg=reg)
+    _run(_st_problem(n, k, m, steps, True, reg), B, expect, seed=B)

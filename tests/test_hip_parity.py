@@ -247,6 +247,56 @@ def test_fused_state_transfer_parity(variant, path, chunks):
     eng.close()
 
 
+ST_MFMA_ROUTES = [(0, 0), (3, 8), (2, 2), (5, 4), (0, 5), (4, 5), (3, 1)]
+
+
+@pytest.mark.parametrize('chunks,kernel', ST_MFMA_ROUTES, ids=['auto_kernel', 'inplace_c3', 'chunk4_c2', 'chunk4s_c5', 'latency', 'latency_c4', 'chunk_c3'])
+@pytest.mark.parametrize('variant', ['c3_small', 'allreg_m2', 'n64_m1', 'n5_m2', 'n20_m3', 'n40_m2', 'n32_forb', 'm4_T1'])
+def test_state_transfer_on_the_mfma_path(variant, chunks, kernel):
+    """State transfer on the MFMA path (round 4): K_t = sum_{j < T} A_t^j / j! (degree T - 1, no squarings: what matvecexp applies to the vectors,
+    tensorflow_state.py:77-97) by the exponential kernels + the thin sweeps of the unitary mode; needs exactly anti-Hermitian generators.  Batch
+    kernels of every tile count (NT = 1 .. 4), padded sizes, the latency mode, with and without state regularisers, against the oracle."""
+    from quantum_optimal_control.core import hip_engine
+    if variant == 'c3_small':
+        c = cases.ALL_CASES['c3_small']()
+    elif variant == 'allreg_m2':
+        c = cases.case_state_small()
+        c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [5.0, 5.0], 'states_forbidden_list': [3, 4],
+                           'speed_up': 0.3, 'amplitude': 0.2}
+        c['Taylor_terms'] = [7, 0]
+    elif variant == 'n64_m1':
+        c = cases.case_c3(n=64, k=6, steps=30, taylor=(10, 0))
+    elif variant == 'n5_m2':
+        c = cases.case_state_small()
+    elif variant in ('n20_m3', 'n40_m2', 'n32_forb'):
+        n, m = {'n20_m3': (20, 3), 'n40_m2': (40, 2), 'n32_forb': (32, 1)}[variant]
+        c = cases.case_c3(n=n, k=4, steps=70, taylor=(8, 0), seed=31)
+        rng = np.random.default_rng(5)
+        vs = [rng.normal(size=n) + 1j * rng.normal(size=n) for _ in range(2 * m)]
+        c['states_concerned_list'] = [v / np.linalg.norm(v) for v in vs[:m]]
+        c['U'] = [v / np.linalg.norm(v) for v in vs[m:]]
+        c['total_time'] = 1.4
+        if variant != 'n32_forb':
+            c['reg_coeffs'] = {'dwdt': 1e-2}
+    else:
+        c = cases.case_state_small(); c['Taylor_terms'] = [1, 0]
+    sp = oracle_system(c)
+    rng = np.random.default_rng(11)
+    bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps)]
+    degree = sp.exp_terms - 1
+    undressed = True
+    ok = degree >= 1 and (kernel != 5 or (degree >= 2 and (sp.n <= 32 or undressed)))
+    if not ok:
+        with pytest.raises(hip_engine.QocError):
+            make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
+        return
+    eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=kernel)
+    assert eng.path == 2
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    eng.close()
+
+
 @pytest.mark.parametrize('variant', ['n40', 'n64_sources', 'n33_m20', 'n20_forced', 'n96_short'])
 def test_gemm_path_parity(variant):
     """Tiled-MFMA GEMM path (path 4: any n, m <= 32) against the oracle."""
@@ -694,8 +744,8 @@ def test_edge_cases_all_paths(name, c, path):
     sp = oracle_system(c)
     bases = [sp.base0, -1.5 * sp.base0 + 0.05]
     eng = make_engine(sp, n_seeds=2, path=path)
-    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'gemm_T23': 4, 'gemm_T47': 4, 'generic_T50': 1, 'st_m5_generic': 4, 'st_n65_generic': 4,
-              'st_nonhermitian_fused': 4, 'st_nonhermitian_generic': 1, 'state_small_auto': 4}
+    expect = {'n1_scalar': 2, 'gemm_m32': 4, 'gemm_n65': 4, 'gemm_k9': 4, 'gemm_T23': 4, 'gemm_T47': 4, 'generic_T50': 1, 'st_m5_generic': 2, 'st_n65_generic': 4,
+              'st_nonhermitian_fused': 4, 'st_nonhermitian_generic': 1, 'state_small_auto': 2}      # (state transfer with anti-Hermitian generators, n <= 32: the MFMA path since round 4)
     if name in expect:
         assert eng.path == expect[name], (name, eng.path)
     eng.set_base(np.stack(bases))
