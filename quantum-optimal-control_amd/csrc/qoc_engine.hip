@@ -530,7 +530,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // x 256: 2.00 (direct Taylor chains) / 3.78; n = 16 x 1: 0.126 / 0.192 / 0.063, x 8: 0.219 / 0.209 / 0.203, x 64: 1.28 / 0.34, x 256: 1.94 / 1.16;
     // n = 48 x 1: 0.245 / 0.72 / 0.120, x 8: 1.02 / 0.77 / 0.58, x 16: 1.87 / 1.11, x 64: 2.60 / 3.31 (with forbidden levels 4.85 / 4.00);
     // n = 64 (C3: k = 6, 1000 slices) x 1: 0.417 / 3.0 / 0.449, x 64: 9.73 / 18.1 -- so: the unitary table for n <= 32 and for 32 < n <= 48 with k <= 4 (NT = 3),
-    // the latency mode of n <= 16 up to 8 control sets, the GEMM route for up to 8 control sets from 25 levels on, and the direct Taylor chains of the GEMM
+    // the latency mode of n <= 16 up to 8 control sets and from 25 levels on up to 4, the GEMM route for up to 8 control sets from 25 levels on, and the direct Taylor chains of the GEMM
     // path for the large batches they win (n <= 32: from 112 control sets of more than 20 levels, 28 with a state regulariser; n > 32: from 48, 112).
     const bool st = cfg->state_transfer != 0;
     const bool mfma_auto = mfma_ok && (!st || n <= 32 || (n <= 48 && k <= 4));
@@ -553,7 +553,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_auto && qoc_mfma_latency_ok(d) && steps >= 64 &&
                               (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && Bp <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
                                 : n > 32 ? (lat_work <= 16384 && Bp <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
-                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? 16 : (st ? 8 : (lat_src ? 2 : 4))))) ||
+                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? ((st && qa_g >= 7) ? 4 : 16) : (st ? 8 : (lat_src ? 2 : 4))))) ||   // (state transfer from 25 levels on: 5 .. 8 control sets go to the GEMM route -- n = 32 x 8: 0.220 against 0.261 ms, with forbidden levels 0.272 / 0.316)
                                (Bp == 1 && steps <= 8192));
         AutoPlan p;
         p.latency = latency;

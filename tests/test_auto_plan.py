@@ -62,7 +62,7 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         elif n > 32:
             lat = work <= LAT_WORK_NT3 and B <= 8
         else:
-            lat = work <= lat_limit_nt2(n, state_reg) and B <= (16 if n > 16 else (8 if st else (2 if state_reg else 4)))
+            lat = work <= lat_limit_nt2(n, state_reg) and B <= ((4 if (st and ceil_div(n, 4) >= 7) else 16) if n > 16 else (8 if st else (2 if state_reg else 4)))
         lat = lat or (B == 1 and steps <= 8192)
     else:
         lat = False
@@ -205,7 +205,7 @@ def test_auto_plan_wide_and_odd_shapes():
 # (n, k, m, control sets, anti-Hermitian generators, forbidden levels): the GEMM-path routes either side of 48 / 112 control sets, the shapes the MFMA path
 # takes since round 4 (n <= 32; 32 < n <= 48 with k <= 4) on both sides of ITS limits (latency mode up to 8 control sets at n <= 16, the GEMM route up to 8
 # from 25 levels on, the direct Taylor chains for large batches), lossy generators, wide and large problems
-ST_ROWS = [(64, 6, 1, 47, True, True), (64, 6, 1, 48, True, True), (64, 6, 1, 1, True, True), (33, 6, 2, 47, True, True), (33, 6, 2, 48, True, True),
+ST_ROWS = [(32, 4, 1, 4, True, True), (32, 4, 1, 5, True, True), (25, 4, 1, 5, True, False), (24, 4, 1, 5, True, False), (64, 6, 1, 47, True, True), (64, 6, 1, 48, True, True), (64, 6, 1, 1, True, True), (33, 6, 2, 47, True, True), (33, 6, 2, 48, True, True),
            (33, 4, 2, 47, True, False), (33, 4, 2, 48, True, False), (48, 4, 1, 1, True, True), (48, 4, 1, 8, True, True), (48, 4, 1, 9, True, True),
            (48, 4, 1, 111, True, True), (48, 4, 1, 112, True, True),
            (32, 4, 1, 1, True, True), (32, 4, 1, 16, True, False), (32, 4, 1, 17, True, False), (32, 4, 1, 64, True, True), (32, 4, 1, 111, True, True), (32, 4, 1, 112, True, True),
