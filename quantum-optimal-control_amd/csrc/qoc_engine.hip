@@ -517,6 +517,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // (profiles/r02_latency_sweep.txt, r02_small_n_sweep.txt): C2 (500 slices) 0.083 ms against 0.189 (GEMM route) and 0.56 (batch
     // kernels) for one seed, still ahead at 12 seeds, level at 16; n <= 16 is padded to 32 and competes with the cheap NT = 1 batch
     // kernels: ahead up to 4 seeds (n = 16 x 500 slices: 0.081 against 0.203 ms for one seed, 0.163 against 0.213 for four)
+    // (round 4, with k_mfma_expm_slice2 on the active strips: ahead up to 6 control sets with or without a state regulariser -- n = 16 x 500 slices x 6: 0.180
+    // against 0.213 ms, with a forbidden level 0.250 against 0.280; x 8: 0.229 / 0.213 and 0.308 / 0.280; n = 9 x 300 x 6: 0.106 / 0.140; profiles/r04_small_n_latency.txt)
     // 32 < n <= 48 (NT = 3 kernels: k_mfma_expm_rows per slice, the same chains, sweeps and gradient): one trajectory of n = 48 x 500
     // slices 0.165 ms against 0.454 (GEMM route) and 0.84 (batch kernels); ahead up to 8 seeds (profiles/r02_mid_n_sweep.txt).
     // With a state regulariser (forbidden levels, speed_up) the backward half is the affine recursion of the batch kernels on the
@@ -553,7 +555,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_auto && qoc_mfma_latency_ok(d) && steps >= 64 &&
                               (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && Bp <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
                                 : n > 32 ? (lat_work <= 16384 && Bp <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
-                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? ((st && qa_g >= 7) ? 4 : 16) : (st ? 8 : (lat_src ? 2 : 4))))) ||   // (state transfer from 25 levels on: 5 .. 8 control sets go to the GEMM route -- n = 32 x 8: 0.220 against 0.261 ms, with forbidden levels 0.272 / 0.316)
+                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? ((st && qa_g >= 7) ? 4 : 16) : (st ? 8 : 6)))) ||   // (state transfer from 25 levels on: 5 .. 8 control sets go to the GEMM route -- n = 32 x 8: 0.220 against 0.261 ms, with forbidden levels 0.272 / 0.316)
                                (Bp == 1 && steps <= 8192));
         AutoPlan p;
         p.latency = latency;

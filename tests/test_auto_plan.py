@@ -3,10 +3,10 @@
 `qoc_create` (csrc/qoc_engine.hip, `plan_for`) picks path, kernel family, chunk count and sweep kernels from the problem shape and the
 batch; the thresholds are measured numbers.  A threshold edit must not silently route a shape to a kernel no test runs, so this file
   (1) restates the table of DESIGN.md section 4 as ordered RULES in Python (`expected_plan`), independent of the C++ text,
-  (2) walks batch sizes {1, 2, 4, 5, 8, 9, 16, 17, 31, 32, 63, 64, 111, 112} x n in {16, 17, 32, 33, 48, 49, 64} x k in {4, 5, 6, 8} x
+  (2) walks batch sizes {1, 2, 4, 5, 6, 7, 8, 9, 16, 17, 31, 32, 63, 64, 111, 112} x n in {16, 17, 32, 33, 48, 49, 64} x k in {4, 5, 6, 8} x
       {no state regulariser, forbidden level} in unitary mode (pulse lengths chosen so that seeds x slices falls on either side of the
       latency-mode limits -- 4608 / 4096 for n <= 16, 512 ceil(n / 4) / min(4096, 768 ceil(n / 4)) for 16 < n <= 32, 16384, 4096 --), and the state-transfer routes either side of 48 / 112 control sets,
-  (3) creates the AUTO engine for each (1032 unitary rows), asserts the plan it reports (`qoc_plan_describe`) is the expected one, and -- for the
+  (3) creates the AUTO engine for each (1240 unitary rows), asserts the plan it reports (`qoc_plan_describe`) is the expected one, and -- for the
       smallest and the largest batch that resolve to each distinct plan of a shape, i.e. on both sides of every threshold that changes the
       kernels -- checks the first and the last control set of the batch against the CPU oracle (reference: core/tensorflow_state.py:25-65,
       204-261, 323-356).
@@ -62,7 +62,7 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         elif n > 32:
             lat = work <= LAT_WORK_NT3 and B <= 8
         else:
-            lat = work <= lat_limit_nt2(n, state_reg) and B <= ((4 if (st and ceil_div(n, 4) >= 7) else 16) if n > 16 else (8 if st else (2 if state_reg else 4)))
+            lat = work <= lat_limit_nt2(n, state_reg) and B <= ((4 if (st and ceil_div(n, 4) >= 7) else 16) if n > 16 else (8 if st else 6))
         lat = lat or (B == 1 and steps <= 8192)
     else:
         lat = False
@@ -103,7 +103,7 @@ def unitary_rows():
     for n in (16, 17, 32, 33, 48, 49, 64):
         for k in (4, 5, 6, 8):
             for reg in (False, True):
-                for B in (1, 2, 4, 5, 8, 9, 16, 17, 31, 32, 63, 64, 111, 112):
+                for B in (1, 2, 4, 5, 6, 7, 8, 9, 16, 17, 31, 32, 63, 64, 111, 112):
                     # every (n, k, regulariser, batch) once at 130 slices; the (k = 4 / k = 5) columns also at the pulse lengths that put
                     # seeds x slices on either side of the latency mode's limit for this class of n
                     lens = {130}
