@@ -1,0 +1,123 @@
+// qoc_gemm_chain_dpp.h -- the direct state-transfer chain at N = 64, one state vector (BASELINE config 3): k_gemm_taylor_chain_dpp.
+// Reference semantics: core/tensorflow_state.py:88-96 (forward recursion psi_n = B psi_n, psi += psi_n / n!), :118-131 (backward, -B).
+//
+// One workgroup of four waves per seed walks all slices; a step is T - 1 DEPENDENT 64 x 64 complex mat-vecs, so what counts is the latency of
+// one mat-vec, not its throughput.  k_gemm_taylor_chain spends ~1100 cycles on one: eight ds_read_b128 of the vector per thread, 64 FMAs, a
+// 26-instruction DPP butterfly over 8 lanes, LDS write, barrier.  Here the generator arrives TRANSPOSED (column c = 1 KB contiguous:
+// k_gemm_assemble_rows on the transposed Hamiltonian stack, QocGemm::HsPT), wave w owns the columns 16 w .. 16 w + 15 and lane = row: the 16
+// vector entries of the wave live one per lane inside every row of 16 lanes and reach the FMAs through the double-precision DPP control
+// row_newbcast:j (v_fmac_f64_dpp, gfx90a+): a complex MAC is four VOP2 instructions, no LDS read of the vector, no butterfly.  What is left
+// of the exchange: the four waves' partial sums of a row meet in LDS -- one ds_write_b128 per lane, one barrier, four ds_read_b128, three
+// complex adds.  The sign of (sign * B) rides on the source modifiers of the DPP operand.  Measured with tools/taylor_dpp_probe.hip:
+// 0.28 us per mat-vec against 0.46.
+// The next-but-one generator (64 KB) is fetched two loads per Taylor term instead of as one burst of 16 per wave: the burst stalled the
+// four waves ~1500 cycles per slice on the vector-memory issue queue (probe: "between inner loops").
+#pragma once
+// (included by qoc_gemm_chains.h after ChainArgs and before the launchers)
+
+#define QOC_DPP_CMAC_(NS0, NS1, NS2, NS3, J) \
+    asm volatile("v_fmac_f64_dpp %0, " NS0 "%2, %4 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %1, " NS1 "%3, %4 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %0, " NS2 "%3, %5 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %1, " NS3 "%2, %5 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" \
+                 : "+v"(re), "+v"(im) : "v"(xr), "v"(xi), "v"(a[J].x), "v"(a[J].y))
+// (re, im) += +-(a[J] * x_J):  re += ar xr - ai xi,  im += ar xi + ai xr
+#define QOC_DPP_CMAC(J) do { if constexpr (NEG) QOC_DPP_CMAC_("-", "-", "", "-", J); else QOC_DPP_CMAC_("", "", "-", "", J); } while (0)
+
+// partial sums of this wave's 16 columns: lane = row; (xr, xi) = the vector entry 16 w + (lane & 15)
+template <bool NEG>
+__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], double xr, double xi, double& re, double& im) {
+    re = 0.0; im = 0.0;
+    asm volatile("s_nop 1" : "+v"(xr), "+v"(xi));          // VALU write of the entry -> DPP read: two wait states
+    QOC_DPP_CMAC(0); QOC_DPP_CMAC(1); QOC_DPP_CMAC(2); QOC_DPP_CMAC(3); QOC_DPP_CMAC(4); QOC_DPP_CMAC(5); QOC_DPP_CMAC(6); QOC_DPP_CMAC(7);
+    QOC_DPP_CMAC(8); QOC_DPP_CMAC(9); QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); QOC_DPP_CMAC(14); QOC_DPP_CMAC(15);
+}
+
+template <bool NEG>
+__device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b, cplx (*part)[4][64], const double* tinv) {
+    constexpr int N = 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int idx = 16 * w + (l & 15);                       // the vector entry this lane carries (replicated over the four rows of 16 lanes)
+    const bool owner = l < 16;
+    const cplx* Kp = a.K + b * a.sKb + (size_t)(16 * w) * N + l;           // column 16 w + c of the transposed image: + c * N
+    const cplx* Ep = a.E + b * a.sEb + (size_t)idx * QOC_TW;
+    cplx* Op = a.Out + b * a.sOb + (size_t)idx * a.ldO;
+    cplx xv = cmake(0.0, 0.0);
+    if (a.X0) xv = a.X0[b * a.sXb + (size_t)idx * QOC_TW];
+    if (a.store_initial && owner) *(Op - a.sOs) = xv;
+    const int last = a.len - 1;
+    const int nterms = a.nterms;
+    cplx* const my_part = &part[0][w][l];
+    const cplx* const rd_part = &part[0][0][idx];
+    int cur = 0;
+    // one Taylor term: v <- (sign B) v, out += v / ii!
+    auto term = [&](const cplx (&k)[16], int ii, double& outr, double& outi) {
+        double inv = tinv[ii & 63];
+        if (ii >= 64) { double fact = 1.0; for (int q = 2; q <= ii; ++q) fact *= (double)q; inv = 1.0 / fact; }
+        double pr, pi;
+        dpp_matvec16<NEG>(k, xv.x, xv.y, pr, pi);
+        my_part[cur * 256] = cmake(pr, pi);
+        lds_barrier();
+        const cplx s0 = rd_part[cur * 256], s1 = rd_part[cur * 256 + 64], s2 = rd_part[cur * 256 + 128], s3 = rd_part[cur * 256 + 192];
+        xv.x = (s0.x + s1.x) + (s2.x + s3.x);
+        xv.y = (s0.y + s1.y) + (s2.y + s3.y);
+        outr = fma(xv.x, inv, outr); outi = fma(xv.y, inv, outi);      // psi += psi_n / factorial     :95 / :131
+        cur ^= 1;                                                         // the next term writes the other buffer: one barrier per term
+    };
+    // slice j on the generator k with addend e; meanwhile the generator / addend of slice jn go into kn / en, two columns per term
+    auto step = [&](int j, const cplx (&k)[16], const cplx& e, cplx (&kn)[16], cplx& en, int jn) {
+        const int jc = min(jn, last);
+        const cplx* kj = Kp + (long long)jc * a.sKs;
+        en = Ep[(long long)jc * a.sEs];
+        double outr = xv.x, outi = xv.y;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            kn[2 * g] = kj[(2 * g) * N];
+            kn[2 * g + 1] = kj[(2 * g + 1) * N];
+            if (g + 1 < nterms) term(k, g + 1, outr, outi);
+        }
+        for (int ii = 9; ii < nterms; ++ii) term(k, ii, outr, outi);
+        xv = cmake(outr + e.x, outi + e.y);
+        if (owner) Op[(long long)j * a.sOs] = xv;
+    };
+    if (a.len > 0) {
+        cplx k0[16], k1[16], k2[16], e0, e1, e2;
+        {
+            const cplx* kj = Kp;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) k0[c] = kj[c * N];
+            e0 = Ep[0];
+            const int jc = min(1, last);
+            kj = Kp + (long long)jc * a.sKs;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) k1[c] = kj[c * N];
+            e1 = Ep[(long long)jc * a.sEs];
+        }
+        int j = 0;
+        for (; j + 3 <= a.len; j += 3) {
+            step(j, k0, e0, k2, e2, j + 2);
+            step(j + 1, k1, e1, k0, e0, j + 3);
+            step(j + 2, k2, e2, k1, e1, j + 4);
+        }
+        if (j < a.len) step(j, k0, e0, k2, e2, j + 2);
+        if (j + 1 < a.len) step(j + 1, k1, e1, k0, e0, j + 3);
+    }
+    if (a.Fin && owner) a.Fin[b * a.sFb + (size_t)idx * QOC_TW] = xv;
+}
+
+// Two argument sets in one launch, as k_gemm_taylor_chain: workgroups 0 .. nb0 - 1 run a0, the rest a1 (forward and z-free backward chain
+// side by side when there is no state regulariser)
+__global__ void __launch_bounds__(256) k_gemm_taylor_chain_dpp(ChainArgs a0, ChainArgs a1, int nb0) {
+    __shared__ __attribute__((aligned(16))) cplx part[2][4][64];
+    __shared__ double tinv[64];
+    const bool second = (int)blockIdx.x >= nb0;
+    const ChainArgs a = second ? a1 : a0;
+    const int b = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
+    if (threadIdx.x < 64) {
+        double fact = 1.0;
+        for (int ii = 2; ii <= (int)threadIdx.x; ++ii) fact *= (double)ii;   // the running factorial of :92-95
+        tinv[threadIdx.x] = 1.0 / fact;
+    }
+    lds_barrier();
+    if (a.sign < 0.0) taylor_chain_dpp_body<true>(a, b, part, tinv); else taylor_chain_dpp_body<false>(a, b, part, tinv);
+}

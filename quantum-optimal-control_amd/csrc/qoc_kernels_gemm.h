@@ -314,6 +314,8 @@ struct QocGemm {
     bool direct = false;      // state transfer as Taylor mat-vec chains on the assembled generators (one chunk, no propagators)
     bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
     cplx* HsP = nullptr;      // [k+1][N][N]
+    cplx* HsPT = nullptr;     // dpp_chain: the same stack transposed -- k_gemm_assemble_rows then writes the generators column-major
+    bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
     size_t tree_off[8];
@@ -365,6 +367,10 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     gm.persistent = N <= 64 && d.m <= 8;
     gm.MV = d.m <= 1 ? 1 : (d.m <= 2 ? 2 : (d.m <= 4 ? 4 : 8));
     gm.direct = direct && d.state_transfer && gm.persistent;
+    {
+        const char* e = getenv("QOC_CHAIN_DPP");                 // A/B switch: 0 = the butterfly kernel k_gemm_taylor_chain
+        gm.dpp_chain = gm.direct && N == 64 && gm.MV == 1 && !(e && e[0] == '0');
+    }
     int L = 0;
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
     // unitary chains get their chunk boundaries in log depth (k_gemm_scan_nodes), so a latency-bound launch (few (seed, chunk)
@@ -392,7 +398,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     size_t root_elems = 0;
     for (int cnt = gm.NC; cnt > 1; cnt = (cnt + 1) / 2) root_elems += (size_t)d.B * ((cnt + 1) / 2) * NN;
     const bool poly = !fused && !gm.direct;                      // launch-per-product route: A2 and ping-pong buffers
-    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && (fused || al((void**)&gm.A, BSP * NN * sizeof(cplx))) &&
+    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.HsPT, gm.dpp_chain ? hp.size() * sizeof(cplx) : 16) && (fused || al((void**)&gm.A, BSP * NN * sizeof(cplx))) &&
               (!poly || al((void**)&gm.P, BSP * NN * sizeof(cplx))) && (!poly || al((void**)&gm.A2, BSP * NN * sizeof(cplx))) &&
               al((void**)&gm.root, (gm.persistent && !d.state_transfer) ? root_elems * sizeof(cplx) : 16) &&
               al((void**)&gm.K, gm.direct ? 16 : BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
@@ -429,6 +435,13 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     }
     if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+    if (gm.dpp_chain) {
+        std::vector<cplx> ht(hp.size());
+        for (int kk = 0; kk <= d.k; ++kk)
+            for (int a = 0; a < N; ++a)
+                for (int c = 0; c < N; ++c) ht[(size_t)kk * NN + (size_t)c * N + a] = hp[(size_t)kk * NN + (size_t)a * N + c];
+        if (hipMemcpy(gm.HsPT, ht.data(), ht.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+    }
     // the persistent chain kernels write only the first m (<= 8) of the 32 thin columns; the rest must read as zero
     bool zeroed = hipMemset(gm.zthin, 0, thin * sizeof(cplx)) == hipSuccess &&
                   hipMemset(gm.interP, 0, BSP * thin * sizeof(cplx)) == hipSuccess &&
@@ -553,7 +566,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
     if (gm.direct) {                                             // the chains apply the Taylor series themselves
-        qoc_gemm_assemble_launch(d, gm.HsP, gm.A, N, gm.SP, 0, s);
+        qoc_gemm_assemble_launch(d, gm.dpp_chain ? gm.HsPT : gm.HsP, gm.A, N, gm.SP, 0, s);   // dpp_chain: generators column-major
         return;
     }
     if (N <= 64) {
@@ -659,9 +672,9 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             // no state regulariser: the costate is linear in the overlap z -- the backward chain starts from -(2/m^2) W and runs
             // beside the forward one; qoc_gemm_backward multiplies by z (C3 x 64: 13.2 -> 8 ms per iteration)
             hipLaunchKernelGGL(k_gemm_zfree_end, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, gm.Ebnd, N, NC);
-            qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s);
+            qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s, gm.dpp_chain);
         }
-        else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s);
+        else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s, gm.dpp_chain);
         hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
         return;
     }
@@ -782,7 +795,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC);
     }
     if (gm.direct) {
-        if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s);
+        if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s, gm.dpp_chain);
     } else if (gm.persistent) {
         ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
         memset(&sw, 0, sizeof sw);

@@ -247,6 +247,40 @@ def test_fused_state_transfer_parity(variant, path, chunks):
     eng.close()
 
 
+@pytest.mark.parametrize('n,steps,terms,reg', [(64, 31, 10, 'forbidden'), (64, 32, 10, 'none'), (50, 7, 13, 'forbidden'), (57, 2, 2, 'none'),
+                                               (64, 1, 5, 'forbidden'), (64, 5, 1, 'none'), (33, 9, 12, 'allreg'), (64, 12, 3, 'allreg')],
+                         ids=['n64_T10_forbidden', 'n64_T10_zfree', 'n50_T13_forbidden', 'n57_two_steps_T2', 'n64_one_step', 'n64_T1', 'n33_T12_allreg',
+                              'n64_T3_allreg'])
+def test_direct_route_on_the_dpp_chain(n, steps, terms, reg, monkeypatch):
+    """k_gemm_taylor_chain_dpp (csrc/qoc_gemm_chain_dpp.h: direct state-transfer route at N = 64 with ONE state vector, generators column-major,
+    vector entries through row_newbcast DPP, two prefetch loads per Taylor term): pulse lengths on every residue of the three-stage rotation,
+    Taylor orders below / at / above the eight unrolled terms, padded sizes, with sources (state regulariser: backward chain after the forward
+    one) and without (both chains side by side in one launch), three control sets -- against the oracle, and bit for bit against the
+    butterfly kernel k_gemm_taylor_chain where the summation order agrees (it does not: compared to 1e-13)."""
+    c = cases.case_c3(n=n, k=3, steps=steps, taylor=(terms, 0))
+    c['total_time'] = 0.1 * steps
+    if reg == 'none':
+        c['reg_coeffs'] = {}
+    elif reg == 'allreg':
+        c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [5.0, 5.0], 'states_forbidden_list': [n - 2, n - 1], 'speed_up': 0.3, 'amplitude': 0.2}
+    sp = oracle_system(c)
+    rng = np.random.default_rng(5)
+    bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 for _ in range(2)]
+    eng = make_engine(sp, n_seeds=3, path=4, chunks=1)
+    assert eng.path == 4 and eng.chunks == 1
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    r = eng.evaluate()
+    eng.close()
+    monkeypatch.setenv('QOC_CHAIN_DPP', '0')                       # the butterfly kernel on row-major generators
+    old = make_engine(sp, n_seeds=3, path=4, chunks=1)
+    old.set_base(np.stack(bases))
+    r0 = old.evaluate()
+    old.close()
+    np.testing.assert_allclose(r['loss'], r0['loss'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r['grad'], r0['grad'], rtol=0, atol=1e-13 * max(1.0, np.max(np.abs(r0['grad']))))
+
+
 ST_MFMA_ROUTES = [(0, 0), (3, 8), (2, 2), (5, 4), (0, 5), (4, 5), (3, 1)]
 
 
