@@ -641,6 +641,7 @@ int qoc_destroy(qoc_handle e) {
     if (!e) return QOC_OK;
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    qoc_gemm_teardown(e->gm);
     for (void* p : e->allocs) hipFree(p);
     for (hipEvent_t x : e->ev) hipEventDestroy(x);
     if (e->t0) hipEventDestroy(e->t0);

@@ -39,7 +39,9 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int idx = 16 * w + (l & 15);                       // the vector entry this lane carries (replicated over the four rows of 16 lanes)
     const bool owner = l < 16;
-    const cplx* Kp = a.K + b * a.sKb + (size_t)(16 * w) * N + l;           // column 16 w + c of the transposed image: + c * N
+    // scalar base + 32-bit lane offset: the loads take the saddr form, no 64-bit VALU address arithmetic between the FMAs of the chain
+    const cplx* Kp = a.K + b * a.sKb;
+    const unsigned koff = (unsigned)(16 * w) * N + l;                       // column 16 w + c of the transposed image: + c * N
     const cplx* Ep = a.E + b * a.sEb + (size_t)idx * QOC_TW;
     cplx* Op = a.Out + b * a.sOb + (size_t)idx * a.ldO;
     cplx xv = cmake(0.0, 0.0);
@@ -72,8 +74,8 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         double outr = xv.x, outi = xv.y;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            kn[2 * g] = kj[(2 * g) * N];
-            kn[2 * g + 1] = kj[(2 * g + 1) * N];
+            kn[2 * g] = kj[koff + (2 * g) * N];
+            kn[2 * g + 1] = kj[koff + (2 * g + 1) * N];
             if (g + 1 < nterms) term(k, g + 1, outr, outi);
         }
         for (int ii = 9; ii < nterms; ++ii) term(k, ii, outr, outi);
@@ -85,12 +87,12 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         {
             const cplx* kj = Kp;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) k0[c] = kj[c * N];
+            for (int c = 0; c < 16; ++c) k0[c] = kj[koff + c * N];
             e0 = Ep[0];
             const int jc = min(1, last);
             kj = Kp + (long long)jc * a.sKs;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) k1[c] = kj[c * N];
+            for (int c = 0; c < 16; ++c) k1[c] = kj[koff + c * N];
             e1 = Ep[(long long)jc * a.sEs];
         }
         int j = 0;

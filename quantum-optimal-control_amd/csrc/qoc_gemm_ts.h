@@ -179,7 +179,7 @@ static inline void qoc_gemm_ts_forward(QocGemm& gm, const QocDev& d, int r, hipS
 static inline void qoc_gemm_ts_suffix(QocGemm& gm, const QocDev& d, int G, hipStream_t s) {
     const int N = gm.N, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
-    hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid(thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC);        // Ebnd[NC - 1] = -(2 / m^2) z W
+    hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid(thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC, QOC_TW);        // Ebnd[NC - 1] = -(2 / m^2) z W
     hipLaunchKernelGGL(k_ts_copy, dim3(gemm_grid(thin)), dim3(256), 0, s, gm.ts_Er + (size_t)G * thin, (const cplx*)(gm.Ebnd + (size_t)(NC - 1) * thin), thin);
     GemmArgs g;
     memset(&g, 0, sizeof g);

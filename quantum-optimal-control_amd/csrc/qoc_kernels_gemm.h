@@ -46,8 +46,9 @@ __global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __r
 // The same with the k + 1 Hamiltonian entries of a thread held in registers over a run of (seed, slice) items (k <= 8, N*N a multiple of
 // 256): k_gemm_assemble re-reads them from L2 for every output entry -- (k + 1) x the written bytes through L2, 2.0 ms for the 4.2 GB of
 // C3 x 64 -- this one is bound by the HBM writes alone.  blockIdx.x = 256-entry column of the matrix, blockIdx.y = run of items.
+// (t0, tn): with tn > 0 the items are the slices t0 .. t0 + tn - 1 of EVERY seed (item = b * tn + t - t0), written to their usual place
 __global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq, int per,
-                                                             size_t item_first, size_t item_count) {
+                                                             size_t item_first, size_t item_count, int t0 = 0, int tn = 0) {
     const size_t NN = (size_t)N * N;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     const double inv = 1.0 / (double)(1 << sq);
@@ -57,7 +58,9 @@ __global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx
     const size_t items = item_first + item_count;
     const size_t i0 = item_first + (size_t)blockIdx.y * per, i1 = i0 + per < items ? i0 + per : items;
     for (size_t item = i0; item < i1; ++item) {
-        const int b = (int)(item / SP), t = (int)(item - (size_t)b * SP);
+        int b, t;
+        if (tn > 0) { b = (int)(item / tn); t = t0 + (int)(item - (size_t)b * tn); }
+        else { b = (int)(item / SP); t = (int)(item - (size_t)b * SP); }
         cplx acc = cmake(0.0, 0.0);
         if (t < d.steps) {
             acc = h[0];
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx
             for (int kk = 0; kk < 8; ++kk)
                 if (kk < d.k) { const double c = ub[(size_t)kk * d.steps]; acc.x = fma(c, h[kk + 1].x, acc.x); acc.y = fma(c, h[kk + 1].y, acc.y); }
         }
-        Aout[item * NN + e] = acc;
+        Aout[((size_t)b * SP + t) * NN + e] = acc;
     }
 }
 // S = c0*I + c1*A (+ cT*A2): top block of the Paterson-Stockmeyer recursion
@@ -152,20 +155,23 @@ __global__ void __launch_bounds__(1024) k_gemm_take_final(QocDev d, const cplx* 
 }
 // sources SrcP[b][tau] (padded thin, tau = 0..SP-1; zero for tau = 0 and tau > steps) and the costate at the END of the
 // last chunk Ebnd[b][NC-1]: -(2/m^2) z W, plus S_steps when there is no padded slice to add it through the recursion
-__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ Ebnd, int N, int SP, int NC) {
-    const size_t per = (size_t)N * QOC_TW;
+// `cols` = columns written per row: QOC_TW, or the MV vector slots in the direct route, whose Taylor chains read nothing else of a thin
+// panel (C3 x 64: 2.1 GB of zero columns, 0.34 ms per iteration, no longer written)
+__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ Ebnd, int N, int SP, int NC, int cols) {
+    const size_t per = (size_t)N * QOC_TW, perw = (size_t)N * cols;
     const bool need_src = d.n_forb > 0 || d.has_speed;
-    const size_t total = (size_t)d.B * (need_src ? SP : 1) * per;
+    const size_t total = (size_t)d.B * (need_src ? SP : 1) * perw;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
-        const size_t bt = o / per, e = o - bt * per;
+        const size_t bt = o / perw, ew = o - bt * perw;
         const int per_seed = need_src ? SP : 1;
         const int b = (int)(bt / per_seed), tau = (int)(bt - (size_t)b * per_seed);
-        const int row = (int)(e / QOC_TW), col = (int)(e - (size_t)row * QOC_TW);
+        const int row = (int)(ew / cols), col = (int)(ew - (size_t)row * cols);
+        const size_t e = (size_t)row * QOC_TW + col;
         const bool valid = row < d.n && col < d.m;
         if (need_src) {
             cplx s = cmake(0.0, 0.0);
             if (valid && tau >= 1 && tau <= d.steps) s = source_at(d, b, tau, row, col);
-            SrcP[o] = s;
+            SrcP[bt * per + e] = s;
         }
         if (tau == 0) {
             cplx v = cmake(0.0, 0.0);
@@ -315,6 +321,9 @@ struct QocGemm {
     bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
     cplx* HsP = nullptr;      // [k+1][N][N]
     cplx* HsPT = nullptr;     // dpp_chain: the same stack transposed -- k_gemm_assemble_rows then writes the generators column-major
+    // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled on a
+    // second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its state
+    hipStream_t aux = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr; int asm_split = 0;
     bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
@@ -456,7 +465,22 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         hipLaunchKernelGGL(k_gemm_pad_identity, dim3(4096), dim3(256), 0, 0, gm.K, d.B, N, d.steps, gm.SP);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { msg = "GEMM path: the padded propagators could not be set"; return -2; }
     }
+    {
+        // generators of the last 13/16 of the pulse assembled beside the forward chain's first part: beside each other a slice costs the chain
+        // ~4.1 us (2.95 alone) and the assembly ~0.95 us (0.85 alone), so the tail is ready when the first part ends
+        const char* e = getenv("QOC_ASM_OVERLAP");                  // A/B switch: 0 = one assembly launch in front of the chain
+        if (gm.dpp_chain && need_src && d.k <= 8 && d.steps >= 64 && !(e && e[0] == '0')) {
+            if (hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&gm.ev_ready, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&gm.ev_tail, hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: second stream / events could not be created"; return -2; }
+            gm.asm_split = (3 * d.steps) / 16;
+        }
+    }
     return 0;
+}
+static inline void qoc_gemm_teardown(QocGemm& gm) {
+    if (gm.aux) { hipStreamSynchronize(gm.aux); hipStreamDestroy(gm.aux); gm.aux = nullptr; }
+    if (gm.ev_ready) { hipEventDestroy(gm.ev_ready); gm.ev_ready = nullptr; }
+    if (gm.ev_tail) { hipEventDestroy(gm.ev_tail); gm.ev_tail = nullptr; }
 }
 
 template <bool CONJT, int EPI, int SK>
@@ -522,6 +546,15 @@ static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const
 }
 
 static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
+// the slices t0 .. t0 + tn - 1 of every seed (needs what k_gemm_assemble_rows needs: k <= 8, N*N a multiple of 256)
+static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int t0, int tn, hipStream_t s) {
+    const size_t NN = (size_t)N * N, items = (size_t)d.B * tn;
+    const int gx = (int)(NN / 256);
+    int per = (int)((items * gx + 8191) / 8192);
+    if (per < 4) per = 4;
+    const int gy = (int)((items + per - 1) / per);
+    hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, 0, per, (size_t)0, items, t0, tn);
+}
 static inline void qoc_gemm_assemble_launch(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int sq, hipStream_t s,
                                             size_t item_first = 0, size_t item_count = 0) {
     if (item_count == 0) item_count = (size_t)d.B * SP;
@@ -566,6 +599,14 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
     if (gm.direct) {                                             // the chains apply the Taylor series themselves
+        if (gm.asm_split > 0) {                                    // head on this stream, tail on the second one beside the forward chain's first part
+            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, 0, gm.asm_split, s);
+            hipEventRecord(gm.ev_ready, s);                         // the head has the memory system to itself (started together, both took as long as the whole)
+            hipStreamWaitEvent(gm.aux, gm.ev_ready, 0);
+            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_split, gm.SP - gm.asm_split, gm.aux);
+            hipEventRecord(gm.ev_tail, gm.aux);
+            return;
+        }
         qoc_gemm_assemble_launch(d, gm.dpp_chain ? gm.HsPT : gm.HsP, gm.A, N, gm.SP, 0, s);   // dpp_chain: generators column-major
         return;
     }
@@ -673,6 +714,15 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             // beside the forward one; qoc_gemm_backward multiplies by z (C3 x 64: 13.2 -> 8 ms per iteration)
             hipLaunchKernelGGL(k_gemm_zfree_end, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, gm.Ebnd, N, NC);
             qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s, gm.dpp_chain);
+        }
+        else if (gm.asm_split > 0) {
+            ChainArgs h = a, t = a;                              // slices [0, asm_split), then the rest from the state the first part leaves in Aoff
+            h.len = gm.asm_split; h.Fin = gm.Aoff; h.sFb = (long long)thin;
+            qoc_taylor_chain_launch(N, h, gm.zthin, d.B, s, true);
+            hipStreamWaitEvent(s, gm.ev_tail, 0);
+            t.K = a.K + (long long)gm.asm_split * a.sKs; t.X0 = gm.Aoff; t.sXb = (long long)thin;
+            t.Out = a.Out + (long long)gm.asm_split * a.sOs; t.len = a.len - gm.asm_split;
+            qoc_taylor_chain_launch(N, t, gm.zthin, d.B, s, true);
         }
         else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s, gm.dpp_chain);
         hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
@@ -792,7 +842,10 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     if (qoc_gemm_zfree_backward(gm, d)) {                     // the chain ran beside the forward one from -(2/m^2) W: Lambda_t = z Lambda0_t
         hipLaunchKernelGGL(k_gemm_scale_lam, dim3(gemm_grid((size_t)d.B * N * d.steps * gm.MV)), dim3(256), 0, s, d, gm.LamP, N, gm.ldW, d.steps * gm.MV);
     } else {
-    hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * thin)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC);
+    {
+        const int cols = gm.direct ? gm.MV : QOC_TW;
+        hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * N * cols)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC, cols);
+    }
     }
     if (gm.direct) {
         if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s, gm.dpp_chain);
