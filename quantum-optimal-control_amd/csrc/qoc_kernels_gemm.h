@@ -323,7 +323,7 @@ struct QocGemm {
     cplx* HsPT = nullptr;     // dpp_chain: the same stack transposed -- k_gemm_assemble_rows then writes the generators column-major
     // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled on a
     // second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its state
-    hipStream_t aux = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr; int asm_split = 0;
+    hipStream_t aux = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr; int asm_split = 0, asm_tail_wgs = 512;
     bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
@@ -466,13 +466,17 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { msg = "GEMM path: the padded propagators could not be set"; return -2; }
     }
     {
-        // generators of the last 13/16 of the pulse assembled beside the forward chain's first part: beside each other a slice costs the chain
-        // ~4.1 us (2.95 alone) and the assembly ~0.95 us (0.85 alone), so the tail is ready when the first part ends
+        // generators of the last 11/16 of the pulse assembled beside the forward chain's first part, by 512 long-running workgroups: the chain's
+        // prefetch shares the memory system with them (a slice costs it 4-5.6 us beside an unthrottled assembly against 2.9 alone); sweep of
+        // (workgroups, split) at C3 x 64, ms per iteration: (8192, 3/16) 6.81, (2048, 3/16) 6.79, (512, 5/16) 6.67, (512, 8/16) 6.77,
+        // (384, 6/16) 6.68, (256, 5/16) 7.35; one launch in front of the chain 7.03
         const char* e = getenv("QOC_ASM_OVERLAP");                  // A/B switch: 0 = one assembly launch in front of the chain
-        if (gm.dpp_chain && need_src && d.k <= 8 && d.steps >= 64 && !(e && e[0] == '0')) {
+        if (gm.dpp_chain && need_src && d.k <= 8 && d.steps >= 64 && d.B <= 128 && !(e && e[0] == '0')) {       // (256 chains fill the chip: 14.6 against 14.0 ms)
             if (hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&gm.ev_ready, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&gm.ev_tail, hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: second stream / events could not be created"; return -2; }
-            gm.asm_split = (3 * d.steps) / 16;
+            gm.asm_split = (5 * d.steps) / 16;
+            if (const char* t = getenv("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : 512;
+            if (const char* t = getenv("QOC_ASM_SPLIT16")) gm.asm_split = (atoi(t) * d.steps) / 16;
         }
     }
     return 0;
@@ -547,10 +551,10 @@ static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const
 
 static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
 // the slices t0 .. t0 + tn - 1 of every seed (needs what k_gemm_assemble_rows needs: k <= 8, N*N a multiple of 256)
-static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int t0, int tn, hipStream_t s) {
+static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int t0, int tn, hipStream_t s, int target_wgs = 8192) {
     const size_t NN = (size_t)N * N, items = (size_t)d.B * tn;
     const int gx = (int)(NN / 256);
-    int per = (int)((items * gx + 8191) / 8192);
+    int per = (int)((items * gx + target_wgs - 1) / target_wgs);
     if (per < 4) per = 4;
     const int gy = (int)((items + per - 1) / per);
     hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, 0, per, (size_t)0, items, t0, tn);
@@ -603,7 +607,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
             qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, 0, gm.asm_split, s);
             hipEventRecord(gm.ev_ready, s);                         // the head has the memory system to itself (started together, both took as long as the whole)
             hipStreamWaitEvent(gm.aux, gm.ev_ready, 0);
-            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_split, gm.SP - gm.asm_split, gm.aux);
+            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_split, gm.SP - gm.asm_split, gm.aux, gm.asm_tail_wgs);
             hipEventRecord(gm.ev_tail, gm.aux);
             return;
         }

@@ -560,13 +560,15 @@ def test_latency_mode_long_pulses_and_small_systems(n, k, steps, m, seeds):
 
 
 def test_auto_leaves_the_latency_mode_to_few_seeds():
-    """AUTO decides by seeds x time slices: many seeds of a small system stay on the NT = 1 batch kernels; with a state regulariser
-    the latency mode (its backward half on the batch kernels' affine recursion) still takes one or two seeds."""
+    """AUTO decides by seeds x time slices: many seeds of a small system stay on the NT = 1 batch kernels; the latency mode takes up to six
+    control sets of n <= 16 (re-measured in round 4), with a state regulariser as well (its backward half on the batch
+    kernels' affine recursion)."""
     from quantum_optimal_control.core import hip_engine
     c = cases.case_c2(n=9, k=2, steps=300, m=4, taylor=(5, 2), seed=3)
     sp = oracle_system(c)
     for seeds, reg, expect in ((1, {}, 'slice2'), (4, {}, 'slice2'), (8, {}, 'chunk'), (1, {'forbidden_coeff_list': [1.0], 'states_forbidden_list': [8]}, 'slice2'),
-                               (4, {'forbidden_coeff_list': [1.0], 'states_forbidden_list': [8]}, 'chunk')):
+                               (4, {'forbidden_coeff_list': [1.0], 'states_forbidden_list': [8]}, 'slice2'),
+                               (7, {'forbidden_coeff_list': [1.0], 'states_forbidden_list': [8]}, 'chunk')):
         eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling, reg_coeffs=reg, n_seeds=seeds)
         eng.set_base(np.zeros((seeds, sp.k, sp.steps)))
         eng.profile_enable(True)
