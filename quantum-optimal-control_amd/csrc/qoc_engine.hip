@@ -508,7 +508,6 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    20.54 at 64, 38.7 vs 40.7 at 128; at 32 seeds the GEMM path: 2.31 vs 2.59, 10.4 vs 10.7).
     // every batch-size-dependent choice below is taken for Bp = qoc_config.plan_seeds (else the local batch): a shard of a restart
     // batch then runs the same path, kernels and chunking as the whole batch would
-    const int ST_DIRECT_FROM = n <= 32 ? 112 : 48;
     const bool direct_ok = qoc_gemm_direct_supported(d);
     if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
         return bail(fail(QOC_ERR_INVALID, "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
@@ -525,6 +524,12 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // latency mode's chunks, with two-level boundaries (QocMfma::lat_sources): one C2 trajectory with dwdt + forbidden levels 0.189 ms
     // against 0.290 (GEMM route) and 0.72 (batch kernels); ahead up to ~4096 seed-slices (tools/c2_forbidden_single.py).
     const bool lat_src = d.n_forb > 0 || d.has_speed;
+    // n > 32 with ONE state vector: the direct route runs k_gemm_taylor_chain_dpp (round 4: 0.31 against 0.46 us per dependent mat-vec) and wins earlier --
+    // C3 (n = 64, k = 6, 1000 slices), propagator / direct route in ms: x 24 6.03 / 6.20, x 32 8.00 / 6.34; without forbidden levels (both chains side by side)
+    // x 12 2.81 / 3.12, x 16 3.74 / 3.18 (profiles/r04_c3_route_sweep.txt); n = 40, 48 with k = 4 x 500 slices, MFMA batch kernels / direct: x 24 1.48 / 1.64,
+    // x 32 1.84 / 1.70; with forbidden levels x 32 2.14 / 3.20, x 48 3.89 / 3.32 (profiles/r04_st_direct_sweep.txt)
+    const bool dpp_shape = n > 32 && m == 1;
+    const int ST_DIRECT_FROM = n <= 32 ? 112 : (dpp_shape ? (lat_src ? 28 : 14) : 48);
     struct AutoPlan { int path; bool latency; bool gemm_direct; };
     // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by row)
     // State transfer on the MFMA path (round 4, tools/st_path_sweep.py -> profiles/r04_state_transfer_paths.txt; m = 1, T = 10, 500 slices, ms per iteration,
@@ -543,7 +548,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         // n = 20 x 2 0.185 / 0.196, x 4 0.249 / 0.196; with a forbidden level n = 32 x 8 0.436 / 0.473, n = 27 x 8 level, n = 20 x 6 0.373 / 0.360)
         const int qa_g = (n + 3) / 4;
         const int gemm_small = (st && qa_g >= 7) ? 8 : lat_src ? (qa_g <= 5 ? 5 : qa_g == 6 ? 6 : 8) : (qa_g <= 5 ? 2 : qa_g == 6 ? 3 : qa_g == 7 ? 5 : 7);
-        const bool st_big = st && direct_ok && cfg->chunks <= 1 && (n <= 32 ? (Bp >= 112 && n > (lat_src ? 28 : 20)) : Bp >= (lat_src ? 112 : 48));
+        const bool st_big = st && direct_ok && cfg->chunks <= 1 && (n <= 32 ? (Bp >= 112 && n > (lat_src ? 28 : 20)) : Bp >= (dpp_shape ? (lat_src ? 48 : 32) : (lat_src ? 112 : 48)));
         const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= 100) || st_big);
         const long long lat_work = (long long)Bp * steps;
         // 16 < n <= 32: the batch kernels work on the ACTIVE 4-row strips qa = ceil(n / 4) of the padded matrices since round 4 and take over earlier the

@@ -41,13 +41,15 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
     st = state_transfer
     deg = T - 1 if st else T                              # matvecexp sums j < T: the propagator is the Taylor polynomial of degree T - 1
     direct_ok = st and n <= 64 and m <= 8
+    dpp = n > 32 and m == 1                               # the direct route's k_gemm_taylor_chain_dpp
 
     def gemm_state_transfer():
-        # rows "state transfer ...": GEMM path; direct route for large batches (n <= 32: from 112 control sets, n <= 64: from 48) and for
+        # rows "state transfer ...": GEMM path; direct route for large batches (n <= 32: from 112 control sets, n <= 64: from 48 -- with ONE state
+        # vector, where the direct route has the DPP Taylor chain since round 4: from 14, with a state regulariser from 28) and for
         # non-Hermitian generators; the propagator route otherwise; m > 8 or n > 64 cannot run direct
         if m > 32 or not (hermitian or direct_ok):
             return {'path': 'st_fused' if (n <= 64 and m <= 4 and k <= 8) else 'generic'}
-        direct = direct_ok and (not hermitian or B >= (112 if n <= 32 else 48))
+        direct = direct_ok and (not hermitian or B >= (112 if n <= 32 else ((28 if state_reg else 14) if dpp else 48)))
         return {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
     mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= deg <= 22 and hermitian
     if st and not (mfma_ok and (n <= 32 or (n <= 48 and k <= 4))):
@@ -72,13 +74,13 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         return {'path': 'mfma', 'nt': nt, 'expm': 5, 'chunks': ceil_div(steps, L), 'sweeps': 'latency_sources' if state_reg else 'latency'}
     # rows "GEMM": 48 < n <= 64 below the NT = 4 batch sizes; 32 < n <= 48 with fewer than 8 control sets; 16 < n <= 32 with a few control sets
     # (2 / 3 / 5 / 7 for ceil(n / 4) = 5 / 6 / 7 / 8; 5 / 6 / 8 / 8 with a state regulariser; state transfer: 8 from 25 levels on); state transfer: the
-    # large batches that the direct Taylor chains win (n <= 32: from 112 control sets of more than 20 levels -- 28 with a state regulariser; n > 32: from 48 -- 112)
+    # large batches that the direct Taylor chains win (n <= 32: from 112 control sets of more than 20 levels -- 28 with a state regulariser; n > 32: from 48 -- 112; with one state vector from 32 -- 48)
     nt4_batch = n > 48 and ((k <= 4 and B >= 32) or B >= 64)
     qa = ceil_div(n, 4)
     gemm_small = ({5: 5, 6: 6}.get(qa, 8) if state_reg else {5: 2, 6: 3, 7: 5}.get(qa, 7)) if 16 < n <= 32 else 0
     if st and qa >= 7 and 16 < n <= 32:
         gemm_small = 8
-    st_big = direct_ok and ((B >= 112 and n > (28 if state_reg else 20)) if n <= 32 else B >= (112 if state_reg else 48))
+    st_big = direct_ok and ((B >= 112 and n > (28 if state_reg else 20)) if n <= 32 else B >= (((48 if state_reg else 32) if dpp else (112 if state_reg else 48))))
     if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < 8) or (16 < n <= 32 and B <= gemm_small and m <= 8 and steps >= 100) or st_big:
         if st:
             return gemm_state_transfer()
@@ -205,9 +207,9 @@ def test_auto_plan_wide_and_odd_shapes():
 # (n, k, m, control sets, anti-Hermitian generators, forbidden levels): the GEMM-path routes either side of 48 / 112 control sets, the shapes the MFMA path
 # takes since round 4 (n <= 32; 32 < n <= 48 with k <= 4) on both sides of ITS limits (latency mode up to 8 control sets at n <= 16, the GEMM route up to 8
 # from 25 levels on, the direct Taylor chains for large batches), lossy generators, wide and large problems
-ST_ROWS = [(32, 4, 1, 4, True, True), (32, 4, 1, 5, True, True), (25, 4, 1, 5, True, False), (24, 4, 1, 5, True, False), (64, 6, 1, 47, True, True), (64, 6, 1, 48, True, True), (64, 6, 1, 1, True, True), (33, 6, 2, 47, True, True), (33, 6, 2, 48, True, True),
+ST_ROWS = [(32, 4, 1, 4, True, True), (32, 4, 1, 5, True, True), (25, 4, 1, 5, True, False), (24, 4, 1, 5, True, False), (64, 6, 1, 47, True, True), (64, 6, 1, 48, True, True), (64, 6, 1, 27, True, True), (64, 6, 1, 28, True, True), (64, 6, 1, 13, True, False), (64, 6, 1, 14, True, False), (64, 6, 2, 47, True, True), (64, 6, 2, 48, True, True), (64, 6, 1, 1, True, True), (33, 6, 2, 47, True, True), (33, 6, 2, 48, True, True),
            (33, 4, 2, 47, True, False), (33, 4, 2, 48, True, False), (48, 4, 1, 1, True, True), (48, 4, 1, 8, True, True), (48, 4, 1, 9, True, True),
-           (48, 4, 1, 111, True, True), (48, 4, 1, 112, True, True),
+           (48, 4, 1, 47, True, True), (48, 4, 1, 48, True, True), (48, 4, 1, 31, True, False), (48, 4, 1, 32, True, False), (48, 4, 2, 111, True, True), (48, 4, 2, 112, True, True),
            (32, 4, 1, 1, True, True), (32, 4, 1, 16, True, False), (32, 4, 1, 17, True, False), (32, 4, 1, 64, True, True), (32, 4, 1, 111, True, True), (32, 4, 1, 112, True, True),
            (28, 4, 1, 112, True, True), (28, 4, 1, 112, True, False), (20, 4, 1, 112, True, False), (21, 4, 1, 112, True, False), (21, 4, 1, 111, True, False),
            (16, 3, 4, 8, True, True), (16, 3, 4, 9, True, True), (16, 3, 4, 111, True, True), (16, 3, 4, 112, True, True), (8, 2, 1, 64, True, False),
