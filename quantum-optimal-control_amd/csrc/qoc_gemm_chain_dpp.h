@@ -33,7 +33,12 @@ __device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], double xr, dou
     QOC_DPP_CMAC(8); QOC_DPP_CMAC(9); QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); QOC_DPP_CMAC(14); QOC_DPP_CMAC(15);
 }
 
-template <bool NEG>
+// TS: the number of Taylor terms when it is known at compile time (10: C3 and the reference's examples; the guards of the unrolled terms and the LDS
+// reads of 1 / ii! go away), 0 = a.nterms (any), -1 = a.nterms >= 9 (the eight unrolled terms all run: no guards between them either)
+#ifndef QOC_DPP_NO_STATIC
+#define QOC_DPP_NO_STATIC 0     // 1 (A/B builds): ten terms through the a.nterms >= 9 instance
+#endif
+template <bool NEG, int TS>
 __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b, cplx (*part)[4][64], const double* tinv) {
     constexpr int N = 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -48,14 +53,19 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
     if (a.X0) xv = a.X0[b * a.sXb + (size_t)idx * QOC_TW];
     if (a.store_initial && owner) *(Op - a.sOs) = xv;
     const int last = a.len - 1;
-    const int nterms = a.nterms;
+    const int nterms = TS > 0 ? TS : a.nterms;
+    double inv_s[9];                                            // 1 / ii! of the unrolled terms, uniform: scalar registers
+#pragma unroll
+    for (int ii = 1; ii <= 8; ++ii) {
+        const double v = tinv[ii];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v)), hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+        inv_s[ii] = __hiloint2double((int)hi, (int)lo);
+    }
     cplx* const my_part = &part[0][w][l];
     const cplx* const rd_part = &part[0][0][idx];
     int cur = 0;
     // one Taylor term: v <- (sign B) v, out += v / ii!
-    auto term = [&](const cplx (&k)[16], int ii, double& outr, double& outi) {
-        double inv = tinv[ii & 63];
-        if (ii >= 64) { double fact = 1.0; for (int q = 2; q <= ii; ++q) fact *= (double)q; inv = 1.0 / fact; }
+    auto term = [&](const cplx (&k)[16], int ii, double inv, double& outr, double& outi) {
         double pr, pi;
         dpp_matvec16<NEG>(k, xv.x, xv.y, pr, pi);
         my_part[cur * 256] = cmake(pr, pi);
@@ -76,9 +86,13 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         for (int g = 0; g < 8; ++g) {
             kn[2 * g] = kj[koff + (2 * g) * N];
             kn[2 * g + 1] = kj[koff + (2 * g + 1) * N];
-            if (g + 1 < nterms) term(k, g + 1, outr, outi);
+            if (TS != 0 || g + 1 < nterms) term(k, g + 1, inv_s[g + 1], outr, outi);
         }
-        for (int ii = 9; ii < nterms; ++ii) term(k, ii, outr, outi);
+        for (int ii = 9; ii < nterms; ++ii) {
+            double inv = tinv[ii & 63];
+            if (ii >= 64) { double fact = 1.0; for (int q = 2; q <= ii; ++q) fact *= (double)q; inv = 1.0 / fact; }
+            term(k, ii, inv, outr, outi);
+        }
         xv = cmake(outr + e.x, outi + e.y);
         if (owner) Op[(long long)j * a.sOs] = xv;
     };
@@ -121,5 +135,7 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain_dpp(ChainArgs a0, Cha
         tinv[threadIdx.x] = 1.0 / fact;
     }
     lds_barrier();
-    if (a.sign < 0.0) taylor_chain_dpp_body<true>(a, b, part, tinv); else taylor_chain_dpp_body<false>(a, b, part, tinv);
+    if (a.nterms == 10 && !QOC_DPP_NO_STATIC) { if (a.sign < 0.0) taylor_chain_dpp_body<true, 10>(a, b, part, tinv); else taylor_chain_dpp_body<false, 10>(a, b, part, tinv); }
+    else if (a.nterms >= 9) { if (a.sign < 0.0) taylor_chain_dpp_body<true, -1>(a, b, part, tinv); else taylor_chain_dpp_body<false, -1>(a, b, part, tinv); }
+    else if (a.sign < 0.0) taylor_chain_dpp_body<true, 0>(a, b, part, tinv); else taylor_chain_dpp_body<false, 0>(a, b, part, tinv);
 }
