@@ -47,7 +47,7 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
     // scalar base + 32-bit lane offset: the loads take the saddr form, no 64-bit VALU address arithmetic between the FMAs of the chain
     const cplx* Kp = a.K + b * a.sKb;
     const unsigned koff = (unsigned)(16 * w) * N + l;                       // column 16 w + c of the transposed image: + c * N
-    const cplx* Ep = a.E + b * a.sEb + (size_t)idx * QOC_TW;
+    const cplx* Ep = a.E + b * a.sEb + (size_t)idx * (a.ldE > 0 ? a.ldE : QOC_TW);
     cplx* Op = a.Out + b * a.sOb + (size_t)idx * a.ldO;
     cplx xv = cmake(0.0, 0.0);
     if (a.X0) xv = a.X0[b * a.sXb + (size_t)idx * QOC_TW];

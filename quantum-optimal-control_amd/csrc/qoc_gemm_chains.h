@@ -22,6 +22,7 @@ struct ChainArgs {
     int len, m;
     int store_initial;                          // also store y0 at Out - sOs
     int nterms; double sign;                    // k_gemm_taylor_chain: y <- sum_{j<nterms} (sign*K)^j y / j!  (+ E)
+    int ldE;                                    // k_gemm_taylor_chain_dpp: row stride of E (0 = QOC_TW, the thin panels; 1 = one vector per step, contiguous)
 };
 
 // dpp_xor<OFF> and lds_barrier() live in qoc_common.h (the MFMA-path backward sweep uses them too).

@@ -157,7 +157,9 @@ __global__ void __launch_bounds__(1024) k_gemm_take_final(QocDev d, const cplx* 
 // last chunk Ebnd[b][NC-1]: -(2/m^2) z W, plus S_steps when there is no padded slice to add it through the recursion
 // `cols` = columns written per row: QOC_TW, or the MV vector slots in the direct route, whose Taylor chains read nothing else of a thin
 // panel (C3 x 64: 2.1 GB of zero columns, 0.34 ms per iteration, no longer written)
-__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ Ebnd, int N, int SP, int NC, int cols) {
+// `compact` (DPP chain, one vector): SrcP[b][tau][row] contiguous -- a thin panel puts the rows of ONE column 512 bytes apart, every 16-byte store its own
+// memory transaction (C3 x 64: 0.11 ms for 4 M entries)
+__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ Ebnd, int N, int SP, int NC, int cols, int compact = 0) {
     const size_t per = (size_t)N * QOC_TW, perw = (size_t)N * cols;
     const bool need_src = d.n_forb > 0 || d.has_speed;
     const size_t total = (size_t)d.B * (need_src ? SP : 1) * perw;
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict
         if (need_src) {
             cplx s = cmake(0.0, 0.0);
             if (valid && tau >= 1 && tau <= d.steps) s = source_at(d, b, tau, row, col);
-            SrcP[bt * per + e] = s;
+            SrcP[compact ? bt * (size_t)N + row : bt * per + e] = s;
         }
         if (tau == 0) {
             cplx v = cmake(0.0, 0.0);
@@ -323,7 +325,7 @@ struct QocGemm {
     cplx* HsPT = nullptr;     // dpp_chain: the same stack transposed -- k_gemm_assemble_rows then writes the generators column-major
     // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled on a
     // second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its state
-    hipStream_t aux = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr; int asm_split = 0, asm_tail_wgs = 512;
+    hipStream_t aux = nullptr, chain_s = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_fwd = nullptr, ev_p1 = nullptr; int asm_split = 0, asm_tail_wgs = 512;
     bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
@@ -472,10 +474,28 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         // (384, 6/16) 6.68, (256, 5/16) 7.35; one launch in front of the chain 7.03
         const char* e = getenv("QOC_ASM_OVERLAP");                  // A/B switch: 0 = one assembly launch in front of the chain
         if (gm.dpp_chain && need_src && d.k <= 8 && d.steps >= 64 && d.B <= 128 && !(e && e[0] == '0')) {       // (256 chains fill the chip: 14.6 against 14.0 ms)
-            if (hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&gm.ev_ready, hipEventDisableTiming) != hipSuccess ||
+            // disjoint CU sets for the two kernels that run beside each other: the assembly's workgroups otherwise land on the chains' CUs as well and
+            // take issue slots from waves whose every instruction is on the critical path.  QOC_ASM_CUMASK=0: plain second stream, chain on the engine's
+            {
+                const char* cm = getenv("QOC_ASM_CUMASK");
+                int ncu = 0, dv = 0;
+                if (hipGetDevice(&dv) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess) ncu = 0;
+                const int chain_cus = cm && atoi(cm) > 0 ? atoi(cm) : 112;
+                if (!(cm && cm[0] == '0') && ncu >= 128 && ncu <= 1024 && d.B + 16 <= chain_cus) {
+                    std::vector<uint32_t> mc((ncu + 31) / 32, 0u), ma((ncu + 31) / 32, 0u);
+                    for (int c = 0; c < ncu; ++c) (c < chain_cus ? mc : ma)[c / 32] |= 1u << (c % 32);
+                    if (hipExtStreamCreateWithCUMask(&gm.chain_s, (uint32_t)mc.size(), mc.data()) != hipSuccess) { gm.chain_s = nullptr; (void)hipGetLastError(); }
+                    else if (hipExtStreamCreateWithCUMask(&gm.aux, (uint32_t)ma.size(), ma.data()) != hipSuccess) { hipStreamDestroy(gm.chain_s); gm.chain_s = nullptr; gm.aux = nullptr; (void)hipGetLastError(); }
+                    if (gm.chain_s && (hipEventCreateWithFlags(&gm.ev_fwd, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&gm.ev_p1, hipEventDisableTiming) != hipSuccess)) { msg = "GEMM path: events could not be created"; return -2; }
+                }
+            }
+            if ((!gm.aux && hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&gm.ev_ready, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&gm.ev_tail, hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: second stream / events could not be created"; return -2; }
-            gm.asm_split = (5 * d.steps) / 16;
-            if (const char* t = getenv("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : 512;
+            // on shared CUs: 512 long-running workgroups from 5/16 of the pulse on; on its own CUs the assembly runs unthrottled from 4/16 on (C3 x 64, ms per
+            // iteration: masks of 80 / 96 / 112 / 128 CUs for the chains 6.31 / 6.31 / 6.25 / 6.34; shared CUs 6.40; 2048 workgroups 6.27 - 6.31; 3/16: 6.35 - 6.50)
+            gm.asm_split = ((gm.chain_s ? 4 : 5) * d.steps) / 16;
+            gm.asm_tail_wgs = gm.chain_s ? 8192 : 512;
+            if (const char* t = getenv("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : gm.asm_tail_wgs;
             if (const char* t = getenv("QOC_ASM_SPLIT16")) gm.asm_split = (atoi(t) * d.steps) / 16;
         }
     }
@@ -483,6 +503,9 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
 }
 static inline void qoc_gemm_teardown(QocGemm& gm) {
     if (gm.aux) { hipStreamSynchronize(gm.aux); hipStreamDestroy(gm.aux); gm.aux = nullptr; }
+    if (gm.chain_s) { hipStreamSynchronize(gm.chain_s); hipStreamDestroy(gm.chain_s); gm.chain_s = nullptr; }
+    if (gm.ev_fwd) { hipEventDestroy(gm.ev_fwd); gm.ev_fwd = nullptr; }
+    if (gm.ev_p1) { hipEventDestroy(gm.ev_p1); gm.ev_p1 = nullptr; }
     if (gm.ev_ready) { hipEventDestroy(gm.ev_ready); gm.ev_ready = nullptr; }
     if (gm.ev_tail) { hipEventDestroy(gm.ev_tail); gm.ev_tail = nullptr; }
 }
@@ -689,7 +712,8 @@ static inline ChainArgs qoc_gemm_direct_backward_args(const QocGemm& gm, const Q
     memset(&a, 0, sizeof a);
     a.K = gm.A + (size_t)(d.steps - 1) * NN; a.sKb = (long long)NN * gm.SP; a.sKs = -(long long)NN;
     a.X0 = gm.Ebnd; a.sXb = (long long)thin;
-    if (need_src) { a.E = gm.SrcP + (size_t)(d.steps - 1) * thin; a.sEb = (long long)thin * gm.SP; a.sEs = -(long long)thin; }
+    if (need_src && gm.dpp_chain) { a.E = gm.SrcP + (size_t)(d.steps - 1) * N; a.sEb = (long long)N * gm.SP; a.sEs = -(long long)N; a.ldE = 1; }   // compact sources
+    else if (need_src) { a.E = gm.SrcP + (size_t)(d.steps - 1) * thin; a.sEb = (long long)thin * gm.SP; a.sEs = -(long long)thin; }
     a.Out = gm.LamP + (long long)(d.steps - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOs = -gm.MV; a.ldO = gm.ldW;
     a.store_initial = 1; a.CI = 1; a.len = d.steps - 1; a.m = d.m; a.nterms = d.T; a.sign = -1.0;
     return a;
@@ -722,7 +746,14 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
         else if (gm.asm_split > 0) {
             ChainArgs h = a, t = a;                              // slices [0, asm_split), then the rest from the state the first part leaves in Aoff
             h.len = gm.asm_split; h.Fin = gm.Aoff; h.sFb = (long long)thin;
-            qoc_taylor_chain_launch(N, h, gm.zthin, d.B, s, true);
+            if (gm.chain_s) {                                    // the first part on its own CUs (the assembly tail runs on the others)
+                hipEventRecord(gm.ev_fwd, s);
+                hipStreamWaitEvent(gm.chain_s, gm.ev_fwd, 0);
+                qoc_taylor_chain_launch(N, h, gm.zthin, d.B, gm.chain_s, true);
+                hipEventRecord(gm.ev_p1, gm.chain_s);
+                hipStreamWaitEvent(s, gm.ev_p1, 0);
+            }
+            else qoc_taylor_chain_launch(N, h, gm.zthin, d.B, s, true);
             hipStreamWaitEvent(s, gm.ev_tail, 0);
             t.K = a.K + (long long)gm.asm_split * a.sKs; t.X0 = gm.Aoff; t.sXb = (long long)thin;
             t.Out = a.Out + (long long)gm.asm_split * a.sOs; t.len = a.len - gm.asm_split;
@@ -848,7 +879,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     } else {
     {
         const int cols = gm.direct ? gm.MV : QOC_TW;
-        hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * N * cols)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC, cols);
+        hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * N * cols)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC, cols, gm.dpp_chain ? 1 : 0);
     }
     }
     if (gm.direct) {
