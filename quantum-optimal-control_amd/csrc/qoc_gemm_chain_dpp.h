@@ -49,6 +49,8 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
     const unsigned koff = (unsigned)(16 * w) * N + l;                       // column 16 w + c of the transposed image: + c * N
     const cplx* Ep = a.E + b * a.sEb + (size_t)idx * (a.ldE > 0 ? a.ldE : QOC_TW);
     cplx* Op = a.Out + b * a.sOb + (size_t)idx * a.ldO;
+    cplx* O2 = a.Out2 ? a.Out2 + b * a.sO2b + idx : nullptr;
+    const bool owner2 = owner && a.Out2 && idx < a.n2;
     cplx xv = cmake(0.0, 0.0);
     if (a.X0) xv = a.X0[b * a.sXb + (size_t)idx * QOC_TW];
     if (a.store_initial && owner) *(Op - a.sOs) = xv;
@@ -95,6 +97,7 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         }
         xv = cmake(outr + e.x, outi + e.y);
         if (owner) Op[(long long)j * a.sOs] = xv;
+        if (owner2) O2[(long long)j * a.sO2s] = xv;
     };
     if (a.len > 0) {
         cplx k0[16], k1[16], k2[16], e0, e1, e2;

@@ -22,6 +22,7 @@ struct ChainArgs {
     int len, m;
     int store_initial;                          // also store y0 at Out - sOs
     int nterms; double sign;                    // k_gemm_taylor_chain: y <- sum_{j<nterms} (sign*K)^j y / j!  (+ E)
+    cplx* Out2; long long sO2b, sO2s; int n2;   // k_gemm_taylor_chain_dpp: second copy of the output, rows < n2 contiguous per step (the API's inter_vecs: no unpad pass)
     int ldE;                                    // k_gemm_taylor_chain_dpp: row stride of E (0 = QOC_TW, the thin panels; 1 = one vector per step, contiguous)
 };
 

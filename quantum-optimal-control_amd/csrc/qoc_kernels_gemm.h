@@ -538,10 +538,11 @@ static inline bool qoc_gemm_takes_wg(const QocGemm& gm, const GemmArgs& g) {
     const bool split = tiles * 2 <= QOC_SK_TARGET && (g.Kdim / 2) % 8 == 0;
     return !split && (g.tiles_m & 1) == 0 && (g.tiles_n & 3) == 0 && (g.Kdim % ZW_KC) == 0 && g.Kdim >= 128 && tiles >= 8 * 1024;
 }
-static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const GemmArgs& g, hipStream_t s) {
+// sk_tiles: tile count the split-K factor is chosen for when the launch is one PART of a product (the parts must sum in the order of the whole)
+static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const GemmArgs& g, hipStream_t s, size_t sk_tiles = 0) {
     const size_t real_tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
     const unsigned blocks = (unsigned)real_tiles;
-    const size_t tiles = (size_t)((double)real_tiles * gm.plan_scale + 0.5);
+    const size_t tiles = (size_t)((double)(sk_tiles ? sk_tiles : real_tiles) * gm.plan_scale + 0.5);
     int sk = 1;
     if (tiles * 2 <= QOC_SK_TARGET && (g.Kdim / 2) % 8 == 0) sk = 2;
     if (tiles * 4 <= QOC_SK_TARGET && (g.Kdim / 4) % 8 == 0) sk = 4;
@@ -737,6 +738,9 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
         a.X0 = gm.Psibnd; a.sXb = (long long)thin;
         a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOs = gm.MV; a.ldO = gm.ldW;
         a.CI = 1; a.len = d.steps; a.m = d.m; a.nterms = d.T; a.sign = 1.0;
+        if (gm.dpp_chain) {                                      // the chain writes inter[b][t + 1] itself (one vector: n contiguous entries per step)
+            a.Out2 = d.inter + d.n; a.sO2b = (long long)(d.steps + 1) * d.n; a.sO2s = d.n; a.n2 = d.n;
+        }
         if (qoc_gemm_zfree_backward(gm, d)) {
             // no state regulariser: the costate is linear in the overlap z -- the backward chain starts from -(2/m^2) W and runs
             // beside the forward one; qoc_gemm_backward multiplies by z (C3 x 64: 13.2 -> 8 ms per iteration)
@@ -756,11 +760,11 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             else qoc_taylor_chain_launch(N, h, gm.zthin, d.B, s, true);
             hipStreamWaitEvent(s, gm.ev_tail, 0);
             t.K = a.K + (long long)gm.asm_split * a.sKs; t.X0 = gm.Aoff; t.sXb = (long long)thin;
-            t.Out = a.Out + (long long)gm.asm_split * a.sOs; t.len = a.len - gm.asm_split;
+            t.Out = a.Out + (long long)gm.asm_split * a.sOs; t.Out2 = a.Out2 + (long long)gm.asm_split * a.sO2s; t.len = a.len - gm.asm_split;
             qoc_taylor_chain_launch(N, t, gm.zthin, d.B, s, true);
         }
         else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s, gm.dpp_chain);
-        hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
+        if (!gm.dpp_chain) hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
         return;
     }
     if (gm.persistent && d.state_transfer) {
@@ -869,6 +873,23 @@ static inline void qoc_gemm_bwd_sweep(QocGemm& gm, const QocDev& d, hipStream_t 
     }
 }
 
+// gradients from the time-major wide layout: one product H_k' [Psi_0 ... Psi_{SP-1}] per control (batch = seeds), contracted column by column
+// with conj(Lambda) (tensorflow_state.py:61-63) -- the columns [c_first, c_end) (multiples of 32) of it
+static inline void qoc_gemm_wide_gradient(QocGemm& gm, const QocDev& d, hipStream_t s, int c_first, int c_end) {
+    const int N = gm.N, tm = N / 32;
+    const size_t NN = (size_t)N * N;
+    GemmArgs h;
+    memset(&h, 0, sizeof h);
+    h.lda = N; h.ldb = h.ldl = gm.ldW; h.Kdim = N;
+    h.tiles_m = tm; h.tiles_n = (c_end - c_first) / 32; h.Bm = gm.interP + c_first; h.L = gm.LamP + c_first;
+    h.partial = gm.partial + c_first; h.ldp = gm.ldW; h.partial_stride = tm * gm.ldW;         // partial[b][k][tile_m][column]
+    // one launch for all (seed, control) pairs: batch index bt = b*k + kk -> A = H'_{kk+1}, Bm / L = buffers of seed b
+    h.A = gm.HsP + NN; h.inner = d.k; h.sA = (long long)NN; h.sA2 = 0;
+    h.sB = h.sL = 0; h.sB2 = h.sL2 = (long long)N * gm.ldW;
+    h.batch = d.B * d.k;
+    qoc_gemm_launch(gm, false, 2, h, s, (size_t)h.batch * tm * (gm.ldW / 32));
+}
+
 static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int N = gm.N, S = gm.S, NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
@@ -883,6 +904,8 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     }
     }
     if (gm.direct) {
+        // (the gradient products of the slices the chain has already left, on the second stream beside the rest of the chain: built and measured in
+        // round 4, 6.19 against 6.17 ms at C3 x 64 -- the products slow the chain's prefetch as much as they save; profiles/EXPERIMENTS.md)
         if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s, gm.dpp_chain);
     } else if (gm.persistent) {
         ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
@@ -938,20 +961,8 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     qoc_gemm_bwd_sweep(gm, d, s, need_src, nullptr);
     }
     if (gm.persistent) {
-        // gradients from the time-major wide layout: one product H_k' [Psi_0 ... Psi_{SP-1}] per control (batch = seeds),
-        // contracted column by column with conj(Lambda)                                          tensorflow_state.py:61-63
-        GemmArgs h;
-        memset(&h, 0, sizeof h);
-        const int tm = N / 32;
-        h.lda = N; h.ldb = h.ldl = gm.ldW; h.Kdim = N;
-        h.tiles_m = tm; h.tiles_n = gm.ldW / 32; h.Bm = gm.interP; h.L = gm.LamP;
-        h.partial = gm.partial; h.ldp = gm.ldW; h.partial_stride = tm * gm.ldW;         // partial[b][k][tile_m][column]
-        // one launch for all (seed, control) pairs: batch index bt = b*k + kk -> A = H'_{kk+1}, Bm / L = buffers of seed b
-        h.A = gm.HsP + NN; h.inner = d.k; h.sA = (long long)NN; h.sA2 = 0;
-        h.sB = h.sL = 0; h.sB2 = h.sL2 = (long long)N * gm.ldW;
-        h.batch = d.B * d.k;
-        qoc_gemm_launch(gm, false, 2, h, s);
-        hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, tm, gm.ldW, gm.MV);
+        qoc_gemm_wide_gradient(gm, d, s, 0, gm.ldW);
+        hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, N / 32, gm.ldW, gm.MV);
         return;
     }
     if (gm.wideW > 0) {

@@ -248,9 +248,10 @@ def test_fused_state_transfer_parity(variant, path, chunks):
 
 
 @pytest.mark.parametrize('n,steps,terms,reg', [(64, 31, 10, 'forbidden'), (64, 32, 10, 'none'), (50, 7, 13, 'forbidden'), (57, 2, 2, 'none'),
-                                               (64, 1, 5, 'forbidden'), (64, 5, 1, 'none'), (33, 9, 12, 'allreg'), (64, 12, 3, 'allreg')],
+                                               (64, 1, 5, 'forbidden'), (64, 5, 1, 'none'), (33, 9, 12, 'allreg'), (64, 12, 3, 'allreg'),
+                                               (64, 130, 10, 'forbidden'), (40, 200, 5, 'allreg'), (64, 97, 9, 'forbidden')],
                          ids=['n64_T10_forbidden', 'n64_T10_zfree', 'n50_T13_forbidden', 'n57_two_steps_T2', 'n64_one_step', 'n64_T1', 'n33_T12_allreg',
-                              'n64_T3_allreg'])
+                              'n64_T3_allreg', 'n64_130_slices_overlap', 'n40_200_slices_overlap', 'n64_97_slices_overlap'])
 def test_direct_route_on_the_dpp_chain(n, steps, terms, reg, monkeypatch):
     """k_gemm_taylor_chain_dpp (csrc/qoc_gemm_chain_dpp.h: direct state-transfer route at N = 64 with ONE state vector, generators column-major,
     vector entries through row_newbcast DPP, two prefetch loads per Taylor term): pulse lengths on every residue of the three-stage rotation,
