@@ -282,6 +282,31 @@ def test_direct_route_on_the_dpp_chain(n, steps, terms, reg, monkeypatch):
     np.testing.assert_allclose(r['grad'], r0['grad'], rtol=0, atol=1e-13 * max(1.0, np.max(np.abs(r0['grad']))))
 
 
+@pytest.mark.parametrize('env', [{'QOC_ASM_CUMASK': '0'}, {'QOC_ASM_OVERLAP': '0'}, {'QOC_ASM_CUMASK': '70', 'QOC_ASM_TAIL_WGS': '300', 'QOC_ASM_SPLIT16': '9'}],
+                         ids=['shared_cus', 'no_overlap', 'other_mask_and_split'])
+def test_direct_route_assembly_overlap_fallbacks(env, monkeypatch):
+    """The generator assembly beside the forward chain (csrc/qoc_kernels_gemm.h, QocGemm::asm_split) in its other forms: both kernels on shared CUs (what
+    runs when more than 96 control sets leave no room for a CU mask), no overlap at all, another mask / throttle / split -- same results as the default
+    form to round-off of nothing (the arithmetic is the same: compared exactly), and against the oracle."""
+    c = cases.case_c3(n=64, k=3, steps=150, taylor=(10, 0))
+    c['total_time'] = 15.0
+    sp = oracle_system(c)
+    rng = np.random.default_rng(9)
+    bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1]
+    ref = make_engine(sp, n_seeds=2, path=4, chunks=1)
+    ref.set_base(np.stack(bases))
+    r0 = ref.evaluate()
+    ref.close()
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    eng = make_engine(sp, n_seeds=2, path=4, chunks=1)
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    r = eng.evaluate()
+    eng.close()
+    assert np.array_equal(r['loss'], r0['loss']) and np.array_equal(r['grad'], r0['grad'])
+
+
 ST_MFMA_ROUTES = [(0, 0), (3, 8), (2, 2), (5, 4), (0, 5), (4, 5), (3, 1)]
 
 
