@@ -43,6 +43,13 @@
                                   // boundary -- measured SLOWER, 0.815 against 0.800 ms per launch: the boundary batch does not wait for the pipe (its
                                   // first instructions need the oldest results), and a batch between two MFMAs of a running group costs more issue slots
 #endif
+#ifndef QOC_INPLACE_STAGE2
+#define QOC_INPLACE_STAGE2 0      // 1: the Hamiltonian strips of A_{t+1} are fetched TWO groups ahead of their assembly (two register sets of k + 1 strips)
+#endif
+#ifndef QOC_INPLACE_SWAP
+#define QOC_INPLACE_SWAP 0        // 1: the chunk product writes R' into the set the squarings vacated and the two sets swap ROLES for the next slice
+                                  // (time loop unrolled by two) instead of copying R' back into R
+#endif
 #ifndef QOC_LAP
 #define QOC_LAP(ph)
 #define QOC_LAP_INIT
@@ -220,6 +227,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
     const double p_c0 = even ? mf.pcoef[2 * mm - 2] : mf.pcoef[2 * mm], p_c1 = even ? mf.pcoef[2 * mm - 1] : 1.0;
 
     Set<NT> SA, SB, R;
+    constexpr bool SWAP = QOC_INPLACE_SWAP && KC <= 4;   // (the KC = 8 instances with two slice bodies crash hipcc's AGPR-copy rewrite pass)
     Ring<NT> ring;
     auto diag = [&](int J, int ib) -> double { return (ib >> 2) == J ? idv[ib & 3] : 0.0; };
     auto no_init = [](auto, double (&)[NT], double (&)[NT]) { return std::false_type{}; };
@@ -228,7 +236,10 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
 #pragma unroll
     for (int J = 0; J < NT; ++J)
 #pragma unroll
-        for (int ib = 0; ib < QS; ++ib) { R.re[J][ib] = diag(J, ib); R.im[J][ib] = 0.0; R.su[J][ib] = diag(J, ib); }
+        for (int ib = 0; ib < QS; ++ib) {
+            R.re[J][ib] = diag(J, ib); R.im[J][ib] = 0.0; R.su[J][ib] = diag(J, ib);
+            if (SWAP && ib >= QA) { SB.re[J][ib] = diag(J, ib); SB.im[J][ib] = 0.0; SB.su[J][ib] = diag(J, ib); }
+        }
 
     const cplx* hk[KC + 1];
     hk[0] = mf.HsD;                                   // Hamiltonian images already scaled by sigma / 2^s
@@ -278,7 +289,7 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
     }
     QOC_LAP(0)
 
-    for (int t = t0; t < t1; ++t) {
+    auto slice = [&](Set<NT>& SB, Set<NT>& R, int t) __attribute__((always_inline)) {
         cplx* Kout = mf.KfD + kitem(mf, d.steps, b, t);
         // ---- S2 = S * S -> SB;  Horner start X = S + c0 I (odd order: the strips of S with a shifted diagonal -- planes, no pairing) or
         //      S2 + c1 S + c0 I (even order) -> image (left operand of the first Horner product) ---------------------------------------------
@@ -350,32 +361,37 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
         {
             double ck[KC];
             coeffs(min(t + 1, d.steps - 1), ck);
-            cplx h[NT][KC + 1];
+            constexpr int HD = QOC_INPLACE_STAGE2 ? 2 : 1;             // groups of look-ahead of the Hamiltonian strips
+            cplx h[HD][NT][KC + 1];
             auto stage = [&](int ib) {
 #pragma unroll
                 for (int J = 0; J < NT; ++J)
 #pragma unroll
-                    for (int kk = 0; kk <= KC; ++kk) h[J][kk] = frag_at(hk[kk], J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane];
+                    for (int kk = 0; kk <= KC; ++kk) h[ib % HD][J][kk] = frag_at(hk[kk], J * QS + ib)[((J * QS + ib) & 3) * 64 + ulane];
             };
             stage(0);
+            if constexpr (HD == 2) stage(1);
+            Set<NT>& RN = SB;                  // R' (with the swap it stays there: the caller exchanges the roles)
             product<NT, QA, false, false, false>(img, imgs, lane, ring, R, no_init,
                                       [&](auto ibc, double (&a)[NT], double (&bq)[NT], double (&cq)[NT], cplx (&ori)[NT], double (&osu)[NT]) {
                 constexpr int ib = decltype(ibc)::value;
 #pragma unroll
                 for (int J = 0; J < NT; ++J) {                          // A_{t+1}, strip (J, ib) -> image
                     double re, im;
-                    assemble(h[J], ck, re, im);
+                    assemble(h[ib % HD][J], ck, re, im);
                     ori[J] = cmake(re, im); osu[J] = re + im;
                 }
-                if constexpr (ib + 1 < QA) stage(ib + 1);
+                if constexpr (ib + HD < QA) stage(ib + HD);
 #pragma unroll
-                for (int J = 0; J < NT; ++J) combine(a[J], bq[J], cq[J], SB.re[J][ib], SB.im[J][ib], SB.su[J][ib]);
+                for (int J = 0; J < NT; ++J) combine(a[J], bq[J], cq[J], RN.re[J][ib], RN.im[J][ib], RN.su[J][ib]);
             });
             QOC_LAP(4)
+            if constexpr (!SWAP) {
 #pragma unroll
-            for (int J = 0; J < NT; ++J)
+                for (int J = 0; J < NT; ++J)
 #pragma unroll
-                for (int ib = 0; ib < QA; ++ib) { R.re[J][ib] = SB.re[J][ib]; R.im[J][ib] = SB.im[J][ib]; R.su[J][ib] = SB.su[J][ib]; }   // (strips beyond QA stay the identity)
+                    for (int ib = 0; ib < QA; ++ib) { R.re[J][ib] = SB.re[J][ib]; R.im[J][ib] = SB.im[J][ib]; R.su[J][ib] = SB.su[J][ib]; }   // (strips beyond QA stay the identity)
+            }
             // right operand of the next A * A: read back from the image; the last strip is still pending, i.e. in registers
             fence();
 #pragma unroll
@@ -387,6 +403,23 @@ __global__ void __launch_bounds__(64, 1) k_mfma_expm_inplace(QocDev d, QocMfma m
             fence();
             QOC_LAP(5)
         }
+    };
+    if constexpr (SWAP) {
+    // the chunk product of slice t lands in the set that was "SB" during that slice: it is "R" of slice t + 1, whose A2 / squaring operand / R''
+    // take the set the old chunk product has left.  (The strips beyond QA of BOTH sets hold the identity.)
+    Set<NT>* Rfin = &R;
+    for (int t = t0; t < t1; t += 2) {
+        slice(SB, R, t); Rfin = &SB;
+        if (t + 1 < t1) { slice(R, SB, t + 1); Rfin = &R; }
+    }
+    if (Rfin != &R) {
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int ib = 0; ib < QS; ++ib) { R.re[J][ib] = SB.re[J][ib]; R.im[J][ib] = SB.im[J][ib]; }
+    }
+    } else {
+        for (int t = t0; t < t1; ++t) slice(SB, R, t);
     }
     // ---- chunk product out: fragD(P_c) from the registers, fragD(P_c^T) through the image ------------------------------------------------
     const size_t pitem = (size_t)b * mf.C + c;
