@@ -15,6 +15,31 @@
 #pragma once
 // (included by qoc_gemm_chains.h after ChainArgs and before the launchers)
 
+#ifndef QOC_DPP_GAUSS
+#define QOC_DPP_GAUSS 1         // 1: complex MAC in the three-multiplication form (48 instead of 64 DPP FMAs per mat-vec); 0: the four-multiplication form
+#endif
+#if QOC_DPP_GAUSS
+// Gauss's form with the sums on the operands that are cheap to combine: k1 += (ar + ai) xr, k2 += ar (xi - xr), k3 += ai (xr + xi);
+// re = k1 - k3, im = k1 + k2.  The matrix side costs one add per entry and SLICE (the plane sa = ar + ai of the current generator, formed when
+// the slice starts: 16 adds against 9 x 16 FMAs saved), the vector side two adds per term; three independent accumulator chains.
+#define QOC_DPP_CMAC_(NS, J) \
+    asm volatile("v_fmac_f64_dpp %0, " NS "%3, %6 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %1, " NS "%4, %7 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_fmac_f64_dpp %2, " NS "%5, %8 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" \
+                 : "+v"(k1), "+v"(k2), "+v"(k3) : "v"(xr), "v"(xd), "v"(xs), "v"(sa[J]), "v"(a[J].x), "v"(a[J].y))
+#define QOC_DPP_CMAC(J) do { if constexpr (NEG) QOC_DPP_CMAC_("-", J); else QOC_DPP_CMAC_("", J); } while (0)
+
+// partial sums of this wave's 16 columns: lane = row; (xr, xi) = the vector entry 16 w + (lane & 15); sa[J] = a[J].x + a[J].y
+template <bool NEG>
+__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], const double (&sa)[16], double xr, double xi, double& re, double& im) {
+    double k1 = 0.0, k2 = 0.0, k3 = 0.0;
+    double xd = xi - xr, xs = xr + xi;
+    asm volatile("s_nop 1" : "+v"(xr), "+v"(xd), "+v"(xs));          // VALU write of the entry -> DPP read: two wait states
+    QOC_DPP_CMAC(0); QOC_DPP_CMAC(1); QOC_DPP_CMAC(2); QOC_DPP_CMAC(3); QOC_DPP_CMAC(4); QOC_DPP_CMAC(5); QOC_DPP_CMAC(6); QOC_DPP_CMAC(7);
+    QOC_DPP_CMAC(8); QOC_DPP_CMAC(9); QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); QOC_DPP_CMAC(14); QOC_DPP_CMAC(15);
+    re = k1 - k3; im = k1 + k2;
+}
+#else
 #define QOC_DPP_CMAC_(NS0, NS1, NS2, NS3, J) \
     asm volatile("v_fmac_f64_dpp %0, " NS0 "%2, %4 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
                  "v_fmac_f64_dpp %1, " NS1 "%3, %4 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
@@ -26,12 +51,14 @@
 
 // partial sums of this wave's 16 columns: lane = row; (xr, xi) = the vector entry 16 w + (lane & 15)
 template <bool NEG>
-__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], double xr, double xi, double& re, double& im) {
+__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], const double (&)[16], double xr, double xi, double& re, double& im) {
     re = 0.0; im = 0.0;
     asm volatile("s_nop 1" : "+v"(xr), "+v"(xi));          // VALU write of the entry -> DPP read: two wait states
     QOC_DPP_CMAC(0); QOC_DPP_CMAC(1); QOC_DPP_CMAC(2); QOC_DPP_CMAC(3); QOC_DPP_CMAC(4); QOC_DPP_CMAC(5); QOC_DPP_CMAC(6); QOC_DPP_CMAC(7);
     QOC_DPP_CMAC(8); QOC_DPP_CMAC(9); QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); QOC_DPP_CMAC(14); QOC_DPP_CMAC(15);
 }
+
+#endif
 
 // TS: the number of Taylor terms when it is known at compile time (10: C3 and the reference's examples; the guards of the unrolled terms and the LDS
 // reads of 1 / ii! go away), 0 = a.nterms (any), -1 = a.nterms >= 9 (the eight unrolled terms all run: no guards between them either)
@@ -67,9 +94,9 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
     const cplx* const rd_part = &part[0][0][idx];
     int cur = 0;
     // one Taylor term: v <- (sign B) v, out += v / ii!
-    auto term = [&](const cplx (&k)[16], int ii, double inv, double& outr, double& outi) {
+    auto term = [&](const cplx (&k)[16], const double (&sk)[16], int ii, double inv, double& outr, double& outi) {
         double pr, pi;
-        dpp_matvec16<NEG>(k, xv.x, xv.y, pr, pi);
+        dpp_matvec16<NEG>(k, sk, xv.x, xv.y, pr, pi);
         my_part[cur * 256] = cmake(pr, pi);
         lds_barrier();
         const cplx s0 = rd_part[cur * 256], s1 = rd_part[cur * 256 + 64], s2 = rd_part[cur * 256 + 128], s3 = rd_part[cur * 256 + 192];
@@ -84,16 +111,19 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         const cplx* kj = Kp + (long long)jc * a.sKs;
         en = Ep[(long long)jc * a.sEs];
         double outr = xv.x, outi = xv.y;
+        double sk[16];                                              // (three-multiplication form) re + im of the slice's generator entries
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sk[c] = QOC_DPP_GAUSS ? k[c].x + k[c].y : 0.0;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             kn[2 * g] = kj[koff + (2 * g) * N];
             kn[2 * g + 1] = kj[koff + (2 * g + 1) * N];
-            if (TS != 0 || g + 1 < nterms) term(k, g + 1, inv_s[g + 1], outr, outi);
+            if (TS != 0 || g + 1 < nterms) term(k, sk, g + 1, inv_s[g + 1], outr, outi);
         }
         for (int ii = 9; ii < nterms; ++ii) {
             double inv = tinv[ii & 63];
             if (ii >= 64) { double fact = 1.0; for (int q = 2; q <= ii; ++q) fact *= (double)q; inv = 1.0 / fact; }
-            term(k, ii, inv, outr, outi);
+            term(k, sk, ii, inv, outr, outi);
         }
         xv = cmake(outr + e.x, outi + e.y);
         if (owner) Op[(long long)j * a.sOs] = xv;
