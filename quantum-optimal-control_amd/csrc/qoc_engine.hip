@@ -529,7 +529,9 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // x 12 2.81 / 3.12, x 16 3.74 / 3.18 (profiles/r04_c3_route_sweep.txt); n = 40, 48 with k = 4 x 500 slices, MFMA batch kernels / direct: x 24 1.48 / 1.64,
     // x 32 1.84 / 1.70; with forbidden levels x 32 2.14 / 3.20, x 48 3.89 / 3.32 (profiles/r04_st_direct_sweep.txt)
     const bool dpp_shape = n > 32 && m == 1;
-    const int ST_DIRECT_FROM = n <= 32 ? 112 : (dpp_shape ? (lat_src ? 28 : 14) : 48);
+    // (three-multiplication form of the DPP chain, profiles/r04_c3_route_sweep_gauss.txt: with forbidden levels x 20 5.05 / 5.43, x 22 5.56 / 5.45, x 24 6.02 / 5.49;
+    // without x 11 2.63 / 2.77, x 12 2.84 / 2.79, x 13 3.11 / 2.81 -- the limits moved from 28 / 14 to 22 / 12)
+    const int ST_DIRECT_FROM = n <= 32 ? 112 : (dpp_shape ? (lat_src ? 22 : 12) : 48);
     struct AutoPlan { int path; bool latency; bool gemm_direct; };
     // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by row)
     // State transfer on the MFMA path (round 4, tools/st_path_sweep.py -> profiles/r04_state_transfer_paths.txt; m = 1, T = 10, 500 slices, ms per iteration,

@@ -45,11 +45,11 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
 
     def gemm_state_transfer():
         # rows "state transfer ...": GEMM path; direct route for large batches (n <= 32: from 112 control sets, n <= 64: from 48 -- with ONE state
-        # vector, where the direct route has the DPP Taylor chain since round 4: from 14, with a state regulariser from 28) and for
+        # vector, where the direct route has the DPP Taylor chain since round 4: from 12, with a state regulariser from 22) and for
         # non-Hermitian generators; the propagator route otherwise; m > 8 or n > 64 cannot run direct
         if m > 32 or not (hermitian or direct_ok):
             return {'path': 'st_fused' if (n <= 64 and m <= 4 and k <= 8) else 'generic'}
-        direct = direct_ok and (not hermitian or B >= (112 if n <= 32 else ((28 if state_reg else 14) if dpp else 48)))
+        direct = direct_ok and (not hermitian or B >= (112 if n <= 32 else ((22 if state_reg else 12) if dpp else 48)))
         return {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
     mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= deg <= 22 and hermitian
     if st and not (mfma_ok and (n <= 32 or (n <= 48 and k <= 4))):
@@ -207,7 +207,7 @@ def test_auto_plan_wide_and_odd_shapes():
 # (n, k, m, control sets, anti-Hermitian generators, forbidden levels): the GEMM-path routes either side of 48 / 112 control sets, the shapes the MFMA path
 # takes since round 4 (n <= 32; 32 < n <= 48 with k <= 4) on both sides of ITS limits (latency mode up to 8 control sets at n <= 16, the GEMM route up to 8
 # from 25 levels on, the direct Taylor chains for large batches), lossy generators, wide and large problems
-ST_ROWS = [(32, 4, 1, 4, True, True), (32, 4, 1, 5, True, True), (25, 4, 1, 5, True, False), (24, 4, 1, 5, True, False), (64, 6, 1, 47, True, True), (64, 6, 1, 48, True, True), (64, 6, 1, 27, True, True), (64, 6, 1, 28, True, True), (64, 6, 1, 13, True, False), (64, 6, 1, 14, True, False), (64, 6, 2, 47, True, True), (64, 6, 2, 48, True, True), (64, 6, 1, 1, True, True), (33, 6, 2, 47, True, True), (33, 6, 2, 48, True, True),
+ST_ROWS = [(32, 4, 1, 4, True, True), (32, 4, 1, 5, True, True), (25, 4, 1, 5, True, False), (24, 4, 1, 5, True, False), (64, 6, 1, 47, True, True), (64, 6, 1, 48, True, True), (64, 6, 1, 21, True, True), (64, 6, 1, 22, True, True), (64, 6, 1, 11, True, False), (64, 6, 1, 12, True, False), (64, 6, 2, 47, True, True), (64, 6, 2, 48, True, True), (64, 6, 1, 1, True, True), (33, 6, 2, 47, True, True), (33, 6, 2, 48, True, True),
            (33, 4, 2, 47, True, False), (33, 4, 2, 48, True, False), (48, 4, 1, 1, True, True), (48, 4, 1, 8, True, True), (48, 4, 1, 9, True, True),
            (48, 4, 1, 47, True, True), (48, 4, 1, 48, True, True), (48, 4, 1, 31, True, False), (48, 4, 1, 32, True, False), (48, 4, 2, 111, True, True), (48, 4, 2, 112, True, True),
            (32, 4, 1, 1, True, True), (32, 4, 1, 16, True, False), (32, 4, 1, 17, True, False), (32, 4, 1, 64, True, True), (32, 4, 1, 111, True, True), (32, 4, 1, 112, True, True),
