@@ -32,14 +32,17 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     if constexpr (NT >= 3) {
         if (v == 7) {
             const size_t lds = qoc_expm_rows_lds<NT>();
-            static bool reserved = false;                                 // (per NT: this function is a template)
-            if (!reserved) {
-                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                reserved = true;
-            }
-            if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_rows<NT, 4>), dim3(d.B * mf.C), dim3(256), lds, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_expm_rows<NT, 8>), dim3(d.B * mf.C), dim3(256), lds, s, d, mf);
+            // active 4-row strips of the problem padded to 16 NT: ceil(n / 4) (4 NT - 3 .. 4 NT); QOC_ROWS_QA_FULL=1 (A/B): the padded problem in full
+            static const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
+            const int qa = full ? 4 * NT : (d.n + 3) / 4;
+#define QOC_ROWS(KCv, QAv) do { static bool reserved = false;                                /* (per instance) */ \
+                                if (!reserved) { hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, KCv, false, QAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); reserved = true; } \
+                                hipLaunchKernelGGL((k_mfma_expm_rows<NT, KCv, false, QAv>), dim3(d.B * mf.C), dim3(256), lds, s, d, mf); } while (0)
+#define QOC_ROWS_QA(KCv) do { if (qa >= 4 * NT) QOC_ROWS(KCv, 4 * NT); else if (qa == 4 * NT - 1) QOC_ROWS(KCv, 4 * NT - 1); \
+                              else if (qa == 4 * NT - 2) QOC_ROWS(KCv, 4 * NT - 2); else QOC_ROWS(KCv, 4 * NT - 3); } while (0)
+            if (d.k <= 4) QOC_ROWS_QA(4); else QOC_ROWS_QA(8);
+#undef QOC_ROWS_QA
+#undef QOC_ROWS
             return;
         }
     }

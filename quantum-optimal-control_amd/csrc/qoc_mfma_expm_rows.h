@@ -22,8 +22,13 @@
 #endif
 // SLICE (latency mode of n > 32): an item is one time slice -- K_t and its transposed copy only; the chunk products are left to
 // k_mfma_chain_rows.
-template <int NT, int KC, bool SLICE = false>
+// QA = ACTIVE 4-row strips, ceil(n / 4) (4 NT - 3 .. 4 NT): every matrix of the slice is block diagonal in (active, padding) -- polynomials of the padded
+// A_t, whose padding rows and columns are zero -- so the block steps over the inner indices 4 QA .. contribute nothing to the active block and are not
+// run: QA / (4 NT) of the MFMAs of the padded product (n = 36: 9 / 12, n = 52: 13 / 16).  What the padding block of K_t and P_c then holds (zero
+// beyond strip QA instead of the identity) never meets a non-zero vector entry: the sweeps' vectors are zero there.
+template <int NT, int KC, bool SLICE = false, int QA = 4 * NT>
 __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k_mfma_expm_rows(QocDev d, QocMfma mf) {
+    static_assert(QA > 4 * NT - 4 && QA <= 4 * NT, "active strips of a problem padded to 16 NT");
     constexpr int NB = NT == 3 ? QOC_ROWS_NB3 : 1;                       // image buffers
     extern __shared__ __attribute__((aligned(16))) char smem_rows[];
     cplx* imgT = (cplx*)smem_rows;                                       // [NB][QNP * QLDS]   left operand: image[column][row]
@@ -69,7 +74,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
     auto product = [&]() {
         const cplx* base = imgT + (size_t)tcur * TSZ + (lane >> 4) * QLDS + (lane & 3) + 4 * NT * w;
         const cplx* sb = imgS + (size_t)scur * SSZ + lane;
-        constexpr int NS = QQS * NT, RA = 4, RS = RA + 1;                 // block steps (kb, r), kb-major
+        constexpr int NS = QA * NT, RA = 4, RS = RA + 1;                  // block steps (kb, r), kb-major, over the ACTIVE inner strips
         cplx vb[RS], rs[2][NT];
 #pragma unroll
         for (int J = 0; J < NT; ++J) rs[0][J] = sb[(J * QQS) * 64];
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
         for (int st = 0; st < NS; ++st) {
             const int kb = st / NT, r = st % NT;
             if (st + RA < NS) vb[(st + RA) % RS] = base[4 * ((st + RA) / NT) * QLDS + 4 * ((st + RA) % NT)];
-            if (r == 0 && kb + 1 < QQS) {
+            if (r == 0 && kb + 1 < QA) {
 #pragma unroll
                 for (int J = 0; J < NT; ++J) rs[(kb + 1) & 1][J] = sb[(J * QQS + kb + 1) * 64];
             }

@@ -1,0 +1,11 @@
+#!/usr/bin/env python
+"""Unitary gates of 33 <= n <= 64 levels x 64 control sets (k = 4, 500 slices, m = 8, (T, s) = (5, 3)): k_mfma_expm_rows runs the block steps over the
+ACTIVE inner 4-row strips ceil(n / 4) of the matrices padded to 48 / 64.  QOC_ROWS_QA_FULL=1: the padded problem in full (A/B)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'quantum-optimal-control_amd'), os.path.join(ROOT, 'tools')]
+import bench_configs
+from tests.golden import cases
+for n in (33, 36, 40, 44, 48, 49, 52, 56, 60, 64):
+    nt = (n + 15) // 16
+    bench_configs.run('n=%d x64 (active strips %d of %d)' % (n, (n + 3) // 4, 4 * nt), cases.case_c2(n=n, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 5)
