@@ -26,8 +26,11 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
         } else if (mf.NT == 2) {
             qoc_launch_forward2_bnd(mf, d, sw, s);
         } else {
-            if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_forward2<3, 4, true>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf);
+            // (33 <= n <= 48: the active 4-column groups of the K padded to 48, ceil(n / 4) = 9 .. 12)
+#define QOC_F3(QAv) do { if (mf.mq <= 2) hipLaunchKernelGGL((k_mfma_forward2<3, 2, true, QAv>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf); \
+                         else hipLaunchKernelGGL((k_mfma_forward2<3, 4, true, QAv>), dim3((sw + 3) / 4), dim3(256), 0, s, d, mf); } while (0)
+            switch ((d.n + 3) / 4) { case 9: QOC_F3(9); break; case 10: QOC_F3(10); break; case 11: QOC_F3(11); break; default: QOC_F3(12); break; }
+#undef QOC_F3
         }
     }
     else if (mf.NT == 1) hipLaunchKernelGGL(k_mfma_forward<1>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
