@@ -16,14 +16,17 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
         if (v == 5) {
             // latency mode of 32 < n <= 64: K_t per slice by the row-block kernel (NT = 3: two workgroups per CU), then the row-split chains
             const size_t lds = qoc_expm_rows_lds<NT>();
-            static bool reserved = false;
-            if (!reserved) {
-                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                reserved = true;
-            }
-            if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_rows<NT, 4, true>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf);
-            else hipLaunchKernelGGL((k_mfma_expm_rows<NT, 8, true>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf);
+            // (active inner strips ceil(n / 4) of the problem padded to 16 NT, as in the batch kernel below)
+            static const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
+            const int qa = full ? 4 * NT : (d.n + 3) / 4;
+#define QOC_ROWS_SL(KCv, QAv) do { static bool reserved = false; \
+                                   if (!reserved) { hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, KCv, true, QAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); reserved = true; } \
+                                   hipLaunchKernelGGL((k_mfma_expm_rows<NT, KCv, true, QAv>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf); } while (0)
+#define QOC_ROWS_SL_QA(KCv) do { if (qa >= 4 * NT) QOC_ROWS_SL(KCv, 4 * NT); else if (qa == 4 * NT - 1) QOC_ROWS_SL(KCv, 4 * NT - 1); \
+                                 else if (qa == 4 * NT - 2) QOC_ROWS_SL(KCv, 4 * NT - 2); else QOC_ROWS_SL(KCv, 4 * NT - 3); } while (0)
+            if (d.k <= 4) QOC_ROWS_SL_QA(4); else QOC_ROWS_SL_QA(8);
+#undef QOC_ROWS_SL_QA
+#undef QOC_ROWS_SL
             hipLaunchKernelGGL(k_mfma_chain_rows2<NT>, dim3(d.B * mf.C * 4 * NT), dim3(64 * NT), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);
             hipLaunchKernelGGL(k_mfma_chain_rows2<NT>, dim3(d.B * mf.NG * 4 * NT), dim3(64 * NT), 0, s, d, mf, (const cplx*)mf.PfD, 0, mf.C, mf.G, mf.GfD, mf.NG, (const cplx*)nullptr, mf.GfT);
             return;
