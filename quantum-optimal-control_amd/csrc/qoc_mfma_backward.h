@@ -230,7 +230,8 @@ __global__ void __launch_bounds__(256) k_mfma_bwd_offsets2(QocDev d, QocMfma mf)
 // dL/du_{k,t} = Re sum_ab H_k'[a][b] Q_t[a][b],  Q_t = conj(Lambda_t) Psi_t^T  (rank-m outer product on the MFMA),
 // which equals Re <Lambda_t, H_k' Psi_t> of the reference's matexp_op_grad (tensorflow_state.py:61-63).
 // 4 waves per workgroup; LDS: fragD image of the k control Hamiltonians (shared) + one transposition pad per wave.
-template <int NT, bool H_IN_LDS, bool SPLIT = false>
+// QA: active 4-row strips of the padded K / chunk products (ceil(n / 4)): the costate's rows beyond are zero, so those strips are neither loaded nor multiplied.
+template <int NT, bool H_IN_LDS, bool SPLIT = false, int QA = 4 * NT>
 __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int single_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -270,9 +271,9 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
     AFragT<NT> A;
     if (!single_chunk) {
         for (int cc = mf.C - 1; cc > c; --cc) {                          // Lambda at the end of this chunk
-            afrag_load<NT, true>(mf.PfD + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            afrag_load<NT, true, QA>(mf.PfD + ((size_t)b * mf.C + cc) * QFR, lane, A);
             CTile acc[NT];
-            mm_colblock<NT>(A, Lam, acc);
+            mm_colblock<NT, QA>(A, Lam, acc);
             for (int Ib = 0; Ib < NT; ++Ib) Lam[Ib] = acc[Ib];
             if (need_src) {                                              // E_{cc-1} = P_cc^dagger E_cc + a_cc
                 CTile off[NT];
@@ -354,9 +355,9 @@ __global__ void __launch_bounds__(256) k_mfma_backward(QocDev d, QocMfma mf, int
         }
         if (t == 0) break;
         // ---- Lambda_{t-1} = K_t^dagger Lambda_t (+ S_{t-1}) ---------------------------------------------------------
-        afrag_load<NT, true>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
+        afrag_load<NT, true, QA>(mf.KfD + kitem(mf, d.steps, b, t), lane, A);
         CTile acc[NT];
-        mm_colblock<NT>(A, Lam, acc);
+        mm_colblock<NT, QA>(A, Lam, acc);
         for (int Ib = 0; Ib < NT; ++Ib) Lam[Ib] = acc[Ib];
         if (need_src) {
 #pragma unroll

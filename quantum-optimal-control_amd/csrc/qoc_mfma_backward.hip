@@ -294,7 +294,10 @@ static inline void qoc_mfma_launch_all_backward(QocMfma& mf, const QocDev& d, hi
     }
     if (NT > 2 && mf.variant != 1) {
         // n > 32: the sweep only propagates the costates, the gradients are formed slice-parallel with the control images in LDS
-        hipLaunchKernelGGL((k_mfma_backward<NT, false, true>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 0);   // no pad, no images
+        // (no pad, no images; on the active strips ceil(n / 4) of the problem padded to 16 NT)
+#define QOC_BWS(QAv) hipLaunchKernelGGL((k_mfma_backward<NT, false, true, QAv>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf, 0)
+        switch (4 * NT - (d.n + 3) / 4) { case 3: QOC_BWS(4 * NT - 3); break; case 2: QOC_BWS(4 * NT - 2); break; case 1: QOC_BWS(4 * NT - 1); break; default: QOC_BWS(4 * NT); break; }
+#undef QOC_BWS
         const int slices = d.B * d.steps;
         int gg = (slices + 3) / 4; if (gg > 1024) gg = 1024;
         constexpr int GN = NT > 2 ? NT : 3;                                  // (never launched for NT <= 2)

@@ -5,7 +5,8 @@
 
 // ---- kernel F: thin forward sweep  Psi_t = K_t Psi_{t-1}  (inter vectors) + final unitary ------------------------
 // grid.x = B*C sweep waves + B*2 final-unitary waves, 4 waves per workgroup, no LDS, no barriers.
-template <int NT>
+// QA: active 4-column groups of the padded K / chunk products (ceil(n / 4); the vectors' rows beyond are zero) in the sweep items
+template <int NT, int QA = 4 * NT>
 __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -30,15 +31,15 @@ __global__ void __launch_bounds__(256) k_mfma_forward(QocDev d, QocMfma mf) {
         }
         AFragT<NT> A;
         for (int cc = 0; cc < c; ++cc) {                                // chunk boundary from the chunk products
-            afrag_load<NT, false>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
+            afrag_load<NT, false, QA>(mf.PfT + ((size_t)b * mf.C + cc) * QFR, lane, A);
             CTile acc[NT];
-            mm_colblock<NT>(A, Psi, acc);
+            mm_colblock<NT, QA>(A, Psi, acc);
             for (int Ib = 0; Ib < NT; ++Ib) Psi[Ib] = acc[Ib];
         }
         for (int t = t0; t < t1; ++t) {
-            afrag_load<NT, false>(mf.KfT + kitem(mf, d.steps, b, t), lane, A);
+            afrag_load<NT, false, QA>(mf.KfT + kitem(mf, d.steps, b, t), lane, A);
             CTile acc[NT];
-            mm_colblock<NT>(A, Psi, acc);
+            mm_colblock<NT, QA>(A, Psi, acc);
             for (int Ib = 0; Ib < NT; ++Ib) Psi[Ib] = acc[Ib];
             cplx* out = iv + (size_t)(t + 1) * d.n * d.m;
 #pragma unroll

@@ -45,7 +45,12 @@ void qoc_mfma_launch_forward(QocMfma& mf, const QocDev& d, hipStream_t s) {
     }
     else if (mf.NT == 2) hipLaunchKernelGGL(k_mfma_forward<2>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
     else if (mf.NT == 3) hipLaunchKernelGGL(k_mfma_forward<3>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
-    else hipLaunchKernelGGL(k_mfma_forward<4>, dim3((items + 3) / 4), dim3(256), 0, s, d, mf);
+    else {
+        // NT = 4: the active column groups ceil(n / 4) = 13 .. 16 of the K padded to 64
+#define QOC_F4(QAv) hipLaunchKernelGGL((k_mfma_forward<4, QAv>), dim3((items + 3) / 4), dim3(256), 0, s, d, mf)
+        switch ((d.n + 3) / 4) { case 13: QOC_F4(13); break; case 14: QOC_F4(14); break; case 15: QOC_F4(15); break; default: QOC_F4(16); break; }
+#undef QOC_F4
+    }
     if (!d.uscale_in_loss && !mf.updown && !d.state_transfer) hipLaunchKernelGGL(k_mfma_uscale, dim3(d.B), dim3(64), 0, s, d);
 }
 

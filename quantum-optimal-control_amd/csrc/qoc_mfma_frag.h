@@ -90,12 +90,14 @@ __device__ __forceinline__ size_t kitem(const QocMfma& mf, int steps, int b, int
 // ---- fragment helpers ---------------------------------------------------------------------------------------------
 
 // A-operand fragments from a fragD matrix (pass fragD(M^T) to multiply by M, fragD(M) with CONJ to multiply by M^dagger)
-template <int NT, bool CONJ>
+// QA: the inner 4-index slices < QA only (the active ones of a padded problem, ceil(n / 4): the right operand's rows beyond are zero, so neither
+// loaded here nor multiplied in mm_colblock<NT, QA>)
+template <int NT, bool CONJ, int QA = 4 * NT>
 __device__ __forceinline__ void afrag_load(const cplx* __restrict__ F, int lane, AFragT<NT>& A) {
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int q = 0; q < QQS; ++q) {
+        for (int q = 0; q < QA; ++q) {
             const cplx v = F[(I * QQS + q) * 64 + lane];
             A.re[I][q] = v.x; A.im[I][q] = CONJ ? -v.y : v.y;
         }
@@ -143,13 +145,13 @@ __device__ __forceinline__ void colblock_identity(int J, int lane, CTile p[NT]) 
 
 // out[I] = sum_k A[I,k] * p[k] for one 16-column block, 3-multiplication complex arithmetic:
 // 12 NT^2 MFMAs (48 for NT = 2), 3 NT independent accumulator chains.
-template <int NT>
+template <int NT, int QA = 4 * NT>
 __device__ __forceinline__ void mm_colblock(const AFragT<NT>& A, const CTile p[NT], CTile out[NT]) {
     d4 a[NT], b[NT], c[NT];
 #pragma unroll
     for (int I = 0; I < NT; ++I) { a[I] = (d4){0, 0, 0, 0}; b[I] = (d4){0, 0, 0, 0}; c[I] = (d4){0, 0, 0, 0}; }
 #pragma unroll
-    for (int q = 0; q < QQS; ++q) {
+    for (int q = 0; q < QA; ++q) {
         const double br = p[q >> 2].re[q & 3], bi = p[q >> 2].im[q & 3], bs = br + bi;
 #pragma unroll
         for (int I = 0; I < NT; ++I) a[I] = QMFMA(A.re[I][q], br, a[I]);
