@@ -17,7 +17,7 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
             // latency mode of 32 < n <= 64: K_t per slice by the row-block kernel (NT = 3: two workgroups per CU), then the row-split chains
             const size_t lds = qoc_expm_rows_lds<NT>();
             // (active inner strips ceil(n / 4) of the problem padded to 16 NT, as in the batch kernel below)
-            static const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
+            const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
             const int qa = full ? 4 * NT : (d.n + 3) / 4;
 #define QOC_ROWS_SL(KCv, QAv) do { static bool reserved = false; \
                                    if (!reserved) { hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, KCv, true, QAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); reserved = true; } \
@@ -35,8 +35,8 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     if constexpr (NT >= 3) {
         if (v == 7) {
             const size_t lds = qoc_expm_rows_lds<NT>();
-            // active 4-row strips of the problem padded to 16 NT: ceil(n / 4) (4 NT - 3 .. 4 NT); QOC_ROWS_QA_FULL=1 (A/B): the padded problem in full
-            static const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
+            // active 4-row strips of the problem padded to 16 NT: ceil(n / 4) (4 NT - 3 .. 4 NT); QOC_ROWS_QA_FULL=1 (A/B, read per launch: the parity test toggles it): the padded problem in full
+            const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
             const int qa = full ? 4 * NT : (d.n + 3) / 4;
 #define QOC_ROWS(KCv, QAv) do { static bool reserved = false;                                /* (per instance) */ \
                                 if (!reserved) { hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, KCv, false, QAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); reserved = true; } \

@@ -1124,3 +1124,33 @@ def test_hip_against_the_reference_text_per_kernel_family(name, kw, B, expect):
     eng.adam_step(float(fx['adam_lr']))
     np.testing.assert_allclose(eng.get_base()[0], fx['base_after_adam'], rtol=0, atol=1e-9)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,k,seeds,chunks,reg', [(33, 4, 3, 0, False), (36, 3, 9, 3, True), (41, 6, 9, 0, True), (47, 4, 2, 0, False), (49, 4, 3, 2, True),
+                                                  (55, 5, 9, 0, False), (62, 8, 2, 0, True), (36, 4, 1, 0, True), (52, 4, 1, 0, False)],
+                         ids=lambda v: str(v))
+def test_padded_sizes_of_the_48_and_64_wide_kernels_on_their_active_strips(n, k, seeds, chunks, reg, monkeypatch):
+    """33 <= n <= 63 is padded to 48 / 64; k_mfma_expm_rows (batch kernel and the latency mode's slice kernel), the costate sweep
+    k_mfma_backward<NT, false, true, QA> and the forward sweeps k_mfma_forward2<3, ., ., QA> / k_mfma_forward<4, QA> run over the ACTIVE strips
+    ceil(n / 4) only (csrc/qoc_mfma_expm_rows.h, qoc_mfma_frag.h: afrag_load / mm_colblock).  Every quantity against the oracle, sizes on each residue of the
+    strip count, one / few / nine control sets (latency mode, batch kernels), with and without forbidden levels; and the exponentials of the padded problem
+    in full (QOC_ROWS_QA_FULL=1) give the same loss to round-off.  Reference: core/tensorflow_state.py:25-46, 204-261."""
+    c = cases.case_c2(n=n, k=k, steps=37, m=5, taylor=(5, 2), seed=300 + n)
+    c['total_time'] = 0.9
+    if reg:
+        c['reg_coeffs'] = {'dwdt': 0.05, 'forbidden_coeff_list': [3.0, 2.0], 'states_forbidden_list': [n - 1, n - 2]}
+    sp = oracle_system(c)
+    rng = np.random.default_rng(n)
+    bases = [sp.base0] + [1.5 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.05 * i for i in range(seeds - 1)]
+    losses = []
+    for full in ('0', '1'):
+        monkeypatch.setenv('QOC_ROWS_QA_FULL', full)
+        eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks)
+        assert eng.path == 2
+        eng.set_base(np.stack(bases))
+        if full == '0':
+            check_eval(eng, sp, bases)
+        losses.append(eng.evaluate()['loss'].copy())
+        eng.close()
+    assert np.max(np.abs(losses[0] - losses[1])) <= 1e-12 * max(1.0, np.max(np.abs(losses[1])))
