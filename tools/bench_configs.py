@@ -49,9 +49,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'c5':           # profiling hook: large Hilbert space only
         run('C5 n=512 k=8 steps=2000 (GEMM path)', cases.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2), 1, 2)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ('n48', 'n64'):  # profiling hooks: NT = 3 / NT = 4 unitary gates x 64 seeds on the MFMA path
+    if len(sys.argv) > 1 and sys.argv[1][0] == 'n' and sys.argv[1][1:].isdigit():  # profiling hooks (n48, n64, n36, ...): NT = 3 / NT = 4 unitary gates x 64 seeds on the MFMA path
         nn = int(sys.argv[1][1:])
-        run('n=%d unitary (MFMA NT=%d) x64' % (nn, nn // 16), cases.case_c2(n=nn, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 5, path=2, variant=int(os.environ.get('QOC_VARIANT', '0')))
+        run('n=%d unitary (MFMA NT=%d) x64' % (nn, (nn + 15) // 16), cases.case_c2(n=nn, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 64, 5, path=2, variant=int(os.environ.get('QOC_VARIANT', '0')))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'c2reg':        # profiling hook: regularised C2 x 64 only
         c = cases.case_c2(); c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [30, 31]}
