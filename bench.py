@@ -197,6 +197,158 @@ def cpu_baseline_reference_ops(max_evals=6, budget_s=10.0):
     return out
 
 
+def _engine_for(c, n_seeds, device):
+    """An engine of a synthetic_systems recipe through the PRODUCT's host pre-processing (core/system_parameters.py mirror of the reference's
+    SystemParameters) -- no oracle on this leg."""
+    from quantum_optimal_control.core import hip_engine
+    from quantum_optimal_control.core.system_parameters import SystemParameters
+    import contextlib
+    np.random.seed(c['np_seed'])
+    U0 = np.identity(len(c['H0'])) if c['U0'] is None else c['U0']
+    with contextlib.redirect_stdout(sys.stderr):                  # the reference prints its Taylor-term choice (system_parameters.py:216): stdout is the JSON line's
+        sp = _system_parameters(SystemParameters, c, U0)
+    Hs, U0e, V, W, Vs = sp.engine_inputs()
+    eng = hip_engine.HipEngine(Hs, U0e, V, W, sp.ops_max_amp, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
+                               state_transfer=sp.state_transfer, reg_coeffs=sp.reg_coeffs, Vs=Vs, n_seeds=n_seeds, device=device)
+    k, steps = len(c['Hops']), c['steps']
+    eng.set_base(np.random.default_rng(0).normal(0, 1 / np.sqrt(steps), (n_seeds, k, steps)))
+    return eng, sp
+
+
+def _system_parameters(SystemParameters, c, U0):
+    return SystemParameters(c['H0'], c['Hops'], c['Hnames'], c['U'], U0, c['total_time'], c['steps'], c['states_concerned_list'], None,
+                          np.asarray(c['maxA'], dtype=float), None, None, False, 1e-4, c['state_transfer'], False, c['reg_coeffs'], False, None,
+                          c['Taylor_terms'], True, True, False, False, False)
+
+
+def _time_engine(eng, params, warm, iters):
+    eng.iterate(params, warm); eng.sync()
+    t0 = time.perf_counter()
+    eng.iterate(params, iters); eng.sync()
+    per = (time.perf_counter() - t0) / iters
+    eng.profile_enable(True)
+    eng.iterate(params, max(1, min(iters, 5)))
+    pr = eng.profile_read()
+    eng.profile_enable(False)
+    sc = eng.scalars()
+    assert int(np.sum(sc['done'])) == 0, 'a control set stopped inside the timed iterations'
+    return per, pr, sc
+
+
+def secondary_configs(device):
+    """BASELINE.json configs 3 and 5 (SURVEY.md 8d "C3", "C5") through the same C ABI, AFTER the timed region, rank 0 at N = 1 only: one C3 trajectory
+    (the reference's own calling mode), 64 C3 control sets, one C5 iteration.  Per entry: ms per iteration of the batch, the plan AUTO resolved, the kernel
+    the engine's hipEvent bracket names with its average time, and TFLOP/s on SURVEY 8d's algorithmic count (an algorithmic rate: the kernels execute
+    fewer flops -- Paterson-Stockmeyer, three-multiplication complex products -- so this is NOT a utilisation)."""
+    from quantum_optimal_control.core import hip_engine
+    from quantum_optimal_control.helper_functions import synthetic_systems
+    params = hip_engine.HipEngine.adam_params(rate=0.01, learning_rate_decay=2500, conv_target=-1.0, min_grad=-1.0, max_iterations=10 ** 9,
+                                              poll_every=10 ** 9)
+    out = {}
+
+    def entry(name, c, seeds, warm, iters, flops_alg):
+        t0 = time.perf_counter()
+        try:
+            eng, sp = _engine_for(c, seeds, device)
+            try:
+                per, pr, sc = _time_engine(eng, params, warm, iters)
+                out[name] = {'ms_per_iteration': per * 1e3, 'iterations_per_s': seeds / per, 'control_sets': seeds, 'timed_iterations': iters,
+                             'path': eng.path, 'plan': eng.plan, 'bracketed_kernel': pr['kernel'],
+                             'bracketed_kernel_ms_per_iteration': pr['total_ms'] / max(1, min(iters, 5)), 'bracketed_launches': pr['launches'],
+                             'algorithmic_TFLOPs': seeds * flops_alg / per / 1e12, 'loss0': float(sc['loss'][0]),
+                             'wall_s': time.perf_counter() - t0}
+            finally:
+                eng.close()
+        except Exception as exc:                                   # a secondary entry never takes the bench line down with it
+            out[name] = {'error': repr(exc)}
+
+    c3 = synthetic_systems.case_c3()
+    T3 = c3['Taylor_terms'][0]
+    f3 = c3['steps'] * 1 * 8.0 * 64 ** 2 * (3 * (T3 - 1) + 6)      # SURVEY 8d: steps*m*8n^2*[3(T-1)+k]
+    entry('c3_single_trajectory', c3, 1, 200, 400, f3)
+    entry('c3_x64', c3, 64, 10, 30, f3)
+    c5 = synthetic_systems.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2)
+    f5 = 2000 * ((5 - 1 + 3) + 1 + 2) * 8.0 * 512 ** 3 + 2000 * 8 * 8.0 * 512 ** 2   # SURVEY 8d unitary count
+    entry('c5_single_trajectory', c5, 1, 1, 3, f5)
+    out['note'] = ('BASELINE configs 3 (state transfer n=64 k=6 steps=1000 m=1 T=10, dwdt + two forbidden levels) and 5 (n=512 k=8 steps=2000 m=8 '
+                   '(T,s)=(5,3)); synthetic_systems recipes, product pre-processing, AUTO path; algorithmic_TFLOPs uses SURVEY 8d counts (not a utilisation)')
+    return out
+
+
+class LivePmc(object):
+    """roofline.traffic measured in THIS run when rocprofv3 is on PATH: two separate PMC passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md's HBM
+    recipe: own runs, --kernel-trace only, gfx950 correction 2 x FETCH_SIZE, both in KB) of this same command at 3 steps, started as a background
+    process chain beside the CPU baseline legs (counters are not timing-sensitive).  Falls back to the committed file."""
+
+    def __init__(self, args):
+        import shutil
+        import tempfile
+        self.exe = shutil.which('rocprofv3')
+        self.proc = None
+        if self.exe is None:
+            return
+        self.dir = tempfile.mkdtemp(prefix='qoc_pmc_', dir='/tmp')
+        inner = '%s %s --steps 3 --warmup 1 --prewarm 0 --no-cpu-baseline --no-single --no-secondary --no-live-pmc --seeds-per-gpu %d --chunks %d' % (
+            sys.executable, os.path.abspath(__file__), args.seeds_per_gpu, args.chunks)
+        cmd = ' ; '.join('%s --pmc %s --kernel-trace -d %s/%s -- %s > %s/%s.log 2>&1' % (self.exe, ctr, self.dir, ctr, inner, self.dir, ctr)
+                         for ctr in ('FETCH_SIZE', 'WRITE_SIZE'))
+        env = dict(os.environ, TMPDIR='/tmp')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        self.proc = subprocess.Popen(['bash', '-c', cmd], cwd='/tmp', env=env, start_new_session=True)
+
+    @staticmethod
+    def _per_kernel(db_path, counter):
+        import sqlite3
+        db = sqlite3.connect(db_path)
+        tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+        ev = [t for t in tabs if t.startswith('rocpd_pmc_event')][0]
+        info = [t for t in tabs if t.startswith('rocpd_info_pmc')][0]
+        disp = [t for t in tabs if t.startswith('rocpd_kernel_dispatch')][0]
+        sym = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
+        scols = [r[1] for r in db.execute('pragma table_info(%s)' % sym)]
+        name_col = 'kernel_name' if 'kernel_name' in scols else 'display_name'
+        q = ('select s.%s, e.value from %s e join %s d on e.event_id = d.event_id join %s s on d.kernel_id = s.id join %s i on e.pmc_id = i.id '
+             'where i.name = ?' % (name_col, ev, disp, sym, info))
+        acc = {}
+        for kname, val in db.execute(q, (counter,)):
+            acc.setdefault(kname, []).append(val)
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+
+    def result(self, kernel, timeout_s=150.0):
+        """(bytes per launch of `kernel`, description) or (None, reason)."""
+        import glob
+        import shutil
+        if self.proc is None:
+            return None, 'rocprofv3 not on PATH'
+        try:
+            self.proc.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(self.proc.pid, 15)            # our own process group (start_new_session), never a pattern
+            except OSError:
+                pass
+            return None, 'PMC passes did not finish in %.0f s' % timeout_s
+        try:
+            vals = {}
+            for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+                dbs = glob.glob(os.path.join(self.dir, ctr, '**', '*_results.db'), recursive=True)
+                if not dbs:
+                    return None, 'no rocpd database for %s' % ctr
+                per = self._per_kernel(dbs[0], ctr)
+                hit = [v for k, v in per.items() if kernel in k]
+                if not hit:
+                    return None, '%s: kernel %s not in the trace' % (ctr, kernel)
+                vals[ctr] = max(hit)
+            return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), \
+                'measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) of this command at 3 steps; ' \
+                '2*FETCH_SIZE + WRITE_SIZE in KB (gfx950 correction); FETCH_SIZE_KB=%.1f WRITE_SIZE_KB=%.1f' % (vals['FETCH_SIZE'], vals['WRITE_SIZE'])
+        except Exception as exc:
+            return None, 'PMC parse failed: %r' % (exc,)
+        finally:
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, and wait."""
     s = socket.socket()
@@ -256,6 +408,8 @@ def main():
     ap.add_argument('--variant', type=int, default=0, help='MFMA path: kernel of the exponentials (qoc_config.variant)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-single', action='store_true', help='skip the one-trajectory latency measurement')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the BASELINE config 3 / config 5 entries (`secondary`)')
+    ap.add_argument('--no-live-pmc', action='store_true', help='roofline.traffic from the committed PMC file instead of rocprofv3 passes in this run')
     ap.add_argument('--groups', type=int, default=1, help='split the seeds of this GPU over G engines/streams')
     ap.add_argument('--prewarm', type=int, default=100, help='untimed iterations BEFORE the W warm-up steps: a GPU that was idle takes tens of '
                                                                'milliseconds to reach its working clocks, more than W = 5 steps of 1.2 ms last')
@@ -422,6 +576,14 @@ def main():
         single = {'value': 1.0 / el1, 'unit': 'GRAPE iterations/s', 'ms_per_iteration': el1 * 1e3, 'path': e1.path,
                   'note': 'one control set (n_seeds=1, AUTO path) of the same C2 workload, 200 iterations; not part of `value`'}
         e1.close()
+    # ---- BASELINE configs 3 and 5, driver-visible (rank 0, N = 1, after the timed region) ------------------------------
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = secondary_configs(local_rank)
+    # ---- HBM traffic of the dominant kernel, re-measured in this run (two rocprofv3 PMC passes beside the CPU legs) --------
+    pmc = None
+    if rank == 0 and world == 1 and roof is not None and not args.no_live_pmc:
+        pmc = LivePmc(args)
     total_seeds = B * world
     value = total_seeds * args.steps / elapsed
     if rank == 0:
@@ -444,6 +606,7 @@ def main():
                        'parallelism': 'seed-sharded x%d, one all-gather of final fidelities, no collective inside the iterations' % world},
             'per_seed_iterations_per_s': args.steps / elapsed, 'prewarm_steps': max(0, args.prewarm),
             'single_trajectory': single,
+            'secondary': secondary,
             'best_fidelity': float(np.max(fidelity)),
             'roofline': roof,
         }
@@ -453,6 +616,13 @@ def main():
                 out['cpu_baseline_reference_ops'] = cpu_baseline_reference_ops()
             except Exception as exc:                         # torch missing etc.: the primary baseline stands
                 out['cpu_baseline_reference_ops'] = {'error': repr(exc)}
+        if pmc is not None:
+            live, how = pmc.result(roof['kernel'])
+            if live is not None:
+                roof['traffic_committed_profile'] = roof['traffic']
+                roof['traffic'], roof['traffic_source'] = live, how
+            else:
+                roof['traffic_source'] += '; live PMC pass unavailable (%s)' % how
         print(json.dumps(out), flush=True)
     for e in engs:
         e.close()

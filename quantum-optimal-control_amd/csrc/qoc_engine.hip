@@ -272,12 +272,17 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
             if (rc == 1) return fail(QOC_ERR_HIP, "time-sharded iteration: clearing the gradient array failed");
             if (rc) return rc;                                          // (the message is the collective's / the profiler's)
         } else {
-        TRY(prof_begin(e));
+        // the hipEvent bracket of qoc_profile_read: the exponentials -- or, on the direct state-transfer route (no exponentials: the assembly of the
+        // generators is all qoc_gemm_expm does there), the backward half of the iteration, which the backward Taylor chain dominates
+        const bool bracket_bwd = e->gm.direct;
+        if (!bracket_bwd) TRY(prof_begin(e));
         qoc_gemm_expm(e->gm, d, e->stream);
-        TRY(prof_end(e));
+        if (!bracket_bwd) TRY(prof_end(e));
         qoc_gemm_forward(e->gm, d, e->stream);
         launch_loss(d, e->stream);
+        if (bracket_bwd) TRY(prof_begin(e));
         qoc_gemm_backward(e->gm, d, e->stream);
+        if (bracket_bwd) TRY(prof_end(e));
         }
     } else if (!d.state_transfer) {
         TRY(prof_begin(e));
@@ -836,7 +841,8 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     CHECK_H(e);
     TRY(prof_collect(e));
     if (kernel_name)
-        *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm32 (batched matexp sequence)")
+        *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.direct ? "k_gemm_taylor_chain (backward chain + sources + gradient products)"
+                                                 : e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm_wg + k_zgemm32 (batched matexp sequence)")
                        : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 6 ? "k_mfma_expm_pair" : qoc_mfma_expm_variant(e->mf, e->d) == 5 ? (e->mf.NT == 3 ? "k_mfma_expm_rows (per slice) + k_mfma_chain_rows" : "k_mfma_expm_slice2 + k_mfma_chain_rows") : qoc_mfma_expm_variant(e->mf, e->d) == 8 ? "k_mfma_expm_inplace" : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
                        : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
