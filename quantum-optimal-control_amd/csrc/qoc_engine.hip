@@ -620,6 +620,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     } else if (path == QOC_PATH_GEMM) {
         std::string msg;
         if (cfg->time_shards >= 1) { e->gm.ts_G = cfg->time_shards; e->gm.ts_rank = cfg->time_rank; }
+        e->gm.antiherm = antiherm;
         rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, gemm_direct, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         if (!qoc_gemm_lds_opt_in()) return bail(fail(QOC_ERR_HIP, "qoc_create: cannot reserve LDS for the GEMM-path kernels"));

@@ -12,8 +12,16 @@
 // 0.28 us per mat-vec against 0.46.
 // The next-but-one generator (64 KB) is fetched two loads per Taylor term instead of as one burst of 16 per wave: the burst stalled the
 // four waves ~1500 cycles per slice on the vector-memory issue queue (probe: "between inner loops").
+// Round 5 -- PACKED generators (PK): with Hermitian Hamiltonians every generator B = -i dt H is anti-Hermitian, B[r][c] = -conj(B[c][r]), so only
+// the 16 x 16 blocks on and below the block diagonal are stored: 10 blocks of 256 entries = 2560 entries (40 KB) per slice instead of 4096 (64 KB),
+// block (R, C), R >= C, at (R (R + 1) / 2 + C) * 256, column-major inside the block.  Wave w (block column w) loads the lanes of the row blocks
+// R >= w as before (column j of the block: 16 lanes = 256 B contiguous) and the lanes of the row blocks R < w from the MIRRORED block (w, R): lane i
+// reads the 16 consecutive entries i * 16 + j of that block and flips the sign of the real part.  The mirrored reads hit lines wave R of the same
+// workgroup fetches for the same slice (L2), so the chain's HBM reads and the assembly's HBM writes both drop to 5/8: C3 x 64 moves 7.9 instead of
+// 12.6 GB per iteration, x 256 31.5 instead of 50.4.
 #pragma once
 // (included by qoc_gemm_chains.h after ChainArgs and before the launchers)
+#define QOC_DPP_PK_ELEMS 2560     // entries of one packed generator
 
 #ifndef QOC_DPP_GAUSS
 #define QOC_DPP_GAUSS 1         // 1: complex MAC in the three-multiplication form (48 instead of 64 DPP FMAs per mat-vec); 0: the four-multiplication form
@@ -65,7 +73,7 @@ __device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], const double (
 #ifndef QOC_DPP_NO_STATIC
 #define QOC_DPP_NO_STATIC 0     // 1 (A/B builds): ten terms through the a.nterms >= 9 instance
 #endif
-template <bool NEG, int TS>
+template <bool NEG, int TS, bool PK>
 __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b, cplx (*part)[4][64], const double* tinv) {
     constexpr int N = 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -73,7 +81,15 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
     const bool owner = l < 16;
     // scalar base + 32-bit lane offset: the loads take the saddr form, no 64-bit VALU address arithmetic between the FMAs of the chain
     const cplx* Kp = a.K + b * a.sKb;
-    const unsigned koff = (unsigned)(16 * w) * N + l;                       // column 16 w + c of the transposed image: + c * N
+    // full image: column 16 w + c of the transposed generator = + c * N; packed image: see the header (row block R = l >> 4 of block column w)
+    const int rb = l >> 4, li = l & 15;
+    const bool mirrored = PK && rb < w;
+    const unsigned koff = !PK ? (unsigned)(16 * w) * N + l
+                          : (mirrored ? (unsigned)((w * (w + 1) / 2 + rb) * 256 + li * 16) : (unsigned)((rb * (rb + 1) / 2 + w) * 256 + li));
+    const unsigned kstr = !PK ? (unsigned)N : (mirrored ? 1u : 16u);
+    // entry c of this lane's run: the mask tells the compiler that the byte offset fits the 32-bit lane offset of the saddr load form
+    auto kidx = [&](int c) -> unsigned { return PK ? ((koff + (unsigned)c * kstr) & 4095u) : koff + (unsigned)c * kstr; };
+    const int flip = mirrored ? (int)0x80000000 : 0;                        // -conj: the sign bit of the real part
     const cplx* Ep = a.E + b * a.sEb + (size_t)idx * (a.ldE > 0 ? a.ldE : QOC_TW);
     cplx* Op = a.Out + b * a.sOb + (size_t)idx * a.ldO;
     cplx* O2 = a.Out2 ? a.Out2 + b * a.sO2b + idx : nullptr;
@@ -106,18 +122,22 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         cur ^= 1;                                                         // the next term writes the other buffer: one barrier per term
     };
     // slice j on the generator k with addend e; meanwhile the generator / addend of slice jn go into kn / en, two columns per term
-    auto step = [&](int j, const cplx (&k)[16], const cplx& e, cplx (&kn)[16], cplx& en, int jn) {
+    auto step = [&](int j, cplx (&k)[16], const cplx& e, cplx (&kn)[16], cplx& en, int jn) {
         const int jc = min(jn, last);
         const cplx* kj = Kp + (long long)jc * a.sKs;
         en = Ep[(long long)jc * a.sEs];
         double outr = xv.x, outi = xv.y;
         double sk[16];                                              // (three-multiplication form) re + im of the slice's generator entries
+        if constexpr (PK) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) k[c].x = __hiloint2double(__double2hiint(k[c].x) ^ flip, __double2loint(k[c].x));
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c) sk[c] = QOC_DPP_GAUSS ? k[c].x + k[c].y : 0.0;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            kn[2 * g] = kj[koff + (2 * g) * N];
-            kn[2 * g + 1] = kj[koff + (2 * g + 1) * N];
+            kn[2 * g] = kj[kidx(2 * g)];
+            kn[2 * g + 1] = kj[kidx(2 * g + 1)];
             if (TS != 0 || g + 1 < nterms) term(k, sk, g + 1, inv_s[g + 1], outr, outi);
         }
         for (int ii = 9; ii < nterms; ++ii) {
@@ -134,12 +154,12 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         {
             const cplx* kj = Kp;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) k0[c] = kj[koff + c * N];
+            for (int c = 0; c < 16; ++c) k0[c] = kj[kidx(c)];
             e0 = Ep[0];
             const int jc = min(1, last);
             kj = Kp + (long long)jc * a.sKs;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) k1[c] = kj[koff + c * N];
+            for (int c = 0; c < 16; ++c) k1[c] = kj[kidx(c)];
             e1 = Ep[(long long)jc * a.sEs];
         }
         int j = 0;
@@ -156,6 +176,7 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
 
 // Two argument sets in one launch, as k_gemm_taylor_chain: workgroups 0 .. nb0 - 1 run a0, the rest a1 (forward and z-free backward chain
 // side by side when there is no state regulariser)
+template <bool PK>
 __global__ void __launch_bounds__(256) k_gemm_taylor_chain_dpp(ChainArgs a0, ChainArgs a1, int nb0) {
     __shared__ __attribute__((aligned(16))) cplx part[2][4][64];
     __shared__ double tinv[64];
@@ -168,7 +189,7 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain_dpp(ChainArgs a0, Cha
         tinv[threadIdx.x] = 1.0 / fact;
     }
     lds_barrier();
-    if (a.nterms == 10 && !QOC_DPP_NO_STATIC) { if (a.sign < 0.0) taylor_chain_dpp_body<true, 10>(a, b, part, tinv); else taylor_chain_dpp_body<false, 10>(a, b, part, tinv); }
-    else if (a.nterms >= 9) { if (a.sign < 0.0) taylor_chain_dpp_body<true, -1>(a, b, part, tinv); else taylor_chain_dpp_body<false, -1>(a, b, part, tinv); }
-    else if (a.sign < 0.0) taylor_chain_dpp_body<true, 0>(a, b, part, tinv); else taylor_chain_dpp_body<false, 0>(a, b, part, tinv);
+    if (a.nterms == 10 && !QOC_DPP_NO_STATIC) { if (a.sign < 0.0) taylor_chain_dpp_body<true, 10, PK>(a, b, part, tinv); else taylor_chain_dpp_body<false, 10, PK>(a, b, part, tinv); }
+    else if (a.nterms >= 9) { if (a.sign < 0.0) taylor_chain_dpp_body<true, -1, PK>(a, b, part, tinv); else taylor_chain_dpp_body<false, -1, PK>(a, b, part, tinv); }
+    else if (a.sign < 0.0) taylor_chain_dpp_body<true, 0, PK>(a, b, part, tinv); else taylor_chain_dpp_body<false, 0, PK>(a, b, part, tinv);
 }

@@ -23,8 +23,8 @@
 // Slices are padded to SP = NC*S per seed; a padded slice gets A = 0, i.e. K = I exactly.
 // (item_first, item_count): the (seed, slice) items this launch assembles -- all of them, or the slices of one rank of a time-sharded engine
 __global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq,
-                                                        size_t item_first, size_t item_count) {
-    const size_t NN = (size_t)N * N;
+                                                        size_t item_first, size_t item_count, int nn = 0) {
+    const size_t NN = nn > 0 ? (size_t)nn : (size_t)N * N;         // (nn: entries per matrix of a packed stack, as in k_gemm_assemble_rows)
     const size_t total = item_count * NN;
     const double inv = 1.0 / (double)(1 << sq);
     for (size_t o0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o0 < total; o0 += (size_t)gridDim.x * blockDim.x) {
@@ -47,9 +47,10 @@ __global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __r
 // 256): k_gemm_assemble re-reads them from L2 for every output entry -- (k + 1) x the written bytes through L2, 2.0 ms for the 4.2 GB of
 // C3 x 64 -- this one is bound by the HBM writes alone.  blockIdx.x = 256-entry column of the matrix, blockIdx.y = run of items.
 // (t0, tn): with tn > 0 the items are the slices t0 .. t0 + tn - 1 of EVERY seed (item = b * tn + t - t0), written to their usual place
+// nn > 0: entries per matrix of the stack and of the output when that is not N * N (the packed anti-Hermitian image of qoc_gemm_chain_dpp.h: 2560)
 __global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq, int per,
-                                                             size_t item_first, size_t item_count, int t0 = 0, int tn = 0) {
-    const size_t NN = (size_t)N * N;
+                                                             size_t item_first, size_t item_count, int t0 = 0, int tn = 0, int nn = 0) {
+    const size_t NN = nn > 0 ? (size_t)nn : (size_t)N * N;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     const double inv = 1.0 / (double)(1 << sq);
     cplx h[9];
@@ -327,6 +328,10 @@ struct QocGemm {
     // second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its state
     hipStream_t aux = nullptr, chain_s = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_fwd = nullptr, ev_p1 = nullptr; int asm_split = 0, asm_tail_wgs = 512;
     bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
+    bool antiherm = false;    // every generator anti-Hermitian (set by the engine before qoc_gemm_setup)
+    bool dpp_packed = false;  // dpp_chain on anti-Hermitian generators: only the blocks on and below the block diagonal are assembled, stored and read
+    int dpp_mode() const { return dpp_chain ? (dpp_packed ? 2 : 1) : 0; }                                   // what qoc_taylor_chain_launch takes
+    size_t gen_elems() const { return dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : (size_t)N * N; }              // entries of one assembled generator
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
     size_t tree_off[8];
@@ -381,6 +386,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     {
         const char* e = getenv("QOC_CHAIN_DPP");                 // A/B switch: 0 = the butterfly kernel k_gemm_taylor_chain
         gm.dpp_chain = gm.direct && N == 64 && gm.MV == 1 && !(e && e[0] == '0');
+        gm.dpp_packed = gm.dpp_chain && gm.antiherm;
     }
     int L = 0;
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
@@ -409,7 +415,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     size_t root_elems = 0;
     for (int cnt = gm.NC; cnt > 1; cnt = (cnt + 1) / 2) root_elems += (size_t)d.B * ((cnt + 1) / 2) * NN;
     const bool poly = !fused && !gm.direct;                      // launch-per-product route: A2 and ping-pong buffers
-    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.HsPT, gm.dpp_chain ? hp.size() * sizeof(cplx) : 16) && (fused || al((void**)&gm.A, BSP * NN * sizeof(cplx))) &&
+    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.HsPT, gm.dpp_chain ? hp.size() * sizeof(cplx) : 16) && (fused || al((void**)&gm.A, BSP * (gm.direct ? gm.gen_elems() : NN) * sizeof(cplx))) &&
               (!poly || al((void**)&gm.P, BSP * NN * sizeof(cplx))) && (!poly || al((void**)&gm.A2, BSP * NN * sizeof(cplx))) &&
               al((void**)&gm.root, (gm.persistent && !d.state_transfer) ? root_elems * sizeof(cplx) : 16) &&
               al((void**)&gm.K, gm.direct ? 16 : BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
@@ -448,10 +454,15 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     if (gm.dpp_chain) {
         std::vector<cplx> ht(hp.size());
+        const size_t ge = gm.gen_elems();
         for (int kk = 0; kk <= d.k; ++kk)
             for (int a = 0; a < N; ++a)
-                for (int c = 0; c < N; ++c) ht[(size_t)kk * NN + (size_t)c * N + a] = hp[(size_t)kk * NN + (size_t)a * N + c];
-        if (hipMemcpy(gm.HsPT, ht.data(), ht.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+                for (int c = 0; c < N; ++c) {
+                    if (!gm.dpp_packed) { ht[(size_t)kk * NN + (size_t)c * N + a] = hp[(size_t)kk * NN + (size_t)a * N + c]; continue; }
+                    const int R = a >> 4, C = c >> 4;             // packed: blocks on and below the block diagonal, column-major inside a block
+                    if (R >= C) ht[(size_t)kk * ge + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)] = hp[(size_t)kk * NN + (size_t)a * N + c];
+                }
+        if (hipMemcpy(gm.HsPT, ht.data(), (size_t)(d.k + 1) * ge * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     }
     // the persistent chain kernels write only the first m (<= 8) of the 32 thin columns; the rest must read as zero
     bool zeroed = hipMemset(gm.zthin, 0, thin * sizeof(cplx)) == hipSuccess &&
@@ -575,26 +586,26 @@ static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const
 
 static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
 // the slices t0 .. t0 + tn - 1 of every seed (needs what k_gemm_assemble_rows needs: k <= 8, N*N a multiple of 256)
-static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int t0, int tn, hipStream_t s, int target_wgs = 8192) {
-    const size_t NN = (size_t)N * N, items = (size_t)d.B * tn;
+static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int t0, int tn, hipStream_t s, int target_wgs = 8192, int nn = 0) {
+    const size_t NN = nn > 0 ? (size_t)nn : (size_t)N * N, items = (size_t)d.B * tn;
     const int gx = (int)(NN / 256);
     int per = (int)((items * gx + target_wgs - 1) / target_wgs);
     if (per < 4) per = 4;
     const int gy = (int)((items + per - 1) / per);
-    hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, 0, per, (size_t)0, items, t0, tn);
+    hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, 0, per, (size_t)0, items, t0, tn, nn);
 }
 static inline void qoc_gemm_assemble_launch(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int sq, hipStream_t s,
-                                            size_t item_first = 0, size_t item_count = 0) {
+                                            size_t item_first = 0, size_t item_count = 0, int nn = 0) {
     if (item_count == 0) item_count = (size_t)d.B * SP;
-    const size_t NN = (size_t)N * N, items = item_count;
+    const size_t NN = nn > 0 ? (size_t)nn : (size_t)N * N, items = item_count;
     if (d.k <= 8 && NN % 256 == 0 && items >= 64) {
         const int gx = (int)(NN / 256);
         int per = (int)((items * gx + 8191) / 8192);                     // ~8192 workgroups
         if (per < 4) per = 4;
         const int gy = (int)((items + per - 1) / per);
-        if (gy <= 65535) { hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, per, item_first, item_count); return; }
+        if (gy <= 65535) { hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, per, item_first, item_count, 0, 0, nn); return; }
     }
-    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(items * NN)), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, item_first, item_count);
+    hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(items * NN)), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, item_first, item_count, nn);
 }
 
 // pairwise product tree: T_l[i] = T_{l-1}[2i+1] * T_{l-1}[2i]  (later slice on the left), T_0 = K
@@ -627,15 +638,16 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
     if (gm.direct) {                                             // the chains apply the Taylor series themselves
+        const int nn = gm.dpp_packed ? QOC_DPP_PK_ELEMS : 0;
         if (gm.asm_split > 0) {                                    // head on this stream, tail on the second one beside the forward chain's first part
-            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, 0, gm.asm_split, s);
+            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, 0, gm.asm_split, s, 8192, nn);
             hipEventRecord(gm.ev_ready, s);                         // the head has the memory system to itself (started together, both took as long as the whole)
             hipStreamWaitEvent(gm.aux, gm.ev_ready, 0);
-            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_split, gm.SP - gm.asm_split, gm.aux, gm.asm_tail_wgs);
+            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_split, gm.SP - gm.asm_split, gm.aux, gm.asm_tail_wgs, nn);
             hipEventRecord(gm.ev_tail, gm.aux);
             return;
         }
-        qoc_gemm_assemble_launch(d, gm.dpp_chain ? gm.HsPT : gm.HsP, gm.A, N, gm.SP, 0, s);   // dpp_chain: generators column-major
+        qoc_gemm_assemble_launch(d, gm.dpp_chain ? gm.HsPT : gm.HsP, gm.A, N, gm.SP, 0, s, 0, 0, nn);   // dpp_chain: generators column-major
         return;
     }
     if (N <= 64) {
@@ -711,7 +723,8 @@ static inline ChainArgs qoc_gemm_direct_backward_args(const QocGemm& gm, const Q
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     ChainArgs a;
     memset(&a, 0, sizeof a);
-    a.K = gm.A + (size_t)(d.steps - 1) * NN; a.sKb = (long long)NN * gm.SP; a.sKs = -(long long)NN;
+    const size_t GE = gm.gen_elems();
+    a.K = gm.A + (size_t)(d.steps - 1) * GE; a.sKb = (long long)GE * gm.SP; a.sKs = -(long long)GE;
     a.X0 = gm.Ebnd; a.sXb = (long long)thin;
     if (need_src && gm.dpp_chain) { a.E = gm.SrcP + (size_t)(d.steps - 1) * N; a.sEb = (long long)N * gm.SP; a.sEs = -(long long)N; a.ldE = 1; }   // compact sources
     else if (need_src) { a.E = gm.SrcP + (size_t)(d.steps - 1) * thin; a.sEb = (long long)thin * gm.SP; a.sEs = -(long long)thin; }
@@ -734,7 +747,8 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
     if (gm.direct) {
         ChainArgs a;
         memset(&a, 0, sizeof a);
-        a.K = gm.A; a.sKb = (long long)NN * gm.SP; a.sKs = (long long)NN;
+        const size_t GE = gm.gen_elems();
+        a.K = gm.A; a.sKb = (long long)GE * gm.SP; a.sKs = (long long)GE;
         a.X0 = gm.Psibnd; a.sXb = (long long)thin;
         a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOs = gm.MV; a.ldO = gm.ldW;
         a.CI = 1; a.len = d.steps; a.m = d.m; a.nterms = d.T; a.sign = 1.0;
@@ -745,7 +759,7 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             // no state regulariser: the costate is linear in the overlap z -- the backward chain starts from -(2/m^2) W and runs
             // beside the forward one; qoc_gemm_backward multiplies by z (C3 x 64: 13.2 -> 8 ms per iteration)
             hipLaunchKernelGGL(k_gemm_zfree_end, dim3(gemm_grid((size_t)d.B * thin)), dim3(256), 0, s, d, gm.Ebnd, N, NC);
-            qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s, gm.dpp_chain);
+            qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s, gm.dpp_mode());
         }
         else if (gm.asm_split > 0) {
             ChainArgs h = a, t = a;                              // slices [0, asm_split), then the rest from the state the first part leaves in Aoff
@@ -753,17 +767,17 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             if (gm.chain_s) {                                    // the first part on its own CUs (the assembly tail runs on the others)
                 hipEventRecord(gm.ev_fwd, s);
                 hipStreamWaitEvent(gm.chain_s, gm.ev_fwd, 0);
-                qoc_taylor_chain_launch(N, h, gm.zthin, d.B, gm.chain_s, true);
+                qoc_taylor_chain_launch(N, h, gm.zthin, d.B, gm.chain_s, gm.dpp_mode());
                 hipEventRecord(gm.ev_p1, gm.chain_s);
                 hipStreamWaitEvent(s, gm.ev_p1, 0);
             }
-            else qoc_taylor_chain_launch(N, h, gm.zthin, d.B, s, true);
+            else qoc_taylor_chain_launch(N, h, gm.zthin, d.B, s, gm.dpp_mode());
             hipStreamWaitEvent(s, gm.ev_tail, 0);
             t.K = a.K + (long long)gm.asm_split * a.sKs; t.X0 = gm.Aoff; t.sXb = (long long)thin;
             t.Out = a.Out + (long long)gm.asm_split * a.sOs; t.Out2 = a.Out2 + (long long)gm.asm_split * a.sO2s; t.len = a.len - gm.asm_split;
-            qoc_taylor_chain_launch(N, t, gm.zthin, d.B, s, true);
+            qoc_taylor_chain_launch(N, t, gm.zthin, d.B, s, gm.dpp_mode());
         }
-        else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s, gm.dpp_chain);
+        else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s, gm.dpp_mode());
         if (!gm.dpp_chain) hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
         return;
     }
@@ -906,7 +920,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     if (gm.direct) {
         // (the gradient products of the slices the chain has already left, on the second stream beside the rest of the chain: built and measured in
         // round 4, 6.19 against 6.17 ms at C3 x 64 -- the products slow the chain's prefetch as much as they save; profiles/EXPERIMENTS.md)
-        if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s, gm.dpp_chain);
+        if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s, gm.dpp_mode());
     } else if (gm.persistent) {
         ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
         memset(&sw, 0, sizeof sw);
