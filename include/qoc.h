@@ -76,7 +76,10 @@ typedef struct qoc_config {
                                  * exponentials by four waves per chunk, a block of rows each (auto for n > 32), 8 = as 4 with
                                  * row-strip-major products whose result rewrites the left-operand image in place (n <= 32, Taylor
                                  * order >= 3; auto for n <= 32 batches since round 3); 2..8 (and auto) run the n <= 32 sweeps on
-                                 * v_mfma_f64_4x4x4 as well */
+                                 * v_mfma_f64_4x4x4 as well.
+                                 * GEMM path requested explicitly (path = QOC_PATH_GEMM), direct state-transfer route at n in 33..64 with one
+                                 * state vector and Hermitian H: 2 = the squared-generator Taylor chain (csrc/qoc_gemm_chain_sq.h; opt-in,
+                                 * measured slower than the default chain), other values = the default chain */
     int32_t plan_seeds;         /* 0, or the batch size AUTO plans for instead of n_seeds: path, kernel family, chunk count and split
                                  * factors are derived from it, so that a restart evolves bit-identically whether it runs in one engine
                                  * of `plan_seeds` control sets or in a shard of it (GrapeSharded passes restarts / GPUs of the node) */

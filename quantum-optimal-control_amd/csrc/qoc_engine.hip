@@ -621,6 +621,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         std::string msg;
         if (cfg->time_shards >= 1) { e->gm.ts_G = cfg->time_shards; e->gm.ts_rank = cfg->time_rank; }
         e->gm.antiherm = antiherm;
+        e->gm.direct_variant = cfg->path == QOC_PATH_GEMM ? cfg->variant : 0;
         rc = qoc_gemm_setup(e->gm, d, (const cplx*)Hs, gemm_direct, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         if (!qoc_gemm_lds_opt_in()) return bail(fail(QOC_ERR_HIP, "qoc_create: cannot reserve LDS for the GEMM-path kernels"));
@@ -885,6 +886,8 @@ int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
         int w = snprintf(tmp, sizeof tmp, "path=gemm route=%s chunks=%d slices_per_chunk=%d chains=%s", g.direct ? "direct" : (e->d.state_transfer ? "propagator" : "unitary"),
                          g.NC, g.S, g.persistent ? "persistent" : "launches");
         if (g.ts_G > 0) snprintf(tmp + w, sizeof tmp - w, " time_shards=%d time_rank=%d", g.ts_G, g.ts_rank);
+        // the kernel of the direct route's Taylor chains: squared (k_gemm_taylor_chain_sq on [B | B^2]), packed / full (k_gemm_taylor_chain_dpp), butterfly (k_gemm_taylor_chain)
+        if (g.direct) snprintf(tmp + w, sizeof tmp - w, " taylor_chain=%s", g.sq_chain ? "squared" : g.dpp_packed ? "packed" : g.dpp_chain ? "full" : "butterfly");
     } else {
         snprintf(tmp, sizeof tmp, "path=%s", e->path == QOC_PATH_ST_FUSED ? "st_fused" : "generic");
     }

@@ -339,6 +339,7 @@ __global__ void __launch_bounds__((TaylorMap<N, MV>::type::THREADS)) k_gemm_tayl
 }
 
 #include "qoc_gemm_chain_dpp.h"     // k_gemm_taylor_chain_dpp: N = 64, one vector, generators column-major
+#include "qoc_gemm_chain_sq.h"      // k_gemm_taylor_chain_sq: the same chain on [B | B^2], 1 + ceil(T/2) - 1 dependent mat-vecs per slice
 
 template <int N>
 static inline void qoc_taylor_chain_launch_n(const ChainArgs& a0, const ChainArgs& a1, int nb0, int blocks, hipStream_t s) {
@@ -348,9 +349,11 @@ static inline void qoc_taylor_chain_launch_n(const ChainArgs& a0, const ChainArg
     else if (mv == 4) hipLaunchKernelGGL((k_gemm_taylor_chain<N, 4>), dim3(blocks), dim3(TaylorMap<N, 4>::type::THREADS), 0, s, a0, a1, nb0);
     else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(TaylorMap<N, 8>::type::THREADS), 0, s, a0, a1, nb0);
 }
-// dpp: 0 = k_gemm_taylor_chain, 1 = k_gemm_taylor_chain_dpp on full generators, 2 = on packed anti-Hermitian generators (qoc_gemm_chain_dpp.h)
+// dpp: 0 = k_gemm_taylor_chain, 1 = k_gemm_taylor_chain_dpp on full generators, 2 = on packed anti-Hermitian generators (qoc_gemm_chain_dpp.h),
+//      3 = k_gemm_taylor_chain_sq on packed [B | B^2] (qoc_gemm_chain_sq.h)
 static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s, int dpp = 0) {
     if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
+    if (dpp == 3) { hipLaunchKernelGGL(k_gemm_taylor_chain_sq, dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
     if (dpp == 2) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<true>, dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
     if (dpp) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<false>, dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
     if (N == 32) qoc_taylor_chain_launch_n<32>(a, a, blocks, blocks, s); else qoc_taylor_chain_launch_n<64>(a, a, blocks, blocks, s);
@@ -359,6 +362,7 @@ static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros
 static inline void qoc_taylor_chain_launch2(int N, ChainArgs a0, ChainArgs a1, const cplx* zeros, int blocks, hipStream_t s, int dpp = 0) {
     if (!a0.E) { a0.E = zeros; a0.sEb = a0.sEc = a0.sEs = 0; }
     if (!a1.E) { a1.E = zeros; a1.sEb = a1.sEc = a1.sEs = 0; }
+    if (dpp == 3) { hipLaunchKernelGGL(k_gemm_taylor_chain_sq, dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
     if (dpp == 2) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<true>, dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
     if (dpp) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<false>, dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
     if (N == 32) qoc_taylor_chain_launch_n<32>(a0, a1, blocks, 2 * blocks, s); else qoc_taylor_chain_launch_n<64>(a0, a1, blocks, 2 * blocks, s);

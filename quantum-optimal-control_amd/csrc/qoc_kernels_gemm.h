@@ -73,6 +73,51 @@ __global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx
         Aout[((size_t)b * SP + t) * NN + e] = acc;
     }
 }
+// ---- squared-generator chain (qoc_gemm_chain_sq.h): B_t and B_t^2 of every (seed, slice), both in the packed anti-Hermitian / Hermitian image ----
+// coefficient row of item (b, t): [1, u_1 .. u_k, u_kk u_ll for kk <= ll (kk-major)] -- P = (k + 1)(k + 2) / 2 doubles, read as scalars by the assembly
+__global__ void __launch_bounds__(256) k_gemm_sq_coefs(QocDev d, double* __restrict__ coef, int SP, int P) {
+    const size_t total = (size_t)d.B * d.steps;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(o / d.steps), t = (int)(o - (size_t)b * d.steps);
+        const double* ub = d.u + (size_t)b * d.k * d.steps + t;
+        double* c = coef + ((size_t)b * SP + t) * P;
+        double u[8];
+        for (int kk = 0; kk < d.k; ++kk) u[kk] = ub[(size_t)kk * d.steps];
+        c[0] = 1.0;
+        int p = 1;
+        for (int kk = 0; kk < d.k; ++kk) c[p++] = u[kk];
+        for (int kk = 0; kk < d.k; ++kk)
+            for (int ll = kk; ll < d.k; ++ll) c[p++] = u[kk] * u[ll];
+    }
+}
+// B_t = h_0 + sum_k u_k h_k and B_t^2 = sum_p c_p q_p for the packed entry e of a thread (its k + 1 + P basis entries in registers over a run of items),
+// written as [B | B^2] (2 x 2560 entries per item).  KK = number of controls.  (t0, tn) as in k_gemm_assemble_rows.
+template <int KK>
+__global__ void __launch_bounds__(256) k_gemm_assemble_sq(QocDev d, const cplx* __restrict__ HsPK, const cplx* __restrict__ HsSQ, const double* __restrict__ coef,
+                                                           cplx* __restrict__ Aout, int SP, int per, size_t item_count, int t0, int tn) {
+    constexpr int P = (KK + 1) * (KK + 2) / 2, GE = QOC_DPP_PK_ELEMS;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    cplx h[KK + 1], q[P];
+#pragma unroll
+    for (int kk = 0; kk <= KK; ++kk) h[kk] = HsPK[(size_t)kk * GE + e];
+#pragma unroll
+    for (int p = 0; p < P; ++p) q[p] = HsSQ[(size_t)p * GE + e];
+    const size_t i0 = (size_t)blockIdx.y * per, i1 = i0 + per < item_count ? i0 + per : item_count;
+    for (size_t item = i0; item < i1; ++item) {
+        int b, t;
+        if (tn > 0) { b = (int)(item / tn); t = t0 + (int)(item - (size_t)b * tn); }
+        else { b = (int)(item / SP); t = (int)(item - (size_t)b * SP); }
+        const double* c = coef + ((size_t)b * SP + t) * P;
+        cplx accB = h[0], accS = q[0];
+#pragma unroll
+        for (int kk = 1; kk <= KK; ++kk) { const double u = c[kk]; accB.x = fma(u, h[kk].x, accB.x); accB.y = fma(u, h[kk].y, accB.y); }
+#pragma unroll
+        for (int p = 1; p < P; ++p) { const double u = c[p]; accS.x = fma(u, q[p].x, accS.x); accS.y = fma(u, q[p].y, accS.y); }
+        cplx* out = Aout + ((size_t)b * SP + t) * (2 * GE);
+        out[e] = accB;
+        out[GE + e] = accS;
+    }
+}
 // S = c0*I + c1*A (+ cT*A2): top block of the Paterson-Stockmeyer recursion
 __global__ void __launch_bounds__(256) k_gemm_ps_init(const cplx* __restrict__ A, const cplx* __restrict__ A2, cplx* __restrict__ S,
                                                        size_t count, int N, double c0, double c1, double cT) {
@@ -327,11 +372,19 @@ struct QocGemm {
     // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled on a
     // second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its state
     hipStream_t aux = nullptr, chain_s = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_fwd = nullptr, ev_p1 = nullptr; int asm_split = 0, asm_tail_wgs = 512;
+    // (round 5) the pulse is cut into asm_win.size() - 1 windows [asm_win[w], asm_win[w + 1]): window 0 is assembled in front of the chain, window w >= 1 on
+    // the second stream while the chain walks window w - 1 (one chain launch per window, each continuing from the state the previous one left in Aoff)
+    std::vector<int> asm_win; std::vector<hipEvent_t> ev_win;
     bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
     bool antiherm = false;    // every generator anti-Hermitian (set by the engine before qoc_gemm_setup)
     bool dpp_packed = false;  // dpp_chain on anti-Hermitian generators: only the blocks on and below the block diagonal are assembled, stored and read
-    int dpp_mode() const { return dpp_chain ? (dpp_packed ? 2 : 1) : 0; }                                   // what qoc_taylor_chain_launch takes
-    size_t gen_elems() const { return dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : (size_t)N * N; }              // entries of one assembled generator
+    // dpp_packed, few enough control sets for the chains to be latency-bound: [B | B^2] per slice and k_gemm_taylor_chain_sq (qoc_gemm_chain_sq.h)
+    bool sq_chain = false;
+    int direct_variant = 0;   // qoc_config.variant of an explicit GEMM-path request: 1 = never the squared-generator chain, 2 = always where it applies
+    cplx* HsSQ = nullptr;     // sq_chain: the (k + 1)(k + 2) / 2 packed basis matrices of B^2
+    double* sqc = nullptr;    // sq_chain: [B][SP][P] coefficient rows (k_gemm_sq_coefs)
+    int dpp_mode() const { return dpp_chain ? (sq_chain ? 3 : (dpp_packed ? 2 : 1)) : 0; }                   // what qoc_taylor_chain_launch takes
+    size_t gen_elems() const { return sq_chain ? (size_t)2 * QOC_DPP_PK_ELEMS : (dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : (size_t)N * N); }   // entries of one slice
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
     size_t tree_off[8];
@@ -387,6 +440,9 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         const char* e = getenv("QOC_CHAIN_DPP");                 // A/B switch: 0 = the butterfly kernel k_gemm_taylor_chain
         gm.dpp_chain = gm.direct && N == 64 && gm.MV == 1 && !(e && e[0] == '0');
         gm.dpp_packed = gm.dpp_chain && gm.antiherm;
+        // opt-in only (qoc_config.variant = 2 with path = GEMM): measured SLOWER than the plain chain at C3 x 64 (7.98 against 5.83 ms per iteration) --
+        // see the header of qoc_gemm_chain_sq.h and profiles/EXPERIMENTS.md
+        gm.sq_chain = gm.dpp_packed && qoc_sq_chain_terms_ok(d.T) && d.k >= 1 && d.k <= 8 && gm.direct_variant == 2;
     }
     int L = 0;
     while (L < 6 && (1 << (2 * (L + 1))) <= d.steps) ++L;        // S = 2^L ~ sqrt(steps), at most 64
@@ -431,6 +487,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
               al((void**)&gm.zthin, thin * sizeof(cplx)) &&
               al((void**)&gm.partial, (size_t)d.B * d.k * (N / 32) * (gm.persistent ? (size_t)gm.ldW : (size_t)d.steps) * sizeof(double));
     if (ok && need_src) ok = al((void**)&gm.SrcP, BSP * thin * sizeof(cplx));
+    const int sqP = (d.k + 1) * (d.k + 2) / 2;
+    if (ok && gm.sq_chain) ok = al((void**)&gm.HsSQ, (size_t)sqP * QOC_DPP_PK_ELEMS * sizeof(cplx)) && al((void**)&gm.sqc, BSP * sqP * sizeof(double));
     // wide gradient products: large matrices with few vectors (row tiles in pairs and column tiles in fours: what k_zgemm_wg takes)
     gm.wideW = (!gm.persistent && N >= 128 && (N / 32) % 2 == 0 && d.m <= QOC_WIDE_MV) ? (int)((((size_t)d.steps * QOC_WIDE_MV + 127) / 128) * 128) : 0;
     if (ok && gm.wideW > 0)
@@ -454,7 +512,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     if (gm.dpp_chain) {
         std::vector<cplx> ht(hp.size());
-        const size_t ge = gm.gen_elems();
+        const size_t ge = gm.dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : NN;       // entries per matrix of the (packed) stack
         for (int kk = 0; kk <= d.k; ++kk)
             for (int a = 0; a < N; ++a)
                 for (int c = 0; c < N; ++c) {
@@ -463,6 +521,34 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
                     if (R >= C) ht[(size_t)kk * ge + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)] = hp[(size_t)kk * NN + (size_t)a * N + c];
                 }
         if (hipMemcpy(gm.HsPT, ht.data(), (size_t)(d.k + 1) * ge * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+    }
+    if (gm.sq_chain) {
+        // M_0 = A_0^2, M_k = A_0 A_k + A_k A_0, M_kl = A_k A_l + A_l A_k (k < l), M_kk = A_k^2 -- Hermitian, packed like the generators
+        std::vector<cplx> hq((size_t)sqP * QOC_DPP_PK_ELEMS);
+        std::vector<cplx> prod(NN);
+        auto accumulate = [&](int x, int y, bool clear) {                        // prod (+)= A_x A_y
+            const cplx* X = &hp[(size_t)x * NN]; const cplx* Y = &hp[(size_t)y * NN];
+            for (int a = 0; a < N; ++a)
+                for (int c = 0; c < N; ++c) {
+                    double re = 0.0, im = 0.0;
+                    for (int j = 0; j < N; ++j) { const cplx u = X[(size_t)a * N + j], v = Y[(size_t)j * N + c]; re += u.x * v.x - u.y * v.y; im += u.x * v.y + u.y * v.x; }
+                    cplx& o = prod[(size_t)a * N + c];
+                    if (clear) { o.x = re; o.y = im; } else { o.x += re; o.y += im; }
+                }
+        };
+        auto pack = [&](int p) {
+            for (int a = 0; a < N; ++a)
+                for (int c = 0; c < N; ++c) {
+                    const int R = a >> 4, C = c >> 4;
+                    if (R >= C) hq[(size_t)p * QOC_DPP_PK_ELEMS + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)] = prod[(size_t)a * N + c];
+                }
+        };
+        int p = 0;
+        accumulate(0, 0, true); pack(p++);
+        for (int kk = 1; kk <= d.k; ++kk) { accumulate(0, kk, true); accumulate(kk, 0, false); pack(p++); }
+        for (int kk = 1; kk <= d.k; ++kk)
+            for (int ll = kk; ll <= d.k; ++ll) { accumulate(kk, ll, true); if (ll != kk) accumulate(ll, kk, false); pack(p++); }
+        if (hipMemcpy(gm.HsSQ, hq.data(), hq.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     }
     // the persistent chain kernels write only the first m (<= 8) of the 32 thin columns; the rest must read as zero
     bool zeroed = hipMemset(gm.zthin, 0, thin * sizeof(cplx)) == hipSuccess &&
@@ -508,6 +594,19 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
             gm.asm_tail_wgs = gm.chain_s ? 8192 : 512;
             if (const char* t = getenv("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : gm.asm_tail_wgs;
             if (const char* t = getenv("QOC_ASM_SPLIT16")) gm.asm_split = (atoi(t) * d.steps) / 16;
+            if (gm.asm_split < 1) gm.asm_split = 1;
+            if (gm.asm_split > d.steps - 1) gm.asm_split = d.steps - 1;
+            // windows: [0, asm_split) in front, the rest in nw - 1 equal windows beside the chain.  More than two windows buy nothing (C3 x 64: 5.85 / 5.87 ms
+            // at nw = 2 / 4 with 4/16 in front, 5.83 with 2/16 and nw = 4: the chain part that runs beside an assembly launch loses what the shorter head
+            // saves) and nine or more chain launches waiting on events of the second stream did not finish at all on ROCm 7.2: profiles/r05_c3_windows.txt
+            int nw = 2;
+            if (const char* t = getenv("QOC_ASM_WINDOWS")) nw = atoi(t) >= 2 ? (atoi(t) <= 4 ? atoi(t) : 4) : 2;
+            if (nw - 1 > d.steps - gm.asm_split) nw = 1 + (d.steps - gm.asm_split);
+            gm.asm_win.assign(1, 0);
+            for (int w = 1; w <= nw; ++w) gm.asm_win.push_back(w == nw ? d.steps : gm.asm_split + (int)(((long long)(d.steps - gm.asm_split) * (w - 1)) / (nw - 1)));
+            gm.ev_win.assign(nw, nullptr);
+            for (int w = 1; w < nw; ++w)
+                if (hipEventCreateWithFlags(&gm.ev_win[w], hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: events could not be created"; return -2; }
         }
     }
     return 0;
@@ -519,6 +618,7 @@ static inline void qoc_gemm_teardown(QocGemm& gm) {
     if (gm.ev_p1) { hipEventDestroy(gm.ev_p1); gm.ev_p1 = nullptr; }
     if (gm.ev_ready) { hipEventDestroy(gm.ev_ready); gm.ev_ready = nullptr; }
     if (gm.ev_tail) { hipEventDestroy(gm.ev_tail); gm.ev_tail = nullptr; }
+    for (auto& ev : gm.ev_win) if (ev) { hipEventDestroy(ev); ev = nullptr; }
 }
 
 template <bool CONJT, int EPI, int SK>
@@ -594,6 +694,28 @@ static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cp
     const int gy = (int)((items + per - 1) / per);
     hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, 0, per, (size_t)0, items, t0, tn, nn);
 }
+// [B | B^2] of the slices t0 .. t0 + tn - 1 of every seed (tn = 0: all items) for the squared-generator chain
+template <int KK>
+static inline void qoc_gemm_assemble_sq_k(const QocDev& d, const cplx* HsPK, const cplx* HsSQ, const double* coef, cplx* Aout, int SP, int t0, int tn, hipStream_t s, int target_wgs) {
+    const size_t items = (size_t)d.B * (tn > 0 ? tn : SP);
+    const int gx = QOC_DPP_PK_ELEMS / 256;
+    int per = (int)((items * gx + target_wgs - 1) / target_wgs);
+    if (per < 4) per = 4;
+    const int gy = (int)((items + per - 1) / per);
+    hipLaunchKernelGGL(k_gemm_assemble_sq<KK>, dim3(gx, gy), dim3(256), 0, s, d, HsPK, HsSQ, coef, Aout, SP, per, items, t0, tn);
+}
+static inline void qoc_gemm_assemble_sq(const QocDev& d, const cplx* HsPK, const cplx* HsSQ, const double* coef, cplx* Aout, int SP, int t0, int tn, hipStream_t s, int target_wgs = 8192) {
+    switch (d.k) {
+        case 1: qoc_gemm_assemble_sq_k<1>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+        case 2: qoc_gemm_assemble_sq_k<2>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+        case 3: qoc_gemm_assemble_sq_k<3>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+        case 4: qoc_gemm_assemble_sq_k<4>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+        case 5: qoc_gemm_assemble_sq_k<5>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+        case 6: qoc_gemm_assemble_sq_k<6>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+        case 7: qoc_gemm_assemble_sq_k<7>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+        default: qoc_gemm_assemble_sq_k<8>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
+    }
+}
 static inline void qoc_gemm_assemble_launch(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int sq, hipStream_t s,
                                             size_t item_first = 0, size_t item_count = 0, int nn = 0) {
     if (item_count == 0) item_count = (size_t)d.B * SP;
@@ -639,12 +761,31 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int nsq = d.state_transfer ? 0 : d.s;
     if (gm.direct) {                                             // the chains apply the Taylor series themselves
         const int nn = gm.dpp_packed ? QOC_DPP_PK_ELEMS : 0;
+        if (gm.sq_chain) {
+            const int P = (d.k + 1) * (d.k + 2) / 2;
+            hipLaunchKernelGGL(k_gemm_sq_coefs, dim3(gemm_grid((size_t)d.B * d.steps)), dim3(256), 0, s, d, gm.sqc, gm.SP, P);
+            if (gm.asm_split > 0) {
+                const int nw = (int)gm.asm_win.size() - 1;
+                qoc_gemm_assemble_sq(d, gm.HsPT, gm.HsSQ, gm.sqc, gm.A, gm.SP, 0, gm.asm_win[1], s);
+                hipEventRecord(gm.ev_ready, s);
+                hipStreamWaitEvent(gm.aux, gm.ev_ready, 0);
+                for (int w = 1; w < nw; ++w) {
+                    qoc_gemm_assemble_sq(d, gm.HsPT, gm.HsSQ, gm.sqc, gm.A, gm.SP, gm.asm_win[w], gm.asm_win[w + 1] - gm.asm_win[w], gm.aux, gm.asm_tail_wgs);
+                    hipEventRecord(gm.ev_win[w], gm.aux);
+                }
+            }
+            else qoc_gemm_assemble_sq(d, gm.HsPT, gm.HsSQ, gm.sqc, gm.A, gm.SP, 0, 0, s);
+            return;
+        }
         if (gm.asm_split > 0) {                                    // head on this stream, tail on the second one beside the forward chain's first part
-            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, 0, gm.asm_split, s, 8192, nn);
+            const int nw = (int)gm.asm_win.size() - 1;
+            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, 0, gm.asm_win[1], s, 8192, nn);
             hipEventRecord(gm.ev_ready, s);                         // the head has the memory system to itself (started together, both took as long as the whole)
             hipStreamWaitEvent(gm.aux, gm.ev_ready, 0);
-            qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_split, gm.SP - gm.asm_split, gm.aux, gm.asm_tail_wgs, nn);
-            hipEventRecord(gm.ev_tail, gm.aux);
+            for (int w = 1; w < nw; ++w) {
+                qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_win[w], gm.asm_win[w + 1] - gm.asm_win[w], gm.aux, gm.asm_tail_wgs, nn);
+                hipEventRecord(gm.ev_win[w], gm.aux);
+            }
             return;
         }
         qoc_gemm_assemble_launch(d, gm.dpp_chain ? gm.HsPT : gm.HsP, gm.A, N, gm.SP, 0, s, 0, 0, nn);   // dpp_chain: generators column-major
@@ -762,20 +903,21 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s, gm.dpp_mode());
         }
         else if (gm.asm_split > 0) {
-            ChainArgs h = a, t = a;                              // slices [0, asm_split), then the rest from the state the first part leaves in Aoff
-            h.len = gm.asm_split; h.Fin = gm.Aoff; h.sFb = (long long)thin;
-            if (gm.chain_s) {                                    // the first part on its own CUs (the assembly tail runs on the others)
-                hipEventRecord(gm.ev_fwd, s);
-                hipStreamWaitEvent(gm.chain_s, gm.ev_fwd, 0);
-                qoc_taylor_chain_launch(N, h, gm.zthin, d.B, gm.chain_s, gm.dpp_mode());
-                hipEventRecord(gm.ev_p1, gm.chain_s);
-                hipStreamWaitEvent(s, gm.ev_p1, 0);
+            // one chain launch per window, each from the state the previous one left in Aoff; with a CU mask the chains keep their own CUs (the
+            // assembly of the later windows runs on the others) and the engine's stream joins after the last window
+            const int nw = (int)gm.asm_win.size() - 1;
+            hipStream_t cs = gm.chain_s ? gm.chain_s : s;
+            if (gm.chain_s) { hipEventRecord(gm.ev_fwd, s); hipStreamWaitEvent(cs, gm.ev_fwd, 0); }
+            for (int w = 0; w < nw; ++w) {
+                ChainArgs p = a;
+                const int t0 = gm.asm_win[w];
+                p.len = gm.asm_win[w + 1] - t0;
+                if (w > 0) { p.X0 = gm.Aoff; p.sXb = (long long)thin; hipStreamWaitEvent(cs, gm.ev_win[w], 0); }
+                if (w + 1 < nw) { p.Fin = gm.Aoff; p.sFb = (long long)thin; }
+                p.K = a.K + (long long)t0 * a.sKs; p.Out = a.Out + (long long)t0 * a.sOs; p.Out2 = a.Out2 + (long long)t0 * a.sO2s;
+                qoc_taylor_chain_launch(N, p, gm.zthin, d.B, cs, gm.dpp_mode());
             }
-            else qoc_taylor_chain_launch(N, h, gm.zthin, d.B, s, gm.dpp_mode());
-            hipStreamWaitEvent(s, gm.ev_tail, 0);
-            t.K = a.K + (long long)gm.asm_split * a.sKs; t.X0 = gm.Aoff; t.sXb = (long long)thin;
-            t.Out = a.Out + (long long)gm.asm_split * a.sOs; t.Out2 = a.Out2 + (long long)gm.asm_split * a.sO2s; t.len = a.len - gm.asm_split;
-            qoc_taylor_chain_launch(N, t, gm.zthin, d.B, s, gm.dpp_mode());
+            if (gm.chain_s) { hipEventRecord(gm.ev_p1, cs); hipStreamWaitEvent(s, gm.ev_p1, 0); }
         }
         else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s, gm.dpp_mode());
         if (!gm.dpp_chain) hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);

@@ -282,6 +282,39 @@ def test_direct_route_on_the_dpp_chain(n, steps, terms, reg, monkeypatch):
     np.testing.assert_allclose(r['grad'], r0['grad'], rtol=0, atol=1e-13 * max(1.0, np.max(np.abs(r0['grad']))))
 
 
+@pytest.mark.parametrize('n,steps,terms,reg', [(64, 31, 10, 'forbidden'), (64, 32, 9, 'none'), (50, 7, 13, 'forbidden'), (64, 2, 3, 'none'), (64, 130, 10, 'allreg'),
+                                               (64, 9, 4, 'forbidden'), (33, 66, 14, 'allreg'), (64, 5, 6, 'none')],
+                         ids=['n64_T10_forbidden', 'n64_T9_zfree', 'n50_T13_forbidden', 'n64_two_steps_T3', 'n64_130_slices_allreg', 'n64_T4', 'n33_T14_allreg', 'n64_T6_zfree'])
+def test_direct_route_on_the_squared_generator_chain(n, steps, terms, reg):
+    """k_gemm_taylor_chain_sq (csrc/qoc_gemm_chain_sq.h; opt-in: variant = 2 of an explicit GEMM-path request): the direct state-transfer chain as
+    v = B x followed by a Horner recursion over B^2 -- 1 + ceil(T/2) - 1 dependent mat-vecs per slice instead of T - 1 --, with B^2 assembled per slice
+    as the quadratic form in the controls over (k + 1)(k + 2) / 2 constant matrices, both in the packed (anti-)Hermitian image.  Every Horner depth
+    1 .. 6 (T = 3 .. 14, even and odd), padded sizes, with and without sources, against the oracle and against the plain chain (1e-12: another
+    association of the same polynomial)."""
+    c = cases.case_c3(n=n, k=3, steps=steps, taylor=(terms, 0))
+    c['total_time'] = 0.1 * steps
+    if reg == 'none':
+        c['reg_coeffs'] = {}
+    elif reg == 'allreg':
+        c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [5.0, 5.0], 'states_forbidden_list': [n - 2, n - 1], 'speed_up': 0.3, 'amplitude': 0.2}
+    sp = oracle_system(c)
+    rng = np.random.default_rng(5)
+    bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 for _ in range(2)]
+    eng = make_engine(sp, n_seeds=3, path=4, chunks=1, variant=2)
+    assert eng.path == 4 and eng.plan.get('taylor_chain') == 'squared'
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
+    r = eng.evaluate()
+    eng.close()
+    plain = make_engine(sp, n_seeds=3, path=4, chunks=1)
+    assert plain.plan.get('taylor_chain') == 'packed'
+    plain.set_base(np.stack(bases))
+    r0 = plain.evaluate()
+    plain.close()
+    np.testing.assert_allclose(r['loss'], r0['loss'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r['grad'], r0['grad'], rtol=0, atol=1e-12 * max(1.0, np.max(np.abs(r0['grad']))))
+
+
 @pytest.mark.parametrize('env', [{'QOC_ASM_CUMASK': '0'}, {'QOC_ASM_OVERLAP': '0'}, {'QOC_ASM_CUMASK': '70', 'QOC_ASM_TAIL_WGS': '300', 'QOC_ASM_SPLIT16': '9'}],
                          ids=['shared_cus', 'no_overlap', 'other_mask_and_split'])
 def test_direct_route_assembly_overlap_fallbacks(env, monkeypatch):
