@@ -444,6 +444,8 @@ def main():
         device = 0
     local_rank = device
     comm = gloo = None
+    comm_init_s = 0.0
+    t_comm = time.perf_counter()
     if world > 1:
         if backend == 'gloo':
             gloo = _GlooTransport(rank, world)
@@ -458,6 +460,7 @@ def main():
                 sys.stderr.write('bench.py: rank %d: %s\n' % (rank, exc))
                 sys.exit(3)
     transport = comm if comm is not None else gloo
+    comm_init_s = time.perf_counter() - t_comm        # RCCL start-up of this rank (id exchange + ncclCommInitRank + first barrier): a straggler shows here
 
     c, Hs, U0, V, W, dt = build_problem()
     B = args.seeds_per_gpu
@@ -517,11 +520,13 @@ def main():
     # who ran where and how long: one row per rank (elapsed ms, HIP device index, compute units, device name as 48 bytes)
     info = hip_engine.device_info(device)
     name_bytes = np.frombuffer(info['name'].encode()[:48].ljust(48, b' '), dtype=np.uint8).astype(np.float64)
-    row = np.concatenate([[elapsed * 1e3, float(device), float(info['compute_units'])], name_bytes])
+    row = np.concatenate([[elapsed * 1e3, float(device), float(info['compute_units']), comm_init_s], name_bytes])
     rows = transport.all_gather(row) if transport is not None else row[None]
     per_rank = [{'rank': r, 'ms_total': float(rows[r][0]), 'ms_per_step': float(rows[r][0]) / args.steps, 'device': int(rows[r][1]),
-                 'compute_units': int(rows[r][2]), 'device_name': bytes(rows[r][3:].astype(np.uint8)).decode(errors='replace').strip()}
+                 'compute_units': int(rows[r][2]), 'comm_init_s': float(rows[r][3]),
+                 'device_name': bytes(rows[r][4:].astype(np.uint8)).decode(errors='replace').strip()}
                 for r in range(world)]
+    ms_all = [q['ms_total'] for q in per_rank]
     if transport is not None:
         elapsed = float(transport.all_reduce_max([elapsed])[0])
 
@@ -598,6 +603,9 @@ def main():
                        'stream_groups': G, 'ranks_seen': len(per_rank), 'fidelities_gathered': int(fidelity.shape[0]),
                        'comm_library': (comm.library if comm is not None else None), 'per_rank': per_rank,
                        'devices_distinct': len(set(q['device'] for q in per_rank)),
+                       # a straggling rank / a slow communicator start is visible here (SCALE_rNN.json keeps the line): max over ranks and spread of the timed region
+                       'rccl_init_s': max(q['comm_init_s'] for q in per_rank) if world > 1 else None,
+                       'rank_ms_total': {'min': min(ms_all), 'max': max(ms_all), 'spread_pct': 100.0 * (max(ms_all) - min(ms_all)) / max(ms_all)},
                        'transport': (comm.library if comm.library.startswith('files') else 'rccl (%s)' % comm.library) if comm is not None
                        else ('gloo (test hook)' if gloo is not None else 'single process'),
                        # an RCCL run that fell back to files must not look like an RCCL result: both keys say so explicitly

@@ -215,6 +215,10 @@ int qoc_chunks_in_use(qoc_handle h);
 int qoc_plan_describe(qoc_handle h, char* buf, int32_t len);
 int qoc_device_count(void);
 int qoc_device_info(int32_t device, char* name, int32_t name_len, int32_t* compute_units, int64_t* hbm_bytes);
+/* hipDeviceCanAccessPeer(device, peer): 1 when `device` can address the memory of `peer` directly (xGMI / PCIe peer-to-peer), which is what RCCL's
+ * device-to-device transports between two ranks of a node need; tools/multi_gpu_selftest.py prints the matrix.  The reference runs on one device
+ * (main_grape/grape.py:106-109) and has no counterpart. */
+int qoc_device_peer_access(int32_t device, int32_t peer, int32_t* can_access);
 const char* qoc_last_error(void);
 const char* qoc_version(void);
 

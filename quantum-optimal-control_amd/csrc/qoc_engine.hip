@@ -373,6 +373,15 @@ int qoc_device_info(int32_t device, char* name, int32_t name_len, int32_t* compu
     return QOC_OK;
 }
 
+int qoc_device_peer_access(int32_t device, int32_t peer, int32_t* can_access) {
+    if (!can_access) return fail(QOC_ERR_INVALID, "qoc_device_peer_access: null argument");
+    int can = 0;
+    if (device == peer) can = 1;
+    else HIP_TRY(hipDeviceCanAccessPeer(&can, device, peer));
+    *can_access = can;
+    return QOC_OK;
+}
+
 int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const double* V, const double* W,
                const double* maxA, const double* one_minus_gauss, const int32_t* forbidden_states,
                const double* forbidden_coeffs, const double* Vs, qoc_handle* out) {

@@ -74,6 +74,7 @@ _SIGNATURES = {
     'qoc_comm_barrier': (C.c_int, [C.c_void_p]),
     'qoc_device_count': (C.c_int, []),
     'qoc_device_info': (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _IP, C.POINTER(C.c_int64)]),
+    'qoc_device_peer_access': (C.c_int, [C.c_int32, C.c_int32, _IP]),
     'qoc_last_error': (C.c_char_p, []),
     'qoc_version': (C.c_char_p, []),
 }
@@ -135,6 +136,14 @@ def device_info(device=0):
     mem = C.c_int64()
     _check(lib.qoc_device_info(device, name, 256, C.byref(cus), C.byref(mem)))
     return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=mem.value)
+
+
+def device_peer_access(device, peer):
+    """True when HIP device `device` can address the memory of device `peer` directly (hipDeviceCanAccessPeer)."""
+    lib = load_library()
+    can = C.c_int32()
+    _check(lib.qoc_device_peer_access(int(device), int(peer), C.byref(can)))
+    return bool(can.value)
 
 
 def reg_config(reg_coeffs, total_time):

@@ -460,3 +460,38 @@ def test_bench_driver_form_fails_when_rccl_cannot_start():
     cfg = j['config']
     assert cfg['transport_fallback'] is True and cfg['ranks_seen'] == 2 and len(cfg['per_rank']) == 2
     assert all(q['device'] == 0 and q['ms_total'] > 0 and q['device_name'] for q in cfg['per_rank'])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_multi_gpu_selftest_plumbing_world2_gloo_without_a_gpu():
+    """tools/multi_gpu_selftest.py (the first-contact check of a multi-GPU node) under its CPU hook: two ranks, gloo, no engine -- partition, all-gather and
+    the comparison of every gathered row run; a mismatch would be a non-zero exit of the launcher."""
+    import subprocess
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+                        str(_free_port()), os.path.join(ROOT, 'tools', 'multi_gpu_selftest.py'), '--transport', 'gloo', '--no-gpu'],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('ALL STAGES OK') == 2, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_multi_gpu_selftest_world1_and_two_ranks_on_one_gpu():
+    """The same script on the GPU box: a world of one (every stage, the RCCL collectives of the time-sharded engine on a one-rank communicator) and two
+    ranks sharing GPU 0 over gloo (stages i and ii: every gathered loss against the rank's own evaluation, GrapeSharded against Grape bit for bit)."""
+    import subprocess
+    script = os.path.join(ROOT, 'tools', 'multi_gpu_selftest.py')
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for tag in ('(i) ', '(ii) ', '(iii) time-sharded', 'peer access', 'ALL STAGES OK'):
+        assert tag in r.stdout, (tag, r.stdout[-3000:])
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+                        str(_free_port()), script, '--transport', 'gloo', '--same-device'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count('ALL STAGES OK') == 2 and r.stdout.count('(ii) GrapeSharded') == 2, r.stdout[-3000:]
