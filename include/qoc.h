@@ -204,7 +204,9 @@ int qoc_comm_barrier(qoc_comm_handle c);
 
 /* Time-sharded engines (qoc_config.time_shards >= 1, time_rank >= 0): the communicator whose ranks hold the other time shards; world and
  * rank must equal time_shards / time_rank.  The engine's iterations then contain RCCL calls: every rank must enqueue the same iterations
- * (and qoc_get_inter_vecs is a collective too: each rank holds the time points of its own slices, the call sums them over the ranks). */
+ * (and qoc_get_inter_vecs is a collective too: each rank holds the time points of its own slices, the call sums them over the ranks).
+ * Lifetime: the communicator must outlive the engine -- qoc_comm_destroy returns QOC_ERR_STATE while an engine still holds it; qoc_destroy
+ * of the engine releases it. */
 int qoc_set_time_comm(qoc_handle h, qoc_comm_handle c);
 
 /* ---- introspection ---------------------------------------------------------------------------------------------*/

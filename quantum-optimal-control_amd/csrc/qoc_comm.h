@@ -96,7 +96,10 @@ struct qoc_comm {
     hipStream_t stream = nullptr;      // collectives that do not belong to an engine (timings, barrier, winner broadcast)
     double* stage = nullptr;           // device staging: [send | recv]
     size_t stage_doubles = 0;
+    int attached = 0;                  // time-sharded engines that enqueue collectives on this communicator (qoc_set_time_comm): it outlives them
 };
+// (called by qoc_destroy, which is compiled before this header)
+void qoc_comm_detach(qoc_comm* c) { if (c && c->attached > 0) --c->attached; }
 
 #define RCCL_TRY(expr)                                                                                                    \
     do {                                                                                                                  \
@@ -179,6 +182,8 @@ int qoc_comm_create(const void* id128, int32_t world, int32_t rank, int32_t devi
 
 int qoc_comm_destroy(qoc_comm_handle c) {
     if (!c) return QOC_OK;
+    if (c->attached > 0)
+        return fail(QOC_ERR_STATE, "qoc_comm_destroy: %d time-sharded engine(s) still use this communicator (qoc_set_time_comm): destroy them first", c->attached);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) qoc_rccl::g_api.CommDestroy(c->comm);
@@ -258,6 +263,7 @@ int qoc_set_time_comm(qoc_handle e, qoc_comm_handle c) {
     if (e->path != QOC_PATH_GEMM || e->gm.ts_G <= 0 || e->gm.ts_rank < 0) return fail(QOC_ERR_INVALID, "qoc_set_time_comm: the engine is not one rank of a time-sharded run");
     if (c->world != e->gm.ts_G || c->rank != e->gm.ts_rank) return fail(QOC_ERR_INVALID, "qoc_set_time_comm: communicator rank %d of %d, engine rank %d of %d", c->rank, c->world, e->gm.ts_rank, e->gm.ts_G);
     if (c->device != e->cfg.device) return fail(QOC_ERR_INVALID, "qoc_set_time_comm: engine on device %d, communicator on %d", e->cfg.device, c->device);
+    if (e->gm.ts_comm != c) { qoc_comm_detach(e->gm.ts_comm); ++c->attached; }
     e->gm.ts_comm = c;
     return QOC_OK;
 }

@@ -664,6 +664,7 @@ int qoc_destroy(qoc_handle e) {
     if (!e) return QOC_OK;
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    qoc_comm_detach(e->gm.ts_comm);                    // (a time-sharded engine: its communicator may be destroyed from now on)
     qoc_gemm_teardown(e->gm);
     for (void* p : e->allocs) hipFree(p);
     for (hipEvent_t x : e->ev) hipEventDestroy(x);

@@ -19,6 +19,7 @@
 #pragma once
 
 struct qoc_comm;
+void qoc_comm_detach(qoc_comm* c);                                                                // qoc_comm.h: an engine lets go of its communicator
 int qoc_ts_all_gather(qoc_comm* c, void* buf, size_t doubles_per_rank, hipStream_t s);      // qoc_comm.h: in place, rank r's block at buf + r * count
 int qoc_ts_all_reduce_sum(qoc_comm* c, double* buf, size_t doubles, hipStream_t s);
 
@@ -149,14 +150,16 @@ static inline void qoc_gemm_ts_forward(QocGemm& gm, const QocDev& d, int r, hipS
     const int c0 = gm.ts_cb[r], c1 = gm.ts_cb[r + 1], nc = c1 - c0;
     const cplx* Pc = qoc_gemm_chunk_products(gm);
     const cplx* Ystart = gm.ts_Yr + (size_t)r * yslot;
+    // Psi at the start of the rank's chunks: the thin block of Ystart, then Psibnd[c + 1] = P_c Psibnd[c] on the m vectors alone (the wide X beside them is
+    // only needed in the prefix over the RANK products, qoc_gemm_ts_prefix; final_state comes from there)
+    hipLaunchKernelGGL(k_ts_take_bnd, dim3(gemm_grid(thin)), dim3(256), 0, s, d, (const cplx*)gm.Y0, Ystart, gm.Psibnd, N, xw, c0, 1);
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.lda = N; g.ldb = g.ldc = ld; g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = ld / 32; g.batch = 1; g.alpha = 1.0;
-    for (int c = c0; c + 1 < c1; ++c) {                           // [X | Psi] at the start of chunk c + 1 (the last chunk's end is the next rank's start)
-        g.A = Pc + (size_t)c * NN; g.Bm = c == c0 ? Ystart : gm.Y0 + (size_t)c * yslot; g.C = gm.Y0 + (size_t)(c + 1) * yslot;
+    g.lda = N; g.ldb = g.ldc = QOC_TW; g.Kdim = N; g.tiles_m = N / 32; g.tiles_n = 1; g.batch = 1; g.alpha = 1.0;
+    for (int c = c0; c + 1 < c1; ++c) {                           // (the last chunk's end is the next rank's start)
+        g.A = Pc + (size_t)c * NN; g.Bm = gm.Psibnd + (size_t)c * thin; g.C = gm.Psibnd + (size_t)(c + 1) * thin;
         qoc_gemm_launch(gm, false, 0, g, s);
     }
-    hipLaunchKernelGGL(k_ts_take_bnd, dim3(gemm_grid((size_t)nc * thin)), dim3(256), 0, s, d, (const cplx*)gm.Y0, Ystart, gm.Psibnd, N, xw, c0, nc);
     GemmArgs h;
     memset(&h, 0, sizeof h);
     h.lda = N; h.sA = (long long)NN * S; h.ldb = h.ldc = QOC_TW; h.Kdim = N; h.tiles_m = N / 32; h.tiles_n = 1;

@@ -201,8 +201,10 @@ class QocComm(object):
         self.library = self._lib.qoc_comm_library().decode()
 
     def close(self):
+        """Destroys the communicator.  While a time-sharded engine still holds it (HipEngine(time_comm=...)) the C ABI refuses (QocError) and the handle
+        stays valid: close the engine first."""
         if getattr(self, '_h', None) is not None and self._h.value:
-            self._lib.qoc_comm_destroy(self._h)
+            _check(self._lib.qoc_comm_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

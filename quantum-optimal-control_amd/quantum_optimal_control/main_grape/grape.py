@@ -127,6 +127,12 @@ def GrapeTimeSharded(*args, comm=None, **kwargs):
     n > 96, at most 8 states of interest; the reference has no counterpart (one device: main_grape/grape.py:106-109)."""
     if comm is None:
         return Grape(*args, **kwargs)
+    from quantum_optimal_control.core import hip_engine
+    if not isinstance(comm, hip_engine.QocComm):
+        # parallel_seeds.open_comm() falls back to a host file transport when RCCL cannot start; that transport cannot carry the two collectives
+        # every iteration enqueues on the engine's stream.  Say so before any rank builds an engine (open it with require_rccl=True to fail earlier).
+        raise TypeError('GrapeTimeSharded needs an RCCL communicator (hip_engine.QocComm, e.g. parallel_seeds.open_comm(require_rccl=True)); got %s%s'
+                        % (type(comm).__name__, (': ' + str(getattr(comm, 'fallback_reason', ''))) if getattr(comm, 'fallback_reason', None) else ''))
     if comm.rank != 0:
         kwargs['save'] = False
         kwargs['show_plots'] = False

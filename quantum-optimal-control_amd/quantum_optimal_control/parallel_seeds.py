@@ -105,6 +105,9 @@ def _private_dir(path):
     """Directory only this user can write (0700), created if missing; anything somebody else planted under the (predictable) name is refused --
     lstat, not stat: a symbolic link to a private directory of this user would pass an ownership check that follows it, and close() removes files there."""
     import stat
+    parent = os.path.dirname(os.path.abspath(path))
+    if parent and not os.path.isdir(parent):
+        os.makedirs(parent, exist_ok=True)           # a QOC_RDZV_DIR that does not exist yet (or is nested): only the LEAF is the private directory checked below
     try:
         os.mkdir(path, 0o700)
     except FileExistsError:
