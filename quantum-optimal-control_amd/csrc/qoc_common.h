@@ -126,6 +126,15 @@ __device__ __forceinline__ double dpp_xor(double v) {
 // still places the vmcnt wait for each prefetched register stage before its first use.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// A/B switches of the kernel families ("experimental switches"): a value of the environment only counts when QOC_EXPERIMENTAL=1 stands beside it,
+// and every switch is read inside qoc_create -- never on a launch path -- into a field of the engine, so that two engines of a process (or the ranks of a
+// launch) can only differ when somebody asked for it twice.  Production runs never set QOC_EXPERIMENTAL.
+static inline const char* qoc_exp_env(const char* name) {
+    const char* on = getenv("QOC_EXPERIMENTAL");
+    return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
+static inline bool qoc_exp_is(const char* name, int value) { const char* e = qoc_exp_env(name); return e && atoi(e) == value; }
+
 // Size of an engine's work-buffer arena: a multiple of 64 MB.  With the exact size the allocator recycled blocks freed by earlier
 // engines of the process, and where such a block landed decided the speed (n = 128 x 4 after a dozen other engines: 21 ms per
 // iteration instead of 8.3; three of three long sequences back at 8.3-8.6 ms with the rounded size).

@@ -24,12 +24,9 @@
 #include "qoc_kernels_gemm.h"
 #include "qoc_gemm_ts.h"
 
-#ifndef QOC_LATENCY_MAX_WORK
-#define QOC_LATENCY_MAX_WORK 4608       // seeds x time slices up to which AUTO takes the latency mode (see latency_auto below): since the batch sweeps
-                                        // take their chunk boundaries and final_state from k_mfma_bnd_scan the batch kernels are ahead from 10 seeds of 500
-                                        // slices on (0.356 ms at 12 seeds against 0.444; 8 seeds: 0.349 against 0.305; profiles/r03_latency_sweep.txt)
-#define QOC_LATENCY_MAX_WORK_SRC 4096   // the same with a state regulariser
-#endif
+#include "qoc_plan_limits.h"            // the measured numbers of AUTO's table (QOC_PLAN_*), shared with tests/test_auto_plan.py
+// (QOC_PLAN_LAT_WORK = 4608 seeds x time slices: since the batch sweeps take their chunk boundaries and final_state from k_mfma_bnd_scan the batch kernels are
+// ahead from 10 seeds of 500 slices on -- 0.356 ms at 12 seeds against 0.444; 8 seeds: 0.349 against 0.305; profiles/r03_latency_sweep.txt)
 static thread_local std::string g_err;
 
 static int fail(int code, const char* fmt, ...) {
@@ -545,7 +542,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const bool dpp_shape = n > 32 && m == 1;
     // (three-multiplication form of the DPP chain, profiles/r04_c3_route_sweep_gauss.txt: with forbidden levels x 20 5.05 / 5.43, x 22 5.56 / 5.45, x 24 6.02 / 5.49;
     // without x 11 2.63 / 2.77, x 12 2.84 / 2.79, x 13 3.11 / 2.81 -- the limits moved from 28 / 14 to 22 / 12)
-    const int ST_DIRECT_FROM = n <= 32 ? 112 : (dpp_shape ? (lat_src ? 22 : 12) : 48);
+    const int ST_DIRECT_FROM = n <= 32 ? QOC_PLAN_ST_DIRECT_N32 : (dpp_shape ? (lat_src ? QOC_PLAN_ST_DIRECT_DPP_SRC : QOC_PLAN_ST_DIRECT_DPP) : QOC_PLAN_ST_DIRECT_N64);
     struct AutoPlan { int path; bool latency; bool gemm_direct; };
     // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by row)
     // State transfer on the MFMA path (round 4, tools/st_path_sweep.py -> profiles/r04_state_transfer_paths.txt; m = 1, T = 10, 500 slices, ms per iteration,
@@ -558,26 +555,36 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const bool st = cfg->state_transfer != 0;
     const bool mfma_auto = mfma_ok && (!st || n <= 32 || (n <= 48 && k <= 4));
     auto plan_for = [&](int Bp) -> AutoPlan {
-        const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= 32) || Bp >= 64);
+        const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= QOC_PLAN_NT4_MIN_SETS_K4) || Bp >= QOC_PLAN_NT4_MIN_SETS);
         // 16 < n <= 32 below the latency mode's reach (long pulses): the GEMM route up to a few control sets, fewer the smaller the active part of the padded
         // matrices is (500 slices, GEMM route / MFMA batch kernels in ms: n = 32 x 6 0.290 / 0.315, x 8 0.340 / 0.318; n = 27 x 4 0.251 / 0.270, x 6 0.288 / 0.271;
         // n = 20 x 2 0.185 / 0.196, x 4 0.249 / 0.196; with a forbidden level n = 32 x 8 0.436 / 0.473, n = 27 x 8 level, n = 20 x 6 0.373 / 0.360)
         const int qa_g = (n + 3) / 4;
-        const int gemm_small = (st && qa_g >= 7) ? 8 : lat_src ? (qa_g <= 5 ? 5 : qa_g == 6 ? 6 : 8) : (qa_g <= 5 ? 2 : qa_g == 6 ? 3 : qa_g == 7 ? 5 : 7);
-        const bool st_big = st && direct_ok && cfg->chunks <= 1 && (n <= 32 ? (Bp >= 112 && n > (lat_src ? 28 : 20)) : Bp >= (dpp_shape ? (lat_src ? 48 : 32) : (lat_src ? 112 : 48)));
-        const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < 8) || (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= 100) || st_big);
+        const int gemm_small = (st && qa_g >= 7) ? QOC_PLAN_GEMM_SMALL_ST_WIDE
+                               : lat_src ? (qa_g <= 5 ? QOC_PLAN_GEMM_SMALL_SRC_Q5 : qa_g == 6 ? QOC_PLAN_GEMM_SMALL_SRC_Q6 : QOC_PLAN_GEMM_SMALL_SRC_Q78)
+                                         : (qa_g <= 5 ? QOC_PLAN_GEMM_SMALL_Q5 : qa_g == 6 ? QOC_PLAN_GEMM_SMALL_Q6 : qa_g == 7 ? QOC_PLAN_GEMM_SMALL_Q7 : QOC_PLAN_GEMM_SMALL_Q8);
+        const bool st_big = st && direct_ok && cfg->chunks <= 1 &&
+                            (n <= 32 ? (Bp >= QOC_PLAN_ST_BIG_N32 && n > (lat_src ? QOC_PLAN_ST_BIG_N32_MIN_LEVELS_SRC : QOC_PLAN_ST_BIG_N32_MIN_LEVELS))
+                                     : Bp >= (dpp_shape ? (lat_src ? QOC_PLAN_ST_BIG_DPP_SRC : QOC_PLAN_ST_BIG_DPP) : (lat_src ? QOC_PLAN_ST_BIG_N64_SRC : QOC_PLAN_ST_BIG_N64)));
+        const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < QOC_PLAN_NT3_MIN_SETS) ||
+                                             (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= QOC_PLAN_GEMM_SMALL_MIN_SLICES) || st_big);
         const long long lat_work = (long long)Bp * steps;
         // 16 < n <= 32: the batch kernels work on the ACTIVE 4-row strips qa = ceil(n / 4) of the padded matrices since round 4 and take over earlier the
         // smaller n is (tools/padded_latency_sweep.py, 500 slices: n = 20 / 24 / 27 / 32 level at ~5 / 6 / 7 / 8.5 control sets; with a forbidden
         // level the latency mode stays ahead up to 8, at n = 20 up to 7): seeds x slices <= 512 qa, with a state regulariser min(4096, 768 qa)
         const int qa = (n + 3) / 4 < 5 ? 5 : (n + 3) / 4;
-        const long long lat_limit = n <= 16 ? (lat_src ? QOC_LATENCY_MAX_WORK_SRC : QOC_LATENCY_MAX_WORK)
-                                            : (lat_src ? std::min<long long>(QOC_LATENCY_MAX_WORK_SRC, 768LL * qa) : 512LL * qa);
-        const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_auto && qoc_mfma_latency_ok(d) && steps >= 64 &&
-                              (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= 4096 && Bp <= 4)   // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8
-                                : n > 32 ? (lat_work <= 16384 && Bp <= 8)     // NT = 3: the competitors are slower (tools/mid_n_sweep.py)
-                                       : (lat_work <= lat_limit && Bp <= (n > 16 ? ((st && qa_g >= 7) ? 4 : 16) : (st ? 8 : 6)))) ||   // (state transfer from 25 levels on: 5 .. 8 control sets go to the GEMM route -- n = 32 x 8: 0.220 against 0.261 ms, with forbidden levels 0.272 / 0.316)
-                               (Bp == 1 && steps <= 8192));
+        const long long lat_limit = n <= 16 ? (lat_src ? QOC_PLAN_LAT_WORK_SRC : QOC_PLAN_LAT_WORK)
+                                            : (lat_src ? std::min<long long>(QOC_PLAN_LAT_WORK_SRC, (long long)QOC_PLAN_LAT_WORK_PER_STRIP_SRC * qa)
+                                                       : (long long)QOC_PLAN_LAT_WORK_PER_STRIP * qa);
+        // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8; NT = 3: the competitors are
+        // slower (tools/mid_n_sweep.py); state transfer from 25 levels on: 5 .. 8 control sets go to the GEMM route -- n = 32 x 8: 0.220 against 0.261 ms, with
+        // forbidden levels 0.272 / 0.316
+        const int lat_sets = n > 16 ? ((st && qa_g >= 7) ? QOC_PLAN_LAT_SETS_N32_ST_WIDE : QOC_PLAN_LAT_SETS_N32) : (st ? QOC_PLAN_LAT_SETS_N16_ST : QOC_PLAN_LAT_SETS_N16);
+        const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_auto && qoc_mfma_latency_ok(d) && steps >= QOC_PLAN_LAT_MIN_SLICES &&
+                              (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= QOC_PLAN_LAT_WORK_NT4 && Bp <= QOC_PLAN_LAT_SETS_NT4)
+                                : n > 32 ? (lat_work <= QOC_PLAN_LAT_WORK_NT3 && Bp <= QOC_PLAN_LAT_SETS_NT3)
+                                         : (lat_work <= lat_limit && Bp <= lat_sets)) ||
+                               (Bp == 1 && steps <= QOC_PLAN_LAT_SINGLE_MAX_SLICES));
         AutoPlan p;
         p.latency = latency;
         p.gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && Bp >= ST_DIRECT_FROM));

@@ -437,7 +437,7 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     gm.MV = d.m <= 1 ? 1 : (d.m <= 2 ? 2 : (d.m <= 4 ? 4 : 8));
     gm.direct = direct && d.state_transfer && gm.persistent;
     {
-        const char* e = getenv("QOC_CHAIN_DPP");                 // A/B switch: 0 = the butterfly kernel k_gemm_taylor_chain
+        const char* e = qoc_exp_env("QOC_CHAIN_DPP");            // experimental switch: 0 = the butterfly kernel k_gemm_taylor_chain
         gm.dpp_chain = gm.direct && N == 64 && gm.MV == 1 && !(e && e[0] == '0');
         gm.dpp_packed = gm.dpp_chain && gm.antiherm;
         // opt-in only (qoc_config.variant = 2 with path = GEMM): measured SLOWER than the plain chain at C3 x 64 (7.98 against 5.83 ms per iteration) --
@@ -569,12 +569,12 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         // prefetch shares the memory system with them (a slice costs it 4-5.6 us beside an unthrottled assembly against 2.9 alone); sweep of
         // (workgroups, split) at C3 x 64, ms per iteration: (8192, 3/16) 6.81, (2048, 3/16) 6.79, (512, 5/16) 6.67, (512, 8/16) 6.77,
         // (384, 6/16) 6.68, (256, 5/16) 7.35; one launch in front of the chain 7.03
-        const char* e = getenv("QOC_ASM_OVERLAP");                  // A/B switch: 0 = one assembly launch in front of the chain
+        const char* e = qoc_exp_env("QOC_ASM_OVERLAP");             // experimental switch: 0 = one assembly launch in front of the chain
         if (gm.dpp_chain && need_src && d.k <= 8 && d.steps >= 64 && d.B <= 128 && !(e && e[0] == '0')) {       // (256 chains fill the chip: 14.6 against 14.0 ms)
             // disjoint CU sets for the two kernels that run beside each other: the assembly's workgroups otherwise land on the chains' CUs as well and
             // take issue slots from waves whose every instruction is on the critical path.  QOC_ASM_CUMASK=0: plain second stream, chain on the engine's
             {
-                const char* cm = getenv("QOC_ASM_CUMASK");
+                const char* cm = qoc_exp_env("QOC_ASM_CUMASK");
                 int ncu = 0, dv = 0;
                 if (hipGetDevice(&dv) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess) ncu = 0;
                 const int chain_cus = cm && atoi(cm) > 0 ? atoi(cm) : 112;
@@ -592,15 +592,15 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
             // iteration: masks of 80 / 96 / 112 / 128 CUs for the chains 6.31 / 6.31 / 6.25 / 6.34; shared CUs 6.40; 2048 workgroups 6.27 - 6.31; 3/16: 6.35 - 6.50)
             gm.asm_split = ((gm.chain_s ? 4 : 5) * d.steps) / 16;
             gm.asm_tail_wgs = gm.chain_s ? 8192 : 512;
-            if (const char* t = getenv("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : gm.asm_tail_wgs;
-            if (const char* t = getenv("QOC_ASM_SPLIT16")) gm.asm_split = (atoi(t) * d.steps) / 16;
+            if (const char* t = qoc_exp_env("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : gm.asm_tail_wgs;
+            if (const char* t = qoc_exp_env("QOC_ASM_SPLIT16")) gm.asm_split = (atoi(t) * d.steps) / 16;
             if (gm.asm_split < 1) gm.asm_split = 1;
             if (gm.asm_split > d.steps - 1) gm.asm_split = d.steps - 1;
             // windows: [0, asm_split) in front, the rest in nw - 1 equal windows beside the chain.  More than two windows buy nothing (C3 x 64: 5.85 / 5.87 ms
             // at nw = 2 / 4 with 4/16 in front, 5.83 with 2/16 and nw = 4: the chain part that runs beside an assembly launch loses what the shorter head
             // saves) and nine or more chain launches waiting on events of the second stream did not finish at all on ROCm 7.2: profiles/r05_c3_windows.txt
             int nw = 2;
-            if (const char* t = getenv("QOC_ASM_WINDOWS")) nw = atoi(t) >= 2 ? (atoi(t) <= 4 ? atoi(t) : 4) : 2;
+            if (const char* t = qoc_exp_env("QOC_ASM_WINDOWS")) nw = atoi(t) >= 2 ? (atoi(t) <= 4 ? atoi(t) : 4) : 2;
             if (nw - 1 > d.steps - gm.asm_split) nw = 1 + (d.steps - gm.asm_split);
             gm.asm_win.assign(1, 0);
             for (int w = 1; w <= nw; ++w) gm.asm_win.push_back(w == nw ? d.steps : gm.asm_split + (int)(((long long)(d.steps - gm.asm_split) * (w - 1)) / (nw - 1)));

@@ -1,6 +1,7 @@
 // qoc_mfma_backward.hip -- translation unit of the MFMA-path backward sweeps / gradient kernels (qoc_mfma_backward.h), their
 // launcher, and the path set-up (it reserves LDS for these kernels).
 #include "qoc_kernels_mfma.h"
+#include "qoc_plan_limits.h"
 #include "qoc_mfma_backward.h"
 #include "qoc_mfma_downup.h"
 
@@ -36,7 +37,10 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     // both sweeps in one kernel, a wave per half chunk (k_mfma_downup; needs the z-free chunk boundaries of the scan: bnd_adj below, and
     // m <= 8: its exchange buffers and images share the LDS with the control images)
     mf.updown = NT == 2 && mf.variant != 1 && mf.variant != 5 && d.k <= 5 && d.m <= 8 && !(d.n_forb > 0 || d.has_speed) &&
-                !(getenv("QOC_UPDOWN") && atoi(getenv("QOC_UPDOWN")) == 0);
+                !qoc_exp_is("QOC_UPDOWN", 0);
+    mf.exp_rows_qa_full = qoc_exp_env("QOC_ROWS_QA_FULL") && !qoc_exp_is("QOC_ROWS_QA_FULL", 0);
+    mf.exp_lat_qa8 = qoc_exp_env("QOC_LAT_QA8") && !qoc_exp_is("QOC_LAT_QA8", 0);
+    mf.exp_lat_offsets_own = qoc_exp_is("QOC_LAT_OFFSETS_IN_SWEEP", 0);
     int C = chunks_req;
     if (C <= 0) {
         // NT = 2: the default exponential kernel is ONE wave of 444 VGPRs per (seed, chunk), i.e. at most one resident wave per
@@ -45,8 +49,8 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
         // Fewer than 32 seeds (NT = 2): chunks down to 8 slices keep all SIMDs busy -- 16 seeds: 0.50 ms per iteration with 63 chunks against
         // 0.62 with 32; 20 seeds: 0.52 (50 chunks) against 0.63; 24 seeds: 0.58 (42) against 0.64 -- the longer boundary recursion of the
         // sweeps costs less than the idle SIMDs of the exponential kernel.
-        C = NT == 2 ? 1024 / d.Bplan : (1024 + d.Bplan - 1) / d.Bplan;          // (the PLANNED batch: a shard of it chunks like the whole)
-        if (C > (NT == 2 ? 64 : 32)) C = NT == 2 ? 64 : 32;
+        C = NT == 2 ? QOC_PLAN_CHUNK_ITEMS / d.Bplan : (QOC_PLAN_CHUNK_ITEMS + d.Bplan - 1) / d.Bplan;          // (the PLANNED batch: a shard of it chunks like the whole)
+        if (C > (NT == 2 ? QOC_PLAN_CHUNKS_MAX_NT2 : QOC_PLAN_CHUNKS_MAX)) C = NT == 2 ? QOC_PLAN_CHUNKS_MAX_NT2 : QOC_PLAN_CHUNKS_MAX;
     }
     // latency mode (variant 5; AUTO for a handful of seeds, qoc_mfma_latency_ok): one wave per SLICE for the exponentials, short
     // chunks whose products come from k_mfma_chain_products, groups of G chunks for two-level chunk boundaries in the sweeps
@@ -110,7 +114,7 @@ int qoc_mfma_setup(QocMfma& mf, const QocDev& d, int chunks_req, const cplx* Hs_
     const bool split_grad = (NT > 2 || (NT == 2 && d.k >= 6)) && mf.variant != 1;   // k <= 5: backward3 (5 images still fit next to its pads)
     if (split_grad && !al(&mf.LamD, (size_t)d.B * d.steps * 16 * NT * 16)) { msg = "MFMA path: out of device memory"; return -3; }
     { const int kg = NT >= 4 ? 2 : 4; mf.grad_lds = (size_t)(d.k < kg ? d.k : kg) * FR * sizeof(cplx); }
-    mf.grad_rt = NT >= 2 && split_grad && d.k <= 8 && !(getenv("QOC_GRAD_RT") && atoi(getenv("QOC_GRAD_RT")) == 0);
+    mf.grad_rt = NT >= 2 && split_grad && d.k <= 8 && !qoc_exp_is("QOC_GRAD_RT", 0);
     if (mf.grad_rt) {
         mf.grad_lds = (size_t)((d.k + 3) & ~3) * NT * 256 * sizeof(cplx);
         if (!al((cplx**)&mf.gpart, ((size_t)NT * d.B * d.k * d.steps + 1) / 2)) { msg = "MFMA path: out of device memory"; return -3; }

@@ -17,8 +17,7 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
             // latency mode of 32 < n <= 64: K_t per slice by the row-block kernel (NT = 3: two workgroups per CU), then the row-split chains
             const size_t lds = qoc_expm_rows_lds<NT>();
             // (active inner strips ceil(n / 4) of the problem padded to 16 NT, as in the batch kernel below)
-            const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
-            const int qa = full ? 4 * NT : (d.n + 3) / 4;
+            const int qa = mf.exp_rows_qa_full ? 4 * NT : (d.n + 3) / 4;
 #define QOC_ROWS_SL(KCv, QAv) do { static bool reserved = false; \
                                    if (!reserved) { hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, KCv, true, QAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); reserved = true; } \
                                    hipLaunchKernelGGL((k_mfma_expm_rows<NT, KCv, true, QAv>), dim3(d.B * d.steps), dim3(256), lds, s, d, mf); } while (0)
@@ -35,9 +34,8 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
     if constexpr (NT >= 3) {
         if (v == 7) {
             const size_t lds = qoc_expm_rows_lds<NT>();
-            // active 4-row strips of the problem padded to 16 NT: ceil(n / 4) (4 NT - 3 .. 4 NT); QOC_ROWS_QA_FULL=1 (A/B, read per launch: the parity test toggles it): the padded problem in full
-            const bool full = getenv("QOC_ROWS_QA_FULL") && atoi(getenv("QOC_ROWS_QA_FULL")) != 0;
-            const int qa = full ? 4 * NT : (d.n + 3) / 4;
+            // active 4-row strips of the problem padded to 16 NT: ceil(n / 4) (4 NT - 3 .. 4 NT); QOC_ROWS_QA_FULL=1 (experimental switch): the padded problem in full
+            const int qa = mf.exp_rows_qa_full ? 4 * NT : (d.n + 3) / 4;
 #define QOC_ROWS(KCv, QAv) do { static bool reserved = false;                                /* (per instance) */ \
                                 if (!reserved) { hipFuncSetAttribute((const void*)k_mfma_expm_rows<NT, KCv, false, QAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); reserved = true; } \
                                 hipLaunchKernelGGL((k_mfma_expm_rows<NT, KCv, false, QAv>), dim3(d.B * mf.C), dim3(256), lds, s, d, mf); } while (0)
@@ -53,8 +51,7 @@ static inline void qoc_mfma_launch_all_expm(QocMfma& mf, const QocDev& d, hipStr
         // latency mode: K_t by two waves per slice, then the chunk products and the products of groups of G chunks
 #define QOC_SL2(QAv) do { if (d.k <= 4) hipLaunchKernelGGL((k_mfma_expm_slice2<4, QAv>), dim3(d.B * d.steps), dim3(128), 0, s, d, mf); \
                           else hipLaunchKernelGGL((k_mfma_expm_slice2<8, QAv>), dim3(d.B * d.steps), dim3(128), 0, s, d, mf); } while (0)
-        { static const bool all8 = getenv("QOC_LAT_QA8") && atoi(getenv("QOC_LAT_QA8")) != 0;   // A/B: the padded problem in full
-          QOC_QA_SWITCH_LAT(all8 ? 8 : qoc_active_strips_lat(d.n), QOC_SL2); }
+        QOC_QA_SWITCH_LAT(mf.exp_lat_qa8 ? 8 : qoc_active_strips_lat(d.n), QOC_SL2);      // (QOC_LAT_QA8=1, experimental: the padded problem in full)
 #undef QOC_SL2
         // (k_mfma_chain_rows2: the columns of the right operand split over the waves of a workgroup -- 9.8 -> 8.5 us per launch at C2)
         hipLaunchKernelGGL(k_mfma_chain_rows2<2>, dim3(d.B * mf.C * 8), dim3(128), 0, s, d, mf, (const cplx*)mf.KfD, 1, d.steps, mf.L, mf.PfD, mf.C, (const cplx*)nullptr, mf.PfT);

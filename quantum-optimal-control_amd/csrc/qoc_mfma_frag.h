@@ -71,6 +71,9 @@ struct QocMfma {
     cplx* AoffL = nullptr;        // [B][C][NT * MQ][64] / GoffL [B][NG][...]: chunk and group offsets of the source recursion, register layout
     cplx* GoffL = nullptr;
     bool lat_dressed = false;     // lat_src_fast with dressed forbidden levels (<= 4): amplitudes formed by k_mfma_loss_lat<NT, true>, sources from QocDev::Fd
+    // experimental switches, read once in qoc_mfma_setup (qoc_exp_env): the padded problem in full in k_mfma_expm_rows / k_mfma_expm_slice2, the chunk
+    // offsets of the source recursion by their own launches
+    bool exp_rows_qa_full = false, exp_lat_qa8 = false, exp_lat_offsets_own = false;
     bool lat_src_fast = false;    // lat_sources on the thin affine sweeps (undressed forbidden levels / speed_up, NT = 2); else the batch kernels' recursion
     double* loss_part = nullptr;  // [B][steps + 1][2] per-time-point partials of k_mfma_loss_lat
     unsigned* lat_count = nullptr; // [B] workgroups of k_mfma_grad_lat that have finished (the last one runs the tail of the iteration)

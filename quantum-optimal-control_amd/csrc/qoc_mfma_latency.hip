@@ -25,7 +25,7 @@ int qoc_mfma_latency_setup(QocMfma& mf, const QocDev& d, std::string& msg) {
 
 // the chunk offsets of the source recursion come out of the forward sweep itself when the sources need nothing but Psi (undressed forbidden levels, no speed_up)
 static inline bool qoc_lat_offsets_in_sweep(const QocMfma& mf, const QocDev& d) {
-    return mf.lat_src_fast && !mf.lat_dressed && !d.has_speed && d.n_forb > 0 && !(getenv("QOC_LAT_OFFSETS_IN_SWEEP") && atoi(getenv("QOC_LAT_OFFSETS_IN_SWEEP")) == 0);
+    return mf.lat_src_fast && !mf.lat_dressed && !d.has_speed && d.n_forb > 0 && !mf.exp_lat_offsets_own;
 }
 
 // forward and z-free adjoint sweep side by side: 2 x (seed, chunk, group of 4 columns) workgroups of NT waves (one row tile each)

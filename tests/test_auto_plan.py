@@ -20,7 +20,25 @@ from tests.test_hip_parity import check_eval
 
 pytestmark = pytest.mark.gpu
 
-LAT_WORK, LAT_WORK_SRC, LAT_WORK_NT3, LAT_WORK_NT4 = 4608, 4096, 16384, 4096      # seeds x slices up to which the latency mode is taken (n <= 16; NT = 3; NT = 4)
+import os
+import re
+
+
+def _plan_limits():
+    """The measured numbers of the table, from the ONE header the engine compiles them from (csrc/qoc_plan_limits.h: `#define QOC_PLAN_<NAME> <integer>`):
+    the rules below are an independent restatement of plan_for's control flow, the numbers exist once."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'quantum-optimal-control_amd', 'csrc', 'qoc_plan_limits.h')
+    out = {}
+    for line in open(path):
+        mt = re.match(r'#define\s+QOC_PLAN_(\w+)\s+(\d+)\b', line)
+        if mt:
+            out[mt.group(1)] = int(mt.group(2))
+    assert len(out) >= 40, 'qoc_plan_limits.h: only %d limits parsed' % len(out)
+    return out
+
+
+LIM = _plan_limits()
+LAT_WORK, LAT_WORK_SRC, LAT_WORK_NT3, LAT_WORK_NT4 = LIM['LAT_WORK'], LIM['LAT_WORK_SRC'], LIM['LAT_WORK_NT3'], LIM['LAT_WORK_NT4']   # seeds x slices up to which the latency mode is taken
 
 
 FORBID = lambda n: {'dwdt': 0.1, 'forbidden_coeff_list': [3.0], 'states_forbidden_list': [n - 1]}      # noqa: E731
@@ -35,7 +53,7 @@ def lat_limit_nt2(n, state_reg):
     if n <= 16:
         return LAT_WORK_SRC if state_reg else LAT_WORK
     qa = max(5, ceil_div(n, 4))
-    return min(LAT_WORK_SRC, 768 * qa) if state_reg else 512 * qa
+    return min(LAT_WORK_SRC, LIM['LAT_WORK_PER_STRIP_SRC'] * qa) if state_reg else LIM['LAT_WORK_PER_STRIP'] * qa
 def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, hermitian=True):
     """DESIGN.md section 4, the AUTO table, as ordered rules -> the dict HipEngine.plan reports."""
     st = state_transfer
@@ -49,7 +67,7 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         # non-Hermitian generators; the propagator route otherwise; m > 8 or n > 64 cannot run direct
         if m > 32 or not (hermitian or direct_ok):
             return {'path': 'st_fused' if (n <= 64 and m <= 4 and k <= 8) else 'generic'}
-        direct = direct_ok and (not hermitian or B >= (112 if n <= 32 else ((22 if state_reg else 12) if dpp else 48)))
+        direct = direct_ok and (not hermitian or B >= (LIM['ST_DIRECT_N32'] if n <= 32 else ((LIM['ST_DIRECT_DPP_SRC'] if state_reg else LIM['ST_DIRECT_DPP']) if dpp else LIM['ST_DIRECT_N64'])))
         return {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
     mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= deg <= 22 and hermitian
     if st and not (mfma_ok and (n <= 32 or (n <= 48 and k <= 4))):
@@ -58,14 +76,15 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         return {'path': 'gemm', 'route': 'unitary'} if m <= 32 else {'path': 'generic'}
     work = B * steps
     # row "latency mode": one or a few control sets
-    if deg >= 2 and steps >= 64:
+    if deg >= 2 and steps >= LIM['LAT_MIN_SLICES']:
         if n > 48 or (n > 32 and k > 4):
-            lat = work <= LAT_WORK_NT4 and B <= 4
+            lat = work <= LAT_WORK_NT4 and B <= LIM['LAT_SETS_NT4']
         elif n > 32:
-            lat = work <= LAT_WORK_NT3 and B <= 8
+            lat = work <= LAT_WORK_NT3 and B <= LIM['LAT_SETS_NT3']
         else:
-            lat = work <= lat_limit_nt2(n, state_reg) and B <= ((4 if (st and ceil_div(n, 4) >= 7) else 16) if n > 16 else (8 if st else 6))
-        lat = lat or (B == 1 and steps <= 8192)
+            lat = work <= lat_limit_nt2(n, state_reg) and B <= ((LIM['LAT_SETS_N32_ST_WIDE'] if (st and ceil_div(n, 4) >= 7) else LIM['LAT_SETS_N32']) if n > 16
+                                                              else (LIM['LAT_SETS_N16_ST'] if st else LIM['LAT_SETS_N16']))
+        lat = lat or (B == 1 and steps <= LIM['LAT_SINGLE_MAX_SLICES'])
     else:
         lat = False
     if lat:
@@ -75,19 +94,22 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
     # rows "GEMM": 48 < n <= 64 below the NT = 4 batch sizes; 32 < n <= 48 with fewer than 8 control sets; 16 < n <= 32 with a few control sets
     # (2 / 3 / 5 / 7 for ceil(n / 4) = 5 / 6 / 7 / 8; 5 / 6 / 8 / 8 with a state regulariser; state transfer: 8 from 25 levels on); state transfer: the
     # large batches that the direct Taylor chains win (n <= 32: from 112 control sets of more than 20 levels -- 28 with a state regulariser; n > 32: from 48 -- 112; with one state vector from 32 -- 48)
-    nt4_batch = n > 48 and ((k <= 4 and B >= 32) or B >= 64)
+    nt4_batch = n > 48 and ((k <= 4 and B >= LIM['NT4_MIN_SETS_K4']) or B >= LIM['NT4_MIN_SETS'])
     qa = ceil_div(n, 4)
-    gemm_small = ({5: 5, 6: 6}.get(qa, 8) if state_reg else {5: 2, 6: 3, 7: 5}.get(qa, 7)) if 16 < n <= 32 else 0
+    gemm_small = ({5: LIM['GEMM_SMALL_SRC_Q5'], 6: LIM['GEMM_SMALL_SRC_Q6']}.get(qa, LIM['GEMM_SMALL_SRC_Q78']) if state_reg
+                  else {5: LIM['GEMM_SMALL_Q5'], 6: LIM['GEMM_SMALL_Q6'], 7: LIM['GEMM_SMALL_Q7']}.get(qa, LIM['GEMM_SMALL_Q8'])) if 16 < n <= 32 else 0
     if st and qa >= 7 and 16 < n <= 32:
-        gemm_small = 8
-    st_big = direct_ok and ((B >= 112 and n > (28 if state_reg else 20)) if n <= 32 else B >= (((48 if state_reg else 32) if dpp else (112 if state_reg else 48))))
-    if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < 8) or (16 < n <= 32 and B <= gemm_small and m <= 8 and steps >= 100) or st_big:
+        gemm_small = LIM['GEMM_SMALL_ST_WIDE']
+    st_big = direct_ok and ((B >= LIM['ST_BIG_N32'] and n > (LIM['ST_BIG_N32_MIN_LEVELS_SRC'] if state_reg else LIM['ST_BIG_N32_MIN_LEVELS'])) if n <= 32
+                            else B >= (((LIM['ST_BIG_DPP_SRC'] if state_reg else LIM['ST_BIG_DPP']) if dpp else (LIM['ST_BIG_N64_SRC'] if state_reg else LIM['ST_BIG_N64']))))
+    if (n > 48 and not nt4_batch) or (32 < n <= 48 and B < LIM['NT3_MIN_SETS']) or \
+            (16 < n <= 32 and B <= gemm_small and m <= 8 and steps >= LIM['GEMM_SMALL_MIN_SLICES']) or st_big:
         if st:
             return gemm_state_transfer()
         return {'path': 'gemm', 'route': 'unitary', 'chains': 'persistent' if m <= 8 else 'launches'}
     # rows "MFMA batch kernels"
     nt = 1 if n <= 16 else 2 if n <= 32 else 3 if n <= 48 else 4
-    C = min(1024 // B if nt == 2 else ceil_div(1024, B), 64 if nt == 2 else 32)
+    C = min(LIM['CHUNK_ITEMS'] // B if nt == 2 else ceil_div(LIM['CHUNK_ITEMS'], B), LIM['CHUNKS_MAX_NT2'] if nt == 2 else LIM['CHUNKS_MAX'])
     C = max(1, min(C, steps))
     C = ceil_div(steps, ceil_div(steps, C))
     if nt == 2:

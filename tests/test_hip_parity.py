@@ -98,6 +98,7 @@ def test_separate_sweep_kernels_behind_the_fused_one(chunks, monkeypatch):
     bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.2]
     out = {}
     for flag in ('1', '0'):
+        monkeypatch.setenv('QOC_EXPERIMENTAL', '1')        # the A/B switches of the library only count beside it (csrc/qoc_common.h: qoc_exp_env)
         monkeypatch.setenv('QOC_UPDOWN', flag)
         eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks, variant=8)
         eng.set_base(np.stack(bases))
@@ -273,6 +274,7 @@ def test_direct_route_on_the_dpp_chain(n, steps, terms, reg, monkeypatch):
     check_eval(eng, sp, bases)
     r = eng.evaluate()
     eng.close()
+    monkeypatch.setenv('QOC_EXPERIMENTAL', '1')        # the A/B switches of the library only count beside it (csrc/qoc_common.h: qoc_exp_env)
     monkeypatch.setenv('QOC_CHAIN_DPP', '0')                       # the butterfly kernel on row-major generators
     old = make_engine(sp, n_seeds=3, path=4, chunks=1)
     old.set_base(np.stack(bases))
@@ -331,6 +333,7 @@ def test_direct_route_assembly_overlap_fallbacks(env, monkeypatch):
     r0 = ref.evaluate()
     ref.close()
     for key, val in env.items():
+        monkeypatch.setenv('QOC_EXPERIMENTAL', '1')        # the A/B switches of the library only count beside it (csrc/qoc_common.h: qoc_exp_env)
         monkeypatch.setenv(key, val)
     eng = make_engine(sp, n_seeds=2, path=4, chunks=1)
     eng.set_base(np.stack(bases))
@@ -665,6 +668,7 @@ def test_row_tile_gradient_kernel_and_auto_for_large_n64_batches(monkeypatch):
         bases = np.random.default_rng(n).normal(0, 0.4, (seeds, sp.k, sp.steps))
         grads = []
         for rt in ('1', '0'):
+            monkeypatch.setenv('QOC_EXPERIMENTAL', '1')        # the A/B switches of the library only count beside it (csrc/qoc_common.h: qoc_exp_env)
             monkeypatch.setenv('QOC_GRAD_RT', rt)
             eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling,
                                        reg_coeffs={}, n_seeds=seeds, path=2, variant=7 if n > 32 else 0)
@@ -1178,6 +1182,7 @@ def test_padded_sizes_of_the_48_and_64_wide_kernels_on_their_active_strips(n, k,
     bases = [sp.base0] + [1.5 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.05 * i for i in range(seeds - 1)]
     losses = []
     for full in ('0', '1'):
+        monkeypatch.setenv('QOC_EXPERIMENTAL', '1')        # the A/B switches of the library only count beside it (csrc/qoc_common.h: qoc_exp_env)
         monkeypatch.setenv('QOC_ROWS_QA_FULL', full)
         eng = make_engine(sp, n_seeds=len(bases), path=2, chunks=chunks)
         assert eng.path == 2

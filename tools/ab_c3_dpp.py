@@ -16,6 +16,7 @@ def run(seeds, iters=20):
     s = eng.scalars(); eng.close()
     return el / iters * 1e3, s['loss'].copy()
 for seeds in (64, 256):
+    os.environ['QOC_EXPERIMENTAL'] = '1'                 # the library's A/B switches only count beside it
     os.environ['QOC_CHAIN_DPP'] = '1'; t1, l1 = run(seeds)
     os.environ['QOC_CHAIN_DPP'] = '0'; t0, l0 = run(seeds)
     print('C3 x %d: dpp %.3f ms, butterfly %.3f ms per iteration; max |loss difference| after 30 Adam iterations %.2e' % (seeds, t1, t0, np.max(np.abs(l1 - l0))))

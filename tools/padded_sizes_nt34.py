@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Unitary gates of 33 <= n <= 64 levels x 64 control sets (k = 4, 500 slices, m = 8, (T, s) = (5, 3)): k_mfma_expm_rows runs the block steps over the
-ACTIVE inner 4-row strips ceil(n / 4) of the matrices padded to 48 / 64.  QOC_ROWS_QA_FULL=1: the padded problem in full (A/B).
+ACTIVE inner 4-row strips ceil(n / 4) of the matrices padded to 48 / 64.  QOC_EXPERIMENTAL=1 QOC_ROWS_QA_FULL=1: the padded problem in full (A/B).
 padded_sizes_nt34.py <seeds>: another number of control sets (1: the latency mode, whose slice kernel takes the active strips too)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -14,6 +14,6 @@ run() {   # label, bench chunks (0 = planned), env...
   python $R/tools/rocpd_kernel_stats.py $(ls $O/$label/*/*_results.db | head -1) 2>&1 | head -9
   rm -rf $O/$label
 }
-run off 0 QOC_UPDOWN=0
+run off 0 QOC_EXPERIMENTAL=1 QOC_UPDOWN=0
 run on 0 QOC_UPDOWN=1
 for c in "$@"; do run on_c$c $c QOC_UPDOWN=1; done
