@@ -68,7 +68,10 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         if m > 32 or not (hermitian or direct_ok):
             return {'path': 'st_fused' if (n <= 64 and m <= 4 and k <= 8) else 'generic'}
         direct = direct_ok and (not hermitian or B >= (LIM['ST_DIRECT_N32'] if n <= 32 else ((LIM['ST_DIRECT_DPP_SRC'] if state_reg else LIM['ST_DIRECT_DPP']) if dpp else LIM['ST_DIRECT_N64'])))
-        return {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
+        out = {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
+        if direct:      # the kernel of the Taylor chains: the DPP chain at 33 .. 64 levels with one vector -- on packed generators when they are anti-Hermitian
+            out['taylor_chain'] = ('packed' if hermitian else 'full') if dpp else 'butterfly'
+        return out
     mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= deg <= 22 and hermitian
     if st and not (mfma_ok and (n <= 32 or (n <= 48 and k <= 4))):
         return gemm_state_transfer()                      # row "state transfer, n > 48 (or 32 < n <= 48 with k > 4), or generators that are not anti-Hermitian"
