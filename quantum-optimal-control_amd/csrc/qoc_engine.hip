@@ -25,8 +25,9 @@
 #include "qoc_gemm_ts.h"
 
 #include "qoc_plan_limits.h"            // the measured numbers of AUTO's table (QOC_PLAN_*), shared with tests/test_auto_plan.py
-// (QOC_PLAN_LAT_WORK = 4608 seeds x time slices: since the batch sweeps take their chunk boundaries and final_state from k_mfma_bnd_scan the batch kernels are
-// ahead from 10 seeds of 500 slices on -- 0.356 ms at 12 seeds against 0.444; 8 seeds: 0.349 against 0.305; profiles/r03_latency_sweep.txt)
+// (QOC_PLAN_LAT_WORK = 4608 seeds x time slices: since the batch sweeps take their chunk boundaries and final_state from k_mfma_bnd_scan
+// the batch kernels are ahead from 10 seeds of 500 slices on -- 0.356 ms at 12 seeds against 0.444; 8 seeds: 0.349 against 0.305;
+// profiles/r03_latency_sweep.txt)
 static thread_local std::string g_err;
 
 static int fail(int code, const char* fmt, ...) {
@@ -64,8 +65,10 @@ struct qoc_engine {
     QocMfma mf;
     QocGemm gm;
     bool evaluated = false;
-    int skip_mask = 0;          // QOC_DEBUG_SKIP (timing experiments only): 1 controls, 2 exponentials, 4 forward, 8 loss, 16 backward, 32 finish
-    bool controls_ready = false;                     // u2 / w2 hold maxA sin(base) of the CURRENT variable (written by the Adam tail or by qoc_get_uks)
+    // QOC_DEBUG_SKIP (timing experiments only): 1 controls, 2 exponentials, 4 forward, 8 loss, 16 backward, 32 finish
+    int skip_mask = 0;
+    // u2 / w2 hold maxA sin(base) of the CURRENT variable (written by the Adam tail or by qoc_get_uks)
+    bool controls_ready = false;
     bool final_stale = false, inter_stale = false;   // MFMA latency mode: Xfinal / uscale not yet formed for the last evaluation
     double* step_lr = nullptr;  // [B] per-seed learning rates of qoc_adam_step
     // profiling of the dominant kernel
@@ -154,7 +157,8 @@ __global__ void __launch_bounds__(256) k_band_twiddles(cplx* tw, int N) {
 
 // Bandpass regulariser (regularization_functions.py:47-67) by direct DFT, outside the one-workgroup-per-seed finish kernel (where the
 // 2 k N^2 terms of a seed took 0.4 ms of one C2 trajectory even with the phase table):
-//   k_band_spectrum: a wave per (seed, control, frequency): F_f = sum_t w_t e^{-2 pi i f t/N}; band_mag = cnt_f |F_f|, band_ph = cnt_f conj(F_f)/|F_f|
+// k_band_spectrum: a wave per (seed, control, frequency): F_f = sum_t w_t e^{-2 pi i f t/N}; band_mag = cnt_f |F_f|, band_ph = cnt_f
+// conj(F_f)/|F_f|
 //   k_band_gradient: a thread per (seed, control, slice): band_dR = sum_f Re(band_ph_f e^{-2 pi i f t/N})
 // cnt_f = how often the reference's two slices (f < lo; hi <= f < N/2) contain f.
 __global__ void __launch_bounds__(256) k_band_spectrum(QocDev d) {
@@ -210,7 +214,8 @@ __global__ void __launch_bounds__(256) k_band_gradient(QocDev d) {
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (f0 + q < fend) acc += qv[q].x * e[q].x - qv[q].y * e[q].y;       // Re(ph_f e^{-2 pi i f t/N}); ph = 0 outside the counted bins
+                // Re(ph_f e^{-2 pi i f t/N}); ph = 0 outside the counted bins
+                if (f0 + q < fend) acc += qv[q].x * e[q].x - qv[q].y * e[q].y;
         }
         d.band_dR[o] = acc;
     }
@@ -231,8 +236,8 @@ static inline void launch_loss(const QocDev& d, hipStream_t s) {
 }
 
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
-    // the slice kernel of the n <= 32 latency mode forms its own controls; everybody else reads u / w: from k_controls, or -- when the Adam tail of
-    // the previous iteration (or qoc_get_uks) has left them in u2 / w2 -- by swapping the two pairs (one launch less per iteration)
+    // the slice kernel of the n <= 32 latency mode forms its own controls; everybody else reads u / w: from k_controls, or -- when the Adam
+    // tail of the previous iteration (or qoc_get_uks) has left them in u2 / w2 -- by swapping the two pairs (one launch less per iteration)
     const bool own_controls = e->path == QOC_PATH_MFMA && e->mf.latency && e->mf.NT == 2;
     const bool swap_in = e->controls_ready && !own_controls && !(e->skip_mask & 1);
     if (swap_in) { std::swap(e->d.u, e->d.u2); std::swap(e->d.w, e->d.w2); }
@@ -248,7 +253,8 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     const bool plain = !(d.has_amp || d.has_env || d.has_dwdt || d.has_d2wdt2 || d.has_band);
     // latency mode: the tail of the iteration runs in the last workgroup of the gradient kernel
     // (with the local pulse regularisers too -- amplitude, envelope, dwdt, d2wdt2; the bandpass DFT keeps its own launch)
-    const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && (!e->mf.lat_sources || e->mf.lat_src_fast) && !d.has_band && !(skip & (16 | 32));
+    const bool fused_tail = e->path == QOC_PATH_MFMA && e->mf.latency && (!e->mf.lat_sources || e->mf.lat_src_fast) && !d.has_band
+        && !(skip & (16 | 32));
     // (latency mode of the MFMA path: the slice kernel of the exponentials forms its own controls)
     if (!(skip & 1) && !own_controls && !swap_in) hipLaunchKernelGGL(k_controls, dim3(cgrid), dim3(QOC_BLOCK), 0, e->stream, d);
     if (e->path == QOC_PATH_MFMA) {
@@ -258,19 +264,22 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         if (!(skip & 4)) qoc_mfma_launch_forward(e->mf, d, e->stream);
         if (skip & 64) qoc_mfma_launch_forward(e->mf, d, e->stream);        // debug: the same launch again (cold-start vs steady cost)
         if (skip & 128) qoc_mfma_launch_backward(e->mf, d, e->stream);
-        if (!(skip & 8) && !e->mf.updown && (!e->mf.latency || (e->mf.lat_sources && !e->mf.lat_src_fast))) launch_loss(d, e->stream);   // latency mode / k_mfma_downup: inside the backward kernel
+        // latency mode / k_mfma_downup: inside the backward kernel
+        if (!(skip & 8) && !e->mf.updown && (!e->mf.latency || (e->mf.lat_sources && !e->mf.lat_src_fast))) launch_loss(d, e->stream);
         if (!(skip & 16)) {
             if (fused_tail) qoc_mfma_latency_gradient(e->mf, d, &ap, e->stream);
             else qoc_mfma_launch_backward(e->mf, d, e->stream);
         }
     } else if (e->path == QOC_PATH_GEMM) {
         if (e->gm.ts_G > 0) {                                           // one trajectory sharded along the time axis (qoc_gemm_ts.h)
-            const int rc = qoc_gemm_ts_evaluate(e->gm, d, e->stream, [&]() { launch_loss(d, e->stream); }, [&]() { return prof_begin(e); }, [&]() { return prof_end(e); });
+            const int rc = qoc_gemm_ts_evaluate(e->gm, d, e->stream, [&]() { launch_loss(d, e->stream); }, [&]() { return prof_begin(e); },
+                [&]() { return prof_end(e); });
             if (rc == 1) return fail(QOC_ERR_HIP, "time-sharded iteration: clearing the gradient array failed");
             if (rc) return rc;                                          // (the message is the collective's / the profiler's)
         } else {
-        // the hipEvent bracket of qoc_profile_read: the exponentials -- or, on the direct state-transfer route (no exponentials: the assembly of the
-        // generators is all qoc_gemm_expm does there), the backward half of the iteration, which the backward Taylor chain dominates
+        // the hipEvent bracket of qoc_profile_read: the exponentials -- or, on the direct state-transfer route (no exponentials: the
+        // assembly of the generators is all qoc_gemm_expm does there), the backward half of the iteration, which the backward Taylor chain
+        // dominates
         const bool bracket_bwd = e->gm.direct;
         if (!bracket_bwd) TRY(prof_begin(e));
         qoc_gemm_expm(e->gm, d, e->stream);
@@ -313,10 +322,13 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
     }
     HIP_TRY(hipGetLastError());
     e->evaluated = true;
-    e->controls_ready = ap.mode != 0 && !own_controls && !(skip & (16 | 32));       // the Adam tail ran: u2 / w2 belong to the moved variable
-    e->final_stale = (e->path == QOC_PATH_MFMA && (e->mf.latency || e->mf.updown)) ||  // final_state / unitary_scale are formed when read back
+    // the Adam tail ran: u2 / w2 belong to the moved variable
+    e->controls_ready = ap.mode != 0 && !own_controls && !(skip & (16 | 32));
+    // final_state / unitary_scale are formed when read back
+    e->final_stale = (e->path == QOC_PATH_MFMA && (e->mf.latency || e->mf.updown)) ||
                      (e->path == QOC_PATH_GEMM && e->gm.ts_G <= 0 && qoc_gemm_lazy_final(e->gm, e->d));
-    e->inter_stale = (e->path == QOC_PATH_MFMA && e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast))   // inter_vecs too, unless the batch kernels' source recursion needed them anyway
+    // inter_vecs too, unless the batch kernels' source recursion needed them anyway
+    e->inter_stale = (e->path == QOC_PATH_MFMA && e->final_stale && (!e->mf.lat_sources || e->mf.lat_src_fast))
                      || (e->path == QOC_PATH_MFMA && e->mf.updown);                  // (k_mfma_downup stores no Psi_t either)
     return QOC_OK;
 }
@@ -324,7 +336,8 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
 // latency mode of the MFMA path: final_state and unitary_scale of the last evaluation, formed on demand
 static int refresh_final(qoc_engine* e) {
     if (!e->final_stale) return QOC_OK;
-    if (e->path == QOC_PATH_GEMM) qoc_gemm_forward(e->gm, e->d, e->stream, true);      // the boundary chain once more, with X beside the vectors
+    // the boundary chain once more, with X beside the vectors
+    if (e->path == QOC_PATH_GEMM) qoc_gemm_forward(e->gm, e->d, e->stream, true);
     else if (e->d.state_transfer) {                                                    // no final_state; unitary_scale from Psi_N
         if (e->inter_stale) { qoc_mfma_unpack_inter(e->mf, e->d, e->stream); e->inter_stale = false; }
         qoc_mfma_uscale_state_transfer(e->d, e->stream);
@@ -383,7 +396,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
                const double* maxA, const double* one_minus_gauss, const int32_t* forbidden_states,
                const double* forbidden_coeffs, const double* Vs, qoc_handle* out) {
     if (!cfg || !Hs || !V || !W || !maxA || !out) return fail(QOC_ERR_INVALID, "qoc_create: null argument");
-    if (cfg->plan_seeds < 0) return fail(QOC_ERR_INVALID, "qoc_create: plan_seeds = %d (0 = plan for n_seeds, > 0 = the batch AUTO plans for)", cfg->plan_seeds);
+    if (cfg->plan_seeds < 0) return fail(QOC_ERR_INVALID,
+        "qoc_create: plan_seeds = %d (0 = plan for n_seeds, > 0 = the batch AUTO plans for)", cfg->plan_seeds);
     if (cfg->n < 1 || cfg->k < 1 || cfg->steps < 1 || cfg->m < 1 || cfg->n_seeds < 1)
         return fail(QOC_ERR_INVALID, "qoc_create: n, k, steps, m, n_seeds must be >= 1");
     if (cfg->taylor_terms < 1 || cfg->scaling < 0 || cfg->scaling > 30)
@@ -428,7 +442,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     int rc = QOC_OK;
     auto bail = [&](int code) { qoc_destroy(e); return code; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QOC_ERR_HIP, "hipStreamCreate failed"));
-    if (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess) return bail(fail(QOC_ERR_HIP, "hipEventCreate failed"));
+    if (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess) return bail(fail(QOC_ERR_HIP,
+        "hipEventCreate failed"));
 
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, ks = (size_t)k * steps;
     // U0*V on the host (tiny): start vector of the thin forward recursion
@@ -502,7 +517,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     // ---- path selection -----------------------------------------------------------------------------------------
     int path = cfg->path;
     const bool antiherm = cfg->state_transfer ? qoc_all_antihermitian((const cplx*)Hs, n, k + 1) : true;
-    const bool mfma_ok = qoc_mfma_supported(d) && antiherm;          // (state transfer: the propagator's adjoint is the reference's gradient only then)
+    // (state transfer: the propagator's adjoint is the reference's gradient only then)
+    const bool mfma_ok = qoc_mfma_supported(d) && antiherm;
     const bool st_ok = st_fused_supported(d);
     const bool gemm_ok = qoc_gemm_supported(d, antiherm);
     // Measured with tools/path_sweep.py (profiles/r01_path_sweep.txt):
@@ -515,72 +531,88 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     //    4 (1.00 vs 0.95) and loses below (0.96 vs 0.62 ms at 2); 48 < n <= 64 (NT = 4; tools/n64_batch_sweep.py): with k <= 4 controls
     //    the MFMA path is ahead from 32 seeds on (4.96 vs 5.14 ms at 32, 9.16 vs 10.05 at 64, 17.4 vs 19.8 at 128 seeds of n = 64 x 500
     //    slices, since the row-tile gradient kernel); with more controls the GEMM path up to 64 seeds, the MFMA path beyond (round 3, after
-    //    k_mfma_expm_rows lost its scratch: k = 6 x 200 slices 4.33 vs 4.35 ms at 64 seeds, 7.86 vs 8.47 at 128; k = 8 x 1000 slices 20.05 vs
+    // k_mfma_expm_rows lost its scratch: k = 6 x 200 slices 4.33 vs 4.35 ms at 64 seeds, 7.86 vs 8.47 at 128; k = 8 x 1000 slices 20.05 vs
     //    20.54 at 64, 38.7 vs 40.7 at 128; at 32 seeds the GEMM path: 2.31 vs 2.59, 10.4 vs 10.7).
     // every batch-size-dependent choice below is taken for Bp = qoc_config.plan_seeds (else the local batch): a shard of a restart
     // batch then runs the same path, kernels and chunking as the whole batch would
     const bool direct_ok = qoc_gemm_direct_supported(d);
     if (cfg->state_transfer && cfg->path == QOC_PATH_GEMM && cfg->chunks > 1 && !antiherm)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
+        return bail(fail(QOC_ERR_INVALID,
+            "qoc_create: the propagator route of the GEMM path (chunks > 1) needs exactly anti-Hermitian generators"));
     // a handful of control sets of an n <= 32 unitary problem (the reference's own use is ONE per Grape() call): the latency mode of
     // the MFMA path.  It spends a workgroup per time slice, so what decides is seeds x slices
     // (profiles/r02_latency_sweep.txt, r02_small_n_sweep.txt): C2 (500 slices) 0.083 ms against 0.189 (GEMM route) and 0.56 (batch
     // kernels) for one seed, still ahead at 12 seeds, level at 16; n <= 16 is padded to 32 and competes with the cheap NT = 1 batch
     // kernels: ahead up to 4 seeds (n = 16 x 500 slices: 0.081 against 0.203 ms for one seed, 0.163 against 0.213 for four)
-    // (round 4, with k_mfma_expm_slice2 on the active strips: ahead up to 6 control sets with or without a state regulariser -- n = 16 x 500 slices x 6: 0.180
-    // against 0.213 ms, with a forbidden level 0.250 against 0.280; x 8: 0.229 / 0.213 and 0.308 / 0.280; n = 9 x 300 x 6: 0.106 / 0.140; profiles/r04_small_n_latency.txt)
-    // 32 < n <= 48 (NT = 3 kernels: k_mfma_expm_rows per slice, the same chains, sweeps and gradient): one trajectory of n = 48 x 500
-    // slices 0.165 ms against 0.454 (GEMM route) and 0.84 (batch kernels); ahead up to 8 seeds (profiles/r02_mid_n_sweep.txt).
-    // With a state regulariser (forbidden levels, speed_up) the backward half is the affine recursion of the batch kernels on the
-    // latency mode's chunks, with two-level boundaries (QocMfma::lat_sources): one C2 trajectory with dwdt + forbidden levels 0.189 ms
-    // against 0.290 (GEMM route) and 0.72 (batch kernels); ahead up to ~4096 seed-slices (tools/c2_forbidden_single.py).
+    // (round 4, with k_mfma_expm_slice2 on the active strips: ahead up to 6 control sets with or without a state regulariser -- n = 16 x
+    // 500 slices x 6: 0.180 against 0.213 ms, with a forbidden level 0.250 against 0.280; x 8: 0.229 / 0.213 and 0.308 / 0.280; n = 9 x 300
+    // x 6: 0.106 / 0.140; profiles/r04_small_n_latency.txt) 32 < n <= 48 (NT = 3 kernels: k_mfma_expm_rows per slice, the same chains,
+    // sweeps and gradient): one trajectory of n = 48 x 500 slices 0.165 ms against 0.454 (GEMM route) and 0.84 (batch kernels); ahead up to
+    // 8 seeds (profiles/r02_mid_n_sweep.txt). With a state regulariser (forbidden levels, speed_up) the backward half is the affine
+    // recursion of the batch kernels on the latency mode's chunks, with two-level boundaries (QocMfma::lat_sources): one C2 trajectory with
+    // dwdt + forbidden levels 0.189 ms against 0.290 (GEMM route) and 0.72 (batch kernels); ahead up to ~4096 seed-slices
+    // (tools/c2_forbidden_single.py).
     const bool lat_src = d.n_forb > 0 || d.has_speed;
-    // n > 32 with ONE state vector: the direct route runs k_gemm_taylor_chain_dpp (round 4: 0.31 against 0.46 us per dependent mat-vec) and wins earlier --
-    // C3 (n = 64, k = 6, 1000 slices), propagator / direct route in ms: x 24 6.03 / 6.20, x 32 8.00 / 6.34; without forbidden levels (both chains side by side)
-    // x 12 2.81 / 3.12, x 16 3.74 / 3.18 (profiles/r04_c3_route_sweep.txt); n = 40, 48 with k = 4 x 500 slices, MFMA batch kernels / direct: x 24 1.48 / 1.64,
-    // x 32 1.84 / 1.70; with forbidden levels x 32 2.14 / 3.20, x 48 3.89 / 3.32 (profiles/r04_st_direct_sweep.txt)
+    // n > 32 with ONE state vector: the direct route runs k_gemm_taylor_chain_dpp (round 4: 0.31 against 0.46 us per dependent mat-vec) and
+    // wins earlier -- C3 (n = 64, k = 6, 1000 slices), propagator / direct route in ms: x 24 6.03 / 6.20, x 32 8.00 / 6.34; without
+    // forbidden levels (both chains side by side) x 12 2.81 / 3.12, x 16 3.74 / 3.18 (profiles/r04_c3_route_sweep.txt); n = 40, 48 with k =
+    // 4 x 500 slices, MFMA batch kernels / direct: x 24 1.48 / 1.64, x 32 1.84 / 1.70; with forbidden levels x 32 2.14 / 3.20, x 48 3.89 /
+    // 3.32 (profiles/r04_st_direct_sweep.txt)
     const bool dpp_shape = n > 32 && m == 1;
-    // (three-multiplication form of the DPP chain, profiles/r04_c3_route_sweep_gauss.txt: with forbidden levels x 20 5.05 / 5.43, x 22 5.56 / 5.45, x 24 6.02 / 5.49;
-    // without x 11 2.63 / 2.77, x 12 2.84 / 2.79, x 13 3.11 / 2.81 -- the limits moved from 28 / 14 to 22 / 12)
-    const int ST_DIRECT_FROM = n <= 32 ? QOC_PLAN_ST_DIRECT_N32 : (dpp_shape ? (lat_src ? QOC_PLAN_ST_DIRECT_DPP_SRC : QOC_PLAN_ST_DIRECT_DPP) : QOC_PLAN_ST_DIRECT_N64);
+    // (three-multiplication form of the DPP chain, profiles/r04_c3_route_sweep_gauss.txt: with forbidden levels x 20 5.05 / 5.43, x 22 5.56
+    // / 5.45, x 24 6.02 / 5.49; without x 11 2.63 / 2.77, x 12 2.84 / 2.79, x 13 3.11 / 2.81 -- the limits moved from 28 / 14 to 22 / 12)
+    const int ST_DIRECT_FROM = n <= 32 ? QOC_PLAN_ST_DIRECT_N32 : (dpp_shape ? (lat_src ? QOC_PLAN_ST_DIRECT_DPP_SRC
+        : QOC_PLAN_ST_DIRECT_DPP) : QOC_PLAN_ST_DIRECT_N64);
     struct AutoPlan { int path; bool latency; bool gemm_direct; };
-    // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by row)
-    // State transfer on the MFMA path (round 4, tools/st_path_sweep.py -> profiles/r04_state_transfer_paths.txt; m = 1, T = 10, 500 slices, ms per iteration,
-    // GEMM path / MFMA batch kernels / latency mode): n = 32 x 1: 0.125 / 0.300 / 0.073, x 4: 0.159 / 0.304 / 0.143, x 16: 0.388 / 0.324, x 64: 1.30 / 0.99,
-    // x 256: 2.00 (direct Taylor chains) / 3.78; n = 16 x 1: 0.126 / 0.192 / 0.063, x 8: 0.219 / 0.209 / 0.203, x 64: 1.28 / 0.34, x 256: 1.94 / 1.16;
-    // n = 48 x 1: 0.245 / 0.72 / 0.120, x 8: 1.02 / 0.77 / 0.58, x 16: 1.87 / 1.11, x 64: 2.60 / 3.31 (with forbidden levels 4.85 / 4.00);
-    // n = 64 (C3: k = 6, 1000 slices) x 1: 0.417 / 3.0 / 0.449, x 64: 9.73 / 18.1 -- so: the unitary table for n <= 32 and for 32 < n <= 48 with k <= 4 (NT = 3),
-    // the latency mode of n <= 16 up to 8 control sets and from 25 levels on up to 4, the GEMM route for up to 8 control sets from 25 levels on, and the direct Taylor chains of the GEMM
-    // path for the large batches they win (n <= 32: from 112 control sets of more than 20 levels, 28 with a state regulariser; n > 32: from 48, 112).
+    // the batch-size-dependent part of AUTO as a function of the batch it plans for (tests/test_auto_plan.py restates this table row by
+    // row) State transfer on the MFMA path (round 4, tools/st_path_sweep.py -> profiles/r04_state_transfer_paths.txt; m = 1, T = 10, 500
+    // slices, ms per iteration, GEMM path / MFMA batch kernels / latency mode): n = 32 x 1: 0.125 / 0.300 / 0.073, x 4: 0.159 / 0.304 /
+    // 0.143, x 16: 0.388 / 0.324, x 64: 1.30 / 0.99, x 256: 2.00 (direct Taylor chains) / 3.78; n = 16 x 1: 0.126 / 0.192 / 0.063, x 8:
+    // 0.219 / 0.209 / 0.203, x 64: 1.28 / 0.34, x 256: 1.94 / 1.16; n = 48 x 1: 0.245 / 0.72 / 0.120, x 8: 1.02 / 0.77 / 0.58, x 16: 1.87 /
+    // 1.11, x 64: 2.60 / 3.31 (with forbidden levels 4.85 / 4.00); n = 64 (C3: k = 6, 1000 slices) x 1: 0.417 / 3.0 / 0.449, x 64: 9.73 /
+    // 18.1 -- so: the unitary table for n <= 32 and for 32 < n <= 48 with k <= 4 (NT = 3), the latency mode of n <= 16 up to 8 control sets
+    // and from 25 levels on up to 4, the GEMM route for up to 8 control sets from 25 levels on, and the direct Taylor chains of the GEMM
+    // path for the large batches they win (n <= 32: from 112 control sets of more than 20 levels, 28 with a state regulariser;
+    // n > 32: from 48, 112).
     const bool st = cfg->state_transfer != 0;
     const bool mfma_auto = mfma_ok && (!st || n <= 32 || (n <= 48 && k <= 4));
     auto plan_for = [&](int Bp) -> AutoPlan {
         const bool nt4_batch = n > 48 && ((k <= 4 && Bp >= QOC_PLAN_NT4_MIN_SETS_K4) || Bp >= QOC_PLAN_NT4_MIN_SETS);
-        // 16 < n <= 32 below the latency mode's reach (long pulses): the GEMM route up to a few control sets, fewer the smaller the active part of the padded
-        // matrices is (500 slices, GEMM route / MFMA batch kernels in ms: n = 32 x 6 0.290 / 0.315, x 8 0.340 / 0.318; n = 27 x 4 0.251 / 0.270, x 6 0.288 / 0.271;
-        // n = 20 x 2 0.185 / 0.196, x 4 0.249 / 0.196; with a forbidden level n = 32 x 8 0.436 / 0.473, n = 27 x 8 level, n = 20 x 6 0.373 / 0.360)
+        // 16 < n <= 32 below the latency mode's reach (long pulses): the GEMM route up to a few control sets, fewer the smaller the active
+        // part of the padded matrices is (500 slices, GEMM route / MFMA batch kernels in ms: n = 32 x 6 0.290 / 0.315, x 8 0.340 / 0.318; n
+        // = 27 x 4 0.251 / 0.270, x 6 0.288 / 0.271; n = 20 x 2 0.185 / 0.196, x 4 0.249 / 0.196; with a forbidden level n = 32 x 8 0.436 /
+        // 0.473, n = 27 x 8 level, n = 20 x 6 0.373 / 0.360)
         const int qa_g = (n + 3) / 4;
         const int gemm_small = (st && qa_g >= 7) ? QOC_PLAN_GEMM_SMALL_ST_WIDE
-                               : lat_src ? (qa_g <= 5 ? QOC_PLAN_GEMM_SMALL_SRC_Q5 : qa_g == 6 ? QOC_PLAN_GEMM_SMALL_SRC_Q6 : QOC_PLAN_GEMM_SMALL_SRC_Q78)
-                                         : (qa_g <= 5 ? QOC_PLAN_GEMM_SMALL_Q5 : qa_g == 6 ? QOC_PLAN_GEMM_SMALL_Q6 : qa_g == 7 ? QOC_PLAN_GEMM_SMALL_Q7 : QOC_PLAN_GEMM_SMALL_Q8);
+                               : lat_src ? (qa_g <= 5 ? QOC_PLAN_GEMM_SMALL_SRC_Q5 : qa_g == 6 ? QOC_PLAN_GEMM_SMALL_SRC_Q6
+                                   : QOC_PLAN_GEMM_SMALL_SRC_Q78)
+                                         : (qa_g <= 5 ? QOC_PLAN_GEMM_SMALL_Q5 : qa_g == 6 ? QOC_PLAN_GEMM_SMALL_Q6 : qa_g == 7
+                                             ? QOC_PLAN_GEMM_SMALL_Q7 : QOC_PLAN_GEMM_SMALL_Q8);
         const bool st_big = st && direct_ok && cfg->chunks <= 1 &&
-                            (n <= 32 ? (Bp >= QOC_PLAN_ST_BIG_N32 && n > (lat_src ? QOC_PLAN_ST_BIG_N32_MIN_LEVELS_SRC : QOC_PLAN_ST_BIG_N32_MIN_LEVELS))
-                                     : Bp >= (dpp_shape ? (lat_src ? QOC_PLAN_ST_BIG_DPP_SRC : QOC_PLAN_ST_BIG_DPP) : (lat_src ? QOC_PLAN_ST_BIG_N64_SRC : QOC_PLAN_ST_BIG_N64)));
+                            (n <= 32 ? (Bp >= QOC_PLAN_ST_BIG_N32
+                                && n > (lat_src ? QOC_PLAN_ST_BIG_N32_MIN_LEVELS_SRC : QOC_PLAN_ST_BIG_N32_MIN_LEVELS))
+                                     : Bp >= (dpp_shape ? (lat_src ? QOC_PLAN_ST_BIG_DPP_SRC : QOC_PLAN_ST_BIG_DPP) : (lat_src
+                                         ? QOC_PLAN_ST_BIG_N64_SRC : QOC_PLAN_ST_BIG_N64)));
         const bool prefer_gemm = gemm_ok && ((n > 48 && !nt4_batch) || (n > 32 && Bp < QOC_PLAN_NT3_MIN_SETS) ||
-                                             (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= QOC_PLAN_GEMM_SMALL_MIN_SLICES) || st_big);
+                                             (n > 16 && n <= 32 && Bp <= gemm_small && m <= 8 && steps >= QOC_PLAN_GEMM_SMALL_MIN_SLICES)
+                                                 || st_big);
         const long long lat_work = (long long)Bp * steps;
-        // 16 < n <= 32: the batch kernels work on the ACTIVE 4-row strips qa = ceil(n / 4) of the padded matrices since round 4 and take over earlier the
-        // smaller n is (tools/padded_latency_sweep.py, 500 slices: n = 20 / 24 / 27 / 32 level at ~5 / 6 / 7 / 8.5 control sets; with a forbidden
-        // level the latency mode stays ahead up to 8, at n = 20 up to 7): seeds x slices <= 512 qa, with a state regulariser min(4096, 768 qa)
+        // 16 < n <= 32: the batch kernels work on the ACTIVE 4-row strips qa = ceil(n / 4) of the padded matrices since round 4 and take
+        // over earlier the smaller n is (tools/padded_latency_sweep.py, 500 slices: n = 20 / 24 / 27 / 32 level at ~5 / 6 / 7 / 8.5 control
+        // sets; with a forbidden level the latency mode stays ahead up to 8, at n = 20 up to 7): seeds x slices <= 512 qa, with a state
+        // regulariser min(4096, 768 qa)
         const int qa = (n + 3) / 4 < 5 ? 5 : (n + 3) / 4;
         const long long lat_limit = n <= 16 ? (lat_src ? QOC_PLAN_LAT_WORK_SRC : QOC_PLAN_LAT_WORK)
-                                            : (lat_src ? std::min<long long>(QOC_PLAN_LAT_WORK_SRC, (long long)QOC_PLAN_LAT_WORK_PER_STRIP_SRC * qa)
+                                            : (lat_src ? std::min<long long>(QOC_PLAN_LAT_WORK_SRC,
+                                                (long long)QOC_PLAN_LAT_WORK_PER_STRIP_SRC * qa)
                                                        : (long long)QOC_PLAN_LAT_WORK_PER_STRIP * qa);
-        // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8; NT = 3: the competitors are
-        // slower (tools/mid_n_sweep.py); state transfer from 25 levels on: 5 .. 8 control sets go to the GEMM route -- n = 32 x 8: 0.220 against 0.261 ms, with
-        // forbidden levels 0.272 / 0.316
-        const int lat_sets = n > 16 ? ((st && qa_g >= 7) ? QOC_PLAN_LAT_SETS_N32_ST_WIDE : QOC_PLAN_LAT_SETS_N32) : (st ? QOC_PLAN_LAT_SETS_N16_ST : QOC_PLAN_LAT_SETS_N16);
-        const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_auto && qoc_mfma_latency_ok(d) && steps >= QOC_PLAN_LAT_MIN_SLICES &&
+        // NT = 4 (also 32 < n <= 48 with k > 4, padded): 0.268 against 0.458 ms (GEMM route) for one seed of 500 slices, level at 8; NT =
+        // 3: the competitors are slower (tools/mid_n_sweep.py); state transfer from 25 levels on: 5 .. 8 control sets go to the GEMM route
+        // -- n = 32 x 8: 0.220 against 0.261 ms, with forbidden levels 0.272 / 0.316
+        const int lat_sets = n > 16 ? ((st && qa_g >= 7) ? QOC_PLAN_LAT_SETS_N32_ST_WIDE : QOC_PLAN_LAT_SETS_N32) : (st
+            ? QOC_PLAN_LAT_SETS_N16_ST : QOC_PLAN_LAT_SETS_N16);
+        const bool latency = cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && mfma_auto && qoc_mfma_latency_ok(d)
+            && steps >= QOC_PLAN_LAT_MIN_SLICES &&
                               (((n > 48 || (n > 32 && k > 4)) ? (lat_work <= QOC_PLAN_LAT_WORK_NT4 && Bp <= QOC_PLAN_LAT_SETS_NT4)
                                 : n > 32 ? (lat_work <= QOC_PLAN_LAT_WORK_NT3 && Bp <= QOC_PLAN_LAT_SETS_NT3)
                                          : (lat_work <= lat_limit && Bp <= lat_sets)) ||
@@ -589,47 +621,58 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         p.latency = latency;
         p.gemm_direct = direct_ok && (!antiherm || cfg->chunks == 1 || (cfg->chunks == 0 && Bp >= ST_DIRECT_FROM));
         p.path = cfg->path != QOC_PATH_AUTO ? cfg->path
-                 : latency ? QOC_PATH_MFMA : (mfma_auto && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
+                 : latency ? QOC_PATH_MFMA : (mfma_auto
+                     && !prefer_gemm) ? QOC_PATH_MFMA : (gemm_ok ? QOC_PATH_GEMM : (st_ok ? QOC_PATH_ST_FUSED : QOC_PATH_GENERIC));
         return p;
     };
     const AutoPlan plan = plan_for(d.Bplan);
     const bool latency_auto = plan.latency, gemm_direct = plan.gemm_direct;
     path = plan.path;
     if (d.Bplan < B) {
-        // a plan for FEWER control sets than the engine holds is legal (a rank that holds several shards of a planned batch keeps bit-identity
-        // with them) but can cost a factor: say so once when it changes what AUTO would have picked for the resident batch
+        // a plan for FEWER control sets than the engine holds is legal (a rank that holds several shards of a planned batch keeps
+        // bit-identity with them) but can cost a factor: say so once when it changes what AUTO would have picked for the resident batch
         const AutoPlan own = plan_for(B);
         if (own.path != plan.path || own.latency != plan.latency || own.gemm_direct != plan.gemm_direct)
-            fprintf(stderr, "libqoc_hip: note: plan_seeds = %d < n_seeds = %d changes the AUTO plan (path %d%s instead of %d%s): kernels tuned for the smaller batch run on the larger one\n",
+            fprintf(stderr, "libqoc_hip: note: plan_seeds = %d < n_seeds = %d changes the AUTO plan (path %d%s instead of %d%s): kernels "
+                "tuned for the smaller batch run on the larger one\n",
                     d.Bplan, B, plan.path, plan.latency ? " latency mode" : "", own.path, own.latency ? " latency mode" : "");
     }
     if (cfg->time_shards >= 1) {
-        if (cfg->time_rank < -1 || cfg->time_rank >= cfg->time_shards) return bail(fail(QOC_ERR_INVALID, "qoc_create: time_rank %d of %d time shards", cfg->time_rank, cfg->time_shards));
-        if (cfg->path != QOC_PATH_AUTO && cfg->path != QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: time sharding runs on the GEMM path"));
+        if (cfg->time_rank < -1 || cfg->time_rank >= cfg->time_shards) return bail(fail(QOC_ERR_INVALID,
+            "qoc_create: time_rank %d of %d time shards", cfg->time_rank, cfg->time_shards));
+        if (cfg->path != QOC_PATH_AUTO && cfg->path != QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID,
+            "qoc_create: time sharding runs on the GEMM path"));
         path = QOC_PATH_GEMM;
     }
     if (path == QOC_PATH_MFMA && !mfma_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs n <= 64, m <= 16, k <= 8, a Taylor degree of 1 .. 22 and, in state transfer, exactly anti-Hermitian generators (n=%d m=%d k=%d T=%d)", n, m, k, d.T));
+        return bail(fail(QOC_ERR_INVALID, "qoc_create: MFMA path needs n <= 64, m <= 16, k <= 8, a Taylor degree of 1 .. 22 and, in state "
+            "transfer, exactly anti-Hermitian generators (n=%d m=%d k=%d T=%d)", n, m, k, d.T));
     if (path == QOC_PATH_ST_FUSED && !st_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
+        return bail(fail(QOC_ERR_INVALID,
+            "qoc_create: fused state-transfer path needs state_transfer, n <= 64, m <= 4, k <= 8 (n=%d m=%d k=%d)", n, m, k));
     if (path == QOC_PATH_GEMM && !gemm_ok)
-        return bail(fail(QOC_ERR_INVALID, "qoc_create: GEMM path needs m <= 32 and, in state transfer, exactly anti-Hermitian generators or n <= 64, m <= 8 (m=%d)", m));
+        return bail(fail(QOC_ERR_INVALID,
+            "qoc_create: GEMM path needs m <= 32 and, in state transfer, exactly anti-Hermitian generators or n <= 64, m <= 8 (m=%d)", m));
     if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
 #ifdef QOC_DEBUG     // timing experiments only (tools/skip_timing.py builds its own library with -DQOC_DEBUG): never in the product library
-    if (const char* sk = getenv("QOC_DEBUG_SKIP")) {                          // wall-clock attribution of one kernel group (results are garbage)
+    // wall-clock attribution of one kernel group (results are garbage)
+    if (const char* sk = getenv("QOC_DEBUG_SKIP")) {
         e->skip_mask = atoi(sk);
-        if (e->skip_mask) fprintf(stderr, "libqoc_hip: WARNING: QOC_DEBUG_SKIP=%d is set -- kernel groups are skipped or repeated, every result of this engine is garbage (timing experiments only)\n", e->skip_mask);
+        if (e->skip_mask) fprintf(stderr, "libqoc_hip: WARNING: QOC_DEBUG_SKIP=%d is set -- kernel groups are skipped or repeated, every "
+            "result of this engine is garbage (timing experiments only)\n", e->skip_mask);
     }
 #endif
     if (path == QOC_PATH_MFMA) {
         std::string msg;
         e->mf.variant = latency_auto ? 5 : cfg->variant;
         if (cfg->variant == 5 && !qoc_mfma_latency_ok(d))
-            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs n <= 32 with k <= 8 (or, with at most 4 dressed forbidden levels, n <= 64), "
+            return bail(fail(QOC_ERR_INVALID, "qoc_create: the latency mode of the MFMA path (variant 5) needs n <= 32 with k <= 8 (or, "
+                "with at most 4 dressed forbidden levels, n <= 64), "
                                               "a Taylor degree >= 2 (n=%d k=%d T=%d)", n, k, d.T));
-        d.T = qoc_mfma_degree(d);                    // state transfer: sum_{j < T} A^j / j! is the polynomial of degree T - 1 (no squarings: d.s = 0)
+        // state transfer: sum_{j < T} A^j / j! is the polynomial of degree T - 1 (no squarings: d.s = 0)
+        d.T = qoc_mfma_degree(d);
         rc = qoc_mfma_setup(e->mf, d, cfg->chunks, (const cplx*)Hs, e->allocs, msg);
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         e->chunks = e->mf.C;
@@ -645,7 +688,8 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         if (e->gm.ts_G > 0) {
             std::string why;
             if (!qoc_gemm_ts_supported(e->gm, d, e->gm.ts_G, why))
-                return bail(fail(QOC_ERR_INVALID, "qoc_create: time_shards = %d needs %s (n=%d m=%d chunks=%d)", e->gm.ts_G, why.c_str(), n, m, e->gm.NC));
+                return bail(fail(QOC_ERR_INVALID, "qoc_create: time_shards = %d needs %s (n=%d m=%d chunks=%d)", e->gm.ts_G, why.c_str(), n,
+                    m, e->gm.NC));
             qoc_gemm_ts_ranges(e->gm, e->gm.ts_G);
         }
     } else if (!cfg->state_transfer) {
@@ -836,7 +880,8 @@ int qoc_get_final_unitary(qoc_handle e, double* Uf) {
 int qoc_get_inter_vecs(qoc_handle e, double* inter) {
     CHECK_H(e);
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_inter_vecs: nothing evaluated yet");
-    if (e->path == QOC_PATH_GEMM) TRY(qoc_gemm_ts_gather_inter(e->gm, e->d, e->stream));   // one rank of a time-sharded run: its own slices, summed over the ranks (a collective)
+    // one rank of a time-sharded run: its own slices, summed over the ranks (a collective)
+    if (e->path == QOC_PATH_GEMM) TRY(qoc_gemm_ts_gather_inter(e->gm, e->d, e->stream));
     if (e->inter_stale) {                                            // latency mode: the sweeps keep Psi_t in their own layout
         qoc_mfma_unpack_inter(e->mf, e->d, e->stream);
         HIP_TRY(hipGetLastError());
@@ -861,8 +906,14 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     TRY(prof_collect(e));
     if (kernel_name)
         *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.direct ? "k_gemm_taylor_chain (backward chain + sources + gradient products)"
-                                                 : e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm_wg + k_zgemm32 (batched matexp sequence)")
-                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows" : qoc_mfma_expm_variant(e->mf, e->d) == 6 ? "k_mfma_expm_pair" : qoc_mfma_expm_variant(e->mf, e->d) == 5 ? (e->mf.NT == 3 ? "k_mfma_expm_rows (per slice) + k_mfma_chain_rows" : "k_mfma_expm_slice2 + k_mfma_chain_rows") : qoc_mfma_expm_variant(e->mf, e->d) == 8 ? "k_mfma_expm_inplace" : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3 ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
+                                                 : e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm_wg + k_zgemm32 (batched "
+                                                     "matexp sequence)")
+                       : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows"
+                           : qoc_mfma_expm_variant(e->mf, e->d) == 6 ? "k_mfma_expm_pair" : qoc_mfma_expm_variant(e->mf, e->d) == 5
+                           ? (e->mf.NT == 3 ? "k_mfma_expm_rows (per slice) + k_mfma_chain_rows" : "k_mfma_expm_slice2 + "
+                           "k_mfma_chain_rows") : qoc_mfma_expm_variant(e->mf, e->d) == 8 ? "k_mfma_expm_inplace"
+                           : qoc_mfma_expm_variant(e->mf, e->d) == 4 ? "k_mfma_expm_chunk4s" : qoc_mfma_expm_variant(e->mf, e->d) == 3
+                           ? "k_mfma_expm_chunk4w" : qoc_mfma_expm_variant(e->mf, e->d) == 2 ? "k_mfma_expm_chunk4" : "k_mfma_expm_chunk")
                        : (e->path == QOC_PATH_ST_FUSED ? "k_st_fwd_fused" : (e->d.state_transfer ? "k_st_fwd_generic" : "k_expm_generic"));
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;
@@ -886,7 +937,8 @@ int qoc_path_in_use(qoc_handle e) { return e ? e->path : QOC_ERR_INVALID; }
 int qoc_chunks_in_use(qoc_handle e) { return e ? e->chunks : QOC_ERR_INVALID; }
 
 // What AUTO resolved to, as one line of key=value pairs (tests/test_auto_plan.py pins the dispatch table of DESIGN.md section 4 with it):
-//   MFMA path:  path=mfma nt=<tiles> expm=<exponential kernel 1..8> chunks=<C> sweeps=<downup|split|row_tile_gradient|latency|latency_sources|one_wave>
+// MFMA path:  path=mfma nt=<tiles> expm=<exponential kernel 1..8> chunks=<C>
+// sweeps=<downup|split|row_tile_gradient|latency|latency_sources|one_wave>
 //   GEMM path:  path=gemm route=<unitary|propagator|direct> chunks=<NC> slices_per_chunk=<S> chains=<persistent|launches>
 //   others:     path=generic | path=st_fused
 int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
@@ -896,15 +948,19 @@ int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
         const QocMfma& mf = e->mf;
         const bool split = (mf.NT > 2 || (mf.NT == 2 && e->d.k >= 6)) && mf.variant != 1;
         const char* sweeps = mf.latency ? (mf.lat_sources ? "latency_sources" : "latency")
-                             : mf.updown ? "downup" : (split ? (mf.grad_rt ? "row_tile_gradient" : "split") : (mf.variant == 1 || mf.NT == 1 || mf.NT == 4 ? "one_wave" : "pair"));
+                             : mf.updown ? "downup" : (split ? (mf.grad_rt ? "row_tile_gradient" : "split") : (mf.variant == 1
+                                 || mf.NT == 1 || mf.NT == 4 ? "one_wave" : "pair"));
         snprintf(tmp, sizeof tmp, "path=mfma nt=%d expm=%d chunks=%d sweeps=%s", mf.NT, qoc_mfma_expm_variant(mf, e->d), mf.C, sweeps);
     } else if (e->path == QOC_PATH_GEMM) {
         const QocGemm& g = e->gm;
-        int w = snprintf(tmp, sizeof tmp, "path=gemm route=%s chunks=%d slices_per_chunk=%d chains=%s", g.direct ? "direct" : (e->d.state_transfer ? "propagator" : "unitary"),
+        int w = snprintf(tmp, sizeof tmp, "path=gemm route=%s chunks=%d slices_per_chunk=%d chains=%s",
+            g.direct ? "direct" : (e->d.state_transfer ? "propagator" : "unitary"),
                          g.NC, g.S, g.persistent ? "persistent" : "launches");
         if (g.ts_G > 0) snprintf(tmp + w, sizeof tmp - w, " time_shards=%d time_rank=%d", g.ts_G, g.ts_rank);
-        // the kernel of the direct route's Taylor chains: squared (k_gemm_taylor_chain_sq on [B | B^2]), packed / full (k_gemm_taylor_chain_dpp), butterfly (k_gemm_taylor_chain)
-        if (g.direct) snprintf(tmp + w, sizeof tmp - w, " taylor_chain=%s", g.sq_chain ? "squared" : g.dpp_packed ? "packed" : g.dpp_chain ? "full" : "butterfly");
+        // the kernel of the direct route's Taylor chains: squared (k_gemm_taylor_chain_sq on [B | B^2]), packed / full
+        // (k_gemm_taylor_chain_dpp), butterfly (k_gemm_taylor_chain)
+        if (g.direct) snprintf(tmp + w, sizeof tmp - w, " taylor_chain=%s",
+            g.sq_chain ? "squared" : g.dpp_packed ? "packed" : g.dpp_chain ? "full" : "butterfly");
     } else {
         snprintf(tmp, sizeof tmp, "path=%s", e->path == QOC_PATH_ST_FUSED ? "st_fused" : "generic");
     }

@@ -21,8 +21,10 @@
 
 // A_t = (H0' + sum_k u_k H_k') / 2^s for every (seed, slice), padded N x N           tensorflow_state.py:30-33
 // Slices are padded to SP = NC*S per seed; a padded slice gets A = 0, i.e. K = I exactly.
-// (item_first, item_count): the (seed, slice) items this launch assembles -- all of them, or the slices of one rank of a time-sharded engine
-__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq,
+// (item_first, item_count): the (seed, slice) items this launch assembles -- all of them, or the slices of one rank of a time-sharded
+// engine
+__global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP,
+    int sq,
                                                         size_t item_first, size_t item_count, int nn = 0) {
     const size_t NN = nn > 0 ? (size_t)nn : (size_t)N * N;         // (nn: entries per matrix of a packed stack, as in k_gemm_assemble_rows)
     const size_t total = item_count * NN;
@@ -47,8 +49,10 @@ __global__ void __launch_bounds__(256) k_gemm_assemble(QocDev d, const cplx* __r
 // 256): k_gemm_assemble re-reads them from L2 for every output entry -- (k + 1) x the written bytes through L2, 2.0 ms for the 4.2 GB of
 // C3 x 64 -- this one is bound by the HBM writes alone.  blockIdx.x = 256-entry column of the matrix, blockIdx.y = run of items.
 // (t0, tn): with tn > 0 the items are the slices t0 .. t0 + tn - 1 of EVERY seed (item = b * tn + t - t0), written to their usual place
-// nn > 0: entries per matrix of the stack and of the output when that is not N * N (the packed anti-Hermitian image of qoc_gemm_chain_dpp.h: 2560)
-__global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP, int sq, int per,
+// nn > 0: entries per matrix of the stack and of the output when that is not N * N (the packed anti-Hermitian image of
+// qoc_gemm_chain_dpp.h: 2560)
+__global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx* __restrict__ HsP, cplx* __restrict__ Aout, int N, int SP,
+    int sq, int per,
                                                              size_t item_first, size_t item_count, int t0 = 0, int tn = 0, int nn = 0) {
     const size_t NN = nn > 0 ? (size_t)nn : (size_t)N * N;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -68,13 +72,15 @@ __global__ void __launch_bounds__(256) k_gemm_assemble_rows(QocDev d, const cplx
             const double* ub = d.u + (size_t)b * d.k * d.steps + t;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
-                if (kk < d.k) { const double c = ub[(size_t)kk * d.steps]; acc.x = fma(c, h[kk + 1].x, acc.x); acc.y = fma(c, h[kk + 1].y, acc.y); }
+                if (kk < d.k) { const double c = ub[(size_t)kk * d.steps]; acc.x = fma(c, h[kk + 1].x, acc.x); acc.y = fma(c, h[kk + 1].y,
+                    acc.y); }
         }
         Aout[((size_t)b * SP + t) * NN + e] = acc;
     }
 }
-// ---- squared-generator chain (qoc_gemm_chain_sq.h): B_t and B_t^2 of every (seed, slice), both in the packed anti-Hermitian / Hermitian image ----
-// coefficient row of item (b, t): [1, u_1 .. u_k, u_kk u_ll for kk <= ll (kk-major)] -- P = (k + 1)(k + 2) / 2 doubles, read as scalars by the assembly
+// ---- squared-generator chain (qoc_gemm_chain_sq.h): B_t and B_t^2 of every (seed, slice), both in the packed anti-Hermitian / Hermitian
+// image ---- coefficient row of item (b, t): [1, u_1 .. u_k, u_kk u_ll for kk <= ll (kk-major)] -- P = (k + 1)(k + 2) / 2 doubles, read as
+// scalars by the assembly
 __global__ void __launch_bounds__(256) k_gemm_sq_coefs(QocDev d, double* __restrict__ coef, int SP, int P) {
     const size_t total = (size_t)d.B * d.steps;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
@@ -90,10 +96,11 @@ __global__ void __launch_bounds__(256) k_gemm_sq_coefs(QocDev d, double* __restr
             for (int ll = kk; ll < d.k; ++ll) c[p++] = u[kk] * u[ll];
     }
 }
-// B_t = h_0 + sum_k u_k h_k and B_t^2 = sum_p c_p q_p for the packed entry e of a thread (its k + 1 + P basis entries in registers over a run of items),
-// written as [B | B^2] (2 x 2560 entries per item).  KK = number of controls.  (t0, tn) as in k_gemm_assemble_rows.
+// B_t = h_0 + sum_k u_k h_k and B_t^2 = sum_p c_p q_p for the packed entry e of a thread (its k + 1 + P basis entries in registers over a
+// run of items), written as [B | B^2] (2 x 2560 entries per item).  KK = number of controls.  (t0, tn) as in k_gemm_assemble_rows.
 template <int KK>
-__global__ void __launch_bounds__(256) k_gemm_assemble_sq(QocDev d, const cplx* __restrict__ HsPK, const cplx* __restrict__ HsSQ, const double* __restrict__ coef,
+__global__ void __launch_bounds__(256) k_gemm_assemble_sq(QocDev d, const cplx* __restrict__ HsPK, const cplx* __restrict__ HsSQ,
+    const double* __restrict__ coef,
                                                            cplx* __restrict__ Aout, int SP, int per, size_t item_count, int t0, int tn) {
     constexpr int P = (KK + 1) * (KK + 2) / 2, GE = QOC_DPP_PK_ELEMS;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -157,7 +164,8 @@ __global__ void __launch_bounds__(256) k_gemm_chain_init(QocDev d, cplx* __restr
 // chunk-start vectors Psibnd[b][c], c = 1 .. NC-1, from the thin blocks (columns N..N+31) of the per-step results: Ys holds one
 // [B][N][ld] result per chunk step (slot c = the vectors at the START of chunk c), so the per-step products of N > 64 need no copy
 // launch between them (31 launches of ~8 us with their gaps per iteration at n = 128)
-__global__ void __launch_bounds__(256) k_gemm_take_bnd_all(QocDev d, const cplx* __restrict__ Ys, cplx* __restrict__ Psibnd, int N, int NC, int xw) {
+__global__ void __launch_bounds__(256) k_gemm_take_bnd_all(QocDev d, const cplx* __restrict__ Ys, cplx* __restrict__ Psibnd, int N, int NC,
+    int xw) {
     const int ld = xw + QOC_TW;
     const size_t per = (size_t)N * QOC_TW, slot = (size_t)d.B * N * ld;
     const size_t total = (size_t)d.B * (NC - 1) * per;
@@ -203,9 +211,10 @@ __global__ void __launch_bounds__(1024) k_gemm_take_final(QocDev d, const cplx* 
 // last chunk Ebnd[b][NC-1]: -(2/m^2) z W, plus S_steps when there is no padded slice to add it through the recursion
 // `cols` = columns written per row: QOC_TW, or the MV vector slots in the direct route, whose Taylor chains read nothing else of a thin
 // panel (C3 x 64: 2.1 GB of zero columns, 0.34 ms per iteration, no longer written)
-// `compact` (DPP chain, one vector): SrcP[b][tau][row] contiguous -- a thin panel puts the rows of ONE column 512 bytes apart, every 16-byte store its own
-// memory transaction (C3 x 64: 0.11 ms for 4 M entries)
-__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ Ebnd, int N, int SP, int NC, int cols, int compact = 0) {
+// `compact` (DPP chain, one vector): SrcP[b][tau][row] contiguous -- a thin panel puts the rows of ONE column 512 bytes apart, every
+// 16-byte store its own memory transaction (C3 x 64: 0.11 ms for 4 M entries)
+__global__ void __launch_bounds__(256) k_gemm_sources(QocDev d, cplx* __restrict__ SrcP, cplx* __restrict__ Ebnd, int N, int SP, int NC,
+    int cols, int compact = 0) {
     const size_t per = (size_t)N * QOC_TW, perw = (size_t)N * cols;
     const bool need_src = d.n_forb > 0 || d.has_speed;
     const size_t total = (size_t)d.B * (need_src ? SP : 1) * perw;
@@ -254,7 +263,8 @@ __global__ void __launch_bounds__(256) k_gemm_scale_lam(QocDev d, cplx* __restri
     }
 }
 // LamP[b][(c+1)S-1] = (Ebnd ? Ebnd[b][c] : 0): costate at the end of every chunk
-__global__ void __launch_bounds__(256) k_gemm_set_chunk_ends(QocDev d, cplx* __restrict__ LamP, const cplx* __restrict__ Ebnd, int N, int S, int NC) {
+__global__ void __launch_bounds__(256) k_gemm_set_chunk_ends(QocDev d, cplx* __restrict__ LamP, const cplx* __restrict__ Ebnd, int N, int S,
+    int NC) {
     const size_t per = (size_t)N * QOC_TW;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < (size_t)d.B * NC * per; o += (size_t)gridDim.x * blockDim.x) {
         const size_t bc = o / per, e = o - bc * per;
@@ -262,7 +272,8 @@ __global__ void __launch_bounds__(256) k_gemm_set_chunk_ends(QocDev d, cplx* __r
     }
 }
 // dst[b] = src[b] for B matrices of NN elements (odd element of a product-tree level moves up unchanged)
-__global__ void __launch_bounds__(256) k_gemm_copy_mats(cplx* __restrict__ dst, long long sD, const cplx* __restrict__ src, long long sS, int B, int NN) {
+__global__ void __launch_bounds__(256) k_gemm_copy_mats(cplx* __restrict__ dst, long long sD, const cplx* __restrict__ src, long long sS,
+    int B, int NN) {
     const size_t total = (size_t)B * NN;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         const size_t bb = o / NN, e = o - bb * NN;
@@ -308,10 +319,10 @@ __global__ void __launch_bounds__(256) k_gemm_grad_reduce(QocDev d, const double
 }
 
 // ---- gradients of large problems (N > 64, m <= 8) as ONE wide product per seed ----------------------------------------------------------
-// The per-slice thin tiles [t][N][32] of Psi_t / Lambda_t carry m <= 8 useful columns of 32: k batched launches of 2000 padded thin products
-// with a dot epilogue ran at ~21 TFLOP/s of mostly padding (C5: 12.7 ms of 215).  Re-packed time-major -- wide[row][t * 8 + col], the layout
-// the persistent chains of N <= 64 write directly -- the products of ALL controls are one batched N x N x (8 steps) GEMM on k_zgemm_wg, and
-// dL/du_{k,t} = Re sum conj(Lambda_t) (H_k' Psi_t) (tensorflow_state.py:61-63) is a column-block dot of its result.
+// The per-slice thin tiles [t][N][32] of Psi_t / Lambda_t carry m <= 8 useful columns of 32: k batched launches of 2000 padded thin
+// products with a dot epilogue ran at ~21 TFLOP/s of mostly padding (C5: 12.7 ms of 215).  Re-packed time-major -- wide[row][t * 8 + col],
+// the layout the persistent chains of N <= 64 write directly -- the products of ALL controls are one batched N x N x (8 steps) GEMM on
+// k_zgemm_wg, and dL/du_{k,t} = Re sum conj(Lambda_t) (H_k' Psi_t) (tensorflow_state.py:61-63) is a column-block dot of its result.
 #define QOC_WIDE_MV 8
 __global__ void __launch_bounds__(256) k_gemm_to_wide(QocDev d, const cplx* __restrict__ thinP, const cplx* __restrict__ thinL,
                                                       cplx* __restrict__ wideP, cplx* __restrict__ wideL, int N, int W, int count) {
@@ -327,7 +338,8 @@ __global__ void __launch_bounds__(256) k_gemm_to_wide(QocDev d, const cplx* __re
 }
 // one wave per (control, slice): rows lane, lane + 64, ...; the 8 columns of a slice are one 128-byte line of a row
 // (column block ti of the wide buffers is slice t_first + ti: the whole pulse, or the slices of one rank of a time-sharded engine)
-__global__ void __launch_bounds__(256) k_gemm_dot_wide(QocDev d, int b, const cplx* __restrict__ wideC, const cplx* __restrict__ wideL, int N, int W,
+__global__ void __launch_bounds__(256) k_gemm_dot_wide(QocDev d, int b, const cplx* __restrict__ wideC, const cplx* __restrict__ wideL,
+    int N, int W,
                                                        int t_first, int count) {
     const int lane = threadIdx.x & 63;
     const size_t item = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -364,27 +376,36 @@ __global__ void __launch_bounds__(256) k_gemm_pad_identity(cplx* __restrict__ K,
 struct QocGemm {
     int N = 0, S = 1, L = 0, NC = 1, SP = 1;
     int MV = 0, ldW = 0;      // persistent mode: vector slots (1/2/4/8) and row stride of the time-major wide buffers
-    double plan_scale = 1.0;  // planned / local batch (QocDev::Bplan / B): split-K factors and kernel families are chosen for the planned batch
+    // planned / local batch (QocDev::Bplan / B): split-K factors and kernel families are chosen for the planned batch
+    double plan_scale = 1.0;
     bool direct = false;      // state transfer as Taylor mat-vec chains on the assembled generators (one chunk, no propagators)
     bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
     cplx* HsP = nullptr;      // [k+1][N][N]
     cplx* HsPT = nullptr;     // dpp_chain: the same stack transposed -- k_gemm_assemble_rows then writes the generators column-major
-    // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled on a
-    // second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its state
-    hipStream_t aux = nullptr, chain_s = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_fwd = nullptr, ev_p1 = nullptr; int asm_split = 0, asm_tail_wgs = 512;
-    // (round 5) the pulse is cut into asm_win.size() - 1 windows [asm_win[w], asm_win[w + 1]): window 0 is assembled in front of the chain, window w >= 1 on
-    // the second stream while the chain walks window w - 1 (one chain launch per window, each continuing from the state the previous one left in Aoff)
+    // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled
+    // on a second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its
+    // state
+    hipStream_t aux = nullptr, chain_s = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_fwd = nullptr, ev_p1 = nullptr;
+        int asm_split = 0, asm_tail_wgs = 512;
+    // (round 5) the pulse is cut into asm_win.size() - 1 windows [asm_win[w], asm_win[w + 1]): window 0 is assembled in front of the chain,
+    // window w >= 1 on the second stream while the chain walks window w - 1 (one chain launch per window, each continuing from the state
+    // the previous one left in Aoff)
     std::vector<int> asm_win; std::vector<hipEvent_t> ev_win;
     bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
     bool antiherm = false;    // every generator anti-Hermitian (set by the engine before qoc_gemm_setup)
-    bool dpp_packed = false;  // dpp_chain on anti-Hermitian generators: only the blocks on and below the block diagonal are assembled, stored and read
-    // dpp_packed, few enough control sets for the chains to be latency-bound: [B | B^2] per slice and k_gemm_taylor_chain_sq (qoc_gemm_chain_sq.h)
+    // dpp_chain on anti-Hermitian generators: only the blocks on and below the block diagonal are assembled, stored and read
+    bool dpp_packed = false;
+    // dpp_packed, few enough control sets for the chains to be latency-bound: [B | B^2] per slice and k_gemm_taylor_chain_sq
+    // (qoc_gemm_chain_sq.h)
     bool sq_chain = false;
-    int direct_variant = 0;   // qoc_config.variant of an explicit GEMM-path request: 1 = never the squared-generator chain, 2 = always where it applies
+    // qoc_config.variant of an explicit GEMM-path request: 1 = never the squared-generator chain, 2 = always where it applies
+    int direct_variant = 0;
     cplx* HsSQ = nullptr;     // sq_chain: the (k + 1)(k + 2) / 2 packed basis matrices of B^2
     double* sqc = nullptr;    // sq_chain: [B][SP][P] coefficient rows (k_gemm_sq_coefs)
-    int dpp_mode() const { return dpp_chain ? (sq_chain ? 3 : (dpp_packed ? 2 : 1)) : 0; }                   // what qoc_taylor_chain_launch takes
-    size_t gen_elems() const { return sq_chain ? (size_t)2 * QOC_DPP_PK_ELEMS : (dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : (size_t)N * N); }   // entries of one slice
+    // what qoc_taylor_chain_launch takes
+    int dpp_mode() const { return dpp_chain ? (sq_chain ? 3 : (dpp_packed ? 2 : 1)) : 0; }
+    // entries of one slice
+    size_t gen_elems() const { return sq_chain ? (size_t)2 * QOC_DPP_PK_ELEMS : (dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : (size_t)N * N); }
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
     size_t tree_off[8];
@@ -399,13 +420,15 @@ struct QocGemm {
     cplx* zthin = nullptr;    // [N][32] zeros
     cplx *Psibnd = nullptr, *Ebnd = nullptr, *Aoff = nullptr;        // [B][NC][N][32] chunk-start Psi, chunk-end Lambda, affine offsets
     double* partial = nullptr; // [B*steps][k][N/32]
-    int wideW = 0;            // > 0: gradients of an N > 64 problem through ONE wide product per seed (k_gemm_to_wide, k_zgemm_wg, k_gemm_dot_wide)
+    // > 0: gradients of an N > 64 problem through ONE wide product per seed (k_gemm_to_wide, k_zgemm_wg, k_gemm_dot_wide)
+    int wideW = 0;
     cplx *wideP = nullptr, *wideL = nullptr, *wideC = nullptr;   // [N][wideW], [N][wideW], [k][N][wideW]
     // time-axis sharding of one trajectory (qoc_gemm_ts.h): G ranks own runs of chunks; ts_rank < 0 emulates all of them in this engine
     int ts_G = 0, ts_rank = -1;
     std::vector<int> ts_cb;                                       // chunk boundaries: rank r owns [ts_cb[r], ts_cb[r + 1])
     cplx *ts_Rall = nullptr, *ts_Rtmp = nullptr;                  // [G][N][N] rank products (all-gathered in place), [2][N][N]
-    cplx *ts_Yr = nullptr, *ts_Er = nullptr;                      // [G + 1][N][N + 32]: [X | Psi] at the rank boundaries; [G + 1][N][32]: costates there
+    // [G + 1][N][N + 32]: [X | Psi] at the rank boundaries; [G + 1][N][32]: costates there
+    cplx *ts_Yr = nullptr, *ts_Er = nullptr;
     struct qoc_comm* ts_comm = nullptr;
 };
 
@@ -415,7 +438,8 @@ struct QocGemm {
 // Any state-transfer problem with n <= 64, m <= 8 can instead run "direct" (k_gemm_taylor_chain: the reference's own
 // mat-vec recursion, forward and backward, on pre-assembled generators; no time parallelism, so it is the large-batch mode).
 static inline bool qoc_gemm_direct_supported(const QocDev& d) { return d.state_transfer && d.n <= 64 && d.m <= 8 && d.T >= 1; }
-// the polynomial coefficient tables (ExpmCoef, invf[]) hold 1/j! for j < QOC_GEMM_MAXT (the MFMA path stops at T = 22: this path takes over)
+// the polynomial coefficient tables (ExpmCoef, invf[]) hold 1/j! for j < QOC_GEMM_MAXT (the MFMA path stops at T = 22: this path takes
+// over)
 static inline bool qoc_gemm_supported(const QocDev& d, bool antiherm) {
     return d.m <= QOC_TW && d.T >= 1 && d.T <= QOC_GEMM_MAXT - 1 && (!d.state_transfer || antiherm || qoc_gemm_direct_supported(d));
 }
@@ -429,7 +453,8 @@ static inline bool qoc_all_antihermitian(const cplx* Hs, int n, int count) {
     return true;
 }
 
-static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, bool direct, std::vector<void*>& allocs, std::string& msg) {
+static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_host, bool direct, std::vector<void*>& allocs,
+    std::string& msg) {
     const int N = ((d.n + 31) / 32) * 32;
     gm.N = N;
     gm.plan_scale = (double)d.Bplan / (double)d.B;
@@ -440,8 +465,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         const char* e = qoc_exp_env("QOC_CHAIN_DPP");            // experimental switch: 0 = the butterfly kernel k_gemm_taylor_chain
         gm.dpp_chain = gm.direct && N == 64 && gm.MV == 1 && !(e && e[0] == '0');
         gm.dpp_packed = gm.dpp_chain && gm.antiherm;
-        // opt-in only (qoc_config.variant = 2 with path = GEMM): measured SLOWER than the plain chain at C3 x 64 (7.98 against 5.83 ms per iteration) --
-        // see the header of qoc_gemm_chain_sq.h and profiles/EXPERIMENTS.md
+        // opt-in only (qoc_config.variant = 2 with path = GEMM): measured SLOWER than the plain chain at C3 x 64 (7.98 against 5.83 ms per
+        // iteration) -- see the header of qoc_gemm_chain_sq.h and profiles/EXPERIMENTS.md
         gm.sq_chain = gm.dpp_packed && qoc_sq_chain_terms_ok(d.T) && d.k >= 1 && d.k <= 8 && gm.direct_variant == 2;
     }
     int L = 0;
@@ -463,7 +488,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     // every work buffer is carved out of ONE allocation: with one hipMalloc per buffer the placement after earlier engines of the
     // same process were freed decided the speed (n = 128 x 4: 8.6 or 17-20 ms per iteration for the same problem)
     std::vector<std::pair<void**, size_t>> wanted;
-    auto al = [&](void** dst, size_t bytes) -> bool { wanted.emplace_back(dst, ((bytes ? bytes : 16) + 4095) & ~(size_t)4095); return true; };
+    auto al = [&](void** dst, size_t bytes) -> bool { wanted.emplace_back(dst,
+        ((bytes ? bytes : 16) + 4095) & ~(size_t)4095); return true; };
     const bool need_src = d.n_forb > 0 || d.has_speed;
     size_t tree_elems = 0;
     for (int l = 1; l <= L; ++l) { gm.tree_off[l] = tree_elems; tree_elems += (size_t)d.B * (gm.SP >> l) * NN; }
@@ -471,7 +497,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
     size_t root_elems = 0;
     for (int cnt = gm.NC; cnt > 1; cnt = (cnt + 1) / 2) root_elems += (size_t)d.B * ((cnt + 1) / 2) * NN;
     const bool poly = !fused && !gm.direct;                      // launch-per-product route: A2 and ping-pong buffers
-    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.HsPT, gm.dpp_chain ? hp.size() * sizeof(cplx) : 16) && (fused || al((void**)&gm.A, BSP * (gm.direct ? gm.gen_elems() : NN) * sizeof(cplx))) &&
+    bool ok = al((void**)&gm.HsP, hp.size() * sizeof(cplx)) && al((void**)&gm.HsPT, gm.dpp_chain ? hp.size() * sizeof(cplx) : 16) && (fused
+        || al((void**)&gm.A, BSP * (gm.direct ? gm.gen_elems() : NN) * sizeof(cplx))) &&
               (!poly || al((void**)&gm.P, BSP * NN * sizeof(cplx))) && (!poly || al((void**)&gm.A2, BSP * NN * sizeof(cplx))) &&
               al((void**)&gm.root, (gm.persistent && !d.state_transfer) ? root_elems * sizeof(cplx) : 16) &&
               al((void**)&gm.K, gm.direct ? 16 : BSP * NN * sizeof(cplx)) && al((void**)&gm.tree, tree_elems * sizeof(cplx)) &&
@@ -488,15 +515,18 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
               al((void**)&gm.partial, (size_t)d.B * d.k * (N / 32) * (gm.persistent ? (size_t)gm.ldW : (size_t)d.steps) * sizeof(double));
     if (ok && need_src) ok = al((void**)&gm.SrcP, BSP * thin * sizeof(cplx));
     const int sqP = (d.k + 1) * (d.k + 2) / 2;
-    if (ok && gm.sq_chain) ok = al((void**)&gm.HsSQ, (size_t)sqP * QOC_DPP_PK_ELEMS * sizeof(cplx)) && al((void**)&gm.sqc, BSP * sqP * sizeof(double));
+    if (ok && gm.sq_chain) ok = al((void**)&gm.HsSQ, (size_t)sqP * QOC_DPP_PK_ELEMS * sizeof(cplx)) && al((void**)&gm.sqc,
+        BSP * sqP * sizeof(double));
     // wide gradient products: large matrices with few vectors (row tiles in pairs and column tiles in fours: what k_zgemm_wg takes)
-    gm.wideW = (!gm.persistent && N >= 128 && (N / 32) % 2 == 0 && d.m <= QOC_WIDE_MV) ? (int)((((size_t)d.steps * QOC_WIDE_MV + 127) / 128) * 128) : 0;
+    gm.wideW = (!gm.persistent && N >= 128 && (N / 32) % 2 == 0
+        && d.m <= QOC_WIDE_MV) ? (int)((((size_t)d.steps * QOC_WIDE_MV + 127) / 128) * 128) : 0;
     if (ok && gm.wideW > 0)
         ok = al((void**)&gm.wideP, (size_t)N * gm.wideW * sizeof(cplx)) && al((void**)&gm.wideL, (size_t)N * gm.wideW * sizeof(cplx)) &&
              al((void**)&gm.wideC, (size_t)d.k * N * gm.wideW * sizeof(cplx));
     if (ok && gm.ts_G > 0)
         ok = al((void**)&gm.ts_Rall, (size_t)gm.ts_G * NN * sizeof(cplx)) && al((void**)&gm.ts_Rtmp, 2 * NN * sizeof(cplx)) &&
-             al((void**)&gm.ts_Yr, (size_t)(gm.ts_G + 1) * N * (N + QOC_TW) * sizeof(cplx)) && al((void**)&gm.ts_Er, (size_t)(gm.ts_G + 1) * thin * sizeof(cplx));
+             al((void**)&gm.ts_Yr, (size_t)(gm.ts_G + 1) * N * (N + QOC_TW) * sizeof(cplx)) && al((void**)&gm.ts_Er,
+                 (size_t)(gm.ts_G + 1) * thin * sizeof(cplx));
     {
         size_t total = 0;
         for (auto& w : wanted) total += w.second;
@@ -509,7 +539,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         }
     }
     if (!ok) { msg = "GEMM path: out of device memory"; return -3; }
-    if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+    if (hipMemcpy(gm.HsP, hp.data(), hp.size() * sizeof(cplx),
+        hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     if (gm.dpp_chain) {
         std::vector<cplx> ht(hp.size());
         const size_t ge = gm.dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : NN;       // entries per matrix of the (packed) stack
@@ -517,10 +548,13 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
             for (int a = 0; a < N; ++a)
                 for (int c = 0; c < N; ++c) {
                     if (!gm.dpp_packed) { ht[(size_t)kk * NN + (size_t)c * N + a] = hp[(size_t)kk * NN + (size_t)a * N + c]; continue; }
-                    const int R = a >> 4, C = c >> 4;             // packed: blocks on and below the block diagonal, column-major inside a block
-                    if (R >= C) ht[(size_t)kk * ge + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)] = hp[(size_t)kk * NN + (size_t)a * N + c];
+                    // packed: blocks on and below the block diagonal, column-major inside a block
+                    const int R = a >> 4, C = c >> 4;
+                    if (R >= C) ht[(size_t)kk * ge + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)]
+                        = hp[(size_t)kk * NN + (size_t)a * N + c];
                 }
-        if (hipMemcpy(gm.HsPT, ht.data(), (size_t)(d.k + 1) * ge * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+        if (hipMemcpy(gm.HsPT, ht.data(), (size_t)(d.k + 1) * ge * sizeof(cplx),
+            hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     }
     if (gm.sq_chain) {
         // M_0 = A_0^2, M_k = A_0 A_k + A_k A_0, M_kl = A_k A_l + A_l A_k (k < l), M_kk = A_k^2 -- Hermitian, packed like the generators
@@ -531,7 +565,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
             for (int a = 0; a < N; ++a)
                 for (int c = 0; c < N; ++c) {
                     double re = 0.0, im = 0.0;
-                    for (int j = 0; j < N; ++j) { const cplx u = X[(size_t)a * N + j], v = Y[(size_t)j * N + c]; re += u.x * v.x - u.y * v.y; im += u.x * v.y + u.y * v.x; }
+                    for (int j = 0; j < N; ++j) { const cplx u = X[(size_t)a * N + j],
+                        v = Y[(size_t)j * N + c]; re += u.x * v.x - u.y * v.y; im += u.x * v.y + u.y * v.x; }
                     cplx& o = prod[(size_t)a * N + c];
                     if (clear) { o.x = re; o.y = im; } else { o.x += re; o.y += im; }
                 }
@@ -540,7 +575,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
             for (int a = 0; a < N; ++a)
                 for (int c = 0; c < N; ++c) {
                     const int R = a >> 4, C = c >> 4;
-                    if (R >= C) hq[(size_t)p * QOC_DPP_PK_ELEMS + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)] = prod[(size_t)a * N + c];
+                    if (R >= C) hq[(size_t)p * QOC_DPP_PK_ELEMS + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)]
+                        = prod[(size_t)a * N + c];
                 }
         };
         int p = 0;
@@ -548,7 +584,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         for (int kk = 1; kk <= d.k; ++kk) { accumulate(0, kk, true); accumulate(kk, 0, false); pack(p++); }
         for (int kk = 1; kk <= d.k; ++kk)
             for (int ll = kk; ll <= d.k; ++ll) { accumulate(kk, ll, true); if (ll != kk) accumulate(ll, kk, false); pack(p++); }
-        if (hipMemcpy(gm.HsSQ, hq.data(), hq.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
+        if (hipMemcpy(gm.HsSQ, hq.data(), hq.size() * sizeof(cplx),
+            hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     }
     // the persistent chain kernels write only the first m (<= 8) of the 32 thin columns; the rest must read as zero
     bool zeroed = hipMemset(gm.zthin, 0, thin * sizeof(cplx)) == hipSuccess &&
@@ -558,55 +595,73 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
                   hipMemset(gm.Ebnd, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess &&
                   hipMemset(gm.Aoff, 0, (size_t)d.B * gm.NC * thin * sizeof(cplx)) == hipSuccess;
     if (gm.wideW > 0) zeroed = zeroed && hipMemset(gm.wideP, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess &&
-                                         hipMemset(gm.wideL, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess;   // (the columns beyond 8 steps)
+                                         // (the columns beyond 8 steps)
+                                         hipMemset(gm.wideL, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess;
     if (!zeroed) { msg = "GEMM path: clearing the work buffers failed"; return -2; }
     if (poly && gm.SP > d.steps) {
         hipLaunchKernelGGL(k_gemm_pad_identity, dim3(4096), dim3(256), 0, 0, gm.K, d.B, N, d.steps, gm.SP);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) { msg = "GEMM path: the padded propagators could not be set"; return -2; }
+        if (hipGetLastError() != hipSuccess
+            || hipStreamSynchronize(0) != hipSuccess) { msg = "GEMM path: the padded propagators could not be set"; return -2; }
     }
     {
-        // generators of the last 11/16 of the pulse assembled beside the forward chain's first part, by 512 long-running workgroups: the chain's
-        // prefetch shares the memory system with them (a slice costs it 4-5.6 us beside an unthrottled assembly against 2.9 alone); sweep of
+        // generators of the last 11/16 of the pulse assembled beside the forward chain's first part, by 512 long-running workgroups: the
+        // chain's prefetch shares the memory system with them (a slice costs it 4-5.6 us beside an unthrottled assembly against 2.9 alone);
+        // sweep of
         // (workgroups, split) at C3 x 64, ms per iteration: (8192, 3/16) 6.81, (2048, 3/16) 6.79, (512, 5/16) 6.67, (512, 8/16) 6.77,
         // (384, 6/16) 6.68, (256, 5/16) 7.35; one launch in front of the chain 7.03
         const char* e = qoc_exp_env("QOC_ASM_OVERLAP");             // experimental switch: 0 = one assembly launch in front of the chain
-        if (gm.dpp_chain && need_src && d.k <= 8 && d.steps >= 64 && d.B <= 128 && !(e && e[0] == '0')) {       // (256 chains fill the chip: 14.6 against 14.0 ms)
-            // disjoint CU sets for the two kernels that run beside each other: the assembly's workgroups otherwise land on the chains' CUs as well and
-            // take issue slots from waves whose every instruction is on the critical path.  QOC_ASM_CUMASK=0: plain second stream, chain on the engine's
+        // (256 chains fill the chip: 14.6 against 14.0 ms)
+        if (gm.dpp_chain && need_src && d.k <= 8 && d.steps >= 64 && d.B <= 128 && !(e && e[0] == '0')) {
+            // disjoint CU sets for the two kernels that run beside each other: the assembly's workgroups otherwise land on the chains' CUs
+            // as well and take issue slots from waves whose every instruction is on the critical path.  QOC_ASM_CUMASK=0: plain second
+            // stream, chain on the engine's
             {
                 const char* cm = qoc_exp_env("QOC_ASM_CUMASK");
                 int ncu = 0, dv = 0;
-                if (hipGetDevice(&dv) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess) ncu = 0;
+                if (hipGetDevice(&dv) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount,
+                    dv) != hipSuccess) ncu = 0;
                 const int chain_cus = cm && atoi(cm) > 0 ? atoi(cm) : 112;
                 if (!(cm && cm[0] == '0') && ncu >= 128 && ncu <= 1024 && d.B + 16 <= chain_cus) {
                     std::vector<uint32_t> mc((ncu + 31) / 32, 0u), ma((ncu + 31) / 32, 0u);
                     for (int c = 0; c < ncu; ++c) (c < chain_cus ? mc : ma)[c / 32] |= 1u << (c % 32);
-                    if (hipExtStreamCreateWithCUMask(&gm.chain_s, (uint32_t)mc.size(), mc.data()) != hipSuccess) { gm.chain_s = nullptr; (void)hipGetLastError(); }
-                    else if (hipExtStreamCreateWithCUMask(&gm.aux, (uint32_t)ma.size(), ma.data()) != hipSuccess) { hipStreamDestroy(gm.chain_s); gm.chain_s = nullptr; gm.aux = nullptr; (void)hipGetLastError(); }
-                    if (gm.chain_s && (hipEventCreateWithFlags(&gm.ev_fwd, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&gm.ev_p1, hipEventDisableTiming) != hipSuccess)) { msg = "GEMM path: events could not be created"; return -2; }
+                    if (hipExtStreamCreateWithCUMask(&gm.chain_s, (uint32_t)mc.size(),
+                        mc.data()) != hipSuccess) { gm.chain_s = nullptr; (void)hipGetLastError(); }
+                    else if (hipExtStreamCreateWithCUMask(&gm.aux, (uint32_t)ma.size(),
+                        ma.data()) != hipSuccess) { hipStreamDestroy(gm.chain_s); gm.chain_s = nullptr; gm.aux
+                        = nullptr; (void)hipGetLastError(); }
+                    if (gm.chain_s && (hipEventCreateWithFlags(&gm.ev_fwd, hipEventDisableTiming) != hipSuccess
+                        || hipEventCreateWithFlags(&gm.ev_p1,
+                        hipEventDisableTiming) != hipSuccess)) { msg = "GEMM path: events could not be created"; return -2; }
                 }
             }
-            if ((!gm.aux && hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&gm.ev_ready, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&gm.ev_tail, hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: second stream / events could not be created"; return -2; }
-            // on shared CUs: 512 long-running workgroups from 5/16 of the pulse on; on its own CUs the assembly runs unthrottled from 4/16 on (C3 x 64, ms per
-            // iteration: masks of 80 / 96 / 112 / 128 CUs for the chains 6.31 / 6.31 / 6.25 / 6.34; shared CUs 6.40; 2048 workgroups 6.27 - 6.31; 3/16: 6.35 - 6.50)
+            if ((!gm.aux && hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&gm.ev_ready,
+                hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&gm.ev_tail,
+                    hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: second stream / events could not be created"; return -2; }
+            // on shared CUs: 512 long-running workgroups from 5/16 of the pulse on; on its own CUs the assembly runs unthrottled from 4/16
+            // on (C3 x 64, ms per
+            // iteration: masks of 80 / 96 / 112 / 128 CUs for the chains 6.31 / 6.31 / 6.25 / 6.34; shared CUs 6.40; 2048 workgroups 6.27 -
+            // 6.31; 3/16: 6.35 - 6.50)
             gm.asm_split = ((gm.chain_s ? 4 : 5) * d.steps) / 16;
             gm.asm_tail_wgs = gm.chain_s ? 8192 : 512;
             if (const char* t = qoc_exp_env("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : gm.asm_tail_wgs;
             if (const char* t = qoc_exp_env("QOC_ASM_SPLIT16")) gm.asm_split = (atoi(t) * d.steps) / 16;
             if (gm.asm_split < 1) gm.asm_split = 1;
             if (gm.asm_split > d.steps - 1) gm.asm_split = d.steps - 1;
-            // windows: [0, asm_split) in front, the rest in nw - 1 equal windows beside the chain.  More than two windows buy nothing (C3 x 64: 5.85 / 5.87 ms
-            // at nw = 2 / 4 with 4/16 in front, 5.83 with 2/16 and nw = 4: the chain part that runs beside an assembly launch loses what the shorter head
-            // saves) and nine or more chain launches waiting on events of the second stream did not finish at all on ROCm 7.2: profiles/r05_c3_windows.txt
+            // windows: [0, asm_split) in front, the rest in nw - 1 equal windows beside the chain.  More than two windows buy nothing (C3 x
+            // 64: 5.85 / 5.87 ms at nw = 2 / 4 with 4/16 in front, 5.83 with 2/16 and nw = 4: the chain part that runs beside an assembly
+            // launch loses what the shorter head saves) and nine or more chain launches waiting on events of the second stream did not
+            // finish at all on ROCm 7.2: profiles/r05_c3_windows.txt
             int nw = 2;
             if (const char* t = qoc_exp_env("QOC_ASM_WINDOWS")) nw = atoi(t) >= 2 ? (atoi(t) <= 4 ? atoi(t) : 4) : 2;
             if (nw - 1 > d.steps - gm.asm_split) nw = 1 + (d.steps - gm.asm_split);
             gm.asm_win.assign(1, 0);
-            for (int w = 1; w <= nw; ++w) gm.asm_win.push_back(w == nw ? d.steps : gm.asm_split + (int)(((long long)(d.steps - gm.asm_split) * (w - 1)) / (nw - 1)));
+            for (int w = 1; w <= nw; ++w) gm.asm_win.push_back(w == nw ? d.steps : gm.asm_split
+                + (int)(((long long)(d.steps - gm.asm_split) * (w - 1)) / (nw - 1)));
             gm.ev_win.assign(nw, nullptr);
             for (int w = 1; w < nw; ++w)
-                if (hipEventCreateWithFlags(&gm.ev_win[w], hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: events could not be created"; return -2; }
+                if (hipEventCreateWithFlags(&gm.ev_win[w],
+                    hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: events could not be created"; return -2; }
         }
     }
     return 0;
@@ -629,16 +684,21 @@ static inline void qoc_gemm_launch_sk(const GemmArgs& g, unsigned blocks, hipStr
 // Kernels that use more than 64 KB of dynamic LDS must opt in, per device: called from qoc_gemm_setup (one engine = one device)
 template <bool CONJT, int EPI>
 static inline bool qoc_gemm_lds_opt_in_sk() {
-    return hipFuncSetAttribute((const void*)k_zgemm32<CONJT, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2048 * (int)sizeof(double)) == hipSuccess;
+    return hipFuncSetAttribute((const void*)k_zgemm32<CONJT, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        7 * 2048 * (int)sizeof(double)) == hipSuccess;
 }
 static inline bool qoc_gemm_lds_opt_in() {
-    return qoc_gemm_lds_opt_in_sk<false, 0>() && qoc_gemm_lds_opt_in_sk<false, 1>() && qoc_gemm_lds_opt_in_sk<false, 2>() && qoc_gemm_lds_opt_in_sk<true, 0>() &&
-           hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (64 + QOC_EXPM_LDPAD) * (int)sizeof(cplx)) == hipSuccess &&
-           hipFuncSetAttribute((const void*)k_gemm_scan_nodes<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qoc_scan_lds(64)) == hipSuccess &&
+    return qoc_gemm_lds_opt_in_sk<false, 0>() && qoc_gemm_lds_opt_in_sk<false, 1>() && qoc_gemm_lds_opt_in_sk<false, 2>()
+        && qoc_gemm_lds_opt_in_sk<true, 0>() &&
+           hipFuncSetAttribute((const void*)k_gemm_expm_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+               2 * 64 * (64 + QOC_EXPM_LDPAD) * (int)sizeof(cplx)) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k_gemm_scan_nodes<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+               (int)qoc_scan_lds(64)) == hipSuccess &&
            qoc_zgemm_wg_opt_in();
 }
-// picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small.  The split factor and the kernel
-// family change the association of the sums, so they follow the PLANNED batch: QocGemm::plan_scale = planned / local batch (qoc_gemm_setup)
+// picks the split-K factor from the launch size: fill ~2 waves per SIMD (2048 waves) when the batch is small.  The split factor and the
+// kernel family change the association of the sums, so they follow the PLANNED batch: QocGemm::plan_scale = planned / local batch
+// (qoc_gemm_setup)
 #ifndef QOC_SK_TARGET
 #define QOC_SK_TARGET 2048     // waves a split-K launch aims at (~2 per SIMD)
 #endif
@@ -649,7 +709,8 @@ static inline bool qoc_gemm_takes_wg(const QocGemm& gm, const GemmArgs& g) {
     const bool split = tiles * 2 <= QOC_SK_TARGET && (g.Kdim / 2) % 8 == 0;
     return !split && (g.tiles_m & 1) == 0 && (g.tiles_n & 3) == 0 && (g.Kdim % ZW_KC) == 0 && g.Kdim >= 128 && tiles >= 8 * 1024;
 }
-// sk_tiles: tile count the split-K factor is chosen for when the launch is one PART of a product (the parts must sum in the order of the whole)
+// sk_tiles: tile count the split-K factor is chosen for when the launch is one PART of a product (the parts must sum in the order of the
+// whole)
 static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const GemmArgs& g, hipStream_t s, size_t sk_tiles = 0) {
     const size_t real_tiles = (size_t)g.batch * g.tiles_m * g.tiles_n;
     const unsigned blocks = (unsigned)real_tiles;
@@ -686,7 +747,8 @@ static inline void qoc_gemm_launch(const QocGemm& gm, bool conjt, int epi, const
 
 static inline int gemm_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
 // the slices t0 .. t0 + tn - 1 of every seed (needs what k_gemm_assemble_rows needs: k <= 8, N*N a multiple of 256)
-static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int t0, int tn, hipStream_t s, int target_wgs = 8192, int nn = 0) {
+static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cplx* Aout, int N, int SP, int t0, int tn, hipStream_t s,
+    int target_wgs = 8192, int nn = 0) {
     const size_t NN = nn > 0 ? (size_t)nn : (size_t)N * N, items = (size_t)d.B * tn;
     const int gx = (int)(NN / 256);
     int per = (int)((items * gx + target_wgs - 1) / target_wgs);
@@ -696,7 +758,8 @@ static inline void qoc_gemm_assemble_window(const QocDev& d, const cplx* HsP, cp
 }
 // [B | B^2] of the slices t0 .. t0 + tn - 1 of every seed (tn = 0: all items) for the squared-generator chain
 template <int KK>
-static inline void qoc_gemm_assemble_sq_k(const QocDev& d, const cplx* HsPK, const cplx* HsSQ, const double* coef, cplx* Aout, int SP, int t0, int tn, hipStream_t s, int target_wgs) {
+static inline void qoc_gemm_assemble_sq_k(const QocDev& d, const cplx* HsPK, const cplx* HsSQ, const double* coef, cplx* Aout, int SP,
+    int t0, int tn, hipStream_t s, int target_wgs) {
     const size_t items = (size_t)d.B * (tn > 0 ? tn : SP);
     const int gx = QOC_DPP_PK_ELEMS / 256;
     int per = (int)((items * gx + target_wgs - 1) / target_wgs);
@@ -704,7 +767,8 @@ static inline void qoc_gemm_assemble_sq_k(const QocDev& d, const cplx* HsPK, con
     const int gy = (int)((items + per - 1) / per);
     hipLaunchKernelGGL(k_gemm_assemble_sq<KK>, dim3(gx, gy), dim3(256), 0, s, d, HsPK, HsSQ, coef, Aout, SP, per, items, t0, tn);
 }
-static inline void qoc_gemm_assemble_sq(const QocDev& d, const cplx* HsPK, const cplx* HsSQ, const double* coef, cplx* Aout, int SP, int t0, int tn, hipStream_t s, int target_wgs = 8192) {
+static inline void qoc_gemm_assemble_sq(const QocDev& d, const cplx* HsPK, const cplx* HsSQ, const double* coef, cplx* Aout, int SP, int t0,
+    int tn, hipStream_t s, int target_wgs = 8192) {
     switch (d.k) {
         case 1: qoc_gemm_assemble_sq_k<1>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
         case 2: qoc_gemm_assemble_sq_k<2>(d, HsPK, HsSQ, coef, Aout, SP, t0, tn, s, target_wgs); break;
@@ -725,7 +789,8 @@ static inline void qoc_gemm_assemble_launch(const QocDev& d, const cplx* HsP, cp
         int per = (int)((items * gx + 8191) / 8192);                     // ~8192 workgroups
         if (per < 4) per = 4;
         const int gy = (int)((items + per - 1) / per);
-        if (gy <= 65535) { hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, per, item_first, item_count, 0, 0, nn); return; }
+        if (gy <= 65535) { hipLaunchKernelGGL(k_gemm_assemble_rows, dim3(gx, gy), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, per, item_first,
+            item_count, 0, 0, nn); return; }
     }
     hipLaunchKernelGGL(k_gemm_assemble, dim3(gemm_grid(items * NN)), dim3(256), 0, s, d, HsP, Aout, N, SP, sq, item_first, item_count, nn);
 }
@@ -742,10 +807,12 @@ static inline void qoc_gemm_tree(QocGemm& gm, const QocDev& d, hipStream_t s, si
     const cplx* prev = gm.K;
     for (int l = 1; l <= gm.L; ++l) {
         cplx* out = gm.tree + gm.tree_off[l];
-        g.A = prev + ((item_first >> (l - 1)) + 1) * NN; g.sA = 2 * (long long)NN; g.Bm = prev + (item_first >> (l - 1)) * NN; g.sB = 2 * (long long)NN;
+        g.A = prev + ((item_first >> (l - 1)) + 1) * NN; g.sA = 2 * (long long)NN; g.Bm = prev + (item_first >> (l - 1)) * NN;
+            g.sB = 2 * (long long)NN;
         g.C = out + (item_first >> l) * NN; g.sC = (long long)NN;
         g.batch = (int)(item_count >> l);
-        const bool want_t = gm.persistent && !gm.direct && l == gm.L;        // chunk products also transposed, for the backward boundary chain
+        // chunk products also transposed, for the backward boundary chain
+        const bool want_t = gm.persistent && !gm.direct && l == gm.L;
         g.CT = want_t ? gm.PcT : nullptr; g.sCT = (long long)NN; g.ldct = N;
         qoc_gemm_launch(gm, false, 0, g, s);
         prev = out;
@@ -770,42 +837,51 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
                 hipEventRecord(gm.ev_ready, s);
                 hipStreamWaitEvent(gm.aux, gm.ev_ready, 0);
                 for (int w = 1; w < nw; ++w) {
-                    qoc_gemm_assemble_sq(d, gm.HsPT, gm.HsSQ, gm.sqc, gm.A, gm.SP, gm.asm_win[w], gm.asm_win[w + 1] - gm.asm_win[w], gm.aux, gm.asm_tail_wgs);
+                    qoc_gemm_assemble_sq(d, gm.HsPT, gm.HsSQ, gm.sqc, gm.A, gm.SP, gm.asm_win[w], gm.asm_win[w + 1] - gm.asm_win[w], gm.aux,
+                        gm.asm_tail_wgs);
                     hipEventRecord(gm.ev_win[w], gm.aux);
                 }
             }
             else qoc_gemm_assemble_sq(d, gm.HsPT, gm.HsSQ, gm.sqc, gm.A, gm.SP, 0, 0, s);
             return;
         }
-        if (gm.asm_split > 0) {                                    // head on this stream, tail on the second one beside the forward chain's first part
+        // head on this stream, tail on the second one beside the forward chain's first part
+        if (gm.asm_split > 0) {
             const int nw = (int)gm.asm_win.size() - 1;
             qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, 0, gm.asm_win[1], s, 8192, nn);
-            hipEventRecord(gm.ev_ready, s);                         // the head has the memory system to itself (started together, both took as long as the whole)
+            // the head has the memory system to itself (started together, both took as long as the whole)
+            hipEventRecord(gm.ev_ready, s);
             hipStreamWaitEvent(gm.aux, gm.ev_ready, 0);
             for (int w = 1; w < nw; ++w) {
-                qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_win[w], gm.asm_win[w + 1] - gm.asm_win[w], gm.aux, gm.asm_tail_wgs, nn);
+                qoc_gemm_assemble_window(d, gm.HsPT, gm.A, N, gm.SP, gm.asm_win[w], gm.asm_win[w + 1] - gm.asm_win[w], gm.aux,
+                    gm.asm_tail_wgs, nn);
                 hipEventRecord(gm.ev_win[w], gm.aux);
             }
             return;
         }
-        qoc_gemm_assemble_launch(d, gm.dpp_chain ? gm.HsPT : gm.HsP, gm.A, N, gm.SP, 0, s, 0, 0, nn);   // dpp_chain: generators column-major
+        // dpp_chain: generators column-major
+        qoc_gemm_assemble_launch(d, gm.dpp_chain ? gm.HsPT : gm.HsP, gm.A, N, gm.SP, 0, s, 0, 0, nn);
         return;
     }
     if (N <= 64) {
         ExpmCoef cf;
         { double f = 1.0; for (int j = 0; j < QOC_GEMM_MAXT; ++j) { if (j > 0) f *= (double)j; cf.c[j] = 1.0 / f; } }
         const size_t lds = 2 * (size_t)N * (N + QOC_EXPM_LDPAD) * sizeof(cplx);
-        if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
-        else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K, gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
+        if (N == 32) hipLaunchKernelGGL(k_gemm_expm_fused<32>, dim3((unsigned)BS), dim3(128), lds, s, d, gm.HsP, gm.K,
+            gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
+        else hipLaunchKernelGGL(k_gemm_expm_fused<64>, dim3((unsigned)BS), dim3(512), lds, s, d, gm.HsP, gm.K,
+            gm.persistent ? gm.KT : (cplx*)nullptr, gm.SP, deg, nsq, cf);
         qoc_gemm_tree(gm, d, s);
         return;
     }
-    // one control set: the padded slices (K = I exactly, written once by qoc_gemm_setup) are not computed -- C5: 16 of 2016 slices, 96 products
+    // one control set: the padded slices (K = I exactly, written once by qoc_gemm_setup) are not computed -- C5: 16 of 2016 slices, 96
+    // products
     qoc_gemm_expm_products(gm, d, s, 0, d.B == 1 ? (size_t)d.steps : BS);
     qoc_gemm_tree(gm, d, s);
 }
 
-// N > 64: K_t of the items [item_first, item_first + item_count) by batched launches (all items, or the slices of one rank of a time-sharded engine)
+// N > 64: K_t of the items [item_first, item_first + item_count) by batched launches (all items, or the slices of one rank of a
+// time-sharded engine)
 static inline void qoc_gemm_expm_products(QocGemm& gm, const QocDev& d, hipStream_t s, size_t item_first, size_t item_count) {
     const int N = gm.N;
     const size_t NN = (size_t)N * N, BS = item_count, off = item_first * NN;
@@ -817,7 +893,8 @@ static inline void qoc_gemm_expm_products(QocGemm& gm, const QocDev& d, hipStrea
     cplx* const bufA = gm.A + off; cplx* const bufA2 = gm.A2 + off; cplx* const bufK = gm.K + off; cplx* const bufP = gm.P + off;
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.lda = g.ldb = g.ldc = g.lde = N; g.sA = g.sB = g.sC = g.sE = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32; g.batch = (int)BS;
+    g.lda = g.ldb = g.ldc = g.lde = N; g.sA = g.sB = g.sC = g.sE = (long long)NN; g.Kdim = N; g.tiles_m = g.tiles_n = N / 32;
+        g.batch = (int)BS;
     double invf[QOC_GEMM_MAXT];
     { double f = 1.0; for (int j = 0; j < QOC_GEMM_MAXT; ++j) { if (j > 0) f *= (double)j; invf[j] = 1.0 / f; } }
     const int mm = deg >> 1;
@@ -829,12 +906,13 @@ static inline void qoc_gemm_expm_products(QocGemm& gm, const QocDev& d, hipStrea
     if (deg >= 2) {
         g.A = bufA; g.Bm = bufA; g.C = bufA2; g.E = nullptr; g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
         qoc_gemm_launch(gm, false, 0, g, s);                         // A2 = A*A
-        // odd order on the workgroup-tiled kernel: the top block S = c_{2m} I + c_{2m+1} A is formed from A while the first Horner product stages
-        // its right operand (GemmArgs::btrans) -- no k_gemm_ps_init pass (C5: 3.2 ms of reading and writing 8.4 GB each)
+        // odd order on the workgroup-tiled kernel: the top block S = c_{2m} I + c_{2m+1} A is formed from A while the first Horner product
+        // stages its right operand (GemmArgs::btrans) -- no k_gemm_ps_init pass (C5: 3.2 ms of reading and writing 8.4 GB each)
         const bool top_in_flight = !even && mm >= 1 && qoc_gemm_takes_wg(gm, g);
         if (even) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, bufA2, cur, BS * NN, N,
                                      invf[2 * mm - 2], invf[2 * mm - 1], invf[deg]);
-        else if (!top_in_flight) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, (const cplx*)nullptr, cur, BS * NN, N,
+        else if (!top_in_flight) hipLaunchKernelGGL(k_gemm_ps_init, dim3(gemm_grid(BS * NN)), dim3(256), 0, s, bufA, (const cplx*)nullptr,
+            cur, BS * NN, N,
                                                     invf[2 * mm], invf[2 * mm + 1], 0.0);
         for (int i = (even ? mm - 2 : mm - 1); i >= 0; --i) {    // S <- c_{2i} I + c_{2i+1} A + A2*S
             g.A = bufA2; g.Bm = cur; g.C = oth; g.E = bufA; g.alpha = 1.0; g.beta = invf[2 * i + 1]; g.gamma = invf[2 * i];
@@ -867,21 +945,26 @@ static inline ChainArgs qoc_gemm_direct_backward_args(const QocGemm& gm, const Q
     const size_t GE = gm.gen_elems();
     a.K = gm.A + (size_t)(d.steps - 1) * GE; a.sKb = (long long)GE * gm.SP; a.sKs = -(long long)GE;
     a.X0 = gm.Ebnd; a.sXb = (long long)thin;
-    if (need_src && gm.dpp_chain) { a.E = gm.SrcP + (size_t)(d.steps - 1) * N; a.sEb = (long long)N * gm.SP; a.sEs = -(long long)N; a.ldE = 1; }   // compact sources
+    // compact sources
+    if (need_src
+        && gm.dpp_chain) { a.E = gm.SrcP + (size_t)(d.steps - 1) * N; a.sEb = (long long)N * gm.SP; a.sEs = -(long long)N; a.ldE = 1; }
     else if (need_src) { a.E = gm.SrcP + (size_t)(d.steps - 1) * thin; a.sEb = (long long)thin * gm.SP; a.sEs = -(long long)thin; }
     a.Out = gm.LamP + (long long)(d.steps - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOs = -gm.MV; a.ldO = gm.ldW;
     a.store_initial = 1; a.CI = 1; a.len = d.steps - 1; a.m = d.m; a.nterms = d.T; a.sign = -1.0;
     return a;
 }
 // direct route without a state regulariser: backward chain beside the forward one (see qoc_gemm_forward)
-static inline bool qoc_gemm_zfree_backward(const QocGemm& gm, const QocDev& d) { return gm.direct && !(d.n_forb > 0 || d.has_speed) && d.steps >= 2; }
+static inline bool qoc_gemm_zfree_backward(const QocGemm& gm, const QocDev& d) { return gm.direct && !(d.n_forb > 0 || d.has_speed)
+    && d.steps >= 2; }
 
-// launch-per-step route in unitary mode: final_state / unitary_scale are formed when they are read back (qoc_gemm_final_state) -- inside the
-// iterations the boundary chain carries the m vectors only, not the N columns of X beside them (C5: 63 products of 512 x 544 columns per iteration)
+// launch-per-step route in unitary mode: final_state / unitary_scale are formed when they are read back (qoc_gemm_final_state) -- inside
+// the iterations the boundary chain carries the m vectors only, not the N columns of X beside them (C5: 63 products of 512 x 544 columns
+// per iteration)
 static inline bool qoc_gemm_lazy_final(const QocGemm& gm, const QocDev& d) { return !gm.persistent && !gm.direct && !d.state_transfer; }
 
 static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s, bool with_final = false) {
-    const int N = gm.N, xw = (d.state_transfer || (qoc_gemm_lazy_final(gm, d) && !with_final)) ? 0 : N, ld = xw + QOC_TW, S = gm.S, NC = gm.NC;
+    const int N = gm.N, xw = (d.state_transfer || (qoc_gemm_lazy_final(gm, d) && !with_final)) ? 0 : N, ld = xw + QOC_TW, S = gm.S,
+        NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
     hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
@@ -893,7 +976,8 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
         a.X0 = gm.Psibnd; a.sXb = (long long)thin;
         a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOs = gm.MV; a.ldO = gm.ldW;
         a.CI = 1; a.len = d.steps; a.m = d.m; a.nterms = d.T; a.sign = 1.0;
-        if (gm.dpp_chain) {                                      // the chain writes inter[b][t + 1] itself (one vector: n contiguous entries per step)
+        // the chain writes inter[b][t + 1] itself (one vector: n contiguous entries per step)
+        if (gm.dpp_chain) {
             a.Out2 = d.inter + d.n; a.sO2b = (long long)(d.steps + 1) * d.n; a.sO2s = d.n; a.n2 = d.n;
         }
         if (qoc_gemm_zfree_backward(gm, d)) {
@@ -903,8 +987,8 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             qoc_taylor_chain_launch2(N, a, qoc_gemm_direct_backward_args(gm, d, false), gm.zthin, d.B, s, gm.dpp_mode());
         }
         else if (gm.asm_split > 0) {
-            // one chain launch per window, each from the state the previous one left in Aoff; with a CU mask the chains keep their own CUs (the
-            // assembly of the later windows runs on the others) and the engine's stream joins after the last window
+            // one chain launch per window, each from the state the previous one left in Aoff; with a CU mask the chains keep their own CUs
+            // (the assembly of the later windows runs on the others) and the engine's stream joins after the last window
             const int nw = (int)gm.asm_win.size() - 1;
             hipStream_t cs = gm.chain_s ? gm.chain_s : s;
             if (gm.chain_s) { hipEventRecord(gm.ev_fwd, s); hipStreamWaitEvent(cs, gm.ev_fwd, 0); }
@@ -920,7 +1004,8 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
             if (gm.chain_s) { hipEventRecord(gm.ev_p1, cs); hipStreamWaitEvent(s, gm.ev_p1, 0); }
         }
         else qoc_taylor_chain_launch(N, a, gm.zthin, d.B, s, gm.dpp_mode());
-        if (!gm.dpp_chain) hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
+        if (!gm.dpp_chain) hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d,
+            gm.interP, N, gm.ldW, gm.MV);
         return;
     }
     if (gm.persistent && d.state_transfer) {
@@ -981,19 +1066,24 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
         qoc_gemm_launch(gm, false, 0, g, s);
     }
     if (!gm.persistent && NC > 1)
-        hipLaunchKernelGGL(k_gemm_take_bnd_all, dim3(gemm_grid((size_t)d.B * (NC - 1) * thin)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
-    if (xw > 0 && !gm.persistent) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(N > 64 ? 1024 : 256), 0, s, d, gm.Y0 + (size_t)NC * yslot, N);
-    if (with_final) return;                                    // read-back of final_state: the boundary chain with X beside the vectors was all that was asked for
+        hipLaunchKernelGGL(k_gemm_take_bnd_all, dim3(gemm_grid((size_t)d.B * (NC - 1) * thin)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC,
+            xw);
+    if (xw > 0 && !gm.persistent) hipLaunchKernelGGL(k_gemm_take_final, dim3(d.B), dim3(N > 64 ? 1024 : 256), 0, s, d,
+        gm.Y0 + (size_t)NC * yslot, N);
+    // read-back of final_state: the boundary chain with X beside the vectors was all that was asked for
+    if (with_final) return;
     if (gm.persistent) {
         // every chunk swept by its own persistent workgroup: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}
         ChainArgs a;
         memset(&a, 0, sizeof a);
         a.K = gm.K; a.sKb = (long long)NN * gm.SP; a.sKc = (long long)NN * S; a.sKs = (long long)NN;
         a.X0 = gm.Psibnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
-        a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOc = (long long)S * gm.MV; a.sOs = gm.MV; a.ldO = gm.ldW;   // time-major wide layout
+        // time-major wide layout
+        a.Out = gm.interP; a.sOb = (long long)N * gm.ldW; a.sOc = (long long)S * gm.MV; a.sOs = gm.MV; a.ldO = gm.ldW;
         a.CI = NC; a.len = S; a.m = d.m;
         qoc_chain_launch(N, false, a, gm.zthin, d.B * NC, s);
-        hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW, gm.MV);
+        hipLaunchKernelGGL(k_gemm_unpad_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.n * d.m)), dim3(256), 0, s, d, gm.interP, N, gm.ldW,
+            gm.MV);
         return;
     }
     // all chunks swept together: Psi_{cS+j} = K_{cS+j} Psi_{cS+j-1}, one launch per j, batch = B*NC
@@ -1029,8 +1119,8 @@ static inline void qoc_gemm_bwd_sweep(QocGemm& gm, const QocDev& d, hipStream_t 
     }
 }
 
-// gradients from the time-major wide layout: one product H_k' [Psi_0 ... Psi_{SP-1}] per control (batch = seeds), contracted column by column
-// with conj(Lambda) (tensorflow_state.py:61-63) -- the columns [c_first, c_end) (multiples of 32) of it
+// gradients from the time-major wide layout: one product H_k' [Psi_0 ... Psi_{SP-1}] per control (batch = seeds), contracted column by
+// column with conj(Lambda) (tensorflow_state.py:61-63) -- the columns [c_first, c_end) (multiples of 32) of it
 static inline void qoc_gemm_wide_gradient(QocGemm& gm, const QocDev& d, hipStream_t s, int c_first, int c_end) {
     const int N = gm.N, tm = N / 32;
     const size_t NN = (size_t)N * N;
@@ -1051,36 +1141,45 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const bool need_src = d.n_forb > 0 || d.has_speed;
     const cplx* Pc = qoc_gemm_chunk_products(gm);
-    if (qoc_gemm_zfree_backward(gm, d)) {                     // the chain ran beside the forward one from -(2/m^2) W: Lambda_t = z Lambda0_t
-        hipLaunchKernelGGL(k_gemm_scale_lam, dim3(gemm_grid((size_t)d.B * N * d.steps * gm.MV)), dim3(256), 0, s, d, gm.LamP, N, gm.ldW, d.steps * gm.MV);
+    // the chain ran beside the forward one from -(2/m^2) W: Lambda_t = z Lambda0_t
+    if (qoc_gemm_zfree_backward(gm, d)) {
+        hipLaunchKernelGGL(k_gemm_scale_lam, dim3(gemm_grid((size_t)d.B * N * d.steps * gm.MV)), dim3(256), 0, s, d, gm.LamP, N, gm.ldW,
+            d.steps * gm.MV);
     } else {
     {
         const int cols = gm.direct ? gm.MV : QOC_TW;
-        hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * N * cols)), dim3(256), 0, s, d, gm.SrcP, gm.Ebnd, N, gm.SP, NC, cols, gm.dpp_chain ? 1 : 0);
+        hipLaunchKernelGGL(k_gemm_sources, dim3(gemm_grid((size_t)d.B * (need_src ? gm.SP : 1) * N * cols)), dim3(256), 0, s, d, gm.SrcP,
+            gm.Ebnd, N, gm.SP, NC, cols, gm.dpp_chain ? 1 : 0);
     }
     }
     if (gm.direct) {
-        // (the gradient products of the slices the chain has already left, on the second stream beside the rest of the chain: built and measured in
-        // round 4, 6.19 against 6.17 ms at C3 x 64 -- the products slow the chain's prefetch as much as they save; profiles/EXPERIMENTS.md)
-        if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s, gm.dpp_mode());
+        // (the gradient products of the slices the chain has already left, on the second stream beside the rest of the chain: built and
+        // measured in round 4, 6.19 against 6.17 ms at C3 x 64 -- the products slow the chain's prefetch as much as they save;
+        // profiles/EXPERIMENTS.md)
+        if (!qoc_gemm_zfree_backward(gm, d)) qoc_taylor_chain_launch(N, qoc_gemm_direct_backward_args(gm, d, need_src), gm.zthin, d.B, s,
+            gm.dpp_mode());
     } else if (gm.persistent) {
         ChainArgs sw;                                        // one chunk, backwards: Lambda_{t-1} = K_t^dagger Lambda_t + S_t
         memset(&sw, 0, sizeof sw);
-        sw.K = gm.KT + (size_t)(S - 1) * NN; sw.sKb = (long long)NN * gm.SP; sw.sKc = (long long)NN * S; sw.sKs = -(long long)NN;   // conj(K^T) = K^H
-        if (need_src) { sw.E = gm.SrcP + (size_t)(S - 1) * thin; sw.sEb = (long long)thin * gm.SP; sw.sEc = (long long)thin * S; sw.sEs = -(long long)thin; }
+        // conj(K^T) = K^H
+        sw.K = gm.KT + (size_t)(S - 1) * NN; sw.sKb = (long long)NN * gm.SP; sw.sKc = (long long)NN * S; sw.sKs = -(long long)NN;
+        if (need_src) { sw.E = gm.SrcP + (size_t)(S - 1) * thin; sw.sEb = (long long)thin * gm.SP; sw.sEc = (long long)thin * S; sw.sEs
+            = -(long long)thin; }
         sw.CI = NC; sw.m = d.m;
         if (need_src && NC > 1) {                            // affine offsets a_c: every chunk run from a zero costate
             ChainArgs a = sw;
             a.len = S; a.Fin = gm.Aoff; a.sFb = (long long)thin * NC; a.sFc = (long long)thin;
             qoc_chain_launch(N, true, a, gm.zthin, d.B * NC, s);
         }
-        if (!need_src && !d.state_transfer) {                // chunk-end costates E_c = P_{c+1}^H ... P_{NC-1}^H E_{NC-1}, log depth (unitary mode: the tree exists)
+        // chunk-end costates E_c = P_{c+1}^H ... P_{NC-1}^H E_{NC-1}, log depth (unitary mode: the tree exists)
+        if (!need_src && !d.state_transfer) {
             ScanArgs a = gm.scan;
             a.X0 = gm.Ebnd + (size_t)(NC - 1) * thin; a.sXb = (long long)thin * NC;
             a.Out = gm.Ebnd; a.sOb = (long long)thin * NC; a.sOc = (long long)thin;
             a.c0 = 0; a.nchains = NC - 1; a.suffix = 1;
             qoc_scan_launch(N, a, d.B, s);
-        } else {                                             // with sources the recursion is affine: E_{c-1} = P_c^dagger E_c + a_c, sequential
+        // with sources the recursion is affine: E_{c-1} = P_c^dagger E_c + a_c, sequential
+        } else {
             ChainArgs a;
             memset(&a, 0, sizeof a);
             const cplx* PcT = gm.L > 0 ? gm.PcT : gm.KT;
@@ -1094,13 +1193,15 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         {
             ChainArgs a = sw;
             a.X0 = gm.Ebnd; a.sXb = (long long)thin * NC; a.sXc = (long long)thin;
-            a.Out = gm.LamP + (long long)(S - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOc = (long long)S * gm.MV; a.sOs = -gm.MV; a.ldO = gm.ldW;
+            a.Out = gm.LamP + (long long)(S - 2) * gm.MV; a.sOb = (long long)N * gm.ldW; a.sOc = (long long)S * gm.MV; a.sOs = -gm.MV;
+                a.ldO = gm.ldW;
             a.store_initial = 1; a.len = S - 1;
             qoc_chain_launch(N, true, a, gm.zthin, d.B * NC, s);
         }
     } else {
     if (need_src && NC > 1) {                                // affine offsets a_c: every chunk run from a zero costate
-        hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)nullptr, N, S, NC);
+        hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP,
+            (const cplx*)nullptr, N, S, NC);
         qoc_gemm_bwd_sweep(gm, d, s, true, gm.Aoff);
     }
     // chunk-end costates: E_{c-1} = P_c^dagger E_c + a_c
@@ -1113,12 +1214,14 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         g.E = need_src ? gm.Aoff + (size_t)c * thin : nullptr;
         qoc_gemm_launch(gm, true, 0, g, s);
     }
-    hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)gm.Ebnd, N, S, NC);
+    hipLaunchKernelGGL(k_gemm_set_chunk_ends, dim3(gemm_grid((size_t)d.B * NC * thin)), dim3(256), 0, s, d, gm.LamP, (const cplx*)gm.Ebnd,
+        N, S, NC);
     qoc_gemm_bwd_sweep(gm, d, s, need_src, nullptr);
     }
     if (gm.persistent) {
         qoc_gemm_wide_gradient(gm, d, s, 0, gm.ldW);
-        hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, N / 32, gm.ldW, gm.MV);
+        hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, N / 32,
+            gm.ldW, gm.MV);
         return;
     }
     if (gm.wideW > 0) {
@@ -1131,9 +1234,11 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
         h.Kdim = N; h.tiles_m = N / 32; h.tiles_n = W / 32; h.batch = d.k; h.alpha = 1.0;
         for (int b = 0; b < d.B; ++b) {
             hipLaunchKernelGGL(k_gemm_to_wide, dim3(gemm_grid((size_t)d.steps * N * QOC_WIDE_MV)), dim3(256), 0, s, d,
-                               (const cplx*)(gm.interP + (size_t)b * gm.SP * thin), (const cplx*)(gm.LamP + (size_t)b * gm.SP * thin), gm.wideP, gm.wideL, N, W, d.steps);
+                               (const cplx*)(gm.interP + (size_t)b * gm.SP * thin), (const cplx*)(gm.LamP + (size_t)b * gm.SP * thin),
+                                   gm.wideP, gm.wideL, N, W, d.steps);
             qoc_gemm_launch(gm, false, 0, h, s);
-            hipLaunchKernelGGL(k_gemm_dot_wide, dim3((unsigned)(((size_t)d.k * d.steps + 3) / 4)), dim3(256), 0, s, d, b, (const cplx*)gm.wideC, (const cplx*)gm.wideL, N, W, 0, d.steps);
+            hipLaunchKernelGGL(k_gemm_dot_wide, dim3((unsigned)(((size_t)d.k * d.steps + 3) / 4)), dim3(256), 0, s, d, b,
+                (const cplx*)gm.wideC, (const cplx*)gm.wideL, N, W, 0, d.steps);
         }
         return;
     }
