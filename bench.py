@@ -237,7 +237,7 @@ def _time_engine(eng, params, warm, iters):
 
 def secondary_configs(device):
     """BASELINE.json configs 3 and 5 (SURVEY.md 8d "C3", "C5") through the same C ABI, AFTER the timed region, rank 0 at N = 1 only: one C3 trajectory
-    (the reference's own calling mode), 64 C3 control sets, one C5 iteration.  Per entry: ms per iteration of the batch, the plan AUTO resolved, the kernel
+    (the reference's own calling mode), 64 and 256 C3 control sets, one C5 iteration.  Per entry: ms per iteration of the batch, the plan AUTO resolved, the kernel
     the engine's hipEvent bracket names with its average time, and TFLOP/s on SURVEY 8d's algorithmic count (an algorithmic rate: the kernels execute
     fewer flops -- Paterson-Stockmeyer, three-multiplication complex products -- so this is NOT a utilisation)."""
     from quantum_optimal_control.core import hip_engine
@@ -267,6 +267,7 @@ def secondary_configs(device):
     f3 = c3['steps'] * 1 * 8.0 * 64 ** 2 * (3 * (T3 - 1) + 6)      # steps*m*8n^2*[3(T-1)+k]
     entry('c3_single_trajectory', c3, 1, 200, 400, f3)
     entry('c3_x64', c3, 64, 10, 30, f3)
+    entry('c3_x256', c3, 256, 5, 15, f3)
     c5 = synthetic_systems.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2)
     f5 = 2000 * ((5 - 1 + 3) + 1 + 2) * 8.0 * 512 ** 3 + 2000 * 8 * 8.0 * 512 ** 2   # SURVEY 8d unitary count
     entry('c5_single_trajectory', c5, 1, 1, 3, f5)

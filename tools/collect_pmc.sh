@@ -6,7 +6,7 @@ O=$R/gpurun_out/pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/$c -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $O/$c -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single --no-secondary --no-live-pmc > /dev/null 2>&1
   python $R/tools/rocpd_pmc_stats.py $(ls $O/$c/*/*_results.db | head -1) > $O/$c.txt 2>&1
   rm -rf $O/$c
 done
