@@ -37,7 +37,7 @@ import numpy as np  # noqa: E402
 N, K_OPS, SLICES, M, TAYLOR = 32, 4, 500, 8, (5, 3)
 SEEDS_PER_GPU = 64
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X public fp64 matrix (= vector) peak; MI355X_MICROARCH.md lists no fp64 row
-PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
 
 
 def build_problem():
