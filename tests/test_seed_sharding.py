@@ -495,3 +495,30 @@ def test_multi_gpu_selftest_world1_and_two_ranks_on_one_gpu():
                         str(_free_port()), script, '--transport', 'gloo', '--same-device'], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count('ALL STAGES OK') == 2 and r.stdout.count('(ii) GrapeSharded') == 2, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_line_n1_carries_secondary_configs_and_a_measured_traffic_figure():
+    """The driver's N = 1 form of bench.py: exactly ONE line on stdout (the pre-processing's prints go to stderr), a JSON object with the contract's
+    keys, `secondary` = BASELINE configs 3 and 5 through the same C ABI without an `error` entry, and roofline.traffic either measured in the run
+    (rocprofv3 on PATH) or taken from the committed profile -- the line says which."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--prewarm', '5', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    out = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in out, key
+    assert out['n_gpus'] == 1 and out['steps'] == 3 and out['dtype'] == 'f64' and out['vs_baseline'] is None
+    sec = out['secondary']
+    for name, sets in (('c3_single_trajectory', 1), ('c3_x64', 64), ('c3_x256', 256), ('c5_single_trajectory', 1)):
+        assert 'error' not in sec[name], sec[name]
+        assert sec[name]['control_sets'] == sets and sec[name]['ms_per_iteration'] > 0
+    assert sec['c3_x64']['plan'].get('taylor_chain') == 'packed' and sec['c3_single_trajectory']['plan'].get('route') == 'propagator'
+    roof = out['roofline']
+    assert roof['bound'] == 'mfma' and 0.3 < roof['frac'] < 1.0
+    assert roof['traffic'] is None or roof['traffic'] > 1e8
+    assert 'measured in this run' in roof['traffic_source'] or 'committed profile' in roof['traffic_source']
