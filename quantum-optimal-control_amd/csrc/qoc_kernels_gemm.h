@@ -385,7 +385,7 @@ struct QocGemm {
     // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled
     // on a second stream BESIDE the forward chain over the first asm_split slices (64 of 256 CUs, 1.4 TB/s), which then continues from its
     // state
-    hipStream_t aux = nullptr, chain_s = nullptr; hipEvent_t ev_ready = nullptr, ev_tail = nullptr, ev_fwd = nullptr, ev_p1 = nullptr;
+    hipStream_t aux = nullptr, chain_s = nullptr; hipEvent_t ev_ready = nullptr, ev_fwd = nullptr, ev_p1 = nullptr;
         int asm_split = 0, asm_tail_wgs = 512;
     // (round 5) the pulse is cut into asm_win.size() - 1 windows [asm_win[w], asm_win[w + 1]): window 0 is assembled in front of the chain,
     // window w >= 1 on the second stream while the chain walks window w - 1 (one chain launch per window, each continuing from the state
@@ -634,14 +634,14 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
                         hipEventDisableTiming) != hipSuccess)) { msg = "GEMM path: events could not be created"; return -2; }
                 }
             }
-            if ((!gm.aux && hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&gm.ev_ready,
-                hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&gm.ev_tail,
-                    hipEventDisableTiming) != hipSuccess) { msg = "GEMM path: second stream / events could not be created"; return -2; }
-            // on shared CUs: 512 long-running workgroups from 5/16 of the pulse on; on its own CUs the assembly runs unthrottled from 4/16
-            // on (C3 x 64, ms per
-            // iteration: masks of 80 / 96 / 112 / 128 CUs for the chains 6.31 / 6.31 / 6.25 / 6.34; shared CUs 6.40; 2048 workgroups 6.27 -
-            // 6.31; 3/16: 6.35 - 6.50)
+            if ((!gm.aux && hipStreamCreateWithFlags(&gm.aux, hipStreamNonBlocking) != hipSuccess) ||
+                hipEventCreateWithFlags(&gm.ev_ready, hipEventDisableTiming) != hipSuccess) {
+                msg = "GEMM path: second stream / events could not be created";
+                return -2;
+            }
+            // on shared CUs: 512 long-running workgroups from 5/16 of the pulse on; on its own CUs the assembly runs unthrottled from 4/16 on
+            // (C3 x 64, ms per iteration: masks of 80 / 96 / 112 / 128 CUs for the chains 6.31 / 6.31 / 6.25 / 6.34; shared CUs 6.40; 2048
+            // workgroups 6.27 - 6.31; 3/16: 6.35 - 6.50)
             gm.asm_split = ((gm.chain_s ? 4 : 5) * d.steps) / 16;
             gm.asm_tail_wgs = gm.chain_s ? 8192 : 512;
             if (const char* t = qoc_exp_env("QOC_ASM_TAIL_WGS")) gm.asm_tail_wgs = atoi(t) > 0 ? atoi(t) : gm.asm_tail_wgs;
@@ -672,7 +672,6 @@ static inline void qoc_gemm_teardown(QocGemm& gm) {
     if (gm.ev_fwd) { hipEventDestroy(gm.ev_fwd); gm.ev_fwd = nullptr; }
     if (gm.ev_p1) { hipEventDestroy(gm.ev_p1); gm.ev_p1 = nullptr; }
     if (gm.ev_ready) { hipEventDestroy(gm.ev_ready); gm.ev_ready = nullptr; }
-    if (gm.ev_tail) { hipEventDestroy(gm.ev_tail); gm.ev_tail = nullptr; }
     for (auto& ev : gm.ev_win) if (ev) { hipEventDestroy(ev); ev = nullptr; }
 }
 
