@@ -317,7 +317,11 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
             hipLaunchKernelGGL(k_band_spectrum, dim3((unsigned)(g1 > 8192 ? 8192 : g1)), dim3(256), 0, e->stream, d);
             hipLaunchKernelGGL(k_band_gradient, dim3((unsigned)(g2 > 8192 ? 8192 : g2)), dim3(256), 0, e->stream, d);
         }
-        if (plain) hipLaunchKernelGGL(k_finish_t<true>, dim3(d.B), fb, 0, e->stream, d, ap);
+        // seeds of 4097 .. 8192 (k, t) elements (C3: 6 x 1000) keep their Adam slots in registers too: eight elements per thread
+        const bool wide = d.k * d.steps > 4 * 1024 && d.k * d.steps <= 8 * 1024;
+        if (plain && wide) hipLaunchKernelGGL((k_finish_t<true, 8>), dim3(d.B), fb, 0, e->stream, d, ap);
+        else if (plain) hipLaunchKernelGGL(k_finish_t<true>, dim3(d.B), fb, 0, e->stream, d, ap);
+        else if (wide) hipLaunchKernelGGL((k_finish_t<false, 8>), dim3(d.B), fb, 0, e->stream, d, ap);
         else hipLaunchKernelGGL(k_finish_t<false>, dim3(d.B), fb, 0, e->stream, d, ap);
     }
     HIP_TRY(hipGetLastError());

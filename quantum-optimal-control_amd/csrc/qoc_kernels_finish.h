@@ -35,12 +35,12 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red /* 
 // dependent chain of global round trips for a single trajectory (17 us of a 133 us iteration): the Adam slots and everything else
 // an element needs are fetched up front and kept in registers (up to QF_E elements per thread), and the two reductions share their
 // barriers.
-#define QF_E 4
+#define QF_E 4            // the default; QFE = 8 instances of the stand-alone kernel for seeds of 4097 .. 8192 elements (C3: k = 6 x 1000 slices)
 // PLAIN: no pulse regulariser is configured -- the same kernel with those branches compiled out (a tenth of the code: for one
 // trajectory this single-workgroup kernel is bound by its instruction fetch and its chain of global round trips, not by arithmetic)
 // (a __device__ body: the latency mode of the MFMA path runs it in the last workgroup of its gradient kernel, qoc_mfma_latency.h)
 // LEVEL: 0 = no pulse regulariser (PLAIN), 1 = the local ones (amplitude, envelope, dwdt, d2wdt2) but no bandpass DFT, 2 = all.
-template <int LEVEL>
+template <int LEVEL, int QFE = QF_E>
 __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */) {
     // no implicit contraction into FMAs in here: the three flavours (and the fused / separate launches of the latency mode) must round
     // alike -- with a regulariser of weight zero they are bit-identical -- and which a*b + c the compiler contracts depends on the code
@@ -59,11 +59,11 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     const int adam_t0 = d.adam_t[b];
     double* am = d.adam_m + (size_t)b * ks;
     double* av = d.adam_v + (size_t)b * ks;
-    const bool in_regs = ks <= QF_E * (int)blockDim.x;             // every element of this thread fits its register file
-    double g_r[QF_E], m_r[QF_E], v_r[QF_E], b_r[QF_E];
+    const bool in_regs = ks <= QFE * (int)blockDim.x;             // every element of this thread fits its register file
+    double g_r[QFE], m_r[QFE], v_r[QFE], b_r[QFE];
     if (in_regs && ap.mode != 0) {
 #pragma unroll
-        for (int e = 0; e < QF_E; ++e) {
+        for (int e = 0; e < QFE; ++e) {
             const int o = threadIdx.x + e * blockDim.x;
             m_r[e] = o < ks ? am[o] : 0.0; v_r[e] = o < ks ? av[o] : 0.0;
         }
@@ -139,7 +139,7 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
         if (in_regs) {
             const int e = (o - (int)threadIdx.x) / (int)blockDim.x;
 #pragma unroll
-            for (int q = 0; q < QF_E; ++q) if (q == e) { g_r[q] = g; b_r[q] = bv; }
+            for (int q = 0; q < QFE; ++q) if (q == e) { g_r[q] = g; b_r[q] = bv; }
         }
     }
     block_sum2(reg, g2, red);
@@ -168,7 +168,7 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     const int tstep = adam_t0 + 1;
     if (in_regs) {
 #pragma unroll
-        for (int e = 0; e < QF_E; ++e) {
+        for (int e = 0; e < QFE; ++e) {
             const int o = threadIdx.x + e * blockDim.x;
             if (o < ks) {
                 const double g = g_r[e];
@@ -194,8 +194,8 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     if (threadIdx.x == 0) d.adam_t[b] = tstep;
 }
 
-template <bool PLAIN>
+template <bool PLAIN, int QFE = QF_E>
 __global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
     __shared__ double red[34];
-    finish_body<PLAIN ? 0 : 2>(d, ap, blockIdx.x, red);
+    finish_body<PLAIN ? 0 : 2, QFE>(d, ap, blockIdx.x, red);
 }

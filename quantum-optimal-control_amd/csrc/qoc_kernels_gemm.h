@@ -391,6 +391,8 @@ struct QocGemm {
     // window w >= 1 on the second stream while the chain walks window w - 1 (one chain launch per window, each continuing from the state
     // the previous one left in Aoff)
     std::vector<int> asm_win; std::vector<hipEvent_t> ev_win;
+    // persistent state transfer: Psibnd[b][0] = Psi0 and inter[b][0] = V never change -- k_gemm_chain_init ran at set-up, not per iteration
+    bool init_once = false;
     bool dpp_chain = false;   // direct route at N = 64, one state vector: k_gemm_taylor_chain_dpp (qoc_gemm_chain_dpp.h)
     bool antiherm = false;    // every generator anti-Hermitian (set by the engine before qoc_gemm_setup)
     // dpp_chain on anti-Hermitian generators: only the blocks on and below the block diagonal are assembled, stored and read
@@ -598,6 +600,16 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
                                          // (the columns beyond 8 steps)
                                          hipMemset(gm.wideL, 0, (size_t)N * gm.wideW * sizeof(cplx)) == hipSuccess;
     if (!zeroed) { msg = "GEMM path: clearing the work buffers failed"; return -2; }
+    if (gm.persistent && d.state_transfer && gm.ts_G <= 0) {   // the constant starts of the chains, once (one launch less per iteration)
+        const size_t work = ((size_t)d.B * N * QOC_TW + 255) / 256;
+        hipLaunchKernelGGL(k_gemm_chain_init, dim3((unsigned)(work > 65535 ? 65535 : work)), dim3(256), 0, 0, d, gm.Y0, gm.Psibnd, N, gm.NC,
+            0);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) {
+            msg = "GEMM path: the chain starts could not be set";
+            return -2;
+        }
+        gm.init_once = true;
+    }
     if (poly && gm.SP > d.steps) {
         hipLaunchKernelGGL(k_gemm_pad_identity, dim3(4096), dim3(256), 0, 0, gm.K, d.B, N, d.steps, gm.SP);
         if (hipGetLastError() != hipSuccess
@@ -639,7 +651,8 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
                 msg = "GEMM path: second stream / events could not be created";
                 return -2;
             }
-            // on shared CUs: 512 long-running workgroups from 5/16 of the pulse on; on its own CUs the assembly runs unthrottled from 4/16 on
+            // on shared CUs: 512 long-running workgroups from 5/16 of the pulse on; on its own CUs the assembly runs unthrottled from 4/16
+            // on
             // (C3 x 64, ms per iteration: masks of 80 / 96 / 112 / 128 CUs for the chains 6.31 / 6.31 / 6.25 / 6.34; shared CUs 6.40; 2048
             // workgroups 6.27 - 6.31; 3/16: 6.35 - 6.50)
             gm.asm_split = ((gm.chain_s ? 4 : 5) * d.steps) / 16;
@@ -966,7 +979,8 @@ static inline void qoc_gemm_forward(QocGemm& gm, const QocDev& d, hipStream_t s,
         NC = gm.NC;
     const size_t NN = (size_t)N * N, thin = (size_t)N * QOC_TW;
     const cplx* Pc = qoc_gemm_chunk_products(gm);                // [B][NC]
-    hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N, NC, xw);
+    if (!gm.init_once) hipLaunchKernelGGL(k_gemm_chain_init, dim3(gemm_grid((size_t)d.B * N * ld)), dim3(256), 0, s, d, gm.Y0, gm.Psibnd, N,
+        NC, xw);
     if (gm.direct) {
         ChainArgs a;
         memset(&a, 0, sizeof a);
