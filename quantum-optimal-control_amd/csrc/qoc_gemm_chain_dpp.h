@@ -38,13 +38,17 @@
 #define QOC_DPP_CMAC(J) do { if constexpr (NEG) QOC_DPP_CMAC_("-", J); else QOC_DPP_CMAC_("", J); } while (0)
 
 // partial sums of this wave's 16 columns: lane = row; (xr, xi) = the vector entry 16 w + (lane & 15); sa[J] = a[J].x + a[J].y
-template <bool NEG>
-__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], const double (&sa)[16], double xr, double xi, double& re, double& im) {
+// CW = the columns this wave multiplies (16, or fewer on the active columns of a padded problem: 10 / 12 / 14)
+template <bool NEG, int CW = 16>
+__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[CW], const double (&sa)[CW], double xr, double xi, double& re, double& im) {
     double k1 = 0.0, k2 = 0.0, k3 = 0.0;
     double xd = xi - xr, xs = xr + xi;
     asm volatile("s_nop 1" : "+v"(xr), "+v"(xd), "+v"(xs));          // VALU write of the entry -> DPP read: two wait states
     QOC_DPP_CMAC(0); QOC_DPP_CMAC(1); QOC_DPP_CMAC(2); QOC_DPP_CMAC(3); QOC_DPP_CMAC(4); QOC_DPP_CMAC(5); QOC_DPP_CMAC(6); QOC_DPP_CMAC(7);
-    QOC_DPP_CMAC(8); QOC_DPP_CMAC(9); QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); QOC_DPP_CMAC(14); QOC_DPP_CMAC(15);
+    QOC_DPP_CMAC(8); QOC_DPP_CMAC(9);
+    if constexpr (CW > 10) { QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); }
+    if constexpr (CW > 12) { QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); }
+    if constexpr (CW > 14) { QOC_DPP_CMAC(14); QOC_DPP_CMAC(15); }
     re = k1 - k3; im = k1 + k2;
 }
 #else
@@ -58,12 +62,15 @@ __device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], const double (
 #define QOC_DPP_CMAC(J) do { if constexpr (NEG) QOC_DPP_CMAC_("-", "-", "", "-", J); else QOC_DPP_CMAC_("", "", "-", "", J); } while (0)
 
 // partial sums of this wave's 16 columns: lane = row; (xr, xi) = the vector entry 16 w + (lane & 15)
-template <bool NEG>
-__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], const double (&)[16], double xr, double xi, double& re, double& im) {
+template <bool NEG, int CW = 16>
+__device__ __forceinline__ void dpp_matvec16(const cplx (&a)[CW], const double (&)[CW], double xr, double xi, double& re, double& im) {
     re = 0.0; im = 0.0;
     asm volatile("s_nop 1" : "+v"(xr), "+v"(xi));          // VALU write of the entry -> DPP read: two wait states
     QOC_DPP_CMAC(0); QOC_DPP_CMAC(1); QOC_DPP_CMAC(2); QOC_DPP_CMAC(3); QOC_DPP_CMAC(4); QOC_DPP_CMAC(5); QOC_DPP_CMAC(6); QOC_DPP_CMAC(7);
-    QOC_DPP_CMAC(8); QOC_DPP_CMAC(9); QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); QOC_DPP_CMAC(14); QOC_DPP_CMAC(15);
+    QOC_DPP_CMAC(8); QOC_DPP_CMAC(9);
+    if constexpr (CW > 10) { QOC_DPP_CMAC(10); QOC_DPP_CMAC(11); }
+    if constexpr (CW > 12) { QOC_DPP_CMAC(12); QOC_DPP_CMAC(13); }
+    if constexpr (CW > 14) { QOC_DPP_CMAC(14); QOC_DPP_CMAC(15); }
 }
 
 #endif
@@ -73,18 +80,23 @@ __device__ __forceinline__ void dpp_matvec16(const cplx (&a)[16], const double (
 #ifndef QOC_DPP_NO_STATIC
 #define QOC_DPP_NO_STATIC 0     // 1 (A/B builds): ten terms through the a.nterms >= 9 instance
 #endif
-template <bool NEG, int TS, bool PK>
+// CW (round 5): columns per wave.  16 = the whole padded matrix; 10 / 12 / 14 = a problem of at most 4 CW levels padded to 64 -- wave w owns the columns
+// CW w .. CW w + CW - 1 (the columns from n on are zero and the last waves simply have fewer non-zero ones), the lanes (lane & 15) < CW of every row of 16
+// lanes carry the vector entries of those columns, and a slice's generator is its first 4 CW columns: 256 CW entries (full column-major image only).
+template <bool NEG, int TS, bool PK, int CW = 16>
 __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b, cplx (*part)[4][64], const double* tinv) {
+    static_assert(CW == 16 || !PK, "the packed image has 16-column blocks");
+    static_assert(CW >= 10 && CW <= 16 && CW % 2 == 0, "columns per wave: 10, 12, 14 or 16");
     constexpr int N = 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int idx = 16 * w + (l & 15);                       // the vector entry this lane carries (replicated over the four rows of 16 lanes)
-    const bool owner = l < 16;
+    const int idx = min(CW * w + (l & 15), N - 1);           // the vector entry this lane carries (replicated over the four rows of 16 lanes; lanes beyond CW: unused)
+    const bool owner = l < CW;
     // scalar base + 32-bit lane offset: the loads take the saddr form, no 64-bit VALU address arithmetic between the FMAs of the chain
     const cplx* Kp = a.K + b * a.sKb;
     // full image: column 16 w + c of the transposed generator = + c * N; packed image: see the header (row block R = l >> 4 of block column w)
     const int rb = l >> 4, li = l & 15;
     const bool mirrored = PK && rb < w;
-    const unsigned koff = !PK ? (unsigned)(16 * w) * N + l
+    const unsigned koff = !PK ? (unsigned)(CW * w) * N + l
                           : (mirrored ? (unsigned)((w * (w + 1) / 2 + rb) * 256 + li * 16) : (unsigned)((rb * (rb + 1) / 2 + w) * 256 + li));
     const unsigned kstr = !PK ? (unsigned)N : (mirrored ? 1u : 16u);
     // entry c of this lane's run: the mask tells the compiler that the byte offset fits the 32-bit lane offset of the saddr load form
@@ -110,9 +122,9 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
     const cplx* const rd_part = &part[0][0][idx];
     int cur = 0;
     // one Taylor term: v <- (sign B) v, out += v / ii!
-    auto term = [&](const cplx (&k)[16], const double (&sk)[16], int ii, double inv, double& outr, double& outi) {
+    auto term = [&](const cplx (&k)[CW], const double (&sk)[CW], int ii, double inv, double& outr, double& outi) {
         double pr, pi;
-        dpp_matvec16<NEG>(k, sk, xv.x, xv.y, pr, pi);
+        dpp_matvec16<NEG, CW>(k, sk, xv.x, xv.y, pr, pi);
         my_part[cur * 256] = cmake(pr, pi);
         lds_barrier();
         const cplx s0 = rd_part[cur * 256], s1 = rd_part[cur * 256 + 64], s2 = rd_part[cur * 256 + 128], s3 = rd_part[cur * 256 + 192];
@@ -122,22 +134,21 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         cur ^= 1;                                                         // the next term writes the other buffer: one barrier per term
     };
     // slice j on the generator k with addend e; meanwhile the generator / addend of slice jn go into kn / en, two columns per term
-    auto step = [&](int j, cplx (&k)[16], const cplx& e, cplx (&kn)[16], cplx& en, int jn) {
+    auto step = [&](int j, cplx (&k)[CW], const cplx& e, cplx (&kn)[CW], cplx& en, int jn) {
         const int jc = min(jn, last);
         const cplx* kj = Kp + (long long)jc * a.sKs;
         en = Ep[(long long)jc * a.sEs];
         double outr = xv.x, outi = xv.y;
-        double sk[16];                                              // (three-multiplication form) re + im of the slice's generator entries
+        double sk[CW];                                              // (three-multiplication form) re + im of the slice's generator entries
         if constexpr (PK) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) k[c].x = __hiloint2double(__double2hiint(k[c].x) ^ flip, __double2loint(k[c].x));
+            for (int c = 0; c < CW; ++c) k[c].x = __hiloint2double(__double2hiint(k[c].x) ^ flip, __double2loint(k[c].x));
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) sk[c] = QOC_DPP_GAUSS ? k[c].x + k[c].y : 0.0;
+        for (int c = 0; c < CW; ++c) sk[c] = QOC_DPP_GAUSS ? k[c].x + k[c].y : 0.0;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            kn[2 * g] = kj[kidx(2 * g)];
-            kn[2 * g + 1] = kj[kidx(2 * g + 1)];
+            if (2 * g < CW) { kn[2 * g] = kj[kidx(2 * g)]; kn[2 * g + 1] = kj[kidx(2 * g + 1)]; }
             if (TS != 0 || g + 1 < nterms) term(k, sk, g + 1, inv_s[g + 1], outr, outi);
         }
         for (int ii = 9; ii < nterms; ++ii) {
@@ -150,16 +161,16 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
         if (owner2) O2[(long long)j * a.sO2s] = xv;
     };
     if (a.len > 0) {
-        cplx k0[16], k1[16], k2[16], e0, e1, e2;
+        cplx k0[CW], k1[CW], k2[CW], e0, e1, e2;
         {
             const cplx* kj = Kp;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) k0[c] = kj[kidx(c)];
+            for (int c = 0; c < CW; ++c) k0[c] = kj[kidx(c)];
             e0 = Ep[0];
             const int jc = min(1, last);
             kj = Kp + (long long)jc * a.sKs;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) k1[c] = kj[kidx(c)];
+            for (int c = 0; c < CW; ++c) k1[c] = kj[kidx(c)];
             e1 = Ep[(long long)jc * a.sEs];
         }
         int j = 0;
@@ -176,7 +187,7 @@ __device__ __forceinline__ void taylor_chain_dpp_body(const ChainArgs& a, int b,
 
 // Two argument sets in one launch, as k_gemm_taylor_chain: workgroups 0 .. nb0 - 1 run a0, the rest a1 (forward and z-free backward chain
 // side by side when there is no state regulariser)
-template <bool PK>
+template <bool PK, int CW = 16>
 __global__ void __launch_bounds__(256) k_gemm_taylor_chain_dpp(ChainArgs a0, ChainArgs a1, int nb0) {
     __shared__ __attribute__((aligned(16))) cplx part[2][4][64];
     __shared__ double tinv[64];
@@ -189,7 +200,8 @@ __global__ void __launch_bounds__(256) k_gemm_taylor_chain_dpp(ChainArgs a0, Cha
         tinv[threadIdx.x] = 1.0 / fact;
     }
     lds_barrier();
-    if (a.nterms == 10 && !QOC_DPP_NO_STATIC) { if (a.sign < 0.0) taylor_chain_dpp_body<true, 10, PK>(a, b, part, tinv); else taylor_chain_dpp_body<false, 10, PK>(a, b, part, tinv); }
-    else if (a.nterms >= 9) { if (a.sign < 0.0) taylor_chain_dpp_body<true, -1, PK>(a, b, part, tinv); else taylor_chain_dpp_body<false, -1, PK>(a, b, part, tinv); }
-    else if (a.sign < 0.0) taylor_chain_dpp_body<true, 0, PK>(a, b, part, tinv); else taylor_chain_dpp_body<false, 0, PK>(a, b, part, tinv);
+    // (the active-column instances CW < 16 have no body of their own for ten terms: the >= 9 one takes them)
+    if (a.nterms == 10 && !QOC_DPP_NO_STATIC && CW == 16) { if (a.sign < 0.0) taylor_chain_dpp_body<true, 10, PK, CW>(a, b, part, tinv); else taylor_chain_dpp_body<false, 10, PK, CW>(a, b, part, tinv); }
+    else if (a.nterms >= 9) { if (a.sign < 0.0) taylor_chain_dpp_body<true, -1, PK, CW>(a, b, part, tinv); else taylor_chain_dpp_body<false, -1, PK, CW>(a, b, part, tinv); }
+    else if (a.sign < 0.0) taylor_chain_dpp_body<true, 0, PK, CW>(a, b, part, tinv); else taylor_chain_dpp_body<false, 0, PK, CW>(a, b, part, tinv);
 }

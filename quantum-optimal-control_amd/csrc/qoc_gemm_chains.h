@@ -350,9 +350,13 @@ static inline void qoc_taylor_chain_launch_n(const ChainArgs& a0, const ChainArg
     else hipLaunchKernelGGL((k_gemm_taylor_chain<N, 8>), dim3(blocks), dim3(TaylorMap<N, 8>::type::THREADS), 0, s, a0, a1, nb0);
 }
 // dpp: 0 = k_gemm_taylor_chain, 1 = k_gemm_taylor_chain_dpp on full generators, 2 = on packed anti-Hermitian generators (qoc_gemm_chain_dpp.h),
-//      3 = k_gemm_taylor_chain_sq on packed [B | B^2] (qoc_gemm_chain_sq.h)
+//      3 = k_gemm_taylor_chain_sq on packed [B | B^2] (qoc_gemm_chain_sq.h), 10 / 12 / 14 = k_gemm_taylor_chain_dpp on the first 4 x 10 / 12 / 14
+//      columns of full generators (padded problems of at most 40 / 48 / 56 levels)
 static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros, int blocks, hipStream_t s, int dpp = 0) {
     if (!a.E) { a.E = zeros; a.sEb = a.sEc = a.sEs = 0; }
+    if (dpp == 10) { hipLaunchKernelGGL((k_gemm_taylor_chain_dpp<false, 10>), dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
+    if (dpp == 12) { hipLaunchKernelGGL((k_gemm_taylor_chain_dpp<false, 12>), dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
+    if (dpp == 14) { hipLaunchKernelGGL((k_gemm_taylor_chain_dpp<false, 14>), dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
     if (dpp == 3) { hipLaunchKernelGGL(k_gemm_taylor_chain_sq, dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
     if (dpp == 2) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<true>, dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
     if (dpp) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<false>, dim3(blocks), dim3(256), 0, s, a, a, blocks); return; }
@@ -362,6 +366,9 @@ static inline void qoc_taylor_chain_launch(int N, ChainArgs a, const cplx* zeros
 static inline void qoc_taylor_chain_launch2(int N, ChainArgs a0, ChainArgs a1, const cplx* zeros, int blocks, hipStream_t s, int dpp = 0) {
     if (!a0.E) { a0.E = zeros; a0.sEb = a0.sEc = a0.sEs = 0; }
     if (!a1.E) { a1.E = zeros; a1.sEb = a1.sEc = a1.sEs = 0; }
+    if (dpp == 10) { hipLaunchKernelGGL((k_gemm_taylor_chain_dpp<false, 10>), dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
+    if (dpp == 12) { hipLaunchKernelGGL((k_gemm_taylor_chain_dpp<false, 12>), dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
+    if (dpp == 14) { hipLaunchKernelGGL((k_gemm_taylor_chain_dpp<false, 14>), dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
     if (dpp == 3) { hipLaunchKernelGGL(k_gemm_taylor_chain_sq, dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
     if (dpp == 2) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<true>, dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }
     if (dpp) { hipLaunchKernelGGL(k_gemm_taylor_chain_dpp<false>, dim3(2 * blocks), dim3(256), 0, s, a0, a1, blocks); return; }

@@ -405,9 +405,16 @@ struct QocGemm {
     cplx* HsSQ = nullptr;     // sq_chain: the (k + 1)(k + 2) / 2 packed basis matrices of B^2
     double* sqc = nullptr;    // sq_chain: [B][SP][P] coefficient rows (k_gemm_sq_coefs)
     // what qoc_taylor_chain_launch takes
-    int dpp_mode() const { return dpp_chain ? (sq_chain ? 3 : (dpp_packed ? 2 : 1)) : 0; }
+    // dpp_chain on a padded problem (n <= 56 levels in N = 64) that is latency-bound (<= 128 control sets) or cannot be packed: columns per wave
+    // 10 / 12 / 14 instead of 16 -- only the first 4 dpp_cw columns of the full image are assembled, stored, read and multiplied.  16: off
+    int dpp_cw = 16;
+    int dpp_mode() const { return dpp_chain ? (sq_chain ? 3 : (dpp_packed ? 2 : (dpp_cw < 16 ? dpp_cw : 1))) : 0; }
     // entries of one slice
-    size_t gen_elems() const { return sq_chain ? (size_t)2 * QOC_DPP_PK_ELEMS : (dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : (size_t)N * N); }
+    size_t gen_elems() const {
+        if (sq_chain) return (size_t)2 * QOC_DPP_PK_ELEMS;
+        if (dpp_packed) return (size_t)QOC_DPP_PK_ELEMS;
+        return dpp_chain && dpp_cw < 16 ? (size_t)256 * dpp_cw : (size_t)N * N;
+    }
     cplx *A = nullptr, *P = nullptr, *K = nullptr, *A2 = nullptr;     // [B*SP][N][N]
     cplx* tree = nullptr;     // levels 1..L of the product tree: level l at tree_off[l], [B][SP >> l][N][N]
     size_t tree_off[8];
@@ -467,6 +474,14 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         const char* e = qoc_exp_env("QOC_CHAIN_DPP");            // experimental switch: 0 = the butterfly kernel k_gemm_taylor_chain
         gm.dpp_chain = gm.direct && N == 64 && gm.MV == 1 && !(e && e[0] == '0');
         gm.dpp_packed = gm.dpp_chain && gm.antiherm;
+        // padded problems: the FMAs of a mat-vec shrink with the columns a wave owns (48 -> 30 / 36 / 42 DPP FMAs), the bytes of a slice to 256 cw
+        // entries (cw = 10: the packed size); where 256 chains are bound by the generator bytes (> 128 control sets) the packed image stays ahead
+        // for cw > 10
+        gm.dpp_cw = 16;
+        if (gm.dpp_chain && d.n <= 56 && d.k <= 8 && gm.direct_variant != 2 && !qoc_exp_is("QOC_DPP_ACTIVE_COLUMNS", 0)) {
+            const int cw = d.n <= 40 ? 10 : (d.n <= 48 ? 12 : 14);
+            if (!gm.dpp_packed || d.Bplan <= 128 || cw == 10) { gm.dpp_cw = cw; gm.dpp_packed = false; }
+        }
         // opt-in only (qoc_config.variant = 2 with path = GEMM): measured SLOWER than the plain chain at C3 x 64 (7.98 against 5.83 ms per
         // iteration) -- see the header of qoc_gemm_chain_sq.h and profiles/EXPERIMENTS.md
         gm.sq_chain = gm.dpp_packed && qoc_sq_chain_terms_ok(d.T) && d.k >= 1 && d.k <= 8 && gm.direct_variant == 2;
@@ -545,11 +560,15 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         hipMemcpyHostToDevice) != hipSuccess) { msg = "GEMM path: upload failed"; return -2; }
     if (gm.dpp_chain) {
         std::vector<cplx> ht(hp.size());
-        const size_t ge = gm.dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : NN;       // entries per matrix of the (packed) stack
+        // entries per matrix of the stack: packed, the first 4 cw columns of the column-major image, or all of it
+        const size_t ge = gm.dpp_packed ? (size_t)QOC_DPP_PK_ELEMS : (gm.dpp_cw < 16 ? (size_t)256 * gm.dpp_cw : NN);
         for (int kk = 0; kk <= d.k; ++kk)
             for (int a = 0; a < N; ++a)
                 for (int c = 0; c < N; ++c) {
-                    if (!gm.dpp_packed) { ht[(size_t)kk * NN + (size_t)c * N + a] = hp[(size_t)kk * NN + (size_t)a * N + c]; continue; }
+                    if (!gm.dpp_packed) {
+                        if (c < 4 * gm.dpp_cw) ht[(size_t)kk * ge + (size_t)c * N + a] = hp[(size_t)kk * NN + (size_t)a * N + c];
+                        continue;
+                    }
                     // packed: blocks on and below the block diagonal, column-major inside a block
                     const int R = a >> 4, C = c >> 4;
                     if (R >= C) ht[(size_t)kk * ge + (size_t)(R * (R + 1) / 2 + C) * 256 + (size_t)(c & 15) * 16 + (a & 15)]
@@ -839,7 +858,7 @@ static inline void qoc_gemm_expm(QocGemm& gm, const QocDev& d, hipStream_t s) {
     const int deg = d.state_transfer ? d.T - 1 : d.T;            // matvecexp sums j < T (tensorflow_state.py:88-96)
     const int nsq = d.state_transfer ? 0 : d.s;
     if (gm.direct) {                                             // the chains apply the Taylor series themselves
-        const int nn = gm.dpp_packed ? QOC_DPP_PK_ELEMS : 0;
+        const int nn = gm.dpp_packed ? QOC_DPP_PK_ELEMS : (gm.dpp_chain && gm.dpp_cw < 16 ? 256 * gm.dpp_cw : 0);
         if (gm.sq_chain) {
             const int P = (d.k + 1) * (d.k + 2) / 2;
             hipLaunchKernelGGL(k_gemm_sq_coefs, dim3(gemm_grid((size_t)d.B * d.steps)), dim3(256), 0, s, d, gm.sqc, gm.SP, P);

@@ -70,7 +70,12 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         direct = direct_ok and (not hermitian or B >= (LIM['ST_DIRECT_N32'] if n <= 32 else ((LIM['ST_DIRECT_DPP_SRC'] if state_reg else LIM['ST_DIRECT_DPP']) if dpp else LIM['ST_DIRECT_N64'])))
         out = {'path': 'gemm', 'route': 'direct' if direct else 'propagator', 'chains': 'persistent' if (n <= 64 and m <= 8) else 'launches'}
         if direct:      # the kernel of the Taylor chains: the DPP chain at 33 .. 64 levels with one vector -- on packed generators when they are anti-Hermitian
-            out['taylor_chain'] = ('packed' if hermitian else 'full') if dpp else 'butterfly'
+            # ... except padded problems (n <= 56) of up to 128 control sets (or that cannot be packed): the first 40 / 48 / 56 columns of the full image
+            cols = 40 if n <= 40 else 48 if n <= 48 else 56 if n <= 56 else 64
+            if dpp and cols < 64 and (not hermitian or B <= 128 or cols == 40):
+                out['taylor_chain'] = 'columns%d' % cols
+            else:
+                out['taylor_chain'] = ('packed' if hermitian else 'full') if dpp else 'butterfly'
         return out
     mfma_ok = n <= 64 and m <= 16 and k <= 8 and 1 <= deg <= 22 and hermitian
     if st and not (mfma_ok and (n <= 32 or (n <= 48 and k <= 4))):
