@@ -965,7 +965,8 @@ int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
         // (k_gemm_taylor_chain_dpp), butterfly (k_gemm_taylor_chain)
         if (g.direct) snprintf(tmp + w, sizeof tmp - w, " taylor_chain=%s",
             g.sq_chain ? "squared" : g.dpp_packed ? "packed"
-            : g.dpp_chain ? (g.dpp_cw == 10 ? "columns40" : g.dpp_cw == 12 ? "columns48" : g.dpp_cw == 14 ? "columns56" : "full") : "butterfly");
+            : g.dpp_chain ? (g.dpp_cw == 10 ? "columns40" : g.dpp_cw == 12 ? "columns48" : g.dpp_cw == 14 ? "columns56" : "full")
+                : "butterfly");
     } else {
         snprintf(tmp, sizeof tmp, "path=%s", e->path == QOC_PATH_ST_FUSED ? "st_fused" : "generic");
     }

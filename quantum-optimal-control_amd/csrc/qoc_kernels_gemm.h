@@ -405,8 +405,9 @@ struct QocGemm {
     cplx* HsSQ = nullptr;     // sq_chain: the (k + 1)(k + 2) / 2 packed basis matrices of B^2
     double* sqc = nullptr;    // sq_chain: [B][SP][P] coefficient rows (k_gemm_sq_coefs)
     // what qoc_taylor_chain_launch takes
-    // dpp_chain on a padded problem (n <= 56 levels in N = 64) that is latency-bound (<= 128 control sets) or cannot be packed: columns per wave
-    // 10 / 12 / 14 instead of 16 -- only the first 4 dpp_cw columns of the full image are assembled, stored, read and multiplied.  16: off
+    // dpp_chain on a padded problem (n <= 56 levels in N = 64) that is latency-bound (<= 128 control sets) or cannot be packed: columns per
+    // wave 10 / 12 / 14 instead of 16 -- only the first 4 dpp_cw columns of the full image are assembled, stored, read and multiplied.  16:
+    // off
     int dpp_cw = 16;
     int dpp_mode() const { return dpp_chain ? (sq_chain ? 3 : (dpp_packed ? 2 : (dpp_cw < 16 ? dpp_cw : 1))) : 0; }
     // entries of one slice
@@ -474,9 +475,9 @@ static inline int qoc_gemm_setup(QocGemm& gm, const QocDev& d, const cplx* Hs_ho
         const char* e = qoc_exp_env("QOC_CHAIN_DPP");            // experimental switch: 0 = the butterfly kernel k_gemm_taylor_chain
         gm.dpp_chain = gm.direct && N == 64 && gm.MV == 1 && !(e && e[0] == '0');
         gm.dpp_packed = gm.dpp_chain && gm.antiherm;
-        // padded problems: the FMAs of a mat-vec shrink with the columns a wave owns (48 -> 30 / 36 / 42 DPP FMAs), the bytes of a slice to 256 cw
-        // entries (cw = 10: the packed size); where 256 chains are bound by the generator bytes (> 128 control sets) the packed image stays ahead
-        // for cw > 10
+        // padded problems: the FMAs of a mat-vec shrink with the columns a wave owns (48 -> 30 / 36 / 42 DPP FMAs), the bytes of a slice to
+        // 256 cw entries (cw = 10: the packed size); where 256 chains are bound by the generator bytes (> 128 control sets) the packed
+        // image stays ahead for cw > 10
         gm.dpp_cw = 16;
         if (gm.dpp_chain && d.n <= 56 && d.k <= 8 && gm.direct_variant != 2 && !qoc_exp_is("QOC_DPP_ACTIVE_COLUMNS", 0)) {
             const int cw = d.n <= 40 ? 10 : (d.n <= 48 ? 12 : 14);
