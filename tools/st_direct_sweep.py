@@ -15,7 +15,7 @@ for reg in (False, True):
         if not reg:
             c['reg_coeffs'] = {'dwdt': 1e-3}
         sp = oracle_system(c)
-        for B in (16, 24, 32, 48, 64, 96, 128):
+        for B in (16, 20, 24, 28, 32, 40, 48, 64, 128):
             mb, _ = ms(sp, B, 2, 0)
             gd, _ = ms(sp, B, 4, 0, chunks=1)
             gp, _ = ms(sp, B, 4, 0, chunks=2) if B <= 32 else (float('nan'), 0)
