@@ -38,7 +38,7 @@
 #define QOC_PLAN_ST_BIG_N32_MIN_LEVELS_SRC 28
 #define QOC_PLAN_ST_BIG_N64 48              // 32 < n <= 48 on the MFMA path
 #define QOC_PLAN_ST_BIG_N64_SRC 112
-#define QOC_PLAN_ST_BIG_DPP 32              // ... with ONE state vector (k_gemm_taylor_chain_dpp)
+#define QOC_PLAN_ST_BIG_DPP 20              // ... with ONE state vector (k_gemm_taylor_chain_dpp on the active columns: r05_st_direct_sweep.txt; 32 in round 4)
 #define QOC_PLAN_ST_BIG_DPP_SRC 48
 #define QOC_PLAN_ST_DIRECT_N32 112          // GEMM path: direct route instead of the propagator route from this many control sets on, n <= 32
 #define QOC_PLAN_ST_DIRECT_N64 48           // n > 32

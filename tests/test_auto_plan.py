@@ -101,7 +101,7 @@ def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, h
         return {'path': 'mfma', 'nt': nt, 'expm': 5, 'chunks': ceil_div(steps, L), 'sweeps': 'latency_sources' if state_reg else 'latency'}
     # rows "GEMM": 48 < n <= 64 below the NT = 4 batch sizes; 32 < n <= 48 with fewer than 8 control sets; 16 < n <= 32 with a few control sets
     # (2 / 3 / 5 / 7 for ceil(n / 4) = 5 / 6 / 7 / 8; 5 / 6 / 8 / 8 with a state regulariser; state transfer: 8 from 25 levels on); state transfer: the
-    # large batches that the direct Taylor chains win (n <= 32: from 112 control sets of more than 20 levels -- 28 with a state regulariser; n > 32: from 48 -- 112; with one state vector from 32 -- 48)
+    # large batches that the direct Taylor chains win (n <= 32: from 112 control sets of more than 20 levels -- 28 with a state regulariser; n > 32: from 48 -- 112; with one state vector from 20 -- 48: csrc/qoc_plan_limits.h)
     nt4_batch = n > 48 and ((k <= 4 and B >= LIM['NT4_MIN_SETS_K4']) or B >= LIM['NT4_MIN_SETS'])
     qa = ceil_div(n, 4)
     gemm_small = ({5: LIM['GEMM_SMALL_SRC_Q5'], 6: LIM['GEMM_SMALL_SRC_Q6']}.get(qa, LIM['GEMM_SMALL_SRC_Q78']) if state_reg
