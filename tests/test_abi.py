@@ -67,3 +67,26 @@ def test_grape_argument_errors_match_reference():
     with pytest.raises(ValueError, match='Initial guess has strength > max_amp'):
         Grape(H0 + np.eye(2), Hops, ['x'], np.eye(2), 1.0, 4, [0, 1], save=False, maxA=[0.1],
               initial_guess=np.ones((1, 4)), reg_coeffs={})
+
+
+def test_plan_limits_header_is_the_single_source_of_autos_numbers():
+    """csrc/qoc_plan_limits.h holds every measured number of AUTO's dispatch table as `#define QOC_PLAN_<NAME> <integer>`: the engine compiles them, tests/test_auto_plan.py
+    parses them.  Here (no GPU): the header parses, the engine sources contain no second copy of the latency-mode limits, and the limits are ordered as the table assumes."""
+    import re
+    csrc = os.path.join(ROOT, 'quantum-optimal-control_amd', 'csrc')
+    lim = {}
+    for line in open(os.path.join(csrc, 'qoc_plan_limits.h')):
+        mt = re.match(r'#define\s+QOC_PLAN_(\w+)\s+(\d+)\b', line)
+        if mt:
+            lim[mt.group(1)] = int(mt.group(2))
+    assert len(lim) >= 40
+    assert lim['LAT_WORK_SRC'] <= lim['LAT_WORK'] and lim['LAT_WORK_PER_STRIP'] < lim['LAT_WORK_PER_STRIP_SRC']
+    assert lim['NT4_MIN_SETS_K4'] <= lim['NT4_MIN_SETS'] and lim['ST_BIG_DPP'] <= lim['ST_BIG_DPP_SRC'] <= lim['ST_BIG_N64_SRC']
+    assert lim['ST_DIRECT_DPP'] <= lim['ST_DIRECT_DPP_SRC'] <= lim['ST_DIRECT_N64'] <= lim['ST_DIRECT_N32']
+    assert lim['CHUNK_ITEMS'] == 1024 and lim['CHUNKS_MAX'] <= lim['CHUNKS_MAX_NT2']
+    engine = open(os.path.join(csrc, 'qoc_engine.hip')).read()
+    assert '#include "qoc_plan_limits.h"' in engine
+    assert 'QOC_LATENCY_MAX_WORK' not in engine                                  # the old private macros are gone
+    for name in lim:
+        used = any(('QOC_PLAN_' + name) in open(os.path.join(csrc, f)).read() for f in ('qoc_engine.hip', 'qoc_mfma_backward.hip'))
+        assert used, 'QOC_PLAN_%s is defined but no engine source uses it' % name
