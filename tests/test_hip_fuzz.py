@@ -84,3 +84,53 @@ def test_random_problem_all_paths(seed):
         finally:
             eng.close()
     assert tried >= 2                                              # AUTO + generic at the very least
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_random_direct_route_one_vector(seed):
+    """The Taylor-chain family of the direct state-transfer route with ONE state vector at 33 .. 64 levels (csrc/qoc_gemm_chain_dpp.h, qoc_gemm_chain_sq.h):
+    random sizes (every class of active columns: <= 40 / 48 / 56 / 64), pulse lengths on every residue of the prefetch rotation, Taylor orders 1 .. 14,
+    Hermitian (packed / active-column images) and lossy (full image) drifts, with and without sources, 1 .. 3 control sets -- the default chain and, where
+    it applies, the squared-generator chain (variant 2), each against the oracle."""
+    import oracle.grape_oracle as go
+    rng = np.random.default_rng(77_000 + seed)
+    for attempt in range(16):
+        n = int(rng.integers(33, 65))
+        steps = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 23, 31, 40]))
+        T = int(rng.integers(1, 15))
+        k = int(rng.integers(1, 5))
+        c = cases.case_c3(n=n, k=k, steps=steps, taylor=(T, 0), seed=seed + 100 * attempt)
+        c['total_time'] = float(rng.uniform(0.1, 0.5)) * steps / 10.0
+        reg = {}
+        if rng.random() < 0.5:
+            f = rng.choice(n, size=2, replace=False)
+            reg['forbidden_coeff_list'] = [float(x) for x in rng.uniform(1, 5, size=2)]
+            reg['states_forbidden_list'] = [int(x) for x in f]
+        if rng.random() < 0.4:
+            reg['dwdt'] = float(rng.uniform(0.01, 0.2))
+        if rng.random() < 0.25:
+            reg['speed_up'] = float(rng.uniform(0.1, 0.8))
+        c['reg_coeffs'] = reg
+        lossy = rng.random() < 0.3
+        if lossy:
+            c['H0'] = c['H0'] + 0.05j * np.diag(np.arange(n) / n)            # generators no longer anti-Hermitian: the full image
+        sp = oracle_system(c)
+        us = go.evaluate(sp, sp.base0)['unitary_scale']
+        if np.isfinite(us) and abs(us) <= 1e6:
+            break
+    else:
+        raise AssertionError('no well-conditioned draw in 16 attempts from seed %d' % seed)
+    B = int(rng.choice([1, 2, 3]))
+    bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 * (i + 1) for i in range(B - 1)]
+    kinds = set()
+    for variant in (0, 2):
+        eng = make_engine(sp, n_seeds=B, path=4, chunks=1, variant=variant)
+        assert eng.plan.get('route') == 'direct', eng.plan
+        kinds.add(eng.plan.get('taylor_chain'))
+        eng.set_base(np.stack(bases))
+        check_eval(eng, sp, bases)
+        eng.close()
+    expect = 'full' if (lossy and n > 56) else ('columns%d' % (40 if n <= 40 else 48 if n <= 48 else 56) if n <= 56 else 'packed')
+    assert expect in kinds, (kinds, n, lossy)
+    if not lossy and 3 <= T <= 14:
+        assert 'squared' in kinds, (kinds, T)
