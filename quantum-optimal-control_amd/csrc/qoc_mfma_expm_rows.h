@@ -14,6 +14,7 @@
 // No re + im sums image: one v_add_f64 per block read (per 3 NT MFMAs).  NT = 3 double-buffers both images (155 KB) and needs one
 // LDS barrier per product; NT = 4 has room for one buffer each (135 KB): a second barrier before the images are overwritten.
 #pragma once
+#include <type_traits>
 #include "qoc_mfma_frag.h"
 #include "qoc_mfma_expm_stream.h"     // QLDS, lds_order()
 
@@ -70,14 +71,18 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
         QOC_LAP(1)
     };
     double a[NT][NT], bq[NT][NT], cq[NT][NT];
-    // acc = (image T[tcur]) * (strips S[scur]) for the own row strips
-    auto product = [&]() {
+    // acc = (image T[tcur]) * (strips S[scur]) for the own row strips.  SAME (round 5): the right operand IS the left one (A * A, the squarings): its strips
+    // are read from the T image -- strip (J, kb), lane (lk, lc) = T[column 16 J + lc][row 4 kb + lk], the conflict-free pattern of the strip stores -- and
+    // the publish before it skipped the 4 NT stores into S (a third of a slice's LDS stores)
+    auto product = [&](auto same) {
+        constexpr bool SAME = decltype(same)::value;
         const cplx* base = imgT + (size_t)tcur * TSZ + (lane >> 4) * QLDS + (lane & 3) + 4 * NT * w;
-        const cplx* sb = imgS + (size_t)scur * SSZ + lane;
+        const cplx* sb = SAME ? imgT + (size_t)tcur * TSZ + (lane & 15) * QLDS + (lane >> 4) : imgS + (size_t)scur * SSZ + lane;
+        auto strip = [&](int J, int kb) -> cplx { return SAME ? sb[16 * J * QLDS + 4 * kb] : sb[(J * QQS + kb) * 64]; };
         constexpr int NS = QA * NT, RA = 4, RS = RA + 1;                  // block steps (kb, r), kb-major, over the ACTIVE inner strips
         cplx vb[RS], rs[2][NT];
 #pragma unroll
-        for (int J = 0; J < NT; ++J) rs[0][J] = sb[(J * QQS) * 64];
+        for (int J = 0; J < NT; ++J) rs[0][J] = strip(J, 0);
 #pragma unroll
         for (int st = 0; st < RA; ++st) vb[st] = base[4 * (st / NT) * QLDS + 4 * (st % NT)];
 #pragma unroll
@@ -86,7 +91,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
             if (st + RA < NS) vb[(st + RA) % RS] = base[4 * ((st + RA) / NT) * QLDS + 4 * ((st + RA) % NT)];
             if (r == 0 && kb + 1 < QA) {
 #pragma unroll
-                for (int J = 0; J < NT; ++J) rs[(kb + 1) & 1][J] = sb[(J * QQS + kb + 1) * 64];
+                for (int J = 0; J < NT; ++J) rs[(kb + 1) & 1][J] = strip(J, kb + 1);
             }
             lds_order();
             const cplx v = vb[st % RS];
@@ -151,8 +156,8 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
         QOC_LAP(0)
         if (d.T >= 2) {
             // ---- A2 = A * A, polynomial start ----------------------------------------------------------------------------------
-            publish(A, true, A, true);
-            product();
+            publish(A, true, A, false);
+            product(std::true_type{});
             flipT(); flipS();
             Rows A2;
 #pragma unroll
@@ -167,7 +172,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
             if (nH > 0) {
                 for (int i = nH - 1; i >= 0; --i) {
                     publish(A2, i == nH - 1, X, true);                  // the left image of A2 stays through the Horner products
-                    product();
+                    product(std::false_type{});
                     flipS();
                     const double d0 = mf.invfact[2 * i], d1 = mf.invfact[2 * i + 1];
 #pragma unroll
@@ -188,8 +193,8 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
         }
         // ---- squarings -------------------------------------------------------------------------------------------------------
         for (int sq = 0; sq < d.s; ++sq) {
-            publish(X, true, X, true);
-            product();
+            publish(X, true, X, false);
+            product(std::true_type{});
             flipT(); flipS();
 #pragma unroll
             for (int r = 0; r < NT; ++r)
@@ -212,7 +217,7 @@ __global__ void __launch_bounds__(256, (NT == 3 && QOC_ROWS_NB3 == 1) ? 2 : 1) k
             }
         }
         if constexpr (SLICE) return;                                    // (uniform: no barrier follows)
-        product();
+        product(std::false_type{});
         flipT(); flipS();
 #pragma unroll
         for (int r = 0; r < NT; ++r)
