@@ -37,6 +37,10 @@ extern "C" {
 #define QOC_PATH_ST_FUSED 3    /* state transfer, n <= 64, m <= 4: register-resident generator, LDS vectors */
 #define QOC_PATH_GEMM 4        /* any n, m <= 32, both modes: fused LDS exponentials + product tree + persistent thin chains (n <= 64),
                                 * batched tiled MFMA GEMM launches above; state transfer by propagators or, with chunks = 1, directly */
+#define QOC_PATH_SMALL 5       /* n <= 16, m <= n, k <= 8, no bandpass, <= 4 forbidden levels: the WHOLE iteration (and qoc_iterate's / qoc_run_adam's loop)
+                                * inside one launch -- a row of 16 lanes per time slice, matrices column-per-lane in registers, plain complex-fp64 FMAs
+                                * (v_fmac_f64_dpp), product tree in LDS, several workgroups per control set for long pulses (csrc/qoc_small.h); AUTO for
+                                * one or a few control sets of the sizes the reference is used at (qubits, qutrits, two / three transmons) */
 
 typedef struct qoc_engine* qoc_handle;
 
@@ -63,7 +67,8 @@ typedef struct qoc_config {
     int32_t device;             /* HIP device ordinal */
     int32_t path;               /* QOC_PATH_* */
     int32_t chunks;             /* MFMA path: time chunks per seed (0 = auto).  GEMM path, state transfer: 1 = direct route (Taylor
-                                 * mat-vec chains, any H), > 1 = propagator route (needs anti-Hermitian generators), 0 = auto */
+                                 * mat-vec chains, any H), > 1 = propagator route (needs anti-Hermitian generators), 0 = auto.
+                                 * Workgroup-resident path (QOC_PATH_SMALL): workgroups per control set (0 = auto) */
     int32_t variant;            /* MFMA path, kernel family: 0 = auto, 1 = v_mfma_f64_16x16x4 everywhere (exponentials by one wave per
                                  * 16-column block of a chunk, one-wave sweeps), 2 = v_mfma_f64_4x4x4 exponentials by one wave per
                                  * 16-column block, 3 = v_mfma_f64_4x4x4 exponentials by one wave per chunk (n <= 32; n > 32: same

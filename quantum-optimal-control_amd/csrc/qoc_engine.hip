@@ -23,6 +23,7 @@
 #include "qoc_kernels_st.h"
 #include "qoc_kernels_gemm.h"
 #include "qoc_gemm_ts.h"
+#include "qoc_small.h"
 
 #include "qoc_plan_limits.h"            // the measured numbers of AUTO's table (QOC_PLAN_*), shared with tests/test_auto_plan.py
 // (QOC_PLAN_LAT_WORK = 4608 seeds x time slices: since the batch sweeps take their chunk boundaries and final_state from k_mfma_bnd_scan
@@ -64,6 +65,7 @@ struct qoc_engine {
     // mfma path
     QocMfma mf;
     QocGemm gm;
+    QocSmall sm;                // workgroup-resident path (csrc/qoc_small.h)
     bool evaluated = false;
     // QOC_DEBUG_SKIP (timing experiments only): 1 controls, 2 exponentials, 4 forward, 8 loss, 16 backward, 32 finish
     int skip_mask = 0;
@@ -235,7 +237,25 @@ static inline void launch_loss(const QocDev& d, hipStream_t s) {
     hipLaunchKernelGGL(k_loss, dim3(d.B), dim3(QOC_BLOCK), 0, s, d);
 }
 
+// workgroup-resident path: ONE launch runs `iters` loop iterations (or one evaluation / explicit step)
+static int enqueue_small(qoc_engine* e, const QocAdamDev& ap, int iters) {
+    QocDev d = e->d;
+    d.skip_done = ap.mode == 1 ? 1 : 0;
+    std::string msg;
+    TRY(prof_begin(e));
+    const int rc = qoc_small_launch(e->sm, d, ap, iters, e->stream, msg);
+    if (rc) return fail(rc == -1 ? QOC_ERR_INVALID : QOC_ERR_HIP, "workgroup-resident iteration: %s", msg.c_str());
+    TRY(prof_end(e));
+    HIP_TRY(hipGetLastError());
+    e->evaluated = true;
+    e->controls_ready = false;                 // the kernel forms its own controls from the variable; d.u / d.w hold those of the last evaluation
+    e->final_stale = true;                     // final_state, unitary_scale and inter_vecs are formed on read-back (refresh_small)
+    e->inter_stale = true;
+    return QOC_OK;
+}
+
 static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
+    if (e->path == QOC_PATH_SMALL) return enqueue_small(e, ap, 1);
     // the slice kernel of the n <= 32 latency mode forms its own controls; everybody else reads u / w: from k_controls, or -- when the Adam
     // tail of the previous iteration (or qoc_get_uks) has left them in u2 / w2 -- by swapping the two pairs (one launch less per iteration)
     const bool own_controls = e->path == QOC_PATH_MFMA && e->mf.latency && e->mf.NT == 2;
@@ -338,7 +358,36 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
 }
 
 // latency mode of the MFMA path: final_state and unitary_scale of the last evaluation, formed on demand
+// workgroup-resident path: inter_vecs, final_state and unitary_scale of the last evaluation, re-formed from its controls (d.u) by the any-size kernels
+static int refresh_small(qoc_engine* e) {
+    if (!e->final_stale && !e->inter_stale) return QOC_OK;
+    QocDev d = e->d;
+    d.skip_done = 0;
+    if (!d.state_transfer) {
+        hipLaunchKernelGGL(k_expm_generic, dim3(e->expm_grid), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->expm_scratch);
+        hipLaunchKernelGGL(k_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->K, e->seed_scratch);
+    } else {
+        hipLaunchKernelGGL(k_st_fwd_generic, dim3(d.B), dim3(QOC_BLOCK), 0, e->stream, d, e->seed_scratch);
+        qoc_mfma_uscale_state_transfer(d, e->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    e->final_stale = false;
+    e->inter_stale = false;
+    return QOC_OK;
+}
+
+// several workgroups per control set: a spin on another workgroup's flag that gave up (it never should) left garbage behind -- say so
+static int small_check(qoc_engine* e) {
+    if (e->path != QOC_PATH_SMALL || e->sm.G <= 1) return QOC_OK;
+    unsigned err = 0;
+    HIP_TRY(hipMemcpy(&err, e->sm.sd.err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) return fail(QOC_ERR_HIP, "workgroup-resident iteration: an exchange between the %d workgroups of a control set timed out (are all %d workgroups "
+        "resident?)", e->sm.G, e->sm.G * e->d.B);
+    return QOC_OK;
+}
+
 static int refresh_final(qoc_engine* e) {
+    if (e->path == QOC_PATH_SMALL) return refresh_small(e);
     if (!e->final_stale) return QOC_OK;
     // the boundary chain once more, with X beside the vectors
     if (e->path == QOC_PATH_GEMM) qoc_gemm_forward(e->gm, e->d, e->stream, true);
@@ -632,6 +681,9 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const AutoPlan plan = plan_for(d.Bplan);
     const bool latency_auto = plan.latency, gemm_direct = plan.gemm_direct;
     path = plan.path;
+    // n <= 16, one or a few control sets (the reference's own use) and small batches: the workgroup-resident iteration (csrc/qoc_small.h) --
+    // 5-20 us per iteration where the paths above pay 42-57 us of launches and dependent round trips whatever n (profiles/r06_small_n_latency.txt)
+    if (cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && cfg->chunks == 0 && cfg->time_shards < 1 && qoc_small_auto(d, antiherm)) path = QOC_PATH_SMALL;
     if (d.Bplan < B) {
         // a plan for FEWER control sets than the engine holds is legal (a rank that holds several shards of a planned batch keeps
         // bit-identity with them) but can cost a factor: say so once when it changes what AUTO would have picked for the resident batch
@@ -657,7 +709,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     if (path == QOC_PATH_GEMM && !gemm_ok)
         return bail(fail(QOC_ERR_INVALID,
             "qoc_create: GEMM path needs m <= 32 and, in state transfer, exactly anti-Hermitian generators or n <= 64, m <= 8 (m=%d)", m));
-    if (path < QOC_PATH_GENERIC || path > QOC_PATH_GEMM) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
+    if (path < QOC_PATH_GENERIC || path > QOC_PATH_SMALL) return bail(fail(QOC_ERR_INVALID, "qoc_create: unknown path %d", path));
     e->path = path;
     e->chunks = 1;
 #ifdef QOC_DEBUG     // timing experiments only (tools/skip_timing.py builds its own library with -DQOC_DEBUG): never in the product library
@@ -695,6 +747,23 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
                 return bail(fail(QOC_ERR_INVALID, "qoc_create: time_shards = %d needs %s (n=%d m=%d chunks=%d)", e->gm.ts_G, why.c_str(), n,
                     m, e->gm.NC));
             qoc_gemm_ts_ranges(e->gm, e->gm.ts_G);
+        }
+    } else if (path == QOC_PATH_SMALL) {
+        std::string msg;
+        rc = qoc_small_setup(e->sm, d, antiherm, cfg->chunks, e->allocs, msg);
+        if (rc) return bail(fail(rc == -1 ? QOC_ERR_INVALID : (rc == -3 ? QOC_ERR_NOMEM : QOC_ERR_HIP), "qoc_create: %s (n=%d m=%d k=%d T=%d steps=%d seeds=%d)",
+            msg.c_str(), n, m, k, d.T, steps, B));
+        e->chunks = e->sm.G;
+        // read-back (inter_vecs, final_state, unitary_scale) runs the any-size kernels on the controls of the last evaluation
+        if (!cfg->state_transfer) {
+            ALLOC(e->K, (size_t)B * steps * nn);
+            int grid = B * steps;
+            if (grid > 4096) grid = 4096;
+            e->expm_grid = grid;
+            ALLOC(e->expm_scratch, (size_t)grid * 3 * nn);
+            ALLOC(e->seed_scratch, (size_t)B * (2 * nn + 2 * nm));
+        } else {
+            ALLOC(e->seed_scratch, (size_t)B * (nn + 3 * nm));
         }
     } else if (!cfg->state_transfer) {
         ALLOC(e->K, (size_t)B * steps * nn);
@@ -764,6 +833,7 @@ int qoc_get_scalars(qoc_handle e, double* loss, double* reg_loss, double* grad_s
     const QocDev& d = e->d;
     if (unitary_scale) TRY(refresh_final(e));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    TRY(small_check(e));
     const size_t sz = (size_t)d.B * sizeof(double);
     if (loss) HIP_TRY(hipMemcpy(loss, d.loss, sz, hipMemcpyDeviceToHost));
     if (reg_loss) HIP_TRY(hipMemcpy(reg_loss, d.reg_loss, sz, hipMemcpyDeviceToHost));
@@ -805,6 +875,7 @@ int qoc_iterate(qoc_handle e, const qoc_adam_params* p, int32_t iters) {
     CHECK_H(e);
     if (!p) return fail(QOC_ERR_INVALID, "qoc_iterate: null params");
     const QocAdamDev ap = loop_params(p);
+    if (e->path == QOC_PATH_SMALL) return iters > 0 ? enqueue_small(e, ap, iters) : QOC_OK;   // the loop runs inside the launch
     for (int i = 0; i < iters; ++i) TRY(enqueue_iteration(e, ap));
     return QOC_OK;
 }
@@ -812,6 +883,7 @@ int qoc_iterate(qoc_handle e, const qoc_adam_params* p, int32_t iters) {
 int qoc_sync(qoc_handle e) {
     CHECK_H(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
+    TRY(small_check(e));
     return QOC_OK;
 }
 
@@ -827,9 +899,11 @@ int qoc_run_adam(qoc_handle e, const qoc_adam_params* p, int32_t* iterations_out
     while (true) {
         int burst = poll;
         if (launched + burst > budget) burst = (int)(budget - launched);
-        for (int i = 0; i < burst; ++i) TRY(enqueue_iteration(e, ap));
+        if (e->path == QOC_PATH_SMALL) TRY(enqueue_small(e, ap, burst));
+        else for (int i = 0; i < burst; ++i) TRY(enqueue_iteration(e, ap));
         launched += burst;
         HIP_TRY(hipStreamSynchronize(e->stream));
+        TRY(small_check(e));
         HIP_TRY(hipMemcpy(done.data(), e->d.done, e->d.B * sizeof(int), hipMemcpyDeviceToHost));
         bool all = true;
         for (int b = 0; b < e->d.B; ++b) all = all && done[b];
@@ -886,7 +960,8 @@ int qoc_get_inter_vecs(qoc_handle e, double* inter) {
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_inter_vecs: nothing evaluated yet");
     // one rank of a time-sharded run: its own slices, summed over the ranks (a collective)
     if (e->path == QOC_PATH_GEMM) TRY(qoc_gemm_ts_gather_inter(e->gm, e->d, e->stream));
-    if (e->inter_stale) {                                            // latency mode: the sweeps keep Psi_t in their own layout
+    if (e->path == QOC_PATH_SMALL) TRY(refresh_small(e));
+    else if (e->inter_stale) {                                       // latency mode: the sweeps keep Psi_t in their own layout
         qoc_mfma_unpack_inter(e->mf, e->d, e->stream);
         HIP_TRY(hipGetLastError());
         e->inter_stale = false;
@@ -909,7 +984,7 @@ int qoc_profile_read(qoc_handle e, const char** kernel_name, int64_t* launches, 
     CHECK_H(e);
     TRY(prof_collect(e));
     if (kernel_name)
-        *kernel_name = e->path == QOC_PATH_GEMM ? (e->gm.direct ? "k_gemm_taylor_chain (backward chain + sources + gradient products)"
+        *kernel_name = e->path == QOC_PATH_SMALL ? "k_small_iter (whole iterations)" : e->path == QOC_PATH_GEMM ? (e->gm.direct ? "k_gemm_taylor_chain (backward chain + sources + gradient products)"
                                                  : e->gm.N <= 64 ? "k_gemm_expm_fused (+ product tree)" : "k_zgemm_wg + k_zgemm32 (batched "
                                                      "matexp sequence)")
                        : e->path == QOC_PATH_MFMA ? (qoc_mfma_expm_variant(e->mf, e->d) == 7 ? "k_mfma_expm_rows"
@@ -967,6 +1042,9 @@ int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
             g.sq_chain ? "squared" : g.dpp_packed ? "packed"
             : g.dpp_chain ? (g.dpp_cw == 10 ? "columns40" : g.dpp_cw == 12 ? "columns48" : g.dpp_cw == 14 ? "columns56" : "full")
                 : "butterfly");
+    } else if (e->path == QOC_PATH_SMALL) {
+        snprintf(tmp, sizeof tmp, "path=small n_pad=%d rows=%d slices_per_row=%d workgroups=%d state_sources=%d lds_kb=%d", e->sm.N, e->sm.R, e->sm.L, e->sm.G,
+            e->sm.src ? 1 : 0, (int)((e->sm.lds_bytes + 1023) / 1024));
     } else {
         snprintf(tmp, sizeof tmp, "path=%s", e->path == QOC_PATH_ST_FUSED ? "st_fused" : "generic");
     }

@@ -1,0 +1,81 @@
+// qoc_small.h -- the workgroup-resident GRAPE iteration for small Hilbert spaces (n <= 16): QOC_PATH_SMALL.
+//
+// The reference's own users run qubits, qutrits and two / three transmons, ONE control set per Grape() call
+// (core/system_parameters.py:272-284; the n < 10 branch of Choose_exp_terms, :128-145, exists for these sizes; what runs is
+// core/tensorflow_state.py:25-46, 204-242, 323-356 and the loop of core/run_session.py:47-69).  At these sizes an iteration is a few
+// hundred kFLOP: what it costs is launches and round trips, not arithmetic.  Here the WHOLE iteration -- controls, per-slice exponentials,
+// the chain, costates, control gradients, regularisers, TF1 Adam and the stop rule -- runs inside ONE launch, and qoc_iterate(iters) /
+// qoc_run_adam loop inside that launch; nothing but the per-seed scalars and, at the end, the pulse goes back to HBM.
+//
+// Mapping (csrc/qoc_small_kernel.h): a ROW of 16 lanes owns L consecutive time slices; lane j of the row holds COLUMN j of every n x n matrix
+// in registers (plain complex fp64, no padding to an MFMA tile).  A product C = A B is n^2 complex MACs per lane on v_fmac_f64_dpp
+// row_newbcast:c -- A[r][c] reaches all lanes of the row from lane c's register r inside the FMA, so neither operand passes through LDS.  The
+// chain over the rows is a product TREE in LDS (log-depth up-sweep, then a barrier-free walk from the root down to each row's start state and
+// end costate); a pulse that does not fit one workgroup takes G workgroups per control set, which hand their subtree products and partial
+// sums to each other through write-through (sc1) stores, one flag per workgroup and epoch (cdna_hip_programming.md, Guideline 16).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "qoc_common.h"
+
+#define QOC_SMALL_NF 4          // forbidden levels the kernel keeps per time point (more: another path)
+#define QOC_SMALL_MAXG 32       // workgroups per control set
+#define QOC_SMALL_WG_BUDGET 128 // control sets x workgroups per control set that may spin on each other (all must be resident: 256 CUs)
+
+// LDS carve of one workgroup, in units of one complex (16 bytes); the same function runs on the host (launch size) and in the kernel.
+struct QocSmallLayout {
+    int hsc, hst, vfs, psi0, wd, wcol, v0, psin, treeM, treeU, treeO, treeOU, qS, wS, misc, total;
+};
+__host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, int k, int Gp, bool src) {
+    QocSmallLayout lo;
+    const int NN = N * N, RL = R * L;
+    int o = 0;
+    lo.hsc = o; o += (k + 1) * NN;                 // generators / 2^s, row-major (lane j reads [r][j])
+    lo.hst = o; o += k * NN;                       // control Hamiltonians transposed (lane a reads [c][a] = H_k[a][c])
+    lo.vfs = o; o += src ? QOC_SMALL_NF * N : 0;   // bras of the forbidden levels
+    lo.psi0 = o; o += NN;                          // U0 V (start of the chain), zero-padded to N columns
+    lo.wd = o; o += NN;                            // W^dagger, [j'][a]
+    lo.wcol = o; o += src ? NN : 0;                // W, [r][j]
+    lo.v0 = o; o += src ? NN : 0;                  // V = inter_vecs[0]
+    lo.psin = o; o += src ? NN : 0;                // Psi_N of this evaluation
+    lo.treeM = o; o += (2 * R - 1) * NN;           // product tree of the rows of this workgroup
+    lo.treeU = o; o += (2 * Gp - 1) * NN;          // ... of the workgroups of the control set (leaves: their subtree roots)
+    lo.treeO = o; o += src ? (2 * R - 1) * NN : 0; // offsets of the affine costate recursion, same shape
+    lo.treeOU = o; o += src ? (2 * Gp - 1) * NN : 0;
+    lo.qS = o; o += k * RL;                        // <Lambda_{t+1}, H_k Psi_{t+1}> of the own slices
+    lo.wS = o; o += (k * (RL + 4) + 1) / 2;        // sin(base) of the own slices + two halo slices either side (doubles)
+    lo.misc = o; o += 64;                          // reductions, scalars, inverse factorials (128 doubles)
+    lo.total = o;
+    return lo;
+}
+
+struct QocSmallDev {            // kernel argument beside QocDev / QocAdamDev
+    int iters;                  // loop iterations inside the launch
+    int G, Gp, LG;              // workgroups per control set, padded to a power of two, log2 of that
+    int Teff;                   // Taylor terms beyond the identity (unitary: T; state transfer: T - 1, no squarings)
+    double* xA;                 // [B][G][XA] exchange A: subtree product + halo controls
+    double* xB;                 // [B][G][XB] exchange B: partial sums of the tail (+ the overlap z from workgroup 0)
+    double* xS;                 // [B][G][XS] exchanges of the state-regulariser flow: partial sums, Psi_N, z_N; offsets
+    unsigned* flags;            // [B][G][4] one word per workgroup and exchange kind: the epoch it has published
+    unsigned* err;              // [1] set when a spin timed out (the host turns it into QOC_ERR_HIP)
+    int xa_stride, xb_stride, xs_stride;
+};
+
+struct QocSmall {
+    bool on = false;
+    int N = 0, L = 0, R = 0, G = 1;
+    bool src = false;
+    size_t lds_bytes = 0;
+    QocSmallDev sd{};
+    size_t flag_bytes = 0;
+};
+
+// host entry points (csrc/qoc_small.hip)
+bool qoc_small_supported(const QocDev& d, bool antiherm, int G_req, std::string* why);
+// picks (N, R, L, G) for the PLANNED batch (d.Bplan) and allocates the exchange buffers; G_req > 0 pins the workgroups per control set
+int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, std::vector<void*>& allocs, std::string& msg);
+// one launch = `iters` loop iterations (mode 1) or one evaluation / explicit step (modes 0, 2)
+int qoc_small_launch(QocSmall& sm, const QocDev& d, const QocAdamDev& ap, int iters, hipStream_t s, std::string& msg);
+// worth taking over the MFMA latency mode / batch kernels for this problem and planned batch? (AUTO; tests/test_auto_plan.py restates it)
+bool qoc_small_auto(const QocDev& d, bool antiherm);

@@ -1,0 +1,743 @@
+// qoc_small_kernel.h -- k_small_iter: the workgroup-resident GRAPE iteration for n <= 16 (see qoc_small.h for the mapping).
+//
+// Reference semantics, file:line under /root/reference/quantum_optimal_control/:
+//   controls u = maxA sin(base)                         core/tensorflow_state.py:176-178
+//   K_t = (sum_{j<=T} A^j / j!)^(2^s), A = H_t / 2^s    core/tensorflow_state.py:25-46    (state transfer: sum_{j<T} B^j / j!, :77-97)
+//   chain, inter vectors, fidelity                      core/tensorflow_state.py:204-242, 282-340
+//   first-order gradient Re<Lambda_{t+1}, H_k Psi_{t+1}> core/tensorflow_state.py:49-65 (:100-133 in state transfer)
+//   regularisers                                        core/regularization_functions.py:15-45, 69-95 (no bandpass on this path)
+//   grad_squared, TF1 Adam                              core/tensorflow_state.py:342-356
+//   stop rule, learning-rate schedule                   core/run_session.py:47-69
+//
+// Time points: Psi_tau = inter_vecs[tau], tau = 0 .. steps (inter_vecs[0] = V is a constant); slice t maps Psi_t to Psi_{t+1}.  The costate is
+// kept as its adjoint Y_tau = Lambda_tau^dagger (m x n), so that the backward recursion Y_tau = Y_{tau+1} K_tau + S_tau^dagger is a RIGHT
+// multiplication by the propagator in the very register layout the exponential leaves it in (column per lane); the control gradients are
+// the contraction of the rank-m product Psi_{t+1} Y_{t+1} with the transposed control Hamiltonians.
+#pragma once
+#include "qoc_small.h"
+
+namespace qsm {
+
+// QOC_SMALL_TIMING (tools/small_phase_timing.sh builds such a library; never the product): workgroup 0 prints the shader-clock stamps of its phase
+// boundaries in the last iteration of a launch
+#ifdef QOC_SMALL_TIMING
+#define QSM_STAMP(i) do { if (it == sd.iters - 1 && blockIdx.x == 0 && threadIdx.x == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QSM_STAMP(i) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+// ---- the product primitive -----------------------------------------------------------------------------------------------------------
+// o += bcast_C(a) * x:  (a.x, a.y) of lane C of this row of 16 lanes reaches every lane inside the FMA (row_newbcast, the one DPP control
+// double-precision VALU has on gfx90a+); four VOP2 instructions per complex MAC, two accumulator chains interleaved.
+template <int C>
+__device__ __forceinline__ void cmac_dpp(cplx& o, const cplx& a, const cplx& x) {
+    asm volatile("v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, -%3, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                 : "+v"(o.x), "+v"(o.y) : "v"(a.x), "v"(a.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+// o += conj(bcast_C(a) * x)
+template <int C>
+__device__ __forceinline__ void cmac_dpp_conj(cplx& o, const cplx& a, const cplx& x) {
+    asm volatile("v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, -%2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, -%3, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, -%3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                 : "+v"(o.x), "+v"(o.y) : "v"(a.x), "v"(a.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+
+template <int N, int C = 0>
+__device__ __forceinline__ void mulb_acc(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N]) {
+    if constexpr (C < N) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) cmac_dpp<C>(o[r], A[r], x[C]);
+        mulb_acc<N, C + 1>(A, x, o);
+    }
+}
+// every register a DPP read may touch is defined before the statement (the compiler cannot see the DPP read inside the asm); then the wait
+// states a DPP read needs behind a VALU write of its source (2) or of EXEC (5): the compiler pads neither for an asm statement
+template <int N>
+__device__ __forceinline__ void dpp_guard(cplx (&A)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm volatile("" : "+v"(A[r].x), "+v"(A[r].y));
+    asm volatile("s_nop 4");
+}
+// o[r] = sum_c A[r][c] x[c]: lane c holds A[.][c] (its column of the left operand), every lane its own column x of the right operand.
+// The same statement is  Y' = Y M  (A = the lanes' columns of Y, x = the own column of M)  and the rank-m product  Psi Y.
+template <int N>
+__device__ __forceinline__ void mulb(cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) o[r] = cmake(0.0, 0.0);
+    dpp_guard<N>(A);
+    mulb_acc<N>(A, x, o);
+}
+
+// sum over the 16 lanes of a row (result in every lane): DPP moves on the VALU (qoc_common.h: dpp_xor)
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_xor<1>(v); v += dpp_xor<2>(v); v += dpp_xor<4>(v); v += dpp_xor<8>(v);
+    return v;
+}
+
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+
+// ---- exchanges between the workgroups of one control set (Guideline 16: write-through payload, one flag word, relaxed polls) -----------
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store((gu64*)(unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((gu64*)(unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// every storing wave has drained its stores; then ONE lane raises the flag
+__device__ __forceinline__ void publish_flag(unsigned* flag, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store((gu32*)flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave 0: lane i polls the flag of workgroup i until it shows the epoch; bounded (a spin that never ends is a dead GPU box)
+__device__ __forceinline__ void wait_flags(unsigned* flags /* stride 4 words */, int G, unsigned epoch, unsigned* err) {
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        unsigned spins = __hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? (1u << 22) : 0u;   // an earlier spin gave up: do not wait again
+        while (true) {
+            const unsigned v = i < G ? __hip_atomic_load((gu32*)(flags + 4 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+            if (__all((int)(v - epoch) >= 0)) break;
+            if (++spins > (1u << 22)) { if (i == 0) __hip_atomic_store((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+}
+
+template <int THREADS>
+__device__ __forceinline__ void wg_sum2(double& a, double& b, double* red /* 2 x waves doubles */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { red[2 * wid] = a; red[2 * wid + 1] = b; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; ++i) { ta += red[2 * i]; tb += red[2 * i + 1]; }
+    a = ta; b = tb;
+}
+
+// misc area (doubles)
+enum { M_RED = 0, M_Z = 34, M_SUM = 36, M_ZN = 40, M_INVF = 48, M_MAXA = 80, M_FA = 88, M_DEC = 92 };
+
+// ---- state regularisers at one time point (core/regularization_functions.py:69-95) ----------------------------------------------------
+// P = the lane's column of Psi_tau.  sf[f] = 2 a_f |phi|^2 phi with phi = <level f | Psi_tau[:, j]> (bare or dressed: VfS holds the bra);
+// returns the lane's share of sum_f a_f |phi|^4 / 2; ztau = <W, Psi_tau> (every lane of the row) when asked for.
+template <int N>
+__device__ __forceinline__ double state_terms(const cplx (&P)[N], const cplx* VfS, const double* faS, int nforb, const cplx* Wcol, int jj,
+                                              bool lane_m, bool want_z, cplx (&sf)[QOC_SMALL_NF], cplx& ztau) {
+    double val = 0.0;
+#pragma unroll
+    for (int f = 0; f < QOC_SMALL_NF; ++f) {
+        sf[f] = cmake(0.0, 0.0);
+        if (f < nforb) {
+            cplx phi = cmake(0.0, 0.0);
+#pragma unroll
+            for (int c = 0; c < N; ++c) cfma_conj(phi, VfS[f * N + c], P[c]);
+            const double pop = phi.x * phi.x + phi.y * phi.y, a = faS[f];
+            if (lane_m) { sf[f] = cscale(phi, 2.0 * a * pop); val += a * 0.5 * pop * pop; }
+        }
+    }
+    ztau = cmake(0.0, 0.0);
+    if (want_z) {
+        cplx zp = cmake(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < N; ++r) cfma_conj(zp, Wcol[r * N + jj], P[r]);
+        if (!lane_m) zp = cmake(0.0, 0.0);
+        ztau = cmake(row_sum16(zp.x), row_sum16(zp.y));
+    }
+    return val;
+}
+// Y += S_tau^dagger: lane a holds column a of Y (entries j' < m).  Forbidden levels: S[a][j'] = Vf[a] sf[j'] (sf lives in lane j');
+// speed_up: S[a][j'] = coef z_tau W[a][j'].
+template <int N, int JP = 0>
+__device__ __forceinline__ void add_forbidden(cplx (&Y)[N], cplx& s, const cplx& vfa) {
+    if constexpr (JP < N) {
+        cmac_dpp_conj<JP>(Y[JP], s, vfa);
+        add_forbidden<N, JP + 1>(Y, s, vfa);
+    }
+}
+template <int N>
+__device__ __forceinline__ void add_sources(cplx (&Y)[N], cplx (&sf)[QOC_SMALL_NF], const cplx* VfS, int nforb, int jj, bool has_speed,
+                                            double coef, const cplx& ztau, const cplx* Wd) {
+#pragma unroll
+    for (int f = 0; f < QOC_SMALL_NF; ++f) {
+        if (f < nforb) {
+            const cplx vfa = VfS[f * N + jj];
+            asm volatile("" : "+v"(sf[f].x), "+v"(sf[f].y));
+            asm volatile("s_nop 4");
+            add_forbidden<N>(Y, sf[f], vfa);
+        }
+    }
+    if (has_speed) {
+        const cplx cz = cmake(coef * ztau.x, -coef * ztau.y);                // coef conj(z_tau)
+#pragma unroll
+        for (int jp = 0; jp < N; ++jp) cfma(Y[jp], cz, Wd[jp * N + jj]);
+    }
+}
+
+// =========================================================================================================================================
+template <int N, int L, int R, bool SRC>
+__global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, QocSmallDev sd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int THREADS = R * 16, RL = R * L, LR = ilog2c(R), NN = N * N;
+    constexpr int QE = (8 * RL + THREADS - 1) / THREADS;            // (k, t) elements per thread, k <= 8
+    const int tid = threadIdx.x, row = tid >> 4, j = tid & 15;
+    const int G = sd.G, g = blockIdx.x % G, b = blockIdx.x / G;
+    const bool act = j < N;
+    const int jj = act ? j : N - 1;
+    const int n = d.n, m = d.m, k = d.k, steps = d.steps, nforb = SRC ? d.n_forb : 0;
+    const bool lane_m = j < m;
+    const int grow = g * R + row, t0 = grow * L, LTOT = LR + sd.LG;
+    const bool multi = G > 1;
+    const bool has_speed = SRC && d.has_speed;
+
+    const QocSmallLayout lo = qoc_small_layout(N, R, L, k, sd.Gp, SRC);
+    cplx* S = (cplx*)smem;
+    cplx* HsC = S + lo.hsc; cplx* HsT = S + lo.hst; cplx* VfS = S + lo.vfs; cplx* Psi0c = S + lo.psi0; cplx* Wd = S + lo.wd;
+    cplx* Wcol = S + lo.wcol; cplx* V0c = S + lo.v0; cplx* PsiN = S + lo.psin;
+    cplx* treeM = S + lo.treeM; cplx* treeU = S + lo.treeU; cplx* treeO = S + lo.treeO; cplx* treeOU = S + lo.treeOU;
+    cplx* qS = S + lo.qS; double* wS = (double*)(S + lo.wS); double* misc = (double*)(S + lo.misc);
+    auto Wv = [&](int kk, int tl) -> double& { return wS[kk * (RL + 4) + 2 + tl]; };
+    // node (level, index) of the two trees: levels below LR live in this workgroup (index relative to its first node of the level)
+    auto lnode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * R - (2 * R >> l)) + i) * NN; };
+    auto unode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * sd.Gp - (2 * sd.Gp >> l)) + i) * NN; };
+
+    // ---- prologue: constants to LDS -------------------------------------------------------------------------------------------------------
+    const int it_start = d.iters[b], adam_t_start = d.adam_t[b];
+    if (ap.mode == 1 && d.done[b]) return;                      // a finished control set keeps its last evaluation (uniform over its workgroups)
+    {
+        const double sc = 1.0 / (double)(1 << d.s);
+        for (int o = tid; o < (k + 1) * NN; o += THREADS) {
+            const int kk = o / NN, rc = o - kk * NN, r = rc / N, c = rc - r * N;
+            cplx v = cmake(0.0, 0.0);
+            if (r < n && c < n) v = d.Hs[(size_t)kk * n * n + r * n + c];
+            HsC[o] = cscale(v, sc);
+            if (kk >= 1) HsT[(kk - 1) * NN + c * N + r] = v;
+        }
+        for (int o = tid; o < NN; o += THREADS) {
+            const int r = o / N, c = o - r * N;                 // [r][lane c]
+            const bool in = r < n && c < m;
+            Psi0c[o] = in ? d.Psi0[r * m + c] : cmake(0.0, 0.0);
+            Wd[c * N + r] = in ? cconj(d.W[r * m + c]) : cmake(0.0, 0.0);      // Wd[j'][a] = conj(W[a][j'])
+            if (SRC) { Wcol[o] = in ? d.W[r * m + c] : cmake(0.0, 0.0); V0c[o] = in ? d.V[r * m + c] : cmake(0.0, 0.0); }
+        }
+        if (SRC) {
+            for (int o = tid; o < QOC_SMALL_NF * N; o += THREADS) {
+                const int f = o / N, c = o - f * N;
+                cplx v = cmake(0.0, 0.0);
+                if (f < nforb && c < n) {
+                    const int st = d.forb_state[f];
+                    v = d.forbid_dressed ? d.Vs[c * n + st] : cmake(c == st ? 1.0 : 0.0, 0.0);
+                }
+                VfS[o] = v;
+            }
+            if (tid < QOC_SMALL_NF) misc[M_FA + tid] = tid < nforb ? d.forb_a[tid] : 0.0;
+        }
+        if (tid < 32) { double f = 1.0; for (int i = 2; i <= tid; ++i) f *= (double)i; misc[M_INVF + tid] = 1.0 / f; }
+        if (tid < 8) misc[M_MAXA + tid] = tid < k ? d.maxA[tid] : 0.0;
+        for (int o = tid; o < k * (RL + 4); o += THREADS) wS[o] = 0.0;
+    }
+    __syncthreads();
+    // the (control, slice) elements of this thread: variable and Adam slots stay in registers for the whole launch
+    double e_base[QE], e_m[QE], e_v[QE], e_w[QE], e_g[QE];
+    int e_kk[QE], e_tl[QE];
+    bool e_ok[QE];
+#pragma unroll
+    for (int e = 0; e < QE; ++e) {
+        const int o = tid + e * THREADS, kk = o / RL, tl = o - kk * RL, t = g * RL + tl;
+        e_kk[e] = kk; e_tl[e] = tl; e_ok[e] = kk < k && t < steps;
+        e_base[e] = 0.0; e_m[e] = 0.0; e_v[e] = 0.0; e_w[e] = 0.0; e_g[e] = 0.0;
+        if (e_ok[e]) {
+            const size_t go = ((size_t)b * k + kk) * steps + t;
+            e_base[e] = d.base[go];
+            if (ap.mode != 0) { e_m[e] = d.adam_m[go]; e_v[e] = d.adam_v[go]; }
+            e_w[e] = sin(e_base[e]);
+            Wv(kk, tl) = e_w[e];
+        }
+    }
+    __syncthreads();
+
+    int it_count = it_start, adam_t = adam_t_start, done_now = 0;
+    double out_loss = 0.0, out_reg = 0.0, out_g2 = 0.0, out_regstate = 0.0;
+    cplx out_z = cmake(0.0, 0.0);
+    const double mm = (double)m * (double)m, c0 = -2.0 / mm;
+    double* xA = sd.xA + ((size_t)b * G) * sd.xa_stride;
+    double* xB = sd.xB + ((size_t)b * G) * sd.xb_stride;
+    double* xS = sd.xS + ((size_t)b * G) * sd.xs_stride;
+    unsigned* flags = sd.flags + ((size_t)b * G) * 4;
+
+#ifdef QOC_SMALL_TIMING
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (int it = 0; it < sd.iters; ++it) {
+        const unsigned epoch = (unsigned)it + 1u;
+        QSM_STAMP(0);
+        // ---- P1: exponentials of the own slices, kept in registers; product of the row --------------------------------------------------
+        cplx Kr[L][N];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int t = t0 + i;
+#pragma unroll
+            for (int r = 0; r < N; ++r) Kr[i][r] = cmake(r == j ? 1.0 : 0.0, 0.0);
+            if (t < steps && sd.Teff >= 1) {
+                cplx A[N], Hn[N], acc[N];
+                const int tl = row * L + i;
+#pragma unroll
+                for (int r = 0; r < N; ++r) A[r] = HsC[r * N + jj];
+                for (int kk = 0; kk < k; ++kk) {
+                    const double u = misc[M_MAXA + kk] * Wv(kk, tl);
+                    const cplx* Hk = HsC + (kk + 1) * NN;
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { const cplx h = Hk[r * N + jj]; A[r].x = fma(u, h.x, A[r].x); A[r].y = fma(u, h.y, A[r].y); }
+                }
+#pragma unroll
+                for (int r = 0; r < N; ++r) { Hn[r] = A[r]; Kr[i][r] = cadd(Kr[i][r], A[r]); }
+#pragma unroll 1
+                for (int ii = 2; ii <= sd.Teff; ++ii) {                          // H_n = H H_n ; matexp += H_n / ii!      tensorflow_state.py:38-41
+                    mulb<N>(A, Hn, acc);
+                    const double f = misc[M_INVF + ii];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { Hn[r] = acc[r]; Kr[i][r].x = fma(acc[r].x, f, Kr[i][r].x); Kr[i][r].y = fma(acc[r].y, f, Kr[i][r].y); }
+                }
+#pragma unroll 1
+                for (int q = 0; q < d.s; ++q) {                                   // squarings                              tensorflow_state.py:43-44
+                    mulb<N>(Kr[i], Kr[i], acc);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) Kr[i][r] = acc[r];
+                }
+            }
+        }
+        QSM_STAMP(1);
+        cplx Mown[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) Mown[r] = Kr[0][r];
+#pragma unroll
+        for (int i = 1; i < L; ++i) {
+            cplx acc[N];
+            mulb<N>(Kr[i], Mown, acc);
+#pragma unroll
+            for (int r = 0; r < N; ++r) Mown[r] = acc[r];
+        }
+        if (act) {
+            cplx* nd = lnode(treeM, 0, row);
+#pragma unroll
+            for (int r = 0; r < N; ++r) nd[r * N + j] = Mown[r];
+        }
+        // ---- P2: up-sweep of the product tree (later times on the left) ---------------------------------------------------------------------
+#pragma unroll 1
+        for (int l = 1; l <= LR; ++l) {
+            __syncthreads();
+            if ((row & ((1 << l) - 1)) == 0) {
+                const cplx* rn = lnode(treeM, l - 1, (row >> (l - 1)) + 1);
+                cplx Ar[N], acc[N];
+#pragma unroll
+                for (int r = 0; r < N; ++r) Ar[r] = rn[r * N + jj];
+                mulb<N>(Ar, Mown, acc);
+                cplx* nd = lnode(treeM, l, row >> l);
+#pragma unroll
+                for (int r = 0; r < N; ++r) { Mown[r] = acc[r]; if (act) nd[r * N + j] = acc[r]; }
+            }
+        }
+        __syncthreads();
+        if (multi) {
+            // exchange A: the subtree product of every workgroup of the control set + the halo controls of the neighbours
+            const double* root = (const double*)lnode(treeM, LR, 0);
+            double* mine = xA + (size_t)g * sd.xa_stride;
+            for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + o, root[o]);
+            if (tid < 4 * k) { const int kk = tid >> 2, h = tid & 3; st_sc1(mine + 2 * NN + tid, Wv(kk, h < 2 ? h : RL - 4 + h)); }
+            publish_flag(flags + 4 * g + 0, epoch);
+            wait_flags(flags + 0, G, epoch, sd.err);
+            for (int o = tid; o < sd.Gp * 2 * NN; o += THREADS) {
+                const int gi = o / (2 * NN), w = o - gi * 2 * NN;
+                double v;
+                if (gi < G) v = ld_sc1(xA + (size_t)gi * sd.xa_stride + w);
+                else { const int e = w >> 1; v = ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; }     // identity leaves pad the tree
+                ((double*)unode(treeU, 0, 0))[o] = v;
+            }
+            if (tid < 4 * k) {                                    // halo: the neighbours' controls of this evaluation
+                const int kk = tid >> 2, h = tid & 3;
+                const int src_g = h < 2 ? g - 1 : g + 1, tl = h < 2 ? h - 2 : RL + (h - 2), t = g * RL + tl;
+                if (src_g >= 0 && src_g < G && t >= 0 && t < steps)
+                    Wv(kk, tl) = ld_sc1(xA + (size_t)src_g * sd.xa_stride + 2 * NN + 4 * kk + (h < 2 ? h + 2 : h - 2));
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int l = 1; l <= sd.LG; ++l) {
+                if (row < (sd.Gp >> l)) {
+                    const cplx* rn = unode(treeU, l - 1, 2 * row + 1);
+                    const cplx* ln = unode(treeU, l - 1, 2 * row);
+                    cplx Ar[N], xl[N], acc[N];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { Ar[r] = rn[r * N + jj]; xl[r] = ln[r * N + jj]; }
+                    mulb<N>(Ar, xl, acc);
+                    cplx* nd = unode(treeU, l, row);
+                    if (act) {
+#pragma unroll
+                        for (int r = 0; r < N; ++r) nd[r * N + j] = acc[r];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        QSM_STAMP(2);
+        // sibling of this row's ancestor at level l - 1 (global level numbering), and which side the row hangs on
+        auto sibling = [&](cplx* loc, cplx* upp, int l, int& bit) -> const cplx* {
+            bit = (grow >> (l - 1)) & 1;
+            const int sib = ((grow >> l) << 1) + (1 - bit);
+            return (l - 1 < LR) ? lnode(loc, l - 1, sib - ((g * R) >> (l - 1))) : unode(upp, l - 1 - LR, sib);
+        };
+
+        // ---- P3 / P4: start state and end costate of the row by a walk from the root; forward and backward sweep over the own slices --------
+        cplx Phi[N], Y[N], Ps[L][N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) { Phi[r] = Psi0c[r * N + jj]; Y[r] = Wd[r * N + jj]; }
+        cplx zfin = cmake(0.0, 0.0);
+        double reg_state = 0.0, coef = 0.0;
+        if constexpr (!SRC) {
+            // z-free costate: Lambda_tau = -(2 / m^2) z Lambda'_tau with Lambda'_N = W; one product per level -- the row is either the right
+            // child (its start state passes the left sibling) or the left one (its end costate passes the right sibling)
+#pragma unroll 1
+            for (int l = LTOT; l >= 1; --l) {
+                int bit;
+                const cplx* sn = sibling(treeM, treeU, l, bit);
+                cplx Ms[N], As[N], xs[N], acc[N];
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    Ms[r] = sn[r * N + jj];
+                    As[r] = bit ? Ms[r] : Y[r];
+                    xs[r] = bit ? Phi[r] : Ms[r];
+                }
+                mulb<N>(As, xs, acc);
+#pragma unroll
+                for (int r = 0; r < N; ++r) { if (bit) Phi[r] = acc[r]; else Y[r] = acc[r]; }
+            }
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                if (i == 0) mulb<N>(Kr[0], Phi, Ps[0]); else mulb<N>(Kr[i], Ps[i - 1], Ps[i]);
+            }
+        } else {
+            // ---- state regularisers: true costate.  Forward first (values, z_tau), then the affine offsets, then the walk for the costate ----
+#pragma unroll 1
+            for (int l = LTOT; l >= 1; --l) {
+                int bit;
+                const cplx* sn = sibling(treeM, treeU, l, bit);
+                if (bit) {
+                    cplx Ms[N], acc[N];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
+                    mulb<N>(Ms, Phi, acc);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) Phi[r] = acc[r];
+                }
+            }
+            double fval = 0.0, zz2 = 0.0;
+            cplx sf[QOC_SMALL_NF], ztau;
+            if (grow == 0) {                                                      // tau = 0: inter_vecs[0] = V
+                cplx P0[N];
+#pragma unroll
+                for (int r = 0; r < N; ++r) P0[r] = V0c[r * N + jj];
+                fval += state_terms<N>(P0, VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
+                if (j == 0) zz2 += ztau.x * ztau.x + ztau.y * ztau.y;
+            }
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                if (i == 0) mulb<N>(Kr[0], Phi, Ps[0]); else mulb<N>(Kr[i], Ps[i - 1], Ps[i]);
+                const int t = t0 + i;
+                if (t < steps) {                                                  // tau = t + 1
+                    const bool last = t == steps - 1;
+                    fval += state_terms<N>(Ps[i], VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed || last, sf, ztau);
+                    if (j == 0 && has_speed) zz2 += ztau.x * ztau.x + ztau.y * ztau.y;
+                    if (last) {
+                        if (j == 0) { misc[M_ZN] = ztau.x; misc[M_ZN + 1] = ztau.y; }
+                        if (act) {
+#pragma unroll
+                            for (int r = 0; r < N; ++r) PsiN[r * N + j] = Ps[i][r];
+                        }
+                    }
+                }
+            }
+            wg_sum2<THREADS>(fval, zz2, misc + M_RED);
+            if (multi) {
+                // exchange A1: partial sums, and Psi_N with z_N from the workgroup that holds the last slice
+                double* mine = xS + (size_t)g * sd.xs_stride;
+                const int glast = (steps - 1) / RL;
+                if (tid == 0) { st_sc1(mine + 0, fval); st_sc1(mine + 1, zz2); }
+                if (g == glast) {
+                    if (tid == 0) { st_sc1(mine + 2, misc[M_ZN]); st_sc1(mine + 3, misc[M_ZN + 1]); }
+                    for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + 4 + o, ((const double*)PsiN)[o]);
+                }
+                publish_flag(flags + 4 * g + 2, epoch);
+                wait_flags(flags + 2, G, epoch, sd.err);
+                fval = 0.0; zz2 = 0.0;
+                for (int gi = 0; gi < G; ++gi) { fval += ld_sc1(xS + (size_t)gi * sd.xs_stride + 0); zz2 += ld_sc1(xS + (size_t)gi * sd.xs_stride + 1); }
+                if (g != glast) {
+                    const double* from = xS + (size_t)glast * sd.xs_stride;
+                    if (tid == 0) { misc[M_ZN] = ld_sc1(from + 2); misc[M_ZN + 1] = ld_sc1(from + 3); }
+                    for (int o = tid; o < 2 * NN; o += THREADS) ((double*)PsiN)[o] = ld_sc1(from + 4 + o);
+                }
+                __syncthreads();
+            }
+            zfin = cmake(misc[M_ZN], misc[M_ZN + 1]);
+            const double resid = (double)(steps + 1) - zz2 / mm;
+            reg_state = fval + (has_speed ? d.a_speed * 0.5 * resid * resid : 0.0);
+            coef = has_speed ? -d.a_speed * resid * 2.0 / mm : 0.0;
+            // offsets of the row: O_tau = O_{tau+1} K_tau + S_tau^dagger for 1 <= tau <= steps - 1 (S_N belongs to the terminal costate)
+            cplx Oown[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) Oown[r] = cmake(0.0, 0.0);
+#pragma unroll
+            for (int i = L - 1; i >= 0; --i) {
+                const int t = t0 + i;
+                cplx acc[N];
+                mulb<N>(Oown, Kr[i], acc);
+#pragma unroll
+                for (int r = 0; r < N; ++r) Oown[r] = acc[r];
+                if (t >= 1 && t <= steps - 1) {
+                    if (i == 0) state_terms<N>(Phi, VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
+                    else state_terms<N>(Ps[i > 0 ? i - 1 : 0], VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
+                    add_sources<N>(Oown, sf, VfS, nforb, jj, has_speed, coef, ztau, Wd);
+                }
+            }
+            if (act) {
+                cplx* nd = lnode(treeO, 0, row);
+#pragma unroll
+                for (int r = 0; r < N; ++r) nd[r * N + j] = Oown[r];
+            }
+#pragma unroll 1
+            for (int l = 1; l <= LR; ++l) {                                      // O = O_right M_left + O_left
+                __syncthreads();
+                if ((row & ((1 << l) - 1)) == 0) {
+                    const cplx* orn = lnode(treeO, l - 1, (row >> (l - 1)) + 1);
+                    const cplx* mln = lnode(treeM, l - 1, row >> (l - 1));
+                    cplx Ar[N], xl[N], acc[N];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { Ar[r] = orn[r * N + jj]; xl[r] = mln[r * N + jj]; }
+                    mulb<N>(Ar, xl, acc);
+                    cplx* nd = lnode(treeO, l, row >> l);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { Oown[r] = cadd(Oown[r], acc[r]); if (act) nd[r * N + j] = Oown[r]; }
+                }
+            }
+            __syncthreads();
+            if (multi) {
+                // exchange A2: the offsets of the subtrees
+                const double* root = (const double*)lnode(treeO, LR, 0);
+                double* mine = xS + (size_t)g * sd.xs_stride + 4 + 2 * NN;
+                for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + o, root[o]);
+                publish_flag(flags + 4 * g + 3, epoch);
+                wait_flags(flags + 3, G, epoch, sd.err);
+                for (int o = tid; o < sd.Gp * 2 * NN; o += THREADS) {
+                    const int gi = o / (2 * NN), w = o - gi * 2 * NN;
+                    ((double*)unode(treeOU, 0, 0))[o] = gi < G ? ld_sc1(xS + (size_t)gi * sd.xs_stride + 4 + 2 * NN + w) : 0.0;
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int l = 1; l <= sd.LG; ++l) {
+                    if (row < (sd.Gp >> l)) {
+                        const cplx* orn = unode(treeOU, l - 1, 2 * row + 1);
+                        const cplx* oln = unode(treeOU, l - 1, 2 * row);
+                        const cplx* mln = unode(treeU, l - 1, 2 * row);
+                        cplx Ar[N], xl[N], acc[N];
+#pragma unroll
+                        for (int r = 0; r < N; ++r) { Ar[r] = orn[r * N + jj]; xl[r] = mln[r * N + jj]; }
+                        mulb<N>(Ar, xl, acc);
+                        cplx* nd = unode(treeOU, l, row);
+                        if (act) {
+#pragma unroll
+                            for (int r = 0; r < N; ++r) nd[r * N + j] = cadd(acc[r], oln[r * N + j]);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            // terminal costate Y_N = conj(c0 z) W^dagger + S_N^dagger
+            {
+                cplx PN[N];
+#pragma unroll
+                for (int r = 0; r < N; ++r) PN[r] = PsiN[r * N + jj];
+                state_terms<N>(PN, VfS, misc + M_FA, nforb, Wcol, jj, lane_m, false, sf, ztau);
+                const cplx cz = cmake(c0 * zfin.x, -c0 * zfin.y);
+#pragma unroll
+                for (int r = 0; r < N; ++r) Y[r] = cmul(cz, Wd[r * N + jj]);
+                add_sources<N>(Y, sf, VfS, nforb, jj, has_speed, coef, zfin, Wd);
+            }
+#pragma unroll 1
+            for (int l = LTOT; l >= 1; --l) {
+                int bit;
+                const cplx* sn = sibling(treeM, treeU, l, bit);
+                if (!bit) {                                                       // left child: the costate passes the right sibling
+                    int bit2;
+                    const cplx* on = sibling(treeO, treeOU, l, bit2);
+                    cplx Ms[N], acc[N];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
+                    mulb<N>(Y, Ms, acc);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) Y[r] = cadd(acc[r], on[r * N + jj]);
+                }
+            }
+            // (the backward sweep below adds S_t^dagger after each slice)
+        }
+
+        QSM_STAMP(3);
+        // ---- backward over the own slices: gradient inner products, costate ---------------------------------------------------------------
+#pragma unroll
+        for (int i = L - 1; i >= 0; --i) {
+            const int t = t0 + i, tl = row * L + i;
+            cplx Rm[N];
+            mulb<N>(Ps[i], Y, Rm);                                               // Rm[c] (lane a) = (Psi_{t+1} Y_{t+1})[c][a]
+            for (int kk = 0; kk < k; ++kk) {
+                const cplx* Hk = HsT + kk * NN;
+                cplx q = cmake(0.0, 0.0);
+#pragma unroll
+                for (int c = 0; c < N; ++c) cfma(q, Hk[c * N + jj], Rm[c]);
+                if (!act) q = cmake(0.0, 0.0);
+                q.x = row_sum16(q.x); q.y = row_sum16(q.y);
+                if (j == 0 && t < steps) qS[kk * RL + tl] = q;
+            }
+            if (!SRC && i == L - 1 && row == 0) {                                // z = <W, Psi_N> = tr(Y_tau Psi_tau) at any tau (a workgroup's own copy)
+                cplx dg = cmake(0.0, 0.0);
+#pragma unroll
+                for (int r = 0; r < N; ++r) if (r == j) dg = Rm[r];
+                dg.x = row_sum16(dg.x); dg.y = row_sum16(dg.y);
+                if (j == 0) { misc[M_Z] = dg.x; misc[M_Z + 1] = dg.y; }
+            }
+            if (i > 0) {
+                cplx acc[N];
+                mulb<N>(Y, Kr[i], acc);
+#pragma unroll
+                for (int r = 0; r < N; ++r) Y[r] = acc[r];
+            }
+            if constexpr (SRC) {
+                if (i > 0 && t >= 1 && t <= steps - 1) {                         // (i == 0: Y_{t0} belongs to the previous row's sweep)
+                    cplx sf[QOC_SMALL_NF], ztau;
+                    state_terms<N>(Ps[i > 0 ? i - 1 : 0], VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
+                    add_sources<N>(Y, sf, VfS, nforb, jj, has_speed, coef, ztau, Wd);
+                }
+            }
+        }
+        __syncthreads();
+        QSM_STAMP(4);
+
+        // ---- P5: tail -- regularisers of the pulse, chain rule, grad_squared, stop rule, TF1 Adam (as finish_body, qoc_kernels_finish.h) ----
+        {
+#pragma clang fp contract(off)
+            // the overlap: every workgroup of a control set holds its own copy (equal up to rounding) for its gradient elements; the loss and the
+            // stop rule use workgroup 0's, which travels with the partial sums
+            cplx z = SRC ? zfin : cmake(misc[M_Z], misc[M_Z + 1]);
+            const double dt = d.dt;
+            double reg = 0.0, g2 = 0.0;
+#pragma unroll
+            for (int e = 0; e < QE; ++e) {
+                if (e_ok[e]) {
+                    const int kk = e_kk[e], tl = e_tl[e], t = g * RL + tl;
+                    const double wv = Wv(kk, tl), wm1 = Wv(kk, tl - 1), wm2 = Wv(kk, tl - 2), wp1 = Wv(kk, tl + 1), wp2 = Wv(kk, tl + 2);
+                    double dR = 0.0;
+                    if (d.has_amp) { reg += d.a_amp * 0.5 * wv * wv; dR += d.a_amp * wv; }                  // regularization_functions.py:15-18
+                    if (d.has_env) {                                                                        // :21-25
+                        const double ev = d.omg[(size_t)kk * steps + t];
+                        reg += d.a_env * 0.5 * (ev * wv) * (ev * wv);
+                        dR += d.a_env * ev * ev * wv;
+                    }
+                    if (d.has_dwdt) {                                                                       // :28-35 (padded differences: the last slice owns the closing one)
+                        const double dm = (wv - wm1) / dt, dp = (wp1 - wv) / dt;
+                        double acc = dm * dm;
+                        if (t == steps - 1) acc += dp * dp;
+                        reg += d.a_dwdt * 0.5 * acc;
+                        dR += d.a_dwdt * (dm - dp) / dt;
+                    }
+                    if (d.has_d2wdt2) {                                                                     // :38-45
+                        const double dt2 = dt * dt;
+                        const double e0 = (wv - 2.0 * wm1 + wm2) / dt2, e1 = (wp1 - 2.0 * wv + wm1) / dt2, e2 = (wp2 - 2.0 * wp1 + wv) / dt2;
+                        double acc = e0 * e0;
+                        if (t == steps - 1) acc += e1 * e1 + e2 * e2;
+                        reg += d.a_d2wdt2 * 0.5 * acc;
+                        dR += d.a_d2wdt2 * (e0 - 2.0 * e1 + e2) / dt2;
+                    }
+                    const cplx q = qS[kk * RL + tl];
+                    const double dLdu = SRC ? q.x : (c0 * z.x) * q.x + (c0 * z.y) * q.y;                    // Re(conj(c0 z) q')
+                    const double gv = cos(e_base[e]) * (misc[M_MAXA + kk] * dLdu + dR);                     // tensorflow_state.py:176-178
+                    e_g[e] = gv; g2 += gv * gv;
+                }
+            }
+            wg_sum2<THREADS>(reg, g2, misc + M_RED);
+            if (multi) {
+                // exchange B: partial sums of the regularisers and of grad_squared, summed in the same order by every workgroup
+                double* mine = xB + (size_t)g * sd.xb_stride;
+                if (tid == 0) { st_sc1(mine + 0, reg); st_sc1(mine + 1, g2); st_sc1(mine + 2, z.x); st_sc1(mine + 3, z.y); }
+                publish_flag(flags + 4 * g + 1, epoch);
+                wait_flags(flags + 1, G, epoch, sd.err);
+                reg = 0.0; g2 = 0.0;
+                for (int gi = 0; gi < G; ++gi) { reg += ld_sc1(xB + (size_t)gi * sd.xb_stride + 0); g2 += ld_sc1(xB + (size_t)gi * sd.xb_stride + 1); }
+                z = cmake(ld_sc1(xB + 2), ld_sc1(xB + 3));
+            }
+            QSM_STAMP(5);
+            g2 *= 0.5;
+            const double loss = 1.0 - (z.x * z.x + z.y * z.y) / mm;
+            out_loss = loss; out_regstate = reg_state; out_reg = loss + reg_state + reg; out_g2 = g2; out_z = z;
+            if (ap.mode == 0) break;
+            if (ap.mode == 1) {
+                const bool end = (loss < ap.conv_target) || (g2 < ap.min_grad) || (it_count >= ap.max_iterations);
+                if (end) { done_now = 1; break; }
+                it_count += 1;
+            }
+            const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+            const double lr = ap.mode == 1 ? ap.rate * exp(-(double)it_count / ap.decay) : ap.lr[b];
+            adam_t += 1;
+            const double lr_t = lr * sqrt(1.0 - pow(b2, (double)adam_t)) / (1.0 - pow(b1, (double)adam_t));
+            __syncthreads();                                       // every thread has read its neighbours' controls
+            const bool more = it + 1 < sd.iters;
+#pragma unroll
+            for (int e = 0; e < QE; ++e) {
+                if (e_ok[e]) {
+                    const double gv = e_g[e];
+                    const double mv = b1 * e_m[e] + (1.0 - b1) * gv;
+                    const double vv = b2 * e_v[e] + (1.0 - b2) * gv * gv;
+                    e_m[e] = mv; e_v[e] = vv;
+                    e_base[e] = e_base[e] - lr_t * mv / (sqrt(vv) + eps);
+                    if (more) { e_w[e] = sin(e_base[e]); Wv(e_kk[e], e_tl[e]) = e_w[e]; }
+                }
+            }
+            __syncthreads();
+            QSM_STAMP(6);
+        }
+    }
+#ifdef QOC_SMALL_TIMING
+    if (blockIdx.x == 0 && tid == 0) {
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime(), ck1 = __builtin_amdgcn_s_memtime();
+        printf("k_small_iter<%d,%d,%d,%d> G=%d iters=%d: launch %llu clk = %.2f us (100 MHz clock); last iteration: expm+row product %llu, up-sweep(+exchange A) %llu, "
+               "walk+forward(+state terms, offsets) %llu, backward %llu, tail to sums(+exchange B) %llu, stop rule+Adam %llu clk\n", N, L, R, (int)SRC, G, sd.iters,
+               ck1 - ck0, (double)(rt1 - rt0) / 100.0, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4],
+               stamp[6] - stamp[5]);
+    }
+#endif
+
+    // ---- epilogue: the state the C ABI reads back ----------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int e = 0; e < QE; ++e) {
+        if (e_ok[e]) {
+            const size_t go = ((size_t)b * k + e_kk[e]) * steps + g * RL + e_tl[e];
+            d.grad[go] = e_g[e];
+            d.w[go] = e_w[e]; d.u[go] = misc[M_MAXA + e_kk[e]] * e_w[e];          // the controls the LAST evaluation ran on
+            if (ap.mode != 0) { d.base[go] = e_base[e]; d.adam_m[go] = e_m[e]; d.adam_v[go] = e_v[e]; }
+        }
+    }
+    if (g == 0 && tid == 0) {
+        d.loss[b] = out_loss; d.reg_loss[b] = out_reg; d.g2[b] = out_g2; d.reg_state[b] = out_regstate; d.zfin[b] = out_z;
+        if (ap.mode != 0) { d.iters[b] = it_count; d.adam_t[b] = adam_t; if (done_now) d.done[b] = 1; }
+    }
+}
+
+}  // namespace qsm

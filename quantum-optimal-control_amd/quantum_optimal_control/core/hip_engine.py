@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QOC_HIP_LIBRARY') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libqoc_hip.so'))   # override: A/B builds
 
-PATH_AUTO, PATH_GENERIC, PATH_MFMA, PATH_ST_FUSED, PATH_GEMM = 0, 1, 2, 3, 4
+PATH_AUTO, PATH_GENERIC, PATH_MFMA, PATH_ST_FUSED, PATH_GEMM, PATH_SMALL = 0, 1, 2, 3, 4, 5
 
 
 class QocConfig(C.Structure):
