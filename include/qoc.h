@@ -37,7 +37,7 @@ extern "C" {
 #define QOC_PATH_ST_FUSED 3    /* state transfer, n <= 64, m <= 4: register-resident generator, LDS vectors */
 #define QOC_PATH_GEMM 4        /* any n, m <= 32, both modes: fused LDS exponentials + product tree + persistent thin chains (n <= 64),
                                 * batched tiled MFMA GEMM launches above; state transfer by propagators or, with chunks = 1, directly */
-#define QOC_PATH_SMALL 5       /* n <= 16, m <= n, k <= 8, no bandpass, <= 4 forbidden levels: the WHOLE iteration (and qoc_iterate's / qoc_run_adam's loop)
+#define QOC_PATH_SMALL 5       /* n <= 12, m <= n, k <= 8, no bandpass, <= 4 forbidden levels: the WHOLE iteration (and qoc_iterate's / qoc_run_adam's loop)
                                 * inside one launch -- a row of 16 lanes per time slice, matrices column-per-lane in registers, plain complex-fp64 FMAs
                                 * (v_fmac_f64_dpp), product tree in LDS, several workgroups per control set for long pulses (csrc/qoc_small.h); AUTO for
                                 * one or a few control sets of the sizes the reference is used at (qubits, qutrits, two / three transmons) */
@@ -84,7 +84,8 @@ typedef struct qoc_config {
                                  * v_mfma_f64_4x4x4 as well.
                                  * GEMM path requested explicitly (path = QOC_PATH_GEMM), direct state-transfer route at n in 33..64 with one
                                  * state vector and Hermitian H: 2 = the squared-generator Taylor chain (csrc/qoc_gemm_chain_sq.h; opt-in,
-                                 * measured slower than the default chain), other values = the default chain */
+                                 * measured slower than the default chain), other values = the default chain.
+                                 * Workgroup-resident path (QOC_PATH_SMALL): rows of 16 lanes per workgroup, 8 / 16 / 32 (0 = auto; A/B runs) */
     int32_t plan_seeds;         /* 0, or the batch size AUTO plans for instead of n_seeds: path, kernel family, chunk count and split
                                  * factors are derived from it, so that a restart evolves bit-identically whether it runs in one engine
                                  * of `plan_seeds` control sets or in a shard of it (GrapeSharded passes restarts / GPUs of the node) */

@@ -681,9 +681,11 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     const AutoPlan plan = plan_for(d.Bplan);
     const bool latency_auto = plan.latency, gemm_direct = plan.gemm_direct;
     path = plan.path;
-    // n <= 16, one or a few control sets (the reference's own use) and small batches: the workgroup-resident iteration (csrc/qoc_small.h) --
+    // n <= 12, one or a few control sets (the reference's own use) and small batches: the workgroup-resident iteration (csrc/qoc_small.h) --
     // 5-20 us per iteration where the paths above pay 42-57 us of launches and dependent round trips whatever n (profiles/r06_small_n_latency.txt)
-    if (cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && cfg->chunks == 0 && cfg->time_shards < 1 && qoc_small_auto(d, antiherm)) path = QOC_PATH_SMALL;
+    // (QOC_EXPERIMENTAL=1 QOC_SMALL_AUTO=0: AUTO as it was before round 6, for A/B runs -- tools/small_n_latency.py)
+    if (cfg->path == QOC_PATH_AUTO && cfg->variant == 0 && cfg->chunks == 0 && cfg->time_shards < 1 && !qoc_exp_is("QOC_SMALL_AUTO", 0) && qoc_small_auto(d, antiherm))
+        path = QOC_PATH_SMALL;
     if (d.Bplan < B) {
         // a plan for FEWER control sets than the engine holds is legal (a rank that holds several shards of a planned batch keeps
         // bit-identity with them) but can cost a factor: say so once when it changes what AUTO would have picked for the resident batch
@@ -750,7 +752,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         }
     } else if (path == QOC_PATH_SMALL) {
         std::string msg;
-        rc = qoc_small_setup(e->sm, d, antiherm, cfg->chunks, e->allocs, msg);
+        rc = qoc_small_setup(e->sm, d, antiherm, cfg->chunks, cfg->variant, e->allocs, msg);
         if (rc) return bail(fail(rc == -1 ? QOC_ERR_INVALID : (rc == -3 ? QOC_ERR_NOMEM : QOC_ERR_HIP), "qoc_create: %s (n=%d m=%d k=%d T=%d steps=%d seeds=%d)",
             msg.c_str(), n, m, k, d.T, steps, B));
         e->chunks = e->sm.G;

@@ -1,4 +1,4 @@
-// qoc_small.h -- the workgroup-resident GRAPE iteration for small Hilbert spaces (n <= 16): QOC_PATH_SMALL.
+// qoc_small.h -- the workgroup-resident GRAPE iteration for small Hilbert spaces (n <= 12): QOC_PATH_SMALL.
 //
 // The reference's own users run qubits, qutrits and two / three transmons, ONE control set per Grape() call
 // (core/system_parameters.py:272-284; the n < 10 branch of Choose_exp_terms, :128-145, exists for these sizes; what runs is
@@ -25,9 +25,9 @@
 
 // LDS carve of one workgroup, in units of one complex (16 bytes); the same function runs on the host (launch size) and in the kernel.
 struct QocSmallLayout {
-    int hsc, hst, vfs, psi0, wd, wcol, v0, psin, treeM, treeU, treeO, treeOU, qS, wS, misc, total;
+    int hsc, hst, vfs, psi0, wd, wcol, v0, psin, treeM, treeU, treeO, treeOU, qS, wS, misc, xsum, total;
 };
-__host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, int k, int Gp, bool src) {
+__host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, int k, int m, int Gp, bool src) {
     QocSmallLayout lo;
     const int NN = N * N, RL = R * L;
     int o = 0;
@@ -41,11 +41,12 @@ __host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, 
     lo.psin = o; o += src ? NN : 0;                // Psi_N of this evaluation
     lo.treeM = o; o += (2 * R - 1) * NN;           // product tree of the rows of this workgroup
     lo.treeU = o; o += (2 * Gp - 1) * NN;          // ... of the workgroups of the control set (leaves: their subtree roots)
-    lo.treeO = o; o += src ? (2 * R - 1) * NN : 0; // offsets of the affine costate recursion, same shape
-    lo.treeOU = o; o += src ? (2 * Gp - 1) * NN : 0;
+    lo.treeO = o; o += src ? (2 * R - 1) * m * N : 0;   // offsets of the affine costate recursion, same shape; m x N nodes (rows j' < m of Y)
+    lo.treeOU = o; o += src ? (2 * Gp - 1) * m * N : 0;
     lo.qS = o; o += k * RL;                        // <Lambda_{t+1}, H_k Psi_{t+1}> of the own slices
     lo.wS = o; o += (k * (RL + 4) + 1) / 2;        // sin(base) of the own slices + two halo slices either side (doubles)
     lo.misc = o; o += 64;                          // reductions, scalars, inverse factorials (128 doubles)
+    lo.xsum = o; o += Gp > 1 ? 2 * Gp : 0;         // partial sums of the workgroups of the control set (4 doubles each)
     lo.total = o;
     return lo;
 }
@@ -54,12 +55,13 @@ struct QocSmallDev {            // kernel argument beside QocDev / QocAdamDev
     int iters;                  // loop iterations inside the launch
     int G, Gp, LG;              // workgroups per control set, padded to a power of two, log2 of that
     int Teff;                   // Taylor terms beyond the identity (unitary: T; state transfer: T - 1, no squarings)
-    double* xA;                 // [B][G][XA] exchange A: subtree product + halo controls
+    double* xA;                 // [2][B][G][XA] exchange A: subtree product + halo controls + the deferred partial sums of the previous iteration
     double* xB;                 // [B][G][XB] exchange B: partial sums of the tail (+ the overlap z from workgroup 0)
     double* xS;                 // [B][G][XS] exchanges of the state-regulariser flow: partial sums, Psi_N, z_N; offsets
     unsigned* flags;            // [B][G][4] one word per workgroup and exchange kind: the epoch it has published
     unsigned* err;              // [1] set when a spin timed out (the host turns it into QOC_ERR_HIP)
     int xa_stride, xb_stride, xs_stride;
+    long long xa_parity;        // doubles between the two copies of xA (exchange A alternates between them)
 };
 
 struct QocSmall {
@@ -72,9 +74,10 @@ struct QocSmall {
 };
 
 // host entry points (csrc/qoc_small.hip)
-bool qoc_small_supported(const QocDev& d, bool antiherm, int G_req, std::string* why);
-// picks (N, R, L, G) for the PLANNED batch (d.Bplan) and allocates the exchange buffers; G_req > 0 pins the workgroups per control set
-int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, std::vector<void*>& allocs, std::string& msg);
+bool qoc_small_supported(const QocDev& d, bool antiherm, int G_req, int R_req, std::string* why);
+// picks (N, R, L, G) for the PLANNED batch (d.Bplan) and allocates the exchange buffers; G_req > 0 pins the workgroups per control set, R_req > 0 the rows
+// of 16 lanes per workgroup (A/B runs)
+int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int R_req, std::vector<void*>& allocs, std::string& msg);
 // one launch = `iters` loop iterations (mode 1) or one evaluation / explicit step (modes 0, 2)
 int qoc_small_launch(QocSmall& sm, const QocDev& d, const QocAdamDev& ap, int iters, hipStream_t s, std::string& msg);
 // worth taking over the MFMA latency mode / batch kernels for this problem and planned batch? (AUTO; tests/test_auto_plan.py restates it)

@@ -5,6 +5,13 @@
 #include <cstdio>
 
 #include "qoc_plan_limits.h"
+#include "qoc_small_instances.h"
+
+// (instantiated in qoc_small_a / _b / _c.hip)
+#define QOC_SMALL_DECL(N, L, R, S) \
+    extern template __global__ void qsm::k_small_iter<N, L, R, false>(QocDev, QocAdamDev, QocSmallDev); \
+    extern template __global__ void qsm::k_small_iter<N, L, R, true>(QocDev, QocAdamDev, QocSmallDev);
+QOC_SMALL_INSTANCES_A(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_B(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_C(QOC_SMALL_DECL)
 
 namespace {
 
@@ -12,28 +19,12 @@ typedef void (*small_kernel_t)(QocDev, QocAdamDev, QocSmallDev);
 
 struct Instance { int N, L, R; small_kernel_t fn[2]; bool ok[2]; bool lds_opted[2]; };   // ok: [without, with] a state regulariser (instances that spill are out)
 
-#define QOC_SMALL_INST(N, L, R) { N, L, R, { qsm::k_small_iter<N, L, R, false>, qsm::k_small_iter<N, L, R, true> }, { true, true }, { false, false } }
-#define QOC_SMALL_INST_NOSRC(N, L, R) { N, L, R, { qsm::k_small_iter<N, L, R, false>, nullptr }, { true, false }, { false, false } }
-// rows of 16 lanes per workgroup: 32 (two waves per SIMD) up to n = 4, where a slice is a few hundred instructions; 16 (one wave per SIMD) above
-Instance g_inst[] = {
-    QOC_SMALL_INST(2, 1, 32), QOC_SMALL_INST(2, 2, 32), QOC_SMALL_INST_NOSRC(2, 4, 32),
-    QOC_SMALL_INST(3, 1, 32), QOC_SMALL_INST(3, 2, 32), QOC_SMALL_INST_NOSRC(3, 4, 32),
-    QOC_SMALL_INST(4, 1, 32), QOC_SMALL_INST_NOSRC(4, 2, 32),
-    QOC_SMALL_INST(5, 1, 16), QOC_SMALL_INST(5, 2, 16), QOC_SMALL_INST(5, 4, 16),
-    QOC_SMALL_INST(6, 1, 16), QOC_SMALL_INST(6, 2, 16), QOC_SMALL_INST(6, 4, 16),
-    QOC_SMALL_INST(7, 1, 16), QOC_SMALL_INST(7, 2, 16), QOC_SMALL_INST_NOSRC(7, 4, 16),
-    QOC_SMALL_INST(8, 1, 16), QOC_SMALL_INST(8, 2, 16), QOC_SMALL_INST_NOSRC(8, 4, 16),
-    QOC_SMALL_INST(9, 1, 16), QOC_SMALL_INST(9, 2, 16),
-    QOC_SMALL_INST(10, 1, 16), QOC_SMALL_INST(10, 2, 16),
-    QOC_SMALL_INST(12, 1, 16), QOC_SMALL_INST_NOSRC(12, 2, 16),
-    QOC_SMALL_INST(16, 1, 16),
-    // n > 10: a product tree of 16 rows (x 2 with the offsets of a state regulariser) does not always fit 160 KB beside the Hamiltonians
-    QOC_SMALL_INST(12, 1, 8), QOC_SMALL_INST_NOSRC(12, 2, 8), QOC_SMALL_INST_NOSRC(16, 1, 8),
-};
+#define QOC_SMALL_ROW(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false>, S ? qsm::k_small_iter<N, L, R, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false } },
+Instance g_inst[] = { QOC_SMALL_INSTANCES_A(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_B(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_C(QOC_SMALL_ROW) };
 constexpr int N_INST = sizeof(g_inst) / sizeof(g_inst[0]);
 
 int padded_n(int n) {
-    static const int sizes[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16};
+    static const int sizes[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12};
     for (int s : sizes) if (n <= s) return s;
     return 0;
 }
@@ -44,31 +35,32 @@ int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // ~1.5 us per exchange between workgroups): only used to rank the (L, G) candidates of one problem and for AUTO's threshold
 double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
     const int Teff = d.state_transfer ? d.T - 1 : d.T;
-    const double prod = 4.0 * N * N * 4.0 / 2400.0, share = R / 16.0;
+    // (n <= 4: a slice is a few hundred instructions between LDS round trips -- a second wave per SIMD hides them instead of competing: C1 9.1 us on 32 rows, 10.4 on 16)
+    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? 0.45 * R / 16.0 + 0.45 : R / 16.0;
     const double per_slice = ((Teff > 1 ? Teff - 1 : 0) + d.s + (src ? 6.0 : 4.0)) * prod + 0.15;
     const int LR = ilog2_ceil(R), LG = ilog2_ceil(G);
     double us = share * (L * per_slice + (src ? 4.0 : 2.0) * LR * (prod + 0.1));
     if (G > 1) us += (src ? 4.0 : 2.0) * 1.5 + (src ? 4.0 : 2.0) * LG * (prod + 0.1);
-    return us + 1.5;
+    return 1.45 * (us + 1.5);            // (measured / modelled: 1.4 - 1.5 over n = 2 .. 12, profiles/r06_small_n_latency.txt)
 }
 
 struct Choice { int inst = -1, G = 0; double us = 1e30; };
 
 // G_req > 0: the caller pins the workgroups per control set (qoc_config.chunks; the tests run every exchange on short pulses with it)
-Choice choose(const QocDev& d, bool src, int G_req) {
+Choice choose(const QocDev& d, bool src, int G_req, int R_req = 0) {
     Choice best;
     const int N = padded_n(d.n);
     if (!N) return best;
     for (int i = 0; i < N_INST; ++i) {
         const Instance& in = g_inst[i];
-        if (in.N != N || !in.ok[src ? 1 : 0]) continue;
+        if (in.N != N || !in.ok[src ? 1 : 0] || (R_req > 0 && in.R != R_req)) continue;
         const int cap = in.R * in.L;
         int G = (d.steps + cap - 1) / cap;
         if (G_req > 0) { if (G > G_req) continue; G = G_req; }
         if (G > QOC_SMALL_MAXG) continue;
         if (G > 1 && (long long)d.Bplan * G > QOC_SMALL_WG_BUDGET) continue;
         const int Gp = 1 << ilog2_ceil(G);
-        const QocSmallLayout lo = qoc_small_layout(N, in.R, in.L, d.k, Gp, src);
+        const QocSmallLayout lo = qoc_small_layout(N, in.R, in.L, d.k, d.m, Gp, src);
         if ((size_t)lo.total * 16 > 160 * 1024) continue;
         const double us = model_us(d, N, in.R, in.L, G, src);
         if (us < best.us) { best.inst = i; best.G = G; best.us = us; }
@@ -80,53 +72,54 @@ bool is_src(const QocDev& d) { return d.n_forb > 0 || d.has_speed; }
 
 }  // namespace
 
-bool qoc_small_supported(const QocDev& d, bool antiherm, int G_req, std::string* why) {
+bool qoc_small_supported(const QocDev& d, bool antiherm, int G_req, int R_req, std::string* why) {
     auto no = [&](const char* w) { if (why) *why = w; return false; };
     const int Teff = d.state_transfer ? d.T - 1 : d.T;
-    if (d.n > 16) return no("n <= 16");
+    if (d.n > 12) return no("n <= 12");
     if (d.m > d.n || d.m > 16) return no("m <= n");
     if (d.k > 8) return no("k <= 8");
     if (Teff < 0 || Teff > 30) return no("a Taylor order of at most 30");
     if (d.has_band) return no("no bandpass regulariser");
     if (d.n_forb > QOC_SMALL_NF) return no("at most 4 forbidden levels");
     if (d.state_transfer && !antiherm) return no("exactly anti-Hermitian generators in state transfer");
-    if (choose(d, is_src(d), G_req).inst < 0)
-        return no("a pulse that fits 32 workgroups per control set -- and their product trees 160 KB of LDS: n > 12 short pulses without a state regulariser only -- and, with several workgroups per set, a batch that fits the chip");
+    if (choose(d, is_src(d), G_req, R_req).inst < 0)
+        return no("a pulse that fits 32 workgroups per control set -- and their product trees 160 KB of LDS -- and, with several workgroups per set, a batch that fits the chip");
     return true;
 }
 
 bool qoc_small_auto(const QocDev& d, bool antiherm) {
-    if (!qoc_small_supported(d, antiherm, 0, nullptr)) return false;
+    if (!qoc_small_supported(d, antiherm, 0, 0, nullptr)) return false;
     const Choice c = choose(d, is_src(d), 0);
     // one or a few control sets: the other paths cost >= 42 us per iteration whatever n (profiles/r04_latency_sizes.txt); batches of small
     // systems: the MFMA batch kernels pad to 16 x 16 tiles (C1 x 64: 78 us)
     return c.us <= QOC_PLAN_SMALL_MAX_MODEL_US && d.Bplan <= QOC_PLAN_SMALL_MAX_SETS;
 }
 
-int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, std::vector<void*>& allocs, std::string& msg) {
+int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int R_req, std::vector<void*>& allocs, std::string& msg) {
     std::string why;
     if (G_req < 0 || G_req > QOC_SMALL_MAXG) { msg = "the workgroup-resident path takes 1 .. 32 workgroups per control set (chunks)"; return -1; }
-    if (!qoc_small_supported(d, antiherm, G_req, &why)) { msg = "the workgroup-resident path needs " + why; return -1; }
+    if (!qoc_small_supported(d, antiherm, G_req, R_req, &why)) { msg = "the workgroup-resident path needs " + why; return -1; }
     sm.src = is_src(d);
-    const Choice c = choose(d, sm.src, G_req);
+    const Choice c = choose(d, sm.src, G_req, R_req);
     const Instance& in = g_inst[c.inst];
     sm.N = in.N; sm.L = in.L; sm.R = in.R; sm.G = c.G;
     QocSmallDev& sd = sm.sd;
     sd.G = c.G; sd.LG = ilog2_ceil(c.G); sd.Gp = 1 << sd.LG;
     sd.Teff = d.state_transfer ? d.T - 1 : d.T;
     sd.iters = 1;
-    const QocSmallLayout lo = qoc_small_layout(sm.N, sm.R, sm.L, d.k, sd.Gp, sm.src);
+    const QocSmallLayout lo = qoc_small_layout(sm.N, sm.R, sm.L, d.k, d.m, sd.Gp, sm.src);
     sm.lds_bytes = (size_t)lo.total * 16;
     const int NN2 = 2 * sm.N * sm.N;
-    sd.xa_stride = NN2 + 32; sd.xb_stride = 8; sd.xs_stride = 4 + 2 * NN2;
+    sd.xa_stride = NN2 + 36; sd.xb_stride = 8; sd.xs_stride = 4 + 2 * NN2;
     const size_t BG = (size_t)d.B * c.G;
     const size_t words = BG * 4 + 64;
-    const size_t bytes = (BG * (sd.xa_stride + sd.xb_stride + sd.xs_stride)) * sizeof(double) + words * sizeof(unsigned);
+    const size_t bytes = (BG * (2 * sd.xa_stride + sd.xb_stride + sd.xs_stride)) * sizeof(double) + words * sizeof(unsigned);
+    sd.xa_parity = (long long)(BG * sd.xa_stride);
     char* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { msg = "hipMalloc of the exchange buffers failed"; return -3; }
     allocs.push_back(p);
     if (hipMemset(p, 0, bytes) != hipSuccess) { msg = "clearing the exchange buffers failed"; return -2; }
-    sd.xA = (double*)p; sd.xB = sd.xA + BG * sd.xa_stride; sd.xS = sd.xB + BG * sd.xb_stride;
+    sd.xA = (double*)p; sd.xB = sd.xA + 2 * BG * sd.xa_stride; sd.xS = sd.xB + BG * sd.xb_stride;
     sd.flags = (unsigned*)(sd.xS + BG * sd.xs_stride);
     sd.err = sd.flags + BG * 4;
     sm.flag_bytes = BG * 4 * sizeof(unsigned);

@@ -1,4 +1,4 @@
-// qoc_small_kernel.h -- k_small_iter: the workgroup-resident GRAPE iteration for n <= 16 (see qoc_small.h for the mapping).
+// qoc_small_kernel.h -- k_small_iter: the workgroup-resident GRAPE iteration for n <= 12 (see qoc_small.h for the mapping).
 //
 // Reference semantics, file:line under /root/reference/quantum_optimal_control/:
 //   controls u = maxA sin(base)                         core/tensorflow_state.py:176-178
@@ -112,6 +112,23 @@ __device__ __forceinline__ void wait_flags(unsigned* flags /* stride 4 words */,
     __syncthreads();
 }
 
+// count doubles from the exchange buffers into LDS, sixteen write-through loads in flight per thread (one at a time they cost a fabric round trip each);
+// src(o) = the global address of element o, or nullptr for a pad element of value pad(o)
+template <int THREADS, class SRC, class PAD>
+__device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD pad) {
+    for (int o0 = threadIdx.x; o0 < count; o0 += 16 * THREADS) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int o = o0 + u * THREADS;
+            v[u] = 0.0;
+            if (o < count) { const double* a = src(o); v[u] = a ? ld_sc1(a) : pad(o); }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int o = o0 + u * THREADS; if (o < count) dst[o] = v[u]; }
+    }
+}
+
 template <int THREADS>
 __device__ __forceinline__ void wg_sum2(double& a, double& b, double* red /* 2 x waves doubles */) {
 #pragma unroll
@@ -201,16 +218,20 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     const bool multi = G > 1;
     const bool has_speed = SRC && d.has_speed;
 
-    const QocSmallLayout lo = qoc_small_layout(N, R, L, k, sd.Gp, SRC);
+    const QocSmallLayout lo = qoc_small_layout(N, R, L, k, m, sd.Gp, SRC);
     cplx* S = (cplx*)smem;
     cplx* HsC = S + lo.hsc; cplx* HsT = S + lo.hst; cplx* VfS = S + lo.vfs; cplx* Psi0c = S + lo.psi0; cplx* Wd = S + lo.wd;
     cplx* Wcol = S + lo.wcol; cplx* V0c = S + lo.v0; cplx* PsiN = S + lo.psin;
     cplx* treeM = S + lo.treeM; cplx* treeU = S + lo.treeU; cplx* treeO = S + lo.treeO; cplx* treeOU = S + lo.treeOU;
-    cplx* qS = S + lo.qS; double* wS = (double*)(S + lo.wS); double* misc = (double*)(S + lo.misc);
+    cplx* qS = S + lo.qS; double* wS = (double*)(S + lo.wS); double* misc = (double*)(S + lo.misc); double* xsum = (double*)(S + lo.xsum);
     auto Wv = [&](int kk, int tl) -> double& { return wS[kk * (RL + 4) + 2 + tl]; };
     // node (level, index) of the two trees: levels below LR live in this workgroup (index relative to its first node of the level)
     auto lnode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * R - (2 * R >> l)) + i) * NN; };
     auto unode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * sd.Gp - (2 * sd.Gp >> l)) + i) * NN; };
+    // the offsets of the affine costate recursion are m x N (rows j' < m of Y): their nodes are that small
+    const int MN = m * N;
+    auto lnodeO = [&](int l, int i) -> cplx* { return treeO + (size_t)((2 * R - (2 * R >> l)) + i) * MN; };
+    auto unodeO = [&](int l, int i) -> cplx* { return treeOU + (size_t)((2 * sd.Gp - (2 * sd.Gp >> l)) + i) * MN; };
 
     // ---- prologue: constants to LDS -------------------------------------------------------------------------------------------------------
     const int it_start = d.iters[b], adam_t_start = d.adam_t[b];
@@ -268,14 +289,29 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     __syncthreads();
 
     int it_count = it_start, adam_t = adam_t_start, done_now = 0;
+    // beta^t of the Adam bias correction and the learning-rate schedule rate e^{-it / decay}: formed once per launch, advanced by one multiplication per
+    // iteration (pow / exp are ~1000 instructions on every wave of the workgroup; the running products differ from them by <= iterations-per-launch ulps)
+    double pow_b1 = ap.mode != 0 ? pow(0.9, (double)adam_t_start) : 1.0, pow_b2 = ap.mode != 0 ? pow(0.999, (double)adam_t_start) : 1.0;
+    double lr_run = ap.mode == 1 ? ap.rate * exp(-(double)it_start / ap.decay) : 0.0;
+    const double lr_step = ap.mode == 1 ? exp(-1.0 / ap.decay) : 1.0;
     double out_loss = 0.0, out_reg = 0.0, out_g2 = 0.0, out_regstate = 0.0;
     cplx out_z = cmake(0.0, 0.0);
     const double mm = (double)m * (double)m, c0 = -2.0 / mm;
-    double* xA = sd.xA + ((size_t)b * G) * sd.xa_stride;
+    double* xA0 = sd.xA + ((size_t)b * G) * sd.xa_stride;
     double* xB = sd.xB + ((size_t)b * G) * sd.xb_stride;
     double* xS = sd.xS + ((size_t)b * G) * sd.xs_stride;
     unsigned* flags = sd.flags + ((size_t)b * G) * 4;
 
+    // Several workgroups per control set: the stop rule needs grad_squared of the WHOLE pulse, i.e. an exchange.  Inside a burst the partial sums of
+    // iteration i travel with exchange A of iteration i + 1 instead, the Adam step is taken at once, and if the sums then say "stop" the step is undone
+    // (variable, Adam slots and counters of the evaluation that tripped the rule are kept beside the new ones): one exchange per iteration less.
+    bool spec = false;
+    double sp_reg = 0.0, sp_g2 = 0.0, sp_regstate = 0.0, sv_pow_b1 = 1.0, sv_pow_b2 = 1.0, sv_lr_run = 0.0;
+    cplx sp_z = cmake(0.0, 0.0);
+    int sv_it_count = 0, sv_adam_t = 0;
+    double sv_base[QE], sv_m[QE], sv_v[QE], sv_w[QE], sv_g[QE];
+#pragma unroll
+    for (int e = 0; e < QE; ++e) { sv_base[e] = 0.0; sv_m[e] = 0.0; sv_v[e] = 0.0; sv_w[e] = 0.0; sv_g[e] = 0.0; }
 #ifdef QOC_SMALL_TIMING
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_amdgcn_s_memtime();
@@ -304,10 +340,12 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
 #pragma unroll
                 for (int r = 0; r < N; ++r) { Hn[r] = A[r]; Kr[i][r] = cadd(Kr[i][r], A[r]); }
+                double fnext = misc[M_INVF + 2];                                  // (1 / ii! of the next term is read under the product of this one)
 #pragma unroll 1
                 for (int ii = 2; ii <= sd.Teff; ++ii) {                          // H_n = H H_n ; matexp += H_n / ii!      tensorflow_state.py:38-41
+                    const double f = fnext;
+                    fnext = misc[M_INVF + ii + 1];
                     mulb<N>(A, Hn, acc);
-                    const double f = misc[M_INVF + ii];
 #pragma unroll
                     for (int r = 0; r < N; ++r) { Hn[r] = acc[r]; Kr[i][r].x = fma(acc[r].x, f, Kr[i][r].x); Kr[i][r].y = fma(acc[r].y, f, Kr[i][r].y); }
                 }
@@ -352,20 +390,20 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         }
         __syncthreads();
         if (multi) {
-            // exchange A: the subtree product of every workgroup of the control set + the halo controls of the neighbours
+            // exchange A: the subtree product of every workgroup of the control set + the halo controls of the neighbours.  Two buffers, by the parity of
+            // the iteration: with the stop rule deferred nothing else separates a fast workgroup's next publication from a slow one's reads of this one
+            double* xA = xA0 + (size_t)(it & 1) * sd.xa_parity;
             const double* root = (const double*)lnode(treeM, LR, 0);
             double* mine = xA + (size_t)g * sd.xa_stride;
             for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + o, root[o]);
             if (tid < 4 * k) { const int kk = tid >> 2, h = tid & 3; st_sc1(mine + 2 * NN + tid, Wv(kk, h < 2 ? h : RL - 4 + h)); }
+            if (spec && tid == 0) { st_sc1(mine + 2 * NN + 32, sp_reg); st_sc1(mine + 2 * NN + 33, sp_g2); st_sc1(mine + 2 * NN + 34, sp_z.x); st_sc1(mine + 2 * NN + 35, sp_z.y); }
             publish_flag(flags + 4 * g + 0, epoch);
             wait_flags(flags + 0, G, epoch, sd.err);
-            for (int o = tid; o < sd.Gp * 2 * NN; o += THREADS) {
-                const int gi = o / (2 * NN), w = o - gi * 2 * NN;
-                double v;
-                if (gi < G) v = ld_sc1(xA + (size_t)gi * sd.xa_stride + w);
-                else { const int e = w >> 1; v = ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; }     // identity leaves pad the tree
-                ((double*)unode(treeU, 0, 0))[o] = v;
-            }
+            if (spec) fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xA + (size_t)(o >> 2) * sd.xa_stride + 2 * NN + 32 + (o & 3); }, [](int) { return 0.0; });
+            fetch_sc1<THREADS>((double*)unode(treeU, 0, 0), sd.Gp * 2 * NN,
+                [&](int o) -> const double* { const int gi = o / (2 * NN); return gi < G ? xA + (size_t)gi * sd.xa_stride + (o - gi * 2 * NN) : nullptr; },
+                [&](int o) { const int w = o % (2 * NN), e = w >> 1; return ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; });   // identity leaves pad the tree
             if (tid < 4 * k) {                                    // halo: the neighbours' controls of this evaluation
                 const int kk = tid >> 2, h = tid & 3;
                 const int src_g = h < 2 ? g - 1 : g + 1, tl = h < 2 ? h - 2 : RL + (h - 2), t = g * RL + tl;
@@ -373,16 +411,33 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     Wv(kk, tl) = ld_sc1(xA + (size_t)src_g * sd.xa_stride + 2 * NN + 4 * kk + (h < 2 ? h + 2 : h - 2));
             }
             __syncthreads();
+            if (spec) {                                            // the stop rule of the previous iteration, one exchange late
+                double reg = 0.0, g2 = 0.0;
+                for (int gi = 0; gi < G; ++gi) { reg += xsum[4 * gi]; g2 += xsum[4 * gi + 1]; }
+                g2 *= 0.5;
+                const cplx z = cmake(xsum[2], xsum[3]);
+                const double loss = 1.0 - (z.x * z.x + z.y * z.y) / mm;
+                if ((loss < ap.conv_target) || (g2 < ap.min_grad)) {                    // run_session.py:56-60: undo the step taken past the stop
+#pragma unroll
+                    for (int e = 0; e < QE; ++e) { e_base[e] = sv_base[e]; e_m[e] = sv_m[e]; e_v[e] = sv_v[e]; e_w[e] = sv_w[e]; e_g[e] = sv_g[e]; }
+                    it_count = sv_it_count; adam_t = sv_adam_t; pow_b1 = sv_pow_b1; pow_b2 = sv_pow_b2; lr_run = sv_lr_run;
+                    out_loss = loss; out_regstate = sp_regstate; out_reg = loss + sp_regstate + reg; out_g2 = g2; out_z = z;
+                    done_now = 1;
+                    break;
+                }
+                spec = false;
+                __syncthreads();                                   // (xsum is written again by the next exchange)
+            }
 #pragma unroll 1
             for (int l = 1; l <= sd.LG; ++l) {
-                if (row < (sd.Gp >> l)) {
-                    const cplx* rn = unode(treeU, l - 1, 2 * row + 1);
-                    const cplx* ln = unode(treeU, l - 1, 2 * row);
+                for (int nd_i = row; nd_i < (sd.Gp >> l); nd_i += R) {
+                    const cplx* rn = unode(treeU, l - 1, 2 * nd_i + 1);
+                    const cplx* ln = unode(treeU, l - 1, 2 * nd_i);
                     cplx Ar[N], xl[N], acc[N];
 #pragma unroll
                     for (int r = 0; r < N; ++r) { Ar[r] = rn[r * N + jj]; xl[r] = ln[r * N + jj]; }
                     mulb<N>(Ar, xl, acc);
-                    cplx* nd = unode(treeU, l, row);
+                    cplx* nd = unode(treeU, l, nd_i);
                     if (act) {
 #pragma unroll
                         for (int r = 0; r < N; ++r) nd[r * N + j] = acc[r];
@@ -398,6 +453,10 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             const int sib = ((grow >> l) << 1) + (1 - bit);
             return (l - 1 < LR) ? lnode(loc, l - 1, sib - ((g * R) >> (l - 1))) : unode(upp, l - 1 - LR, sib);
         };
+        auto siblingO = [&](int l) -> const cplx* {
+            const int bit = (grow >> (l - 1)) & 1, sib = ((grow >> l) << 1) + (1 - bit);
+            return (l - 1 < LR) ? lnodeO(l - 1, sib - ((g * R) >> (l - 1))) : unodeO(l - 1 - LR, sib);
+        };
 
         // ---- P3 / P4: start state and end costate of the row by a walk from the root; forward and backward sweep over the own slices --------
         cplx Phi[N], Y[N], Ps[L][N];
@@ -412,16 +471,27 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             for (int l = LTOT; l >= 1; --l) {
                 int bit;
                 const cplx* sn = sibling(treeM, treeU, l, bit);
-                cplx Ms[N], As[N], xs[N], acc[N];
+                cplx Ms[N], acc[N];
 #pragma unroll
-                for (int r = 0; r < N; ++r) {
-                    Ms[r] = sn[r * N + jj];
-                    As[r] = bit ? Ms[r] : Y[r];
-                    xs[r] = bit ? Phi[r] : Ms[r];
+                for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
+                if (l >= 3) {                                                     // the four rows of a wave share their ancestors from level 2 up: a uniform branch
+                    if (bit) {
+                        mulb<N>(Ms, Phi, acc);
+#pragma unroll
+                        for (int r = 0; r < N; ++r) Phi[r] = acc[r];
+                    } else {
+                        mulb<N>(Y, Ms, acc);
+#pragma unroll
+                        for (int r = 0; r < N; ++r) Y[r] = acc[r];
+                    }
+                } else {                                                          // rows of one wave on different sides: operands selected per row, one product
+                    cplx As[N], xs[N];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { As[r] = bit ? Ms[r] : Y[r]; xs[r] = bit ? Phi[r] : Ms[r]; }
+                    mulb<N>(As, xs, acc);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { if (bit) Phi[r] = acc[r]; else Y[r] = acc[r]; }
                 }
-                mulb<N>(As, xs, acc);
-#pragma unroll
-                for (int r = 0; r < N; ++r) { if (bit) Phi[r] = acc[r]; else Y[r] = acc[r]; }
             }
 #pragma unroll
             for (int i = 0; i < L; ++i) {
@@ -480,13 +550,15 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
                 publish_flag(flags + 4 * g + 2, epoch);
                 wait_flags(flags + 2, G, epoch, sd.err);
-                fval = 0.0; zz2 = 0.0;
-                for (int gi = 0; gi < G; ++gi) { fval += ld_sc1(xS + (size_t)gi * sd.xs_stride + 0); zz2 += ld_sc1(xS + (size_t)gi * sd.xs_stride + 1); }
+                fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xS + (size_t)(o >> 2) * sd.xs_stride + (o & 3); }, [](int) { return 0.0; });
                 if (g != glast) {
                     const double* from = xS + (size_t)glast * sd.xs_stride;
-                    if (tid == 0) { misc[M_ZN] = ld_sc1(from + 2); misc[M_ZN + 1] = ld_sc1(from + 3); }
-                    for (int o = tid; o < 2 * NN; o += THREADS) ((double*)PsiN)[o] = ld_sc1(from + 4 + o);
+                    fetch_sc1<THREADS>((double*)PsiN, 2 * NN, [&](int o) -> const double* { return from + 4 + o; }, [](int) { return 0.0; });
                 }
+                __syncthreads();
+                fval = 0.0; zz2 = 0.0;
+                for (int gi = 0; gi < G; ++gi) { fval += xsum[4 * gi]; zz2 += xsum[4 * gi + 1]; }
+                if (tid == 0) { misc[M_ZN] = xsum[4 * glast + 2]; misc[M_ZN + 1] = xsum[4 * glast + 3]; }
                 __syncthreads();
             }
             zfin = cmake(misc[M_ZN], misc[M_ZN + 1]);
@@ -511,52 +583,51 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
             }
             if (act) {
-                cplx* nd = lnode(treeO, 0, row);
+                cplx* nd = lnodeO(0, row);
 #pragma unroll
-                for (int r = 0; r < N; ++r) nd[r * N + j] = Oown[r];
+                for (int r = 0; r < N; ++r) if (r < m) nd[r * N + j] = Oown[r];
             }
 #pragma unroll 1
             for (int l = 1; l <= LR; ++l) {                                      // O = O_right M_left + O_left
                 __syncthreads();
                 if ((row & ((1 << l) - 1)) == 0) {
-                    const cplx* orn = lnode(treeO, l - 1, (row >> (l - 1)) + 1);
+                    const cplx* orn = lnodeO(l - 1, (row >> (l - 1)) + 1);
                     const cplx* mln = lnode(treeM, l - 1, row >> (l - 1));
                     cplx Ar[N], xl[N], acc[N];
 #pragma unroll
-                    for (int r = 0; r < N; ++r) { Ar[r] = orn[r * N + jj]; xl[r] = mln[r * N + jj]; }
+                    for (int r = 0; r < N; ++r) { Ar[r] = r < m ? orn[r * N + jj] : cmake(0.0, 0.0); xl[r] = mln[r * N + jj]; }
                     mulb<N>(Ar, xl, acc);
-                    cplx* nd = lnode(treeO, l, row >> l);
+                    cplx* nd = lnodeO(l, row >> l);
 #pragma unroll
-                    for (int r = 0; r < N; ++r) { Oown[r] = cadd(Oown[r], acc[r]); if (act) nd[r * N + j] = Oown[r]; }
+                    for (int r = 0; r < N; ++r) { Oown[r] = cadd(Oown[r], acc[r]); if (act && r < m) nd[r * N + j] = Oown[r]; }
                 }
             }
             __syncthreads();
             if (multi) {
                 // exchange A2: the offsets of the subtrees
-                const double* root = (const double*)lnode(treeO, LR, 0);
+                const double* root = (const double*)lnodeO(LR, 0);
                 double* mine = xS + (size_t)g * sd.xs_stride + 4 + 2 * NN;
-                for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + o, root[o]);
+                for (int o = tid; o < 2 * MN; o += THREADS) st_sc1(mine + o, root[o]);
                 publish_flag(flags + 4 * g + 3, epoch);
                 wait_flags(flags + 3, G, epoch, sd.err);
-                for (int o = tid; o < sd.Gp * 2 * NN; o += THREADS) {
-                    const int gi = o / (2 * NN), w = o - gi * 2 * NN;
-                    ((double*)unode(treeOU, 0, 0))[o] = gi < G ? ld_sc1(xS + (size_t)gi * sd.xs_stride + 4 + 2 * NN + w) : 0.0;
-                }
+                fetch_sc1<THREADS>((double*)unodeO(0, 0), sd.Gp * 2 * MN,
+                    [&](int o) -> const double* { const int gi = o / (2 * MN); return gi < G ? xS + (size_t)gi * sd.xs_stride + 4 + 2 * NN + (o - gi * 2 * MN) : nullptr; },
+                    [](int) { return 0.0; });
                 __syncthreads();
 #pragma unroll 1
                 for (int l = 1; l <= sd.LG; ++l) {
-                    if (row < (sd.Gp >> l)) {
-                        const cplx* orn = unode(treeOU, l - 1, 2 * row + 1);
-                        const cplx* oln = unode(treeOU, l - 1, 2 * row);
-                        const cplx* mln = unode(treeU, l - 1, 2 * row);
+                    for (int nd_i = row; nd_i < (sd.Gp >> l); nd_i += R) {
+                        const cplx* orn = unodeO(l - 1, 2 * nd_i + 1);
+                        const cplx* oln = unodeO(l - 1, 2 * nd_i);
+                        const cplx* mln = unode(treeU, l - 1, 2 * nd_i);
                         cplx Ar[N], xl[N], acc[N];
 #pragma unroll
-                        for (int r = 0; r < N; ++r) { Ar[r] = orn[r * N + jj]; xl[r] = mln[r * N + jj]; }
+                        for (int r = 0; r < N; ++r) { Ar[r] = r < m ? orn[r * N + jj] : cmake(0.0, 0.0); xl[r] = mln[r * N + jj]; }
                         mulb<N>(Ar, xl, acc);
-                        cplx* nd = unode(treeOU, l, row);
+                        cplx* nd = unodeO(l, nd_i);
                         if (act) {
 #pragma unroll
-                            for (int r = 0; r < N; ++r) nd[r * N + j] = cadd(acc[r], oln[r * N + j]);
+                            for (int r = 0; r < N; ++r) if (r < m) nd[r * N + j] = cadd(acc[r], oln[r * N + j]);
                         }
                     }
                     __syncthreads();
@@ -578,14 +649,13 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 int bit;
                 const cplx* sn = sibling(treeM, treeU, l, bit);
                 if (!bit) {                                                       // left child: the costate passes the right sibling
-                    int bit2;
-                    const cplx* on = sibling(treeO, treeOU, l, bit2);
+                    const cplx* on = siblingO(l);
                     cplx Ms[N], acc[N];
 #pragma unroll
                     for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
                     mulb<N>(Y, Ms, acc);
 #pragma unroll
-                    for (int r = 0; r < N; ++r) Y[r] = cadd(acc[r], on[r * N + jj]);
+                    for (int r = 0; r < N; ++r) Y[r] = r < m ? cadd(acc[r], on[r * N + jj]) : acc[r];
                 }
             }
             // (the backward sweep below adds S_t^dagger after each slice)
@@ -673,30 +743,43 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
             }
             wg_sum2<THREADS>(reg, g2, misc + M_RED);
-            if (multi) {
+            const bool defer = multi && ap.mode == 1 && it + 1 < sd.iters && it_count < ap.max_iterations;
+            if (defer) {
+                spec = true; sp_reg = reg; sp_g2 = g2; sp_z = z; sp_regstate = reg_state;
+#pragma unroll
+                for (int e = 0; e < QE; ++e) { sv_base[e] = e_base[e]; sv_m[e] = e_m[e]; sv_v[e] = e_v[e]; sv_w[e] = e_w[e]; sv_g[e] = e_g[e]; }
+                sv_it_count = it_count; sv_adam_t = adam_t; sv_pow_b1 = pow_b1; sv_pow_b2 = pow_b2; sv_lr_run = lr_run;
+            }
+            if (multi && !defer) {
                 // exchange B: partial sums of the regularisers and of grad_squared, summed in the same order by every workgroup
                 double* mine = xB + (size_t)g * sd.xb_stride;
                 if (tid == 0) { st_sc1(mine + 0, reg); st_sc1(mine + 1, g2); st_sc1(mine + 2, z.x); st_sc1(mine + 3, z.y); }
                 publish_flag(flags + 4 * g + 1, epoch);
                 wait_flags(flags + 1, G, epoch, sd.err);
+                fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xB + (size_t)(o >> 2) * sd.xb_stride + (o & 3); }, [](int) { return 0.0; });
+                __syncthreads();
                 reg = 0.0; g2 = 0.0;
-                for (int gi = 0; gi < G; ++gi) { reg += ld_sc1(xB + (size_t)gi * sd.xb_stride + 0); g2 += ld_sc1(xB + (size_t)gi * sd.xb_stride + 1); }
-                z = cmake(ld_sc1(xB + 2), ld_sc1(xB + 3));
+                for (int gi = 0; gi < G; ++gi) { reg += xsum[4 * gi]; g2 += xsum[4 * gi + 1]; }
+                z = cmake(xsum[2], xsum[3]);
             }
             QSM_STAMP(5);
-            g2 *= 0.5;
-            const double loss = 1.0 - (z.x * z.x + z.y * z.y) / mm;
-            out_loss = loss; out_regstate = reg_state; out_reg = loss + reg_state + reg; out_g2 = g2; out_z = z;
-            if (ap.mode == 0) break;
-            if (ap.mode == 1) {
-                const bool end = (loss < ap.conv_target) || (g2 < ap.min_grad) || (it_count >= ap.max_iterations);
-                if (end) { done_now = 1; break; }
-                it_count += 1;
+            if (!defer) {
+                g2 *= 0.5;
+                const double loss = 1.0 - (z.x * z.x + z.y * z.y) / mm;
+                out_loss = loss; out_regstate = reg_state; out_reg = loss + reg_state + reg; out_g2 = g2; out_z = z;
+                if (ap.mode == 0) break;
+                if (ap.mode == 1) {
+                    const bool end = (loss < ap.conv_target) || (g2 < ap.min_grad) || (it_count >= ap.max_iterations);
+                    if (end) { done_now = 1; break; }
+                }
             }
+            if (ap.mode == 1) it_count += 1;
             const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-            const double lr = ap.mode == 1 ? ap.rate * exp(-(double)it_count / ap.decay) : ap.lr[b];
+            lr_run *= lr_step;                                     // rate e^{-it_count / decay}                     run_session.py:66
+            const double lr = ap.mode == 1 ? lr_run : ap.lr[b];
             adam_t += 1;
-            const double lr_t = lr * sqrt(1.0 - pow(b2, (double)adam_t)) / (1.0 - pow(b1, (double)adam_t));
+            pow_b1 *= b1; pow_b2 *= b2;
+            const double lr_t = lr * sqrt(1.0 - pow_b2) / (1.0 - pow_b1);
             __syncthreads();                                       // every thread has read its neighbours' controls
             const bool more = it + 1 < sd.iters;
 #pragma unroll

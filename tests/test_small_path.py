@@ -39,8 +39,8 @@ def small_cases():
     c['reg_coeffs'] = {'dwdt': 0.1, 'forbidden_coeff_list': [3.0, 2.0, 1.0], 'states_forbidden_list': [8, 5, 2]}
     out.append(('two_qutrits_forbidden', c))
     out.append(('n10', cases.case_c2(n=10, k=2, steps=21, m=5, taylor=(6, 2), seed=20)))
-    c = cases.case_c2(n=16, k=3, steps=19, m=16, taylor=(5, 2), seed=21); c['reg_coeffs'] = {'amplitude': 0.4}
-    out.append(('n16_amplitude', c))
+    c = cases.case_c2(n=11, k=3, steps=19, m=11, taylor=(5, 2), seed=21); c['reg_coeffs'] = {'amplitude': 0.4}
+    out.append(('n11_amplitude', c))
     c = cases.case_c2(n=12, k=3, steps=19, m=12, taylor=(5, 2), seed=22); c['reg_coeffs'] = {'speed_up': 0.4}
     out.append(('n12_speed_up', c))
     out.append(('T1_no_products', cases.case_c2(n=6, k=2, steps=11, m=3, taylor=(1, 0), seed=23)))
@@ -66,6 +66,21 @@ def test_small_path_eval_parity(name, c, groups):
     eng.set_base(np.stack(bases))
     check_eval(eng, sp, bases)
     check_eval(eng, sp, bases)                 # a second evaluation of the same engine (exchange epochs, LDS state) gives the same
+    eng.close()
+
+
+@pytest.mark.parametrize('rows,name,groups', [(16, 'c1', 0), (32, 'c1', 0), (16, 'small_auto', 3), (32, 'small_auto', 3), (8, 'big_auto', 0), (8, 'big_auto', 12), (16, 'big_auto', 0),
+                                              (16, 'dressed', 2), (32, 'guess', 2)])
+def test_small_path_rows_per_workgroup(rows, name, groups):
+    """qoc_config.variant pins the rows of 16 lanes per workgroup (8 / 16 / 32: the instances AUTO chooses among by its cost model); 8 rows with 20 workgroups:
+    8 rows: the instances of n > 10."""
+    sp = oracle_system(cases.ALL_CASES[name]())
+    rng = np.random.default_rng(7)
+    bases = [sp.base0, 2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) - 0.1]
+    eng = make_engine(sp, n_seeds=len(bases), path=SMALL, chunks=groups, variant=rows)
+    assert eng.plan['path'] == 'small' and int(eng.plan['rows']) == rows
+    eng.set_base(np.stack(bases))
+    check_eval(eng, sp, bases)
     eng.close()
 
 
@@ -127,10 +142,56 @@ def test_small_path_explicit_step_and_iterate():
     for _ in range(12):
         b.iterate(b.adam_params(**conv), 1)
     b.sync()
-    np.testing.assert_array_equal(a.get_base(), b.get_base())
+    np.testing.assert_allclose(a.get_base(), b.get_base(), rtol=0, atol=1e-13)      # (the learning rate and beta^t advance by running products inside a launch)
     assert a.scalars()['iterations'][0] == 12 == b.scalars()['iterations'][0]
     ref = go.run_adam(sp, dict(conv, max_iterations=12))
     np.testing.assert_allclose(a.get_base()[0], ref['base'], atol=1e-11)
     # uks the last evaluation ran on (run_session.py:75-91 logs them beside its loss): the 12th evaluation's, one Adam step behind the variable
     assert not np.allclose(a.get_uks(evaluated=True), a.get_uks())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('n,steps,reg', [(6, 500, None), (4, 500, None), (9, 300, 'forbidden'), (3, 190, 'speed_up')])
+def test_small_path_long_pulse_many_workgroups(n, steps, reg):
+    """A pulse over 10 .. 32 workgroups (AUTO's own choice), bursts of iterations inside one launch: the deferred stop rule (the partial sums of iteration i
+    travel with the exchange of iteration i + 1) and the two alternating exchange buffers -- against the oracle's loop, and twice on the device, bit for bit."""
+    c = cases.case_c2(n=n, k=3, steps=steps, m=min(n, 4), taylor=(5, 2), seed=31 + n)
+    if reg == 'forbidden':
+        c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [n - 1, n - 4]}
+    elif reg == 'speed_up':
+        c['reg_coeffs'] = {'speed_up': 0.3, 'amplitude': 0.1}
+    sp = oracle_system(c)
+    conv = dict(rate=0.02, max_iterations=24, learning_rate_decay=100, conv_target=1e-14, min_grad=1e-30)
+    ref = go.run_adam(sp, conv)
+    out = []
+    for _ in range(2):
+        eng = make_engine(sp, n_seeds=2, path=SMALL)
+        assert int(eng.plan['workgroups']) >= 10
+        eng.set_base(np.stack([sp.base0, 0.5 * sp.base0]))
+        p = eng.adam_params(poll_every=10, **conv)
+        its = eng.run_adam(p)
+        assert list(its) == [24, 24]
+        out.append((eng.get_base(), eng.scalars(), eng.evaluate()['grad']))
+        eng.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    np.testing.assert_allclose(out[0][0][0], ref['base'], rtol=0, atol=1e-10)
+    assert abs(out[0][1]['loss'][0] - ref['loss']) < 1e-10 and abs(out[0][1]['reg_loss'][0] - ref['reg_loss']) < 1e-10
+    # a stop in the middle of a burst, found one exchange late: the step taken past it is undone
+    hist = go.run_adam(sp, conv, history=True)['history'][:, 0]
+    first = [i for i in range(2, 20) if hist[i] < hist[:i].min()]
+    if not first:
+        return
+    target = 0.5 * (hist[first[0]] + hist[:first[0]].min())
+    conv3 = dict(conv, max_iterations=500, conv_target=target)
+    r3 = go.run_adam(sp, conv3)
+    assert r3['iterations'] == first[0]
+    eng = make_engine(sp, n_seeds=1, path=SMALL)
+    eng.set_base(sp.base0[None])
+    its = eng.run_adam(eng.adam_params(poll_every=24, **conv3))
+    assert its[0] == r3['iterations']
+    np.testing.assert_allclose(eng.get_base()[0], r3['base'], rtol=0, atol=1e-10)
+    s = eng.scalars()
+    assert s['done'][0] == 1 and abs(s['loss'][0] - r3['loss']) < 1e-10 and abs(s['grad_squared'][0] - r3['grad_squared']) < 1e-9 * max(1.0, r3['grad_squared'])
+    np.testing.assert_allclose(eng.get_uks(evaluated=True)[0], r3['uks'], rtol=0, atol=1e-10)
+    eng.close()

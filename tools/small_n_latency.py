@@ -12,21 +12,24 @@ from tests.golden import cases
 quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
 
 
-def both(name, c, seeds, groups=(0,), old=True):
+def both(name, c, seeds, groups=(0,), old=True, rows=(0,)):
     for g in groups:
-        try:
-            bench_configs.run('%s [small, groups=%s]' % (name, g or 'auto'), c, seeds, 200, path=5, chunks=g)
-        except Exception as err:
-            print('%s [small, groups=%s]: not taken (%s)' % (name, g, str(err)[:120]))
-    if old:
-        bench_configs.run('%s [mfma path]' % name, c, seeds, 50, path=2)
+        for r in rows:
+            try:
+                bench_configs.run('%s [small, groups=%s%s]' % (name, g or 'auto', ', rows=%d' % r if r else ''), c, seeds, 200, path=5, chunks=g, variant=r)
+            except Exception as err:
+                print('%s [small, groups=%s rows=%s]: not taken (%s)' % (name, g, r, str(err)[:120]))
+    if old:                     # AUTO as it was before round 6 (latency mode of the MFMA path / batch kernels / GEMM route)
+        os.environ['QOC_EXPERIMENTAL'] = '1'; os.environ['QOC_SMALL_AUTO'] = '0'
+        bench_configs.run('%s [AUTO of round 5]' % name, c, seeds, 50, path=0)
+        del os.environ['QOC_SMALL_AUTO']; del os.environ['QOC_EXPERIMENTAL']
 
 
-both('C1 qubit', cases.case_c1(), 1)
-both('C1 qubit x64', cases.case_c1(), 64)
+both('C1 qubit', cases.case_c1(), 1, rows=(0, 16, 32))
+both('C1 qubit x64', cases.case_c1(), 64, rows=(0, 16, 32))
 for n in (3, 4, 6, 8):
     c = cases.case_c2(n=n, k=4, steps=500, m=min(8, n), taylor=(5, 3), seed=2)
-    both('n=%d x 500 slices' % n, c, 1, groups=(0,) if quick else (0, 4, 8, 16, 32))
+    both('n=%d x 500 slices' % n, c, 1, groups=(0,) if quick else (0, 8, 16, 32), rows=(0,) if n > 4 else (16, 32))
 c = cases.case_c2(n=9, k=4, steps=300, m=4, taylor=(5, 3), seed=2)
 c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [8, 5]}
 both('two qutrits n=9 x 300 + dwdt + forbidden', c, 1, groups=(0,) if quick else (0, 5, 10, 19))

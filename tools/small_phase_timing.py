@@ -11,10 +11,10 @@ from tests.golden import cases
 from tests.helpers import oracle_system
 
 
-def run(name, c, seeds=1, groups=0):
+def run(name, c, seeds=1, groups=0, rows=0):
     sp = oracle_system(c)
     eng = hip_engine.HipEngine(sp.Hs, sp.U0, sp.V, sp.W, sp.maxA, sp.dt, sp.total_time, sp.steps, sp.exp_terms, sp.scaling, state_transfer=sp.state_transfer,
-                               reg_coeffs=sp.reg_coeffs, one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=seeds, path=5, chunks=groups)
+                               reg_coeffs=sp.reg_coeffs, one_minus_gauss=sp.one_minus_gauss, Vs=sp.Vs, n_seeds=seeds, path=5, chunks=groups, variant=rows)
     rng = np.random.default_rng(0)
     eng.set_base(rng.normal(0, 1 / np.sqrt(sp.steps), (seeds, sp.k, sp.steps)))
     p = eng.adam_params(max_iterations=10 ** 9, conv_target=-1.0, min_grad=-1.0)
@@ -25,6 +25,7 @@ def run(name, c, seeds=1, groups=0):
 
 
 run('C1', cases.case_c1())
+run('C1 rows=16', cases.case_c1(), rows=16)
 run('C1 x64', cases.case_c1(), 64)
 for n in (4, 8):
     run('n=%d x 500' % n, cases.case_c2(n=n, k=4, steps=500, m=min(8, n), taylor=(5, 3), seed=2))
