@@ -36,7 +36,7 @@ int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
     const int Teff = d.state_transfer ? d.T - 1 : d.T;
     // (n <= 4: a slice is a few hundred instructions between LDS round trips -- a second wave per SIMD hides them instead of competing: C1 9.1 us on 32 rows, 10.4 on 16)
-    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? 0.45 * R / 16.0 + 0.45 : R / 16.0;
+    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? 0.45 * R / 16.0 + 0.45 : (R <= 16 ? 1.0 : R / 16.0);
     const double per_slice = ((Teff > 1 ? Teff - 1 : 0) + d.s + (src ? 6.0 : 4.0)) * prod + 0.15;
     const int LR = ilog2_ceil(R), LG = ilog2_ceil(G);
     double us = share * (L * per_slice + (src ? 4.0 : 2.0) * LR * (prod + 0.1));
@@ -46,10 +46,18 @@ double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
 
 struct Choice { int inst = -1, G = 0; double us = 1e30; };
 
+// control sets x workgroups per control set that may spin on each other: all of them must be resident at once, one per CU -- half the CUs of the device
+// the engine is created on, at most QOC_SMALL_WG_BUDGET (MI355X: 256 CUs -> 128)
+int wg_budget() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus / 2 < QOC_SMALL_WG_BUDGET ? cus / 2 : QOC_SMALL_WG_BUDGET;
+}
+
 // G_req > 0: the caller pins the workgroups per control set (qoc_config.chunks; the tests run every exchange on short pulses with it)
 Choice choose(const QocDev& d, bool src, int G_req, int R_req = 0) {
     Choice best;
-    const int N = padded_n(d.n);
+    const int N = padded_n(d.n), budget = wg_budget();
     if (!N) return best;
     for (int i = 0; i < N_INST; ++i) {
         const Instance& in = g_inst[i];
@@ -58,7 +66,7 @@ Choice choose(const QocDev& d, bool src, int G_req, int R_req = 0) {
         int G = (d.steps + cap - 1) / cap;
         if (G_req > 0) { if (G > G_req) continue; G = G_req; }
         if (G > QOC_SMALL_MAXG) continue;
-        if (G > 1 && (long long)d.Bplan * G > QOC_SMALL_WG_BUDGET) continue;
+        if (G > 1 && ((long long)d.Bplan * G > budget || (long long)d.B * G > 2 * budget)) continue;     // (planned batch; and never more resident-or-deadlocked workgroups than CUs)
         const int Gp = 1 << ilog2_ceil(G);
         const QocSmallLayout lo = qoc_small_layout(N, in.R, in.L, d.k, d.m, Gp, src);
         if ((size_t)lo.total * 16 > 160 * 1024) continue;
@@ -92,7 +100,7 @@ bool qoc_small_auto(const QocDev& d, bool antiherm) {
     const Choice c = choose(d, is_src(d), 0);
     // one or a few control sets: the other paths cost >= 42 us per iteration whatever n (profiles/r04_latency_sizes.txt); batches of small
     // systems: the MFMA batch kernels pad to 16 x 16 tiles (C1 x 64: 78 us)
-    return c.us <= QOC_PLAN_SMALL_MAX_MODEL_US && d.Bplan <= QOC_PLAN_SMALL_MAX_SETS;
+    return c.us <= (is_src(d) ? QOC_PLAN_SMALL_MAX_MODEL_US_SRC : QOC_PLAN_SMALL_MAX_MODEL_US) && d.Bplan <= QOC_PLAN_SMALL_MAX_SETS;
 }
 
 int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int R_req, std::vector<void*>& allocs, std::string& msg) {

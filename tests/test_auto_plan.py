@@ -33,7 +33,7 @@ def _plan_limits():
         mt = re.match(r'#define\s+QOC_PLAN_(\w+)\s+(\d+)\b', line)
         if mt:
             out[mt.group(1)] = int(mt.group(2))
-    assert len(out) >= 40, 'qoc_plan_limits.h: only %d limits parsed' % len(out)
+    assert len(out) >= 42, 'qoc_plan_limits.h: only %d limits parsed' % len(out)
     return out
 
 
@@ -54,9 +54,59 @@ def lat_limit_nt2(n, state_reg):
         return LAT_WORK_SRC if state_reg else LAT_WORK
     qa = max(5, ceil_div(n, 4))
     return min(LAT_WORK_SRC, LIM['LAT_WORK_PER_STRIP_SRC'] * qa) if state_reg else LIM['LAT_WORK_PER_STRIP'] * qa
-def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, hermitian=True):
+def _small_instances():
+    """(n_pad, slices per row, rows per workgroup, with-state-regulariser-too) of k_small_iter, in table order (csrc/qoc_small_instances.h: X(N, L, R, S))."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'quantum-optimal-control_amd', 'csrc', 'qoc_small_instances.h')
+    out = [tuple(int(v) for v in mt.groups()) for mt in re.finditer(r'X\((\d+), (\d+), (\d+), ([01])\)', open(path).read())]
+    assert len(out) >= 30
+    return out
+
+
+SMALL_INSTANCES = _small_instances()
+
+
+def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up=False, bandpass=False, hermitian=True):
+    """Row "workgroup-resident path" (csrc/qoc_small.hip: qoc_small_supported, choose, model_us, qoc_small_auto), restated: which instance AUTO takes for one or a
+    few control sets of n <= 12 levels, or None.  LDS carve: csrc/qoc_small.h (units of 16 bytes)."""
+    Teff = T - 1 if state_transfer else T
+    s = 0 if state_transfer else s
+    src = n_forb > 0 or speed_up
+    if n > 12 or m > n or k > 8 or not (0 <= Teff <= 30) or bandpass or n_forb > 4 or (state_transfer and not hermitian):
+        return None
+    N = [v for v in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12) if v >= n][0]
+    clog2 = lambda v: max(0, (v - 1).bit_length())                                   # noqa: E731
+    best = None
+    for (Ni, L, R, S) in SMALL_INSTANCES:
+        if Ni != N or (src and not S):
+            continue
+        G = ceil_div(steps, R * L)
+        if G > 32 or (G > 1 and B * G > 128):
+            continue
+        Gp, NN, RL = 1 << clog2(G), N * N, R * L
+        lds = ((k + 1) * NN + k * NN + (4 * N if src else 0) + 2 * NN + (3 * NN if src else 0) + (2 * R - 1) * NN + (2 * Gp - 1) * NN
+               + ((2 * R - 1 + 2 * Gp - 1) * m * N if src else 0) + k * RL + (k * (RL + 4) + 1) // 2 + 64 + (2 * Gp if Gp > 1 else 0))
+        if lds * 16 > 160 * 1024:
+            continue
+        prod = 4.0 * N * N * 5.9 / 2400.0
+        share = (0.45 * R / 16.0 + 0.45) if N <= 4 else max(1.0, R / 16.0)
+        per_slice = (max(Teff - 1, 0) + s + (6.0 if src else 4.0)) * prod + 0.15
+        us = share * (L * per_slice + (4.0 if src else 2.0) * clog2(R) * (prod + 0.1))
+        if G > 1:
+            us += (4.0 if src else 2.0) * 1.5 + (4.0 if src else 2.0) * clog2(G) * (prod + 0.1)
+        us = 1.45 * (us + 1.5)
+        if best is None or us < best[0]:
+            best = (us, N, R, L, G)
+    if best is None or best[0] > (LIM['SMALL_MAX_MODEL_US_SRC'] if src else LIM['SMALL_MAX_MODEL_US']) or B > LIM['SMALL_MAX_SETS']:
+        return None
+    return {'path': 'small', 'n_pad': best[1], 'rows': best[2], 'slices_per_row': best[3], 'workgroups': best[4], 'state_sources': 1 if src else 0}
+
+
+def expected_plan(n, k, m, steps, T, B, state_transfer=False, state_reg=False, hermitian=True, s=2):
     """DESIGN.md section 4, the AUTO table, as ordered rules -> the dict HipEngine.plan reports."""
     st = state_transfer
+    small = small_plan(n, k, m, steps, T, s, B, state_transfer=st, n_forb=(2 if st else 1) if state_reg else 0, hermitian=hermitian)
+    if small is not None:                                 # row "n <= 12, one or a few control sets": the whole iteration inside one launch
+        return small
     deg = T - 1 if st else T                              # matvecexp sums j < T: the propagator is the Taylor polynomial of degree T - 1
     direct_ok = st and n <= 64 and m <= 8
     dpp = n > 32 and m == 1                               # the direct route's k_gemm_taylor_chain_dpp
@@ -274,3 +324,34 @@ def test_auto_plan_state_transfer_rows(n, k, m, B, hermitian, reg):
 def test_auto_plan_state_transfer_long_pulses(n, k, m, B, steps, reg):
     expect = expected_plan(n, k, m, steps, 8, B, state_transfer=True, state_reg=reg)
     _run(_st_problem(n, k, m, steps, True, reg), B, expect, seed=B)
+
+
+# (n, k, m, slices, control sets, forbidden level): the workgroup-resident path either side of its limits -- 12 / 13 levels, the modelled 45 us (85 with a state regulariser: long pulses of the
+# larger sizes), 128 workgroups spinning on each other (control sets x workgroups per set), 256 control sets
+SMALL_ROWS = [(2, 1, 2, 100, 1, False), (2, 1, 2, 100, 64, False), (2, 1, 2, 100, 256, False), (2, 1, 2, 100, 257, False), (4, 2, 4, 200, 1, False), (4, 2, 4, 200, 16, True),
+              (8, 4, 8, 500, 1, False), (8, 4, 8, 500, 4, False), (8, 4, 8, 500, 5, False), (8, 4, 8, 100, 16, False), (8, 4, 8, 100, 64, False), (9, 4, 4, 300, 1, True),
+              (12, 3, 8, 100, 1, False), (12, 3, 8, 400, 1, False), (13, 3, 8, 100, 1, False), (10, 2, 5, 64, 2, True), (10, 2, 5, 700, 1, True), (6, 8, 6, 130, 3, False),
+              (5, 2, 2, 1100, 1, False), (3, 1, 3, 4000, 1, False), (3, 1, 3, 4200, 1, False)]
+
+
+@pytest.mark.parametrize('n,k,m,steps,B,reg', SMALL_ROWS, ids=['n%d_k%d_m%d_%dslices_B%d%s' % (r[0], r[1], r[2], r[3], r[4], '_forb' if r[5] else '') for r in SMALL_ROWS])
+def test_auto_plan_small_rows(n, k, m, steps, B, reg):
+    expect = expected_plan(n, k, m, steps, 5, B, state_reg=reg)
+    _run(_problem(n, k, steps, m, 5, 2, reg, seed=200 + n), B, expect, seed=B, check=B <= 64 and steps <= 1200)
+
+
+def test_auto_plan_small_rows_cover_both_sides():
+    plans = [expected_plan(n, k, m, steps, 5, B, state_reg=reg) for (n, k, m, steps, B, reg) in SMALL_ROWS]
+    small = [p for p in plans if p.get('path') == 'small']
+    assert 8 <= len(small) <= len(plans) - 5
+    assert {p['workgroups'] > 1 for p in small} == {True, False} and {p['rows'] for p in small} >= {16, 32}
+
+
+def test_auto_plan_small_excluded_shapes():
+    """A bandpass regulariser, more than four forbidden levels and Taylor orders beyond 30 stay on the other paths."""
+    c = _problem(4, 2, 64, 3, 5, 2, False, seed=9)
+    c['reg_coeffs'] = {'bandpass': 0.1, 'band': [0.5, 2.0]}
+    _run(c, 1, {'path': 'mfma'}, seed=1)
+    c = _problem(8, 2, 64, 3, 5, 2, False, seed=9)
+    c['reg_coeffs'] = {'forbidden_coeff_list': [1.0] * 5, 'states_forbidden_list': [7, 6, 5, 4, 3]}
+    _run(c, 1, {'path': 'mfma'}, seed=1)
