@@ -37,7 +37,8 @@ import numpy as np  # noqa: E402
 N, K_OPS, SLICES, M, TAYLOR = 32, 4, 500, 8, (5, 3)
 SEEDS_PER_GPU = 64
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X public fp64 matrix (= vector) peak; MI355X_MICROARCH.md lists no fp64 row
-PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json')
 
 
 def build_problem():
@@ -246,31 +247,72 @@ def secondary_configs(device):
                                               poll_every=10 ** 9)
     out = {}
 
-    def entry(name, c, seeds, warm, iters, flops_alg):
+    def entry(name, c, seeds, warm, iters, flops_alg, roof=None):
+        """roof(per_iteration_s, bracketed_ms_per_iteration, eng) -> the entry's `roofline` dict: what bounds the configuration and how far below that bound it runs."""
         t0 = time.perf_counter()
         try:
             eng, sp = _engine_for(c, seeds, device)
             try:
                 per, pr, sc = _time_engine(eng, params, warm, iters)
+                brk = pr['total_ms'] / max(1, min(iters, 5))
                 out[name] = {'ms_per_iteration': per * 1e3, 'iterations_per_s': seeds / per, 'control_sets': seeds, 'timed_iterations': iters,
                              'path': eng.path, 'plan': eng.plan, 'bracketed_kernel': pr['kernel'],
-                             'bracketed_kernel_ms_per_iteration': pr['total_ms'] / max(1, min(iters, 5)), 'bracketed_launches': pr['launches'],
+                             'bracketed_kernel_ms_per_iteration': brk, 'bracketed_launches': pr['launches'],
                              'algorithmic_TFLOPs': seeds * flops_alg / per / 1e12, 'loss0': float(sc['loss'][0]),
                              'wall_s': time.perf_counter() - t0}
+                if roof is not None:
+                    out[name]['roofline'] = roof(per, brk, eng)
             finally:
                 eng.close()
         except Exception as exc:                                   # a secondary entry never takes the bench line down with it
             out[name] = {'error': repr(exc)}
 
+    def frac_of(achieved, peak, unit, bound, what):
+        return {'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak, 'counting': what}
+
     c3 = synthetic_systems.case_c3()
     T3 = c3['Taylor_terms'][0]
     f3 = c3['steps'] * 1 * 8.0 * 64 ** 2 * (3 * (T3 - 1) + 6)      # SURVEY 8d: steps*m*8n^2*[3(T-1)+k]
-    entry('c3_single_trajectory', c3, 1, 200, 400, f3)
-    entry('c3_x64', c3, 64, 10, 30, f3)
-    entry('c3_x256', c3, 256, 5, 15, f3)
+    # one C3 trajectory: propagator route; the bracket is k_gemm_expm_fused (+ product tree): 4 products per slice of the degree-9 / no-squaring form, three real
+    # products per complex one on v_mfma_f64_16x16x4 (6 n^3 flops each), against the fp64 matrix peak
+    entry('c3_single_trajectory', c3, 1, 200, 400, f3,
+          lambda per, brk, eng: frac_of(c3['steps'] * 4 * 6.0 * 64 ** 3 / (brk * 1e-3) / 1e12, FP64_MATRIX_PEAK_TFLOPS, 'TFLOP/s', 'mfma',
+                                        'EXECUTED flops of the bracketed exponential kernel (4 products per slice x 6 n^3) / its hipEvent time; the iteration is '
+                                        'launch- and chain-latency-bound beyond it (DESIGN.md 4.2)'))
+    # C3 x 64: two dependent Taylor chains per control set, one workgroup each (64 of 256 CUs): executed flops of the chains (9 mat-vecs per slice, three-multiplication
+    # complex MACs: 6 n^2 each, forward + backward) and of the gradient products (k wide products: 8 n^2 per control and slice) over the ITERATION, against the fp64
+    # vector peak -- a latency-bound configuration, so a small number
+    entry('c3_x64', c3, 64, 10, 30, f3,
+          lambda per, brk, eng: frac_of(64 * c3['steps'] * (2 * (T3 - 1) * 6.0 * 64 ** 2 + 6 * 8.0 * 64 ** 2) / per / 1e12, FP64_MATRIX_PEAK_TFLOPS, 'TFLOP/s', 'mfma',
+                                        'EXECUTED flops of an iteration (2 x 9 dependent 64 x 64 mat-vecs per slice at 6 n^2 + 6 gradient products at 8 n^2) / iteration time; '
+                                        'one workgroup per control set: latency-bound by construction (DESIGN.md 4.2, profiles/r05_chain_micro_probe.txt)'))
+    # C3 x 256: bound by the packed generators (40 KB per slice) written once by the assembly and read by both chains
+    entry('c3_x256', c3, 256, 5, 15, f3,
+          lambda per, brk, eng: frac_of(3 * 256 * c3['steps'] * 2560 * 16.0 / per / 1e9, HBM_PEAK_GBS, 'GB/s', 'hbm',
+                                        'ALGORITHMIC bytes of an iteration (packed generators, 40 KB per slice and control set: written once, read twice) / iteration time'))
     c5 = synthetic_systems.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2)
     f5 = 2000 * ((5 - 1 + 3) + 1 + 2) * 8.0 * 512 ** 3 + 2000 * 8 * 8.0 * 512 ** 2   # SURVEY 8d unitary count
-    entry('c5_single_trajectory', c5, 1, 1, 3, f5)
+    # C5: the batched products of the exponentials + product tree (k_zgemm_wg): executed_products_per_slice(5, 3) = 7 products of 6 n^3 per slice, + the wide
+    # gradient product (k x m columns per slice), over the iteration
+    entry('c5_single_trajectory', c5, 1, 1, 3, f5,
+          lambda per, brk, eng: frac_of((2000 * executed_products_per_slice(5, 3) * 6.0 * 512 ** 3 + 2000 * 8 * 8 * 6.0 * 512 ** 2) / per / 1e12, FP64_MATRIX_PEAK_TFLOPS,
+                                        'TFLOP/s', 'mfma', 'EXECUTED MFMA flops of an iteration (7 products per slice x 6 n^3 + the wide gradient product) / iteration time'))
+    # the sizes the reference is used at, on the workgroup-resident path (row g2 of the round-5 verdict): BASELINE config 1 with one control set and with 64, and one
+    # control set of two transmons (n = 8, k = 4, 500 slices).  Bound: the latency of the dependent chain inside ONE launch; the fraction is executed fp64 FMA flops
+    # (complex products of n^2 MACs per lane row) against the vector peak -- small by construction, the number to watch is us per iteration
+    from tests.golden import cases
+    def small_roof(n, steps, T, s, L_products_extra):
+        return lambda per, brk, eng: frac_of(eng.n_seeds * steps * (max(T - 1, 0) + s + L_products_extra) * 8.0 * n ** 3 / per / 1e12, FP64_MATRIX_PEAK_TFLOPS, 'TFLOP/s', 'latency',
+                                             'EXECUTED complex-product flops of an iteration (Taylor + squarings + chain / tree / sweeps: 8 n^3 each) / iteration time; the whole iteration is one '
+                                             'launch of dependent phases (csrc/qoc_small_kernel.h): us_per_iteration is the figure of merit')
+    c1 = cases.case_c1()
+    entry('c1_single_trajectory', c1, 1, 2000, 4000, c1['steps'] * 8.0 * 2 ** 3 * 6, small_roof(2, 100, 4, 0, 5))
+    entry('c1_x64', c1, 64, 2000, 4000, c1['steps'] * 8.0 * 2 ** 3 * 6, small_roof(2, 100, 4, 0, 5))
+    c8 = synthetic_systems.case_c2(n=8, k=4, steps=500, m=8, taylor=(5, 3), seed=2)
+    entry('n8_single_trajectory', c8, 1, 1000, 2000, 500 * ((5 - 1 + 3) + 1 + 2) * 8.0 * 8 ** 3, small_roof(8, 500, 5, 3, 5))
+    for key in ('c1_single_trajectory', 'c1_x64', 'n8_single_trajectory'):
+        if 'ms_per_iteration' in out.get(key, {}):
+            out[key]['us_per_iteration'] = out[key]['ms_per_iteration'] * 1e3
     out['note'] = ('BASELINE configs 3 (state transfer n=64 k=6 steps=1000 m=1 T=10, dwdt + two forbidden levels) and 5 (n=512 k=8 steps=2000 m=8 '
                    '(T,s)=(5,3)); synthetic_systems recipes, product pre-processing, AUTO path; algorithmic_TFLOPs uses SURVEY 8d counts (not a utilisation)')
     return out
@@ -323,14 +365,21 @@ class LivePmc(object):
         if self.proc is None:
             return None, 'rocprofv3 not on PATH'
         try:
-            self.proc.wait(timeout=timeout_s)
-        except subprocess.TimeoutExpired:
             try:
-                os.killpg(self.proc.pid, 15)            # our own process group (start_new_session), never a pattern
-            except OSError:
-                pass
-            return None, 'PMC passes did not finish in %.0f s' % timeout_s
-        try:
+                self.proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                # our own process group (start_new_session), never a pattern: TERM, wait for the children (a rocprofv3 GPU job must not outlive the JSON line), then KILL
+                for sig, grace in ((15, 10.0), (9, 5.0)):
+                    try:
+                        os.killpg(self.proc.pid, sig)
+                    except OSError:
+                        break
+                    try:
+                        self.proc.wait(timeout=grace)
+                        break
+                    except subprocess.TimeoutExpired:
+                        continue
+                return None, 'PMC passes did not finish in %.0f s' % timeout_s
             vals = {}
             for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
                 dbs = glob.glob(os.path.join(self.dir, ctr, '**', '*_results.db'), recursive=True)
@@ -454,7 +503,7 @@ def main():
             # a launcher started the ranks (the driver's form): RCCL or nothing, unless --allow-file-transport / QOC_TRANSPORT=file say otherwise
             require = args.require_rccl
             if require is None:
-                require = os.environ.get('QOC_BENCH_SELF_SPAWNED') != '1' and os.environ.get('QOC_TRANSPORT', 'rccl') != 'file'
+                require = os.environ.get('QOC_TRANSPORT', 'rccl') != 'file'      # (self-spawned ranks too, since round 6: a broken RCCL must not yield a line that only `transport_fallback` tells apart)
             try:
                 comm = parallel_seeds.open_comm(rank=rank, world=world, device=device, require_rccl=bool(require))
             except parallel_seeds.RcclRequired as exc:

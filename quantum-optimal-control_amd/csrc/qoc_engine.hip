@@ -1037,7 +1037,7 @@ int qoc_plan_describe(qoc_handle e, char* buf, int32_t len) {
         int w = snprintf(tmp, sizeof tmp, "path=gemm route=%s chunks=%d slices_per_chunk=%d chains=%s",
             g.direct ? "direct" : (e->d.state_transfer ? "propagator" : "unitary"),
                          g.NC, g.S, g.persistent ? "persistent" : "launches");
-        if (g.ts_G > 0) snprintf(tmp + w, sizeof tmp - w, " time_shards=%d time_rank=%d", g.ts_G, g.ts_rank);
+        if (g.ts_G > 0) w += snprintf(tmp + w, sizeof tmp - w, " time_shards=%d time_rank=%d", g.ts_G, g.ts_rank);
         // the kernel of the direct route's Taylor chains: squared (k_gemm_taylor_chain_sq on [B | B^2]), packed / full
         // (k_gemm_taylor_chain_dpp), butterfly (k_gemm_taylor_chain)
         if (g.direct) snprintf(tmp + w, sizeof tmp - w, " taylor_chain=%s",

@@ -200,10 +200,23 @@ class QocComm(object):
                                          self.device, C.byref(self._h)))
         self.library = self._lib.qoc_comm_library().decode()
 
+    def _attach(self, engine):
+        import weakref
+        if not hasattr(self, '_engines'):
+            self._engines = weakref.WeakSet()
+        self._engines.add(engine)
+
+    def _detach(self, engine):
+        if hasattr(self, '_engines'):
+            self._engines.discard(engine)
+
     def close(self):
-        """Destroys the communicator.  While a time-sharded engine still holds it (HipEngine(time_comm=...)) the C ABI refuses (QocError) and the handle
-        stays valid: close the engine first."""
+        """Destroys the communicator.  Time-sharded engines that still hold it (HipEngine(time_comm=...)) are closed FIRST -- the C ABI refuses to destroy a
+        communicator an engine still uses, and a close() in a caller's finally block after an engine-side exception must neither leak the communicator nor
+        mask that exception with a second one."""
         if getattr(self, '_h', None) is not None and self._h.value:
+            for eng in list(getattr(self, '_engines', ())):
+                eng.close()
             _check(self._lib.qoc_comm_destroy(self._h))
             self._h = C.c_void_p()
 
@@ -294,12 +307,16 @@ class HipEngine(object):
         if time_comm is not None:
             _check(lib.qoc_set_time_comm(self._h, time_comm._h))
             self._time_comm = time_comm                # keep it alive as long as the engine
+            time_comm._attach(self)                    # ... and let it close this engine before it goes (QocComm.close)
 
     # -- lifetime ---------------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             self._lib.qoc_destroy(self._h)
             self._h = C.c_void_p()
+            tc = getattr(self, '_time_comm', None)
+            if tc is not None:
+                tc._detach(self)
 
     def __del__(self):
         try:

@@ -25,10 +25,19 @@ def launch_env():
 
 
 def launch_key():
-    """What the ranks of ONE launch share and no other launch does: master port + the launcher's PID (the ranks of one
-    torch.distributed.run / bench.py launch are siblings: os.getppid() is the same number on all of them) + the launcher's start time in
-    clock ticks (/proc/<pid>/stat field 22: a recycled PID of a crashed earlier launch gives another key, so its left-over files are
-    never read as fresh exchanges)."""
+    """What the ranks of ONE launch share and no other launch does, in this order of preference:
+      1. QOC_RDZV_KEY -- whatever the launcher says (any launcher that wraps every rank in its own shell -- srun, mpirun, a job script per GPU -- has no common parent
+         process: give all ranks of the launch one value, e.g. the job id);
+      2. TORCHELASTIC_RUN_ID (+ master port) when torch.distributed.run was given a real --rdzv-id (its default for a static rendezvous is the literal "none");
+      3. master port + the launcher's PID (the ranks of one torch.distributed.run / bench.py launch are siblings: os.getppid() is the same number on all of them) + the
+         launcher's start time in clock ticks (/proc/<pid>/stat field 22: a recycled PID of a crashed earlier launch gives another key, so its left-over files are
+         never read as fresh exchanges)."""
+    explicit = os.environ.get('QOC_RDZV_KEY')
+    if explicit:
+        return 'k' + ''.join(ch if (ch.isalnum() or ch in '-_.') else '_' for ch in explicit)[:96]
+    run_id = os.environ.get('TORCHELASTIC_RUN_ID', '')
+    if run_id and run_id.lower() != 'none':
+        return 'e%s_%s' % (''.join(ch if (ch.isalnum() or ch in '-_.') else '_' for ch in run_id)[:64], os.environ.get('MASTER_PORT', '0'))
     ppid = os.getppid()
     start = '0'
     try:
@@ -51,7 +60,22 @@ def device_for_rank(local_rank, visible_devices):
     return local_rank % visible_devices
 
 
-def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=300.0):
+def rendezvous_timeout():
+    """Seconds a rank waits for the OTHER ranks of its launch to show up (QOC_RDZV_TIMEOUT, default 60): the ranks of one node start within seconds of each other, so
+    a longer silence means the key differs between them (see launch_key) or a rank died -- say so soon, with the names involved."""
+    try:
+        return max(1.0, float(os.environ.get('QOC_RDZV_TIMEOUT', '60')))
+    except ValueError:
+        return 60.0
+
+
+def _where(path, key):
+    return ('%s (key %r: QOC_RDZV_KEY=%r TORCHELASTIC_RUN_ID=%r MASTER_PORT=%r parent pid %d; every rank of a launch must derive the same key -- set QOC_RDZV_KEY '
+            'when the ranks do not share a parent process; QOC_RDZV_TIMEOUT changes the wait)' % (path, key, os.environ.get('QOC_RDZV_KEY'),
+            os.environ.get('TORCHELASTIC_RUN_ID'), os.environ.get('MASTER_PORT'), os.getppid()))
+
+
+def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=None):
     """Hand `make_payload()` (bytes, evaluated on rank 0 only) to every rank of a one-node job through a file.
 
     key: anything all ranks agree on and no other live job shares; default = master port + the launcher's PID (the
@@ -61,6 +85,8 @@ def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=300.
         return make_payload()
     if key is None:
         key = launch_key()
+    if timeout is None:
+        timeout = rendezvous_timeout()
     directory = directory or os.environ.get('QOC_RDZV_DIR', '/tmp')
     path = os.path.join(directory, 'qoc_rdzv_%d_%s' % (os.getuid(), key))
     if rank == 0:
@@ -80,7 +106,7 @@ def rendezvous(rank, world, make_payload, key=None, directory=None, timeout=300.
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:
-            raise TimeoutError('rendezvous: rank %d saw no %s within %.0f s' % (rank, path, timeout))
+            raise TimeoutError('rendezvous: rank %d of %d saw no file from rank 0 within %.0f s: %s' % (rank, world, timeout, _where(path, key)))
         time.sleep(0.01)
 
 
@@ -129,6 +155,7 @@ class FileComm(object):
         self.device = int(os.environ.get('LOCAL_RANK', 0))        # GrapeSharded reads the GPU of this rank from its communicator
         self.library = 'files (host)' + ((': ' + reason) if reason else '')
         self._dir = os.path.join(directory or os.environ.get('QOC_RDZV_DIR', '/tmp'), 'qoc_fc_%d_%s' % (os.getuid(), key))
+        self._key = key
         _private_dir(self._dir)
         self._seq = 0
 
@@ -151,7 +178,8 @@ class FileComm(object):
                     break
                 except (FileNotFoundError, ValueError, EOFError):
                     if time.time() - t0 > self.timeout:
-                        raise TimeoutError('FileComm: rank %d saw nothing from rank %d in exchange %d' % (self.rank, r, seq))
+                        raise TimeoutError('FileComm: rank %d of %d saw nothing from rank %d in exchange %d within %.0f s: %s' % (
+                            self.rank, self.world, r, seq, self.timeout, _where(self._path(seq, r), self._key)))
                     time.sleep(0.001)
         # whoever wrote exchange seq - 1 had read all of seq - 2, and this rank has just seen every file of seq - 1 or later
         if seq >= 2:
@@ -251,10 +279,14 @@ def open_comm(rank=None, world=None, device=None, key=None, require_rccl=None, c
         call_index = os.environ.get('QOC_COMM_CALL')
     if call_index is None:
         call_index, _OPEN_CALLS = _OPEN_CALLS, _OPEN_CALLS + 1
-    files = FileComm(rank, world, '%s_c%d' % (key, int(call_index)))
+    # the agreement below is a matter of seconds: a rank that waits longer is waiting for files nobody writes (other key, dead rank); the data-phase exchanges of
+    # a fallback transport (ranks finish minutes apart) get the long timeout back
+    files = FileComm(rank, world, '%s_c%d' % (key, int(call_index)), timeout=rendezvous_timeout())
     files.fallback_reason = None
 
     def fall_back(reason):
+        if (rank == 0 or require_rccl) and reason != 'QOC_TRANSPORT=file':
+            describe_node(sys.stderr, device)            # what a first run on a new multi-GPU node needs beside the reason: devices, peer access, librccl
         if require_rccl:
             try:
                 files.close()
@@ -263,6 +295,7 @@ def open_comm(rank=None, world=None, device=None, key=None, require_rccl=None, c
             raise RcclRequired('RCCL is required (require_rccl / QOC_REQUIRE_RCCL=1) and is not usable: %s' % reason)
         files.library = 'files (host): ' + reason
         files.fallback_reason = reason
+        files.timeout = 600.0
         if rank == 0 and os.environ.get('QOC_TRANSPORT', 'rccl') != 'file':
             sys.stderr.write('quantum_optimal_control.parallel_seeds: WARNING: RCCL is NOT in use, the ranks exchange their results '
                              'through files (%s)\n' % reason)
@@ -311,6 +344,26 @@ def open_comm(rank=None, world=None, device=None, key=None, require_rccl=None, c
         except Exception:
             pass
     return fall_back('RCCL initialisation failed on rank(s) %s%s' % (bad, ('; ' + why) if why else ''))
+
+
+def describe_node(out, device=None):
+    """Devices, the hipDeviceCanAccessPeer matrix (what RCCL's device-to-device transports between two ranks of a node need) and the RCCL library of this process,
+    one block of text: printed when RCCL cannot start (tools/multi_gpu_selftest.py prints the same on purpose)."""
+    from quantum_optimal_control.core import hip_engine
+    try:
+        n = hip_engine.device_count()
+        out.write('quantum_optimal_control.parallel_seeds: node as rank %s (HIP device %s) sees it: %d HIP device(s); HSA_ENABLE_IPC_MODE_LEGACY=%r HIP_VISIBLE_DEVICES=%r '
+                  'ROCR_VISIBLE_DEVICES=%r QOC_RCCL_LIBRARY=%r\n' % (os.environ.get('RANK', '0'), device, n, os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                                                                      os.environ.get('HIP_VISIBLE_DEVICES'), os.environ.get('ROCR_VISIBLE_DEVICES'), os.environ.get('QOC_RCCL_LIBRARY')))
+        for d in range(n):
+            info = hip_engine.device_info(d)
+            row = ''.join('1' if hip_engine.device_peer_access(d, p) else '0' for p in range(n))
+            out.write('  device %d: %s, %d CUs, %.0f GB; can access peers: %s\n' % (d, info['name'], info['compute_units'], info['hbm_bytes'] / 2.0 ** 30, row))
+        lib = hip_engine.load_library().qoc_comm_library().decode()
+        out.write('  RCCL library in use: %s\n' % (lib or '(none opened yet)'))
+    except Exception as exc:                             # diagnostics must never replace the error they accompany
+        out.write('quantum_optimal_control.parallel_seeds: (node description failed: %r)\n' % (exc,))
+    out.flush()
 
 
 def _dist_device(dist):

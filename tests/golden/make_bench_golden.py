@@ -5,7 +5,8 @@ regularisers (what a plain Grape() call runs: n_seeds=1, AUTO = latency mode).
 Outputs come from the CPU oracle (oracle/grape_oracle.py, the restatement of core/tensorflow_state.py:204-242,323-356 and
 core/run_session.py:47-69); they are stored so that the GPU-box tests cost no CPU seconds.  Run in the build container:
 
-    python tests/golden/make_bench_golden.py
+    python tests/golden/make_bench_golden.py        (C2 files)
+    python tests/golden/make_bench_golden.py c3     (c3_bench_batch.npz: the C3 x 64 / x 256 engines of bench.secondary_configs)
 """
 import os
 import sys
@@ -50,7 +51,45 @@ def pack(sp, bases):
     return {k: np.array(v) for k, v in out.items()}
 
 
+C3_SETS = (0, 31, 63, 127, 255)      # {0, 31, 63} of the 64-set and {0, 127, 255} of the 256-set C3 engine of bench.secondary_configs (the first 64 of 256 ARE the 64)
+
+
+def c3_system():
+    """BASELINE config 3 exactly as bench.secondary_configs builds it (synthetic_systems.case_c3: n = 64, k = 6, 1000 slices, one state vector, T = 10, dwdt + two
+    forbidden levels), through the oracle's pre-processing."""
+    c = synthetic_systems.case_c3()
+    np.random.seed(c['np_seed'])
+    return c, go.OracleSystem(c['H0'], c['Hops'], c['U'], c['total_time'], c['steps'], c['states_concerned_list'], U0=c['U0'], reg_coeffs=c['reg_coeffs'],
+                              dressed_info=None, maxA=c['maxA'], initial_guess=c['initial_guess'], state_transfer=c['state_transfer'],
+                              Taylor_terms=c['Taylor_terms'])
+
+
+def c3_bases(n_seeds, c):
+    """bench._engine_for's control sets: default_rng(0).normal(0, 1 / sqrt(steps), (n_seeds, k, steps))."""
+    return np.random.default_rng(0).normal(0, 1 / np.sqrt(c['steps']), (n_seeds, len(c['Hops']), c['steps']))
+
+
+def pack_c3():
+    c, sp = c3_system()
+    b256, b64 = c3_bases(256, c), c3_bases(64, c)
+    assert np.array_equal(b256[:64], b64)
+    out = {key: [] for key in ('loss', 'reg_loss', 'grad_squared', 'unitary_scale', 'grad', 'final_vecs', 'adam_base', 'adam_loss', 'adam_reg_loss')}
+    for sidx in C3_SETS:
+        o = go.evaluate(sp, b256[sidx], want_inter=True)
+        for key in ('loss', 'reg_loss', 'grad_squared', 'unitary_scale', 'grad'):
+            out[key].append(o[key])
+        out['final_vecs'].append(o['inter_vecs'][-1])
+        r = go.run_adam(sp, ADAM, base=b256[sidx])
+        assert r['iterations'] == 3
+        out['adam_base'].append(r['base']); out['adam_loss'].append(r['loss']); out['adam_reg_loss'].append(r['reg_loss'])
+    return {k: np.array(v) for k, v in out.items()}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'c3':
+        np.savez_compressed(os.path.join(HERE, 'c3_bench_batch.npz'), sets=np.array(C3_SETS), **pack_c3())
+        print('written c3_bench_batch.npz')
+        return
     bases = bench.seed_bases(0, bench.SEEDS_PER_GPU)
     sp = system({})
     g = pack(sp, [bases[s] for s in SEEDS])

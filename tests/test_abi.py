@@ -84,9 +84,10 @@ def test_plan_limits_header_is_the_single_source_of_autos_numbers():
     assert lim['NT4_MIN_SETS_K4'] <= lim['NT4_MIN_SETS'] and lim['ST_BIG_DPP'] <= lim['ST_BIG_DPP_SRC'] <= lim['ST_BIG_N64_SRC']
     assert lim['ST_DIRECT_DPP'] <= lim['ST_DIRECT_DPP_SRC'] <= lim['ST_DIRECT_N64'] <= lim['ST_DIRECT_N32']
     assert lim['CHUNK_ITEMS'] == 1024 and lim['CHUNKS_MAX'] <= lim['CHUNKS_MAX_NT2']
+    assert lim['SMALL_MAX_MODEL_US'] <= lim['SMALL_MAX_MODEL_US_SRC'] and lim['SMALL_MAX_SETS'] >= 64
     engine = open(os.path.join(csrc, 'qoc_engine.hip')).read()
     assert '#include "qoc_plan_limits.h"' in engine
     assert 'QOC_LATENCY_MAX_WORK' not in engine                                  # the old private macros are gone
     for name in lim:
-        used = any(('QOC_PLAN_' + name) in open(os.path.join(csrc, f)).read() for f in ('qoc_engine.hip', 'qoc_mfma_backward.hip'))
+        used = any(('QOC_PLAN_' + name) in open(os.path.join(csrc, f)).read() for f in ('qoc_engine.hip', 'qoc_mfma_backward.hip', 'qoc_small.hip'))
         assert used, 'QOC_PLAN_%s is defined but no engine source uses it' % name

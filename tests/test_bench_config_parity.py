@@ -108,3 +108,41 @@ def test_bench_batch_configuration_against_the_reference_text():
     for s, f in fx.items():
         np.testing.assert_allclose(base[s], f['base_after_adam'], rtol=0, atol=1e-9)
     eng.close()
+
+
+@pytest.mark.parametrize('n_seeds,rows', [(1, (0,)), (64, (0, 31, 63)), (256, (0, 127, 255))], ids=['c3_single_trajectory', 'c3_x64', 'c3_x256'])
+def test_secondary_c3_engines_against_the_oracle(n_seeds, rows):
+    """The C3 engines whose times the bench line prints under `secondary` ("Next round" 2), built by bench._engine_for exactly as bench.secondary_configs
+    builds them -- one trajectory (propagator route), 64 control sets (packed Taylor chains, assembly beside the forward chain on masked CUs) and 256 (no overlap) --
+    against committed oracle values of the named control sets (tests/golden/make_bench_golden.py c3): one evaluation and three iterations of the device loop.
+    Reference: core/tensorflow_state.py:77-133, 244-261; core/regularization_functions.py:28-35, 71-85; core/run_session.py:47-69."""
+    from quantum_optimal_control.helper_functions import synthetic_systems
+    g = load_golden('c3_bench_batch.npz')
+    at = {int(s): i for i, s in enumerate(g['sets'])}
+    c3 = synthetic_systems.case_c3()
+    eng, sp = bench._engine_for(c3, n_seeds, 0)
+    try:
+        assert eng.plan['path'] == 'gemm' and eng.plan['route'] == ('propagator' if n_seeds == 1 else 'direct')
+        if n_seeds > 1:
+            assert eng.plan['taylor_chain'] == 'packed'
+        bases = np.random.default_rng(0).normal(0, 1 / np.sqrt(c3['steps']), (n_seeds, len(c3['Hops']), c3['steps']))
+        r = eng.evaluate()
+        inter = eng.get_inter_vecs()
+        for b in rows:
+            i = at[b]
+            for key in ('loss', 'reg_loss', 'grad_squared', 'unitary_scale'):
+                assert abs(r[key][b] - g[key][i]) <= L_ATOL * max(1.0, abs(g[key][i])), (key, b, r[key][b], g[key][i])
+            gmax = np.max(np.abs(g['grad'][i]))
+            assert np.max(np.abs(r['grad'][b] - g['grad'][i])) <= G_RTOL * gmax, (b, np.max(np.abs(r['grad'][b] - g['grad'][i])), gmax)
+            np.testing.assert_allclose(inter[b][-1], g['final_vecs'][i], rtol=0, atol=U_ATOL)
+        del inter
+        eng.set_base(bases)
+        its = eng.run_adam(eng.adam_params(rate=0.01, learning_rate_decay=2500, conv_target=1e-8, min_grad=1e-25, max_iterations=3, poll_every=3))
+        assert np.all(its == 3)
+        base, sc = eng.get_base(), eng.scalars()
+        for b in rows:
+            i = at[b]
+            np.testing.assert_allclose(base[b], g['adam_base'][i], rtol=0, atol=1e-10)
+            assert abs(sc['loss'][b] - g['adam_loss'][i]) <= 1e-10 and abs(sc['reg_loss'][b] - g['adam_reg_loss'][i]) <= 1e-10
+    finally:
+        eng.close()

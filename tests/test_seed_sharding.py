@@ -2,6 +2,7 @@
 import os
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -522,3 +523,62 @@ def test_bench_line_n1_carries_secondary_configs_and_a_measured_traffic_figure()
     assert roof['bound'] == 'mfma' and 0.3 < roof['frac'] < 1.0
     assert roof['traffic'] is None or roof['traffic'] > 1e8
     assert 'measured in this run' in roof['traffic_source'] or 'committed profile' in roof['traffic_source']
+
+
+# ---- round 6: first-contact hardening of the N > 1 start-up ("Next round" 7) ----------------------------------------------------------------
+
+def test_launch_key_prefers_an_explicit_key_then_the_elastic_run_id(monkeypatch):
+    from quantum_optimal_control import parallel_seeds as ps
+    for k in ('QOC_RDZV_KEY', 'TORCHELASTIC_RUN_ID'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('MASTER_PORT', '29512')
+    by_parent = ps.launch_key()
+    assert by_parent.startswith('29512_%d_' % os.getppid())
+    monkeypatch.setenv('TORCHELASTIC_RUN_ID', 'none')                # torch.distributed.run's default for a static rendezvous: not a key
+    assert ps.launch_key() == by_parent
+    monkeypatch.setenv('TORCHELASTIC_RUN_ID', 'job 4711/a')
+    assert ps.launch_key() == 'ejob_4711_a_29512'
+    monkeypatch.setenv('QOC_RDZV_KEY', 'slurm-99.0')
+    assert ps.launch_key() == 'kslurm-99.0'
+
+
+def test_rendezvous_gives_up_soon_and_names_file_and_key(monkeypatch, tmp_path):
+    from quantum_optimal_control import parallel_seeds as ps
+    monkeypatch.setenv('QOC_RDZV_DIR', str(tmp_path))
+    monkeypatch.setenv('QOC_RDZV_TIMEOUT', '1')
+    monkeypatch.setenv('QOC_RDZV_KEY', 'nobody-writes-this')
+    assert ps.rendezvous_timeout() == 1.0
+    t0 = time.time()
+    with pytest.raises(TimeoutError) as err:
+        ps.rendezvous(1, 2, lambda: b'x')
+    assert time.time() - t0 < 10
+    msg = str(err.value)
+    assert 'qoc_rdzv_' in msg and 'knobody-writes-this' in msg and 'QOC_RDZV_KEY' in msg and str(tmp_path) in msg
+    fc = ps.FileComm(1, 2, 'knobody-writes-this_c0', timeout=1.0)
+    with pytest.raises(TimeoutError) as err:
+        fc.all_gather([1.0])
+    assert 'rank 0' in str(err.value) and 'QOC_RDZV_KEY' in str(err.value)
+
+
+def test_ranks_without_a_common_parent_meet_through_qoc_rdzv_key(tmp_path):
+    """A launcher that wraps every rank in its own shell (srun, a job script per GPU): os.getppid() differs between the ranks, QOC_RDZV_KEY is what they share.
+    World 2 on the file transport (no GPU involved): both ranks gather each other's rows; without the key they would wait for files nobody writes."""
+    import subprocess
+    code = ("import os, sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np\n"
+            "from quantum_optimal_control import parallel_seeds as ps\n"
+            "c = ps.open_comm(call_index=0)\n"
+            "rows = c.all_gather([float(c.rank) + 0.5, float(os.getppid())])\n"
+            "assert rows.shape == (2, 2) and rows[0, 0] == 0.5 and rows[1, 0] == 1.5 and rows[0, 1] != rows[1, 1], rows\n"
+            "c.close(); print('RANK_OK', c.rank)\n") % (ROOT, os.path.join(ROOT, 'quantum-optimal-control_amd'))
+    script = tmp_path / 'rank.py'
+    script.write_text(code)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29571', QOC_TRANSPORT='file',
+                   QOC_RDZV_DIR=str(tmp_path), QOC_RDZV_KEY='job-%d' % os.getpid(), QOC_RDZV_TIMEOUT='30')
+        env.pop('TORCHELASTIC_RUN_ID', None)
+        procs.append(subprocess.Popen(['bash', '-c', '%s %s; exit $?' % (sys.executable, script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and 'RANK_OK %d' % r in so, (so[-800:], se[-1500:])
