@@ -359,8 +359,11 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
 
 // latency mode of the MFMA path: final_state and unitary_scale of the last evaluation, formed on demand
 // workgroup-resident path: inter_vecs, final_state and unitary_scale of the last evaluation, re-formed from its controls (d.u) by the any-size kernels
-static int refresh_small(qoc_engine* e) {
-    if (!e->final_stale && !e->inter_stale) return QOC_OK;
+static int refresh_small(qoc_engine* e, bool need_inter) {
+    if (!e->final_stale && !(need_inter && e->inter_stale)) return QOC_OK;
+    // unitary mode: the launch itself leaves final_state and unitary_scale of its last evaluation (from the root of its product tree), unless a deferred stop rule
+    // undid that evaluation's successor; inter_vecs are always re-formed here
+    if (!need_inter && !e->d.state_transfer && qoc_small_final_valid(e->sm, e->stream)) { e->final_stale = false; return QOC_OK; }
     QocDev d = e->d;
     d.skip_done = 0;
     if (!d.state_transfer) {
@@ -387,7 +390,7 @@ static int small_check(qoc_engine* e) {
 }
 
 static int refresh_final(qoc_engine* e) {
-    if (e->path == QOC_PATH_SMALL) return refresh_small(e);
+    if (e->path == QOC_PATH_SMALL) return refresh_small(e, false);
     if (!e->final_stale) return QOC_OK;
     // the boundary chain once more, with X beside the vectors
     if (e->path == QOC_PATH_GEMM) qoc_gemm_forward(e->gm, e->d, e->stream, true);
@@ -962,7 +965,7 @@ int qoc_get_inter_vecs(qoc_handle e, double* inter) {
     if (!e->evaluated) return fail(QOC_ERR_STATE, "qoc_get_inter_vecs: nothing evaluated yet");
     // one rank of a time-sharded run: its own slices, summed over the ranks (a collective)
     if (e->path == QOC_PATH_GEMM) TRY(qoc_gemm_ts_gather_inter(e->gm, e->d, e->stream));
-    if (e->path == QOC_PATH_SMALL) TRY(refresh_small(e));
+    if (e->path == QOC_PATH_SMALL) TRY(refresh_small(e, true));
     else if (e->inter_stale) {                                       // latency mode: the sweeps keep Psi_t in their own layout
         qoc_mfma_unpack_inter(e->mf, e->d, e->stream);
         HIP_TRY(hipGetLastError());

@@ -60,6 +60,7 @@ struct QocSmallDev {            // kernel argument beside QocDev / QocAdamDev
     double* xS;                 // [B][G][XS] exchanges of the state-regulariser flow: partial sums, Psi_N, z_N; offsets
     unsigned* flags;            // [B][G][4] one word per workgroup and exchange kind: the epoch it has published
     unsigned* err;              // [1] set when a spin timed out (the host turns it into QOC_ERR_HIP)
+    int* final_valid;           // [B] 1: the launch left final_state / unitary_scale of its last evaluation in d.Xfinal / d.uscale (unitary mode)
     int xa_stride, xb_stride, xs_stride;
     long long xa_parity;        // doubles between the two copies of xA (exchange A alternates between them)
 };
@@ -71,7 +72,10 @@ struct QocSmall {
     size_t lds_bytes = 0;
     QocSmallDev sd{};
     size_t flag_bytes = 0;
+    int B = 0;
 };
+// did the last launch leave final_state / unitary_scale of every control set behind (else the read-back re-forms them)?  Synchronises the stream.
+bool qoc_small_final_valid(const QocSmall& sm, hipStream_t s);
 
 // host entry points (csrc/qoc_small.hip)
 bool qoc_small_supported(const QocDev& d, bool antiherm, int G_req, int R_req, std::string* why);

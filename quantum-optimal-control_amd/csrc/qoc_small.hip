@@ -120,7 +120,7 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
     const int NN2 = 2 * sm.N * sm.N;
     sd.xa_stride = NN2 + 36; sd.xb_stride = 8; sd.xs_stride = 4 + 2 * NN2;
     const size_t BG = (size_t)d.B * c.G;
-    const size_t words = BG * 4 + 64;
+    const size_t words = BG * 4 + 64 + (size_t)d.B;
     const size_t bytes = (BG * (2 * sd.xa_stride + sd.xb_stride + sd.xs_stride)) * sizeof(double) + words * sizeof(unsigned);
     sd.xa_parity = (long long)(BG * sd.xa_stride);
     char* p = nullptr;
@@ -130,6 +130,8 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
     sd.xA = (double*)p; sd.xB = sd.xA + 2 * BG * sd.xa_stride; sd.xS = sd.xB + BG * sd.xb_stride;
     sd.flags = (unsigned*)(sd.xS + BG * sd.xs_stride);
     sd.err = sd.flags + BG * 4;
+    sd.final_valid = (int*)(sd.err + 64);
+    sm.B = d.B;
     sm.flag_bytes = BG * 4 * sizeof(unsigned);
     const int s = sm.src ? 1 : 0;
     if (sm.lds_bytes > 64 * 1024 && !g_inst[c.inst].lds_opted[s]) {
@@ -151,4 +153,12 @@ int qoc_small_launch(QocSmall& sm, const QocDev& d, const QocAdamDev& ap, int it
     if (sm.G > 1 && hipMemsetAsync(sd.flags, 0, sm.flag_bytes, s) != hipSuccess) { msg = "clearing the exchange flags failed"; return -2; }
     hipLaunchKernelGGL(g_inst[inst].fn[sm.src ? 1 : 0], dim3((unsigned)(d.B * sm.G)), dim3((unsigned)(sm.R * 16)), sm.lds_bytes, s, d, ap, sd);
     return 0;
+}
+
+bool qoc_small_final_valid(const QocSmall& sm, hipStream_t s) {
+    std::vector<int> v((size_t)sm.B, 0);
+    if (hipStreamSynchronize(s) != hipSuccess) return false;
+    if (hipMemcpy(v.data(), sm.sd.final_valid, v.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (int x : v) if (!x) return false;
+    return true;
 }

@@ -236,6 +236,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     // ---- prologue: constants to LDS -------------------------------------------------------------------------------------------------------
     const int it_start = d.iters[b], adam_t_start = d.adam_t[b];
     if (ap.mode == 1 && d.done[b]) return;                      // a finished control set keeps its last evaluation (uniform over its workgroups)
+    if (g == 0 && tid == 0) sd.final_valid[b] = 0;              // final_state / unitary_scale of this launch's last evaluation: set in the epilogue when formed here
+    bool tree_is_last = true;                                   // the product tree in LDS belongs to the evaluation the launch reports
     {
         const double sc = 1.0 / (double)(1 << d.s);
         for (int o = tid; o < (k + 1) * NN; o += THREADS) {
@@ -423,6 +425,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     it_count = sv_it_count; adam_t = sv_adam_t; pow_b1 = sv_pow_b1; pow_b2 = sv_pow_b2; lr_run = sv_lr_run;
                     out_loss = loss; out_regstate = sp_regstate; out_reg = loss + sp_regstate + reg; out_g2 = g2; out_z = z;
                     done_now = 1;
+                    tree_is_last = false;                          // (the tree is the undone evaluation's: final_state is formed on read-back instead)
                     break;
                 }
                 spec = false;
@@ -816,6 +819,26 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             d.w[go] = e_w[e]; d.u[go] = misc[M_MAXA + e_kk[e]] * e_w[e];          // the controls the LAST evaluation ran on
             if (ap.mode != 0) { d.base[go] = e_base[e]; d.adam_m[go] = e_m[e]; d.adam_v[go] = e_v[e]; }
         }
+    }
+    // unitary mode: final_state = (product of all propagators) U0 is one product away from the root of the tree, unitary_scale = (1/n) sum_c |sum_a X[c][a]|^2 a row
+    // reduction away from that (core/tensorflow_state.py:204-227): formed here, so that a poll of the progress line needs no second pass over the pulse
+    if (!d.state_transfer && tree_is_last && g == 0 && row == 0) {
+        const cplx* root = multi ? unode(treeU, sd.LG, 0) : lnode(treeM, LR, 0);
+        cplx Ar[N], Uc[N], X[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            Ar[r] = root[r * N + jj];
+            Uc[r] = (r < n && j < n) ? d.U0[r * n + j] : cmake(0.0, 0.0);
+        }
+        mulb<N>(Ar, Uc, X);
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            if (r < n && j < n) d.Xfinal[(size_t)b * n * n + r * n + j] = X[r];
+            const double sx = row_sum16(j < n ? X[r].x : 0.0), sy = row_sum16(j < n ? X[r].y : 0.0);
+            if (r < n) part += sx * sx + sy * sy;
+        }
+        if (j == 0) { d.uscale[b] = part / (double)n; sd.final_valid[b] = 1; }
     }
     if (g == 0 && tid == 0) {
         d.loss[b] = out_loss; d.reg_loss[b] = out_reg; d.g2[b] = out_g2; d.reg_state[b] = out_regstate; d.zfin[b] = out_z;

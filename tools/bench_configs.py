@@ -46,6 +46,13 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'c3x64':        # profiling hook: batched state transfer only
         run('C3 state transfer x64 seeds', cases.case_c3(), 64, 5)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'c1':           # profiling hook: BASELINE config 1 on the workgroup-resident path (one control set, then 64)
+        run('C1 single qubit', cases.case_c1(), 1, 2000)
+        run('C1 single qubit x64 seeds', cases.case_c1(), 64, 2000)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'n8small':      # profiling hook: two transmons (n = 8, k = 4, 500 slices), one control set
+        run('n=8 one control set', cases.case_c2(n=8, k=4, steps=500, m=8, taylor=(5, 3), seed=2), 1, 2000)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'c5':           # profiling hook: large Hilbert space only
         run('C5 n=512 k=8 steps=2000 (GEMM path)', cases.case_c2(n=512, k=8, steps=2000, m=8, taylor=(5, 3), seed=2), 1, 2)
         sys.exit(0)
