@@ -46,7 +46,7 @@ __host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, 
     lo.qS = o; o += k * RL;                        // <Lambda_{t+1}, H_k Psi_{t+1}> of the own slices
     lo.wS = o; o += (k * (RL + 4) + 1) / 2;        // sin(base) of the own slices + two halo slices either side (doubles)
     lo.misc = o; o += 64;                          // reductions, scalars, inverse factorials (128 doubles)
-    lo.xsum = o; o += Gp > 1 ? 2 * Gp + 16 : 0;    // partial sums of the workgroups of the control set (4 doubles each) + the halo controls (4 per control)
+    lo.xsum = o; o += Gp > 1 ? 2 * Gp : 0;         // partial sums of the workgroups of the control set (4 doubles each)
     lo.total = o;
     return lo;
 }
@@ -71,7 +71,7 @@ struct QocSmall {
     bool src = false;
     size_t lds_bytes = 0;
     QocSmallDev sd{};
-    size_t flag_bytes = 0, xa_bytes = 0;
+    size_t flag_bytes = 0;
     int B = 0;
 };
 // did the last launch leave final_state / unitary_scale of every control set behind (else the read-back re-forms them)?  Synchronises the stream.

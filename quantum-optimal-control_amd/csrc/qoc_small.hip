@@ -121,15 +121,13 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
     sd.xa_stride = NN2 + 36; sd.xb_stride = 8; sd.xs_stride = 4 + 2 * NN2;
     const size_t BG = (size_t)d.B * c.G;
     const size_t words = BG * 4 + 64 + (size_t)d.B;
-    // exchange A: two buffers (parity of the iteration) of granules, two per double
-    const size_t bytes = (BG * (4 * sd.xa_stride + sd.xb_stride + sd.xs_stride)) * sizeof(double) + words * sizeof(unsigned);
-    sm.xa_bytes = BG * 4 * sd.xa_stride * sizeof(double);
+    const size_t bytes = (BG * (2 * sd.xa_stride + sd.xb_stride + sd.xs_stride)) * sizeof(double) + words * sizeof(unsigned);
     sd.xa_parity = (long long)(BG * sd.xa_stride);
     char* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { msg = "hipMalloc of the exchange buffers failed"; return -3; }
     allocs.push_back(p);
     if (hipMemset(p, 0, bytes) != hipSuccess) { msg = "clearing the exchange buffers failed"; return -2; }
-    sd.xA = (double*)p; sd.xB = sd.xA + 4 * BG * sd.xa_stride; sd.xS = sd.xB + BG * sd.xb_stride;
+    sd.xA = (double*)p; sd.xB = sd.xA + 2 * BG * sd.xa_stride; sd.xS = sd.xB + BG * sd.xb_stride;
     sd.flags = (unsigned*)(sd.xS + BG * sd.xs_stride);
     sd.err = sd.flags + BG * 4;
     sd.final_valid = (int*)(sd.err + 64);
@@ -152,10 +150,7 @@ int qoc_small_launch(QocSmall& sm, const QocDev& d, const QocAdamDev& ap, int it
     if (inst < 0) { msg = "no kernel instance"; return -1; }
     QocSmallDev sd = sm.sd;
     sd.iters = ap.mode == 1 ? iters : 1;
-    // epochs restart at 1 in every launch: the flag words and the epoch-tagged granules of exchange A start from zero
-    if (sm.G > 1 && (hipMemsetAsync(sd.flags, 0, sm.flag_bytes, s) != hipSuccess || hipMemsetAsync(sd.xA, 0, sm.xa_bytes, s) != hipSuccess)) {
-        msg = "clearing the exchange buffers failed"; return -2;
-    }
+    if (sm.G > 1 && hipMemsetAsync(sd.flags, 0, sm.flag_bytes, s) != hipSuccess) { msg = "clearing the exchange flags failed"; return -2; }
     hipLaunchKernelGGL(g_inst[inst].fn[sm.src ? 1 : 0], dim3((unsigned)(d.B * sm.G)), dim3((unsigned)(sm.R * 16)), sm.lds_bytes, s, d, ap, sd);
     return 0;
 }

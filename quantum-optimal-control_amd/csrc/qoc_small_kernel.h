@@ -129,57 +129,6 @@ __device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD p
     }
 }
 
-// Exchange A travels as GRANULES (Guideline 16, form R2: the data is the flag): a double = two naturally aligned 8-byte words {epoch : 32, half of the double : 32}, each
-// written by ONE write-through store -- no drain, no flag word, no second hop; a consumer re-reads its granules until both carry the epoch of this iteration.  The
-// buffers are zeroed before every launch (epochs restart at 1), and alternate with the parity of the iteration (see the exchange).
-__device__ __forceinline__ void st_gran(unsigned long long* g, unsigned epoch, double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)epoch << 32;
-    __hip_atomic_store((gu64*)g, tag | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((gu64*)(g + 1), tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// count doubles out of granules into LDS: eight elements (sixteen loads) in flight per thread and pass; src(o) = the first granule of element o, or nullptr for a pad
-// element of value pad(o).  Bounded: a producer that never shows up raises the error word instead of hanging the box.
-template <int THREADS, class SRC, class PAD>
-__device__ __forceinline__ void fetch_gran(double* dst, int count, SRC src, PAD pad, unsigned epoch, unsigned* err) {
-    const bool dead = __hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    for (int o0 = threadIdx.x; o0 < count; o0 += 8 * THREADS) {
-        double v[8];
-        const unsigned long long* a[8];
-        unsigned pending = 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int o = o0 + u * THREADS;
-            v[u] = 0.0; a[u] = nullptr;
-            if (o < count) { a[u] = src(o); if (a[u]) pending |= 1u << u; else v[u] = pad(o); }
-        }
-        unsigned spins = 0;
-        while (pending) {
-            unsigned long long x0[8], x1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                x0[u] = 0; x1[u] = 0;
-                if ((pending >> u) & 1u) {
-                    x0[u] = __hip_atomic_load((gu64*)a[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x1[u] = __hip_atomic_load((gu64*)(a[u] + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (((pending >> u) & 1u) && (unsigned)(x0[u] >> 32) == epoch && (unsigned)(x1[u] >> 32) == epoch) {
-                    v[u] = __longlong_as_double((long long)((x0[u] & 0xffffffffull) | (x1[u] << 32)));
-                    pending &= ~(1u << u);
-                }
-            }
-            if (pending) {
-                if (dead || ++spins > (1u << 20)) { __hip_atomic_store((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int o = o0 + u * THREADS; if (o < count) dst[o] = v[u]; }
-    }
-}
-
 template <int THREADS>
 __device__ __forceinline__ void wg_sum2(double& a, double& b, double* red /* 2 x waves doubles */) {
 #pragma unroll
@@ -350,7 +299,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     double out_loss = 0.0, out_reg = 0.0, out_g2 = 0.0, out_regstate = 0.0;
     cplx out_z = cmake(0.0, 0.0);
     const double mm = (double)m * (double)m, c0 = -2.0 / mm;
-    unsigned long long* xA0 = (unsigned long long*)sd.xA + 2 * ((size_t)b * G) * sd.xa_stride;       // (two granules per double)
+    double* xA0 = sd.xA + ((size_t)b * G) * sd.xa_stride;
     double* xB = sd.xB + ((size_t)b * G) * sd.xb_stride;
     double* xS = sd.xS + ((size_t)b * G) * sd.xs_stride;
     unsigned* flags = sd.flags + ((size_t)b * G) * 4;
@@ -445,29 +394,24 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         if (multi) {
             // exchange A: the subtree product of every workgroup of the control set + the halo controls of the neighbours.  Two buffers, by the parity of
             // the iteration: with the stop rule deferred nothing else separates a fast workgroup's next publication from a slow one's reads of this one
-            unsigned long long* xA = xA0 + 2 * (size_t)(it & 1) * sd.xa_parity;
-            auto gran = [&](int gi, int o) -> unsigned long long* { return xA + 2 * ((size_t)gi * sd.xa_stride + o); };
+            double* xA = xA0 + (size_t)(it & 1) * sd.xa_parity;
             const double* root = (const double*)lnode(treeM, LR, 0);
-            for (int o = tid; o < 2 * NN; o += THREADS) st_gran(gran(g, o), epoch, root[o]);
-            if (tid < 4 * k) { const int kk = tid >> 2, h = tid & 3; st_gran(gran(g, 2 * NN + tid), epoch, Wv(kk, h < 2 ? h : RL - 4 + h)); }
-            if (spec && tid == 0) {
-                st_gran(gran(g, 2 * NN + 32), epoch, sp_reg); st_gran(gran(g, 2 * NN + 33), epoch, sp_g2);
-                st_gran(gran(g, 2 * NN + 34), epoch, sp_z.x); st_gran(gran(g, 2 * NN + 35), epoch, sp_z.y);
+            double* mine = xA + (size_t)g * sd.xa_stride;
+            for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + o, root[o]);
+            if (tid < 4 * k) { const int kk = tid >> 2, h = tid & 3; st_sc1(mine + 2 * NN + tid, Wv(kk, h < 2 ? h : RL - 4 + h)); }
+            if (spec && tid == 0) { st_sc1(mine + 2 * NN + 32, sp_reg); st_sc1(mine + 2 * NN + 33, sp_g2); st_sc1(mine + 2 * NN + 34, sp_z.x); st_sc1(mine + 2 * NN + 35, sp_z.y); }
+            publish_flag(flags + 4 * g + 0, epoch);
+            wait_flags(flags + 0, G, epoch, sd.err);
+            if (spec) fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xA + (size_t)(o >> 2) * sd.xa_stride + 2 * NN + 32 + (o & 3); }, [](int) { return 0.0; });
+            fetch_sc1<THREADS>((double*)unode(treeU, 0, 0), sd.Gp * 2 * NN,
+                [&](int o) -> const double* { const int gi = o / (2 * NN); return gi < G ? xA + (size_t)gi * sd.xa_stride + (o - gi * 2 * NN) : nullptr; },
+                [&](int o) { const int w = o % (2 * NN), e = w >> 1; return ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; });   // identity leaves pad the tree
+            if (tid < 4 * k) {                                    // halo: the neighbours' controls of this evaluation
+                const int kk = tid >> 2, h = tid & 3;
+                const int src_g = h < 2 ? g - 1 : g + 1, tl = h < 2 ? h - 2 : RL + (h - 2), t = g * RL + tl;
+                if (src_g >= 0 && src_g < G && t >= 0 && t < steps)
+                    Wv(kk, tl) = ld_sc1(xA + (size_t)src_g * sd.xa_stride + 2 * NN + 4 * kk + (h < 2 ? h + 2 : h - 2));
             }
-            fetch_gran<THREADS>((double*)unode(treeU, 0, 0), sd.Gp * 2 * NN,
-                [&](int o) -> const unsigned long long* { const int gi = o / (2 * NN); return gi < G ? gran(gi, o - gi * 2 * NN) : nullptr; },
-                [&](int o) { const int w = o % (2 * NN), e = w >> 1; return ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; },     // identity leaves pad the tree
-                epoch, sd.err);
-            if (spec) fetch_gran<THREADS>(xsum, 4 * G, [&](int o) -> const unsigned long long* { return gran(o >> 2, 2 * NN + 32 + (o & 3)); }, [](int) { return 0.0; }, epoch, sd.err);
-            // halo: the neighbours' controls of this evaluation (first / last two slices of the workgroups either side)
-            double* halo = xsum + 4 * sd.Gp;
-            fetch_gran<THREADS>(halo, 4 * k,
-                [&](int o) -> const unsigned long long* {
-                    const int kk = o >> 2, h = o & 3, src_g = h < 2 ? g - 1 : g + 1, t = g * RL + (h < 2 ? h - 2 : RL + (h - 2));
-                    return (src_g >= 0 && src_g < G && t >= 0 && t < steps) ? gran(src_g, 2 * NN + 4 * kk + (h < 2 ? h + 2 : h - 2)) : nullptr; },
-                [](int) { return 0.0; }, epoch, sd.err);
-            __syncthreads();
-            if (tid < 4 * k) { const int kk = tid >> 2, h = tid & 3; Wv(kk, h < 2 ? h - 2 : RL + (h - 2)) = halo[tid]; }
             __syncthreads();
             if (spec) {                                            // the stop rule of the previous iteration, one exchange late
                 double reg = 0.0, g2 = 0.0;
