@@ -9,18 +9,24 @@
 
 // (instantiated in qoc_small_a / _b / _c.hip)
 #define QOC_SMALL_DECL(N, L, R, S) \
-    extern template __global__ void qsm::k_small_iter<N, L, R, false>(QocDev, QocAdamDev, QocSmallDev); \
-    extern template __global__ void qsm::k_small_iter<N, L, R, true>(QocDev, QocAdamDev, QocSmallDev);
+    extern template __global__ void qsm::k_small_iter<N, L, R, false, true>(QocDev, QocAdamDev, QocSmallDev); \
+    extern template __global__ void qsm::k_small_iter<N, L, R, true, true>(QocDev, QocAdamDev, QocSmallDev);
+#define QOC_SMALL_DECL1(N, L, R, S) \
+    extern template __global__ void qsm::k_small_iter<N, L, R, false, false>(QocDev, QocAdamDev, QocSmallDev); \
+    extern template __global__ void qsm::k_small_iter<N, L, R, true, false>(QocDev, QocAdamDev, QocSmallDev);
 QOC_SMALL_INSTANCES_A(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_B(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_C(QOC_SMALL_DECL)
+QOC_SMALL_INSTANCES_A(QOC_SMALL_DECL1)
 
 namespace {
 
 typedef void (*small_kernel_t)(QocDev, QocAdamDev, QocSmallDev);
 
-struct Instance { int N, L, R; small_kernel_t fn[2]; bool ok[2]; bool lds_opted[2]; };   // ok: [without, with] a state regulariser (instances that spill are out)
+struct Instance { int N, L, R; small_kernel_t fn[2]; bool ok[2]; bool lds_opted[2]; small_kernel_t fn1[2]; };   // ok: [without, with] a state regulariser (instances that spill are out); fn1: the one-workgroup builds (n <= 4), or null
 
-#define QOC_SMALL_ROW(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false>, S ? qsm::k_small_iter<N, L, R, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false } },
-Instance g_inst[] = { QOC_SMALL_INSTANCES_A(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_B(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_C(QOC_SMALL_ROW) };
+#define QOC_SMALL_ROW(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, true>, S ? qsm::k_small_iter<N, L, R, true, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, { nullptr, nullptr } },
+#define QOC_SMALL_ROW1(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, true>, S ? qsm::k_small_iter<N, L, R, true, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, \
+    { qsm::k_small_iter<N, L, R, false, false>, S ? qsm::k_small_iter<N, L, R, true, false> : (small_kernel_t) nullptr } },
+Instance g_inst[] = { QOC_SMALL_INSTANCES_A(QOC_SMALL_ROW1) QOC_SMALL_INSTANCES_B(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_C(QOC_SMALL_ROW) };
 constexpr int N_INST = sizeof(g_inst) / sizeof(g_inst[0]);
 
 int padded_n(int n) {
@@ -36,7 +42,7 @@ int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
     const int Teff = d.state_transfer ? d.T - 1 : d.T;
     // (n <= 4: a slice is a few hundred instructions between LDS round trips -- a second wave per SIMD hides them instead of competing: C1 9.1 us on 32 rows, 10.4 on 16)
-    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? 0.45 * R / 16.0 + 0.45 : (R <= 16 ? 1.0 : R / 16.0);
+    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? (R >= 32 ? 1.15 : 0.9) : (R <= 16 ? 1.0 : R / 16.0);
     const double per_slice = ((Teff > 1 ? Teff - 1 : 0) + d.s + (src ? 6.0 : 4.0)) * prod + 0.15;
     const int LR = ilog2_ceil(R), LG = ilog2_ceil(G);
     double us = share * (L * per_slice + (src ? 4.0 : 2.0) * LR * (prod + 0.1));
@@ -135,7 +141,8 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
     sm.flag_bytes = BG * 4 * sizeof(unsigned);
     const int s = sm.src ? 1 : 0;
     if (sm.lds_bytes > 64 * 1024 && !g_inst[c.inst].lds_opted[s]) {
-        if (hipFuncSetAttribute((const void*)in.fn[s], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)in.fn[s], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            (in.fn1[s] && hipFuncSetAttribute((const void*)in.fn1[s], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
             msg = "cannot reserve LDS for the workgroup-resident kernel"; return -2;
         }
         g_inst[c.inst].lds_opted[s] = true;
@@ -151,7 +158,9 @@ int qoc_small_launch(QocSmall& sm, const QocDev& d, const QocAdamDev& ap, int it
     QocSmallDev sd = sm.sd;
     sd.iters = ap.mode == 1 ? iters : 1;
     if (sm.G > 1 && hipMemsetAsync(sd.flags, 0, sm.flag_bytes, s) != hipSuccess) { msg = "clearing the exchange flags failed"; return -2; }
-    hipLaunchKernelGGL(g_inst[inst].fn[sm.src ? 1 : 0], dim3((unsigned)(d.B * sm.G)), dim3((unsigned)(sm.R * 16)), sm.lds_bytes, s, d, ap, sd);
+    const int si = sm.src ? 1 : 0;
+    const small_kernel_t kern = (sm.G == 1 && g_inst[inst].fn1[si]) ? g_inst[inst].fn1[si] : g_inst[inst].fn[si];
+    hipLaunchKernelGGL(kern, dim3((unsigned)(d.B * sm.G)), dim3((unsigned)(sm.R * 16)), sm.lds_bytes, s, d, ap, sd);
     return 0;
 }
 

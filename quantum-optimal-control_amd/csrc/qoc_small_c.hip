@@ -2,6 +2,6 @@
 #include "qoc_small_kernel.h"
 #include "qoc_small_instances.h"
 #define QOC_SMALL_DEF(N, L, R, S) \
-    template __global__ void qsm::k_small_iter<N, L, R, false>(QocDev, QocAdamDev, QocSmallDev); \
-    template __global__ void qsm::k_small_iter<N, L, R, true>(QocDev, QocAdamDev, QocSmallDev);
+    template __global__ void qsm::k_small_iter<N, L, R, false, true>(QocDev, QocAdamDev, QocSmallDev); \
+    template __global__ void qsm::k_small_iter<N, L, R, true, true>(QocDev, QocAdamDev, QocSmallDev);
 QOC_SMALL_INSTANCES_C(QOC_SMALL_DEF)

@@ -2,7 +2,7 @@
 // state-regulariser flow compiles without spilling (kernel-resource-usage: ScratchSize 0).  qoc_small.hip builds its table from the list; qoc_small_a / _b / _c.hip
 // instantiate their share of it (three translation units compile side by side).
 #pragma once
-// n <= 4: 32 rows (two waves per SIMD) and 16 rows (one)
+// n <= 4: 32 rows (two waves per SIMD) and 16 rows (one); this list is also instantiated with MM = false (one workgroup per control set, no exchange code)
 #define QOC_SMALL_INSTANCES_A(X) \
     X(2, 1, 32, 1) X(2, 2, 32, 1) X(2, 4, 32, 0) X(3, 1, 32, 1) X(3, 2, 32, 1) X(3, 4, 32, 0) X(4, 1, 32, 1) X(4, 2, 32, 0) \
     X(2, 1, 16, 1) X(2, 2, 16, 1) X(2, 4, 16, 1) X(2, 8, 16, 1) X(3, 1, 16, 1) X(3, 2, 16, 1) X(3, 4, 16, 1) X(3, 8, 16, 1) \

@@ -203,7 +203,9 @@ __device__ __forceinline__ void add_sources(cplx (&Y)[N], cplx (&sf)[QOC_SMALL_N
 }
 
 // =========================================================================================================================================
-template <int N, int L, int R, bool SRC>
+// MM = false: an instance for ONE workgroup per control set -- the exchange code, the deferred stop rule and their live state are compiled out (the 32-row instances of
+// n <= 4 have 256 registers per lane: with the exchanges compiled in they spill in the loop; C1 takes one of these)
+template <int N, int L, int R, bool SRC, bool MM = true>
 __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, QocSmallDev sd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int THREADS = R * 16, RL = R * L, LR = ilog2c(R), NN = N * N;
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     const int n = d.n, m = d.m, k = d.k, steps = d.steps, nforb = SRC ? d.n_forb : 0;
     const bool lane_m = j < m;
     const int grow = g * R + row, t0 = grow * L, LTOT = LR + sd.LG;
-    const bool multi = G > 1;
+    const bool multi = MM && G > 1;
     const bool has_speed = SRC && d.has_speed;
 
     const QocSmallLayout lo = qoc_small_layout(N, R, L, k, m, sd.Gp, SRC);
@@ -290,6 +292,17 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     }
     __syncthreads();
 
+    // n <= 4: a slice is a few hundred instructions between LDS round trips (profiles/r06_small_phase_timing.txt) -- the lane's columns of the drift and of the first two control
+    // Hamiltonians (generator assembly) and their transposes (gradient contraction) stay in registers for the whole launch; further controls come from LDS as for larger n
+    constexpr bool HOIST = N <= 4;
+    cplx H0r[N], H1r[N], H2r[N], T0r[N], T1r[N];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            H0r[r] = HsC[r * N + jj]; H1r[r] = HsC[NN + r * N + jj]; H2r[r] = k > 1 ? HsC[2 * NN + r * N + jj] : cmake(0.0, 0.0);
+            T0r[r] = HsT[r * N + jj]; T1r[r] = k > 1 ? HsT[NN + r * N + jj] : cmake(0.0, 0.0);
+        }
+    }
     int it_count = it_start, adam_t = adam_t_start, done_now = 0;
     // beta^t of the Adam bias correction and the learning-rate schedule rate e^{-it / decay}: formed once per launch, advanced by one multiplication per
     // iteration (pow / exp are ~1000 instructions on every wave of the workgroup; the running products differ from them by <= iterations-per-launch ulps)
@@ -324,6 +337,14 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         QSM_STAMP(0);
         // ---- P1: exponentials of the own slices, kept in registers; product of the row --------------------------------------------------
         cplx Kr[L][N];
+        double uu0[L], uu1[L];                                                   // controls of the own slices (first two), read ahead of the products
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                uu0[i] = misc[M_MAXA] * Wv(0, row * L + i);
+                uu1[i] = k > 1 ? misc[M_MAXA + 1] * Wv(1, row * L + i) : 0.0;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             const int t = t0 + i;
@@ -332,9 +353,17 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             if (t < steps && sd.Teff >= 1) {
                 cplx A[N], Hn[N], acc[N];
                 const int tl = row * L + i;
+                if constexpr (HOIST) {
 #pragma unroll
-                for (int r = 0; r < N; ++r) A[r] = HsC[r * N + jj];
-                for (int kk = 0; kk < k; ++kk) {
+                    for (int r = 0; r < N; ++r) {
+                        A[r].x = fma(uu1[i], H2r[r].x, fma(uu0[i], H1r[r].x, H0r[r].x));
+                        A[r].y = fma(uu1[i], H2r[r].y, fma(uu0[i], H1r[r].y, H0r[r].y));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < N; ++r) A[r] = HsC[r * N + jj];
+                }
+                for (int kk = HOIST ? 2 : 0; kk < k; ++kk) {
                     const double u = misc[M_MAXA + kk] * Wv(kk, tl);
                     const cplx* Hk = HsC + (kk + 1) * NN;
 #pragma unroll
@@ -378,7 +407,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         // ---- P2: up-sweep of the product tree (later times on the left) ---------------------------------------------------------------------
 #pragma unroll 1
         for (int l = 1; l <= LR; ++l) {
-            __syncthreads();
+            // levels 1 and 2 combine rows of ONE wave (four rows per wave): the wave's own LDS traffic is ordered, no workgroup barrier
+            if (l <= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
             if ((row & ((1 << l) - 1)) == 0) {
                 const cplx* rn = lnode(treeM, l - 1, (row >> (l - 1)) + 1);
                 cplx Ar[N], acc[N];
@@ -470,6 +500,26 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         if constexpr (!SRC) {
             // z-free costate: Lambda_tau = -(2 / m^2) z Lambda'_tau with Lambda'_N = W; one product per level -- the row is either the right
             // child (its start state passes the left sibling) or the left one (its end costate passes the right sibling)
+            cplx Sib[(!MM && N <= 4) ? LR : 1][N];
+            if constexpr (!MM && N <= 4) {                                        // one workgroup, tiny matrices: the log2(R) siblings of the walk in ONE batch of LDS reads
+#pragma unroll
+                for (int l = LR; l >= 1; --l) {
+                    int bit;
+                    const cplx* sn = sibling(treeM, treeU, l, bit);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) Sib[l - 1][r] = sn[r * N + jj];
+                }
+#pragma unroll
+                for (int l = LR; l >= 1; --l) {
+                    const int bit = (grow >> (l - 1)) & 1;
+                    cplx As[N], xs[N], acc[N];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { As[r] = bit ? Sib[l - 1][r] : Y[r]; xs[r] = bit ? Phi[r] : Sib[l - 1][r]; }
+                    mulb<N>(As, xs, acc);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { if (bit) Phi[r] = acc[r]; else Y[r] = acc[r]; }
+                }
+            } else
 #pragma unroll 1
             for (int l = LTOT; l >= 1; --l) {
                 int bit;
@@ -592,7 +642,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             }
 #pragma unroll 1
             for (int l = 1; l <= LR; ++l) {                                      // O = O_right M_left + O_left
-                __syncthreads();
+                if (l <= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
                 if ((row & ((1 << l) - 1)) == 0) {
                     const cplx* orn = lnodeO(l - 1, (row >> (l - 1)) + 1);
                     const cplx* mln = lnode(treeM, l - 1, row >> (l - 1));
@@ -671,7 +721,16 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             const int t = t0 + i, tl = row * L + i;
             cplx Rm[N];
             mulb<N>(Ps[i], Y, Rm);                                               // Rm[c] (lane a) = (Psi_{t+1} Y_{t+1})[c][a]
-            for (int kk = 0; kk < k; ++kk) {
+            if constexpr (HOIST) {                                                 // the first two controls against the register copies, both reductions in flight together
+                cplx q0 = cmake(0.0, 0.0), q1 = cmake(0.0, 0.0);
+#pragma unroll
+                for (int c = 0; c < N; ++c) { cfma(q0, T0r[c], Rm[c]); cfma(q1, T1r[c], Rm[c]); }
+                if (!act) { q0 = cmake(0.0, 0.0); q1 = cmake(0.0, 0.0); }
+                q0.x = row_sum16(q0.x); q0.y = row_sum16(q0.y);
+                if (k > 1) { q1.x = row_sum16(q1.x); q1.y = row_sum16(q1.y); }
+                if (j == 0 && t < steps) { qS[tl] = q0; if (k > 1) qS[RL + tl] = q1; }
+            }
+            for (int kk = HOIST ? 2 : 0; kk < k; ++kk) {
                 const cplx* Hk = HsT + kk * NN;
                 cplx q = cmake(0.0, 0.0);
 #pragma unroll
