@@ -592,17 +592,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
             }
             wg_sum2<THREADS>(fval, zz2, misc + M_RED);
-            if (multi) {
-                // exchange A1: partial sums, and Psi_N with z_N from the workgroup that holds the last slice
-                double* mine = xS + (size_t)g * sd.xs_stride;
+            auto fetch_a1 = [&]() {                                               // (after the flags of the exchange that carried the payload)
                 const int glast = (steps - 1) / RL;
-                if (tid == 0) { st_sc1(mine + 0, fval); st_sc1(mine + 1, zz2); }
-                if (g == glast) {
-                    if (tid == 0) { st_sc1(mine + 2, misc[M_ZN]); st_sc1(mine + 3, misc[M_ZN + 1]); }
-                    for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + 4 + o, ((const double*)PsiN)[o]);
-                }
-                publish_flag(flags + 4 * g + 2, epoch);
-                wait_flags(flags + 2, G, epoch, sd.err);
                 fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xS + (size_t)(o >> 2) * sd.xs_stride + (o & 3); }, [](int) { return 0.0; });
                 if (g != glast) {
                     const double* from = xS + (size_t)glast * sd.xs_stride;
@@ -613,8 +604,25 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 for (int gi = 0; gi < G; ++gi) { fval += xsum[4 * gi]; zz2 += xsum[4 * gi + 1]; }
                 if (tid == 0) { misc[M_ZN] = xsum[4 * glast + 2]; misc[M_ZN + 1] = xsum[4 * glast + 3]; }
                 __syncthreads();
+            };
+            if (multi) {
+                // exchange A1: partial sums, and Psi_N with z_N from the workgroup that holds the last slice
+                double* mine = xS + (size_t)g * sd.xs_stride;
+                const int glast = (steps - 1) / RL;
+                if (tid == 0) { st_sc1(mine + 0, fval); st_sc1(mine + 1, zz2); }
+                if (g == glast) {
+                    if (tid == 0) { st_sc1(mine + 2, misc[M_ZN]); st_sc1(mine + 3, misc[M_ZN + 1]); }
+                    for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + 4 + o, ((const double*)PsiN)[o]);
+                }
+                // Without speed_up nothing below needs these sums before the offsets of the subtrees travel (the sources of forbidden levels are local in time):
+                // the payload then rides on exchange A2 -- one exchange less per iteration
+                if (has_speed) {
+                    publish_flag(flags + 4 * g + 2, epoch);
+                    wait_flags(flags + 2, G, epoch, sd.err);
+                    fetch_a1();
+                }
             }
-            zfin = cmake(misc[M_ZN], misc[M_ZN + 1]);
+            if (!multi || has_speed) zfin = cmake(misc[M_ZN], misc[M_ZN + 1]);
             const double resid = (double)(steps + 1) - zz2 / mm;
             reg_state = fval + (has_speed ? d.a_speed * 0.5 * resid * resid : 0.0);
             coef = has_speed ? -d.a_speed * resid * 2.0 / mm : 0.0;
@@ -663,6 +671,11 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 for (int o = tid; o < 2 * MN; o += THREADS) st_sc1(mine + o, root[o]);
                 publish_flag(flags + 4 * g + 3, epoch);
                 wait_flags(flags + 3, G, epoch, sd.err);
+                if (!has_speed) {                                                 // the payload of exchange A1 came with this one
+                    fetch_a1();
+                    zfin = cmake(misc[M_ZN], misc[M_ZN + 1]);
+                    reg_state = fval;
+                }
                 fetch_sc1<THREADS>((double*)unodeO(0, 0), sd.Gp * 2 * MN,
                     [&](int o) -> const double* { const int gi = o / (2 * MN); return gi < G ? xS + (size_t)gi * sd.xs_stride + 4 + 2 * NN + (o - gi * 2 * MN) : nullptr; },
                     [](int) { return 0.0; });
