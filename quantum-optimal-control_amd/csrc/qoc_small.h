@@ -67,7 +67,7 @@ struct QocSmallDev {            // kernel argument beside QocDev / QocAdamDev
 
 struct QocSmall {
     bool on = false;
-    int N = 0, L = 0, R = 0, G = 1;
+    int N = 0, L = 0, R = 0, G = 1, inst = -1;
     bool src = false;
     size_t lds_bytes = 0;
     QocSmallDev sd{};

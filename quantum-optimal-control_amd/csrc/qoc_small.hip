@@ -15,18 +15,18 @@
     extern template __global__ void qsm::k_small_iter<N, L, R, false, false>(QocDev, QocAdamDev, QocSmallDev); \
     extern template __global__ void qsm::k_small_iter<N, L, R, true, false>(QocDev, QocAdamDev, QocSmallDev);
 QOC_SMALL_INSTANCES_A(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_B(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_C(QOC_SMALL_DECL)
-QOC_SMALL_INSTANCES_A(QOC_SMALL_DECL1)
+QOC_SMALL_INSTANCES_A1(QOC_SMALL_DECL1)
 
 namespace {
 
 typedef void (*small_kernel_t)(QocDev, QocAdamDev, QocSmallDev);
 
-struct Instance { int N, L, R; small_kernel_t fn[2]; bool ok[2]; bool lds_opted[2]; small_kernel_t fn1[2]; };   // ok: [without, with] a state regulariser (instances that spill are out); fn1: the one-workgroup builds (n <= 4), or null
+struct Instance { int N, L, R; small_kernel_t fn[2]; bool ok[2]; bool lds_opted[2]; bool single; };   // ok: [without, with] a state regulariser (instances that spill are out); single: a build for one workgroup per control set
 
-#define QOC_SMALL_ROW(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, true>, S ? qsm::k_small_iter<N, L, R, true, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, { nullptr, nullptr } },
-#define QOC_SMALL_ROW1(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, true>, S ? qsm::k_small_iter<N, L, R, true, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, \
-    { qsm::k_small_iter<N, L, R, false, false>, S ? qsm::k_small_iter<N, L, R, true, false> : (small_kernel_t) nullptr } },
-Instance g_inst[] = { QOC_SMALL_INSTANCES_A(QOC_SMALL_ROW1) QOC_SMALL_INSTANCES_B(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_C(QOC_SMALL_ROW) };
+#define QOC_SMALL_ROW(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, true>, S ? qsm::k_small_iter<N, L, R, true, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, false },
+// (one-workgroup builds: a row of their own -- `single` -- that choose() takes for G = 1 only)
+#define QOC_SMALL_ROW1(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, false>, S ? qsm::k_small_iter<N, L, R, true, false> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, true },
+Instance g_inst[] = { QOC_SMALL_INSTANCES_A1(QOC_SMALL_ROW1) QOC_SMALL_INSTANCES_A(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_B(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_C(QOC_SMALL_ROW) };
 constexpr int N_INST = sizeof(g_inst) / sizeof(g_inst[0]);
 
 int padded_n(int n) {
@@ -71,7 +71,7 @@ Choice choose(const QocDev& d, bool src, int G_req, int R_req = 0) {
         const int cap = in.R * in.L;
         int G = (d.steps + cap - 1) / cap;
         if (G_req > 0) { if (G > G_req) continue; G = G_req; }
-        if (G > QOC_SMALL_MAXG) continue;
+        if (G > QOC_SMALL_MAXG || (in.single && G > 1)) continue;
         if (G > 1 && ((long long)d.Bplan * G > budget || (long long)d.B * G > 2 * budget)) continue;     // (planned batch; and never more resident-or-deadlocked workgroups than CUs)
         const int Gp = 1 << ilog2_ceil(G);
         const QocSmallLayout lo = qoc_small_layout(N, in.R, in.L, d.k, d.m, Gp, src);
@@ -116,7 +116,7 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
     sm.src = is_src(d);
     const Choice c = choose(d, sm.src, G_req, R_req);
     const Instance& in = g_inst[c.inst];
-    sm.N = in.N; sm.L = in.L; sm.R = in.R; sm.G = c.G;
+    sm.N = in.N; sm.L = in.L; sm.R = in.R; sm.G = c.G; sm.inst = c.inst;
     QocSmallDev& sd = sm.sd;
     sd.G = c.G; sd.LG = ilog2_ceil(c.G); sd.Gp = 1 << sd.LG;
     sd.Teff = d.state_transfer ? d.T - 1 : d.T;
@@ -141,8 +141,7 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
     sm.flag_bytes = BG * 4 * sizeof(unsigned);
     const int s = sm.src ? 1 : 0;
     if (sm.lds_bytes > 64 * 1024 && !g_inst[c.inst].lds_opted[s]) {
-        if (hipFuncSetAttribute((const void*)in.fn[s], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            (in.fn1[s] && hipFuncSetAttribute((const void*)in.fn1[s], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
+        if (hipFuncSetAttribute((const void*)in.fn[s], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             msg = "cannot reserve LDS for the workgroup-resident kernel"; return -2;
         }
         g_inst[c.inst].lds_opted[s] = true;
@@ -152,15 +151,11 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
 }
 
 int qoc_small_launch(QocSmall& sm, const QocDev& d, const QocAdamDev& ap, int iters, hipStream_t s, std::string& msg) {
-    int inst = -1;
-    for (int i = 0; i < N_INST; ++i) if (g_inst[i].N == sm.N && g_inst[i].L == sm.L && g_inst[i].R == sm.R) inst = i;
-    if (inst < 0) { msg = "no kernel instance"; return -1; }
+    if (sm.inst < 0 || sm.inst >= N_INST) { msg = "no kernel instance"; return -1; }
     QocSmallDev sd = sm.sd;
     sd.iters = ap.mode == 1 ? iters : 1;
     if (sm.G > 1 && hipMemsetAsync(sd.flags, 0, sm.flag_bytes, s) != hipSuccess) { msg = "clearing the exchange flags failed"; return -2; }
-    const int si = sm.src ? 1 : 0;
-    const small_kernel_t kern = (sm.G == 1 && g_inst[inst].fn1[si]) ? g_inst[inst].fn1[si] : g_inst[inst].fn[si];
-    hipLaunchKernelGGL(kern, dim3((unsigned)(d.B * sm.G)), dim3((unsigned)(sm.R * 16)), sm.lds_bytes, s, d, ap, sd);
+    hipLaunchKernelGGL(g_inst[sm.inst].fn[sm.src ? 1 : 0], dim3((unsigned)(d.B * sm.G)), dim3((unsigned)(sm.R * 16)), sm.lds_bytes, s, d, ap, sd);
     return 0;
 }
 

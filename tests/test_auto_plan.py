@@ -57,7 +57,12 @@ def lat_limit_nt2(n, state_reg):
 def _small_instances():
     """(n_pad, slices per row, rows per workgroup, with-state-regulariser-too) of k_small_iter, in table order (csrc/qoc_small_instances.h: X(N, L, R, S))."""
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'quantum-optimal-control_amd', 'csrc', 'qoc_small_instances.h')
-    out = [tuple(int(v) for v in mt.groups()) for mt in re.finditer(r'X\((\d+), (\d+), (\d+), ([01])\)', open(path).read())]
+    text = open(path).read()
+    out = []
+    for name in ('A1', 'A', 'B', 'C'):                    # the order of the engine's table; list A1 = builds for ONE workgroup per control set
+        body = text[text.index('#define QOC_SMALL_INSTANCES_%s(X)' % name):]
+        body = body[:body.index('\n//') if '\n//' in body else len(body)]
+        out += [tuple(int(v) for v in mt.groups()) + (name == 'A1',) for mt in re.finditer(r'X\((\d+), (\d+), (\d+), ([01])\)', body)]
     assert len(out) >= 30
     return out
 
@@ -76,11 +81,11 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
     N = [v for v in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12) if v >= n][0]
     clog2 = lambda v: max(0, (v - 1).bit_length())                                   # noqa: E731
     best = None
-    for (Ni, L, R, S) in SMALL_INSTANCES:
+    for (Ni, L, R, S, single) in SMALL_INSTANCES:
         if Ni != N or (src and not S):
             continue
         G = ceil_div(steps, R * L)
-        if G > 32 or (G > 1 and B * G > 128):
+        if G > 32 or (single and G > 1) or (G > 1 and B * G > 128):
             continue
         Gp, NN, RL = 1 << clog2(G), N * N, R * L
         lds = ((k + 1) * NN + k * NN + (4 * N if src else 0) + 2 * NN + (3 * NN if src else 0) + (2 * R - 1) * NN + (2 * Gp - 1) * NN
