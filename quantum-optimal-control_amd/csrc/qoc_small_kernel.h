@@ -58,6 +58,14 @@ __device__ __forceinline__ void mulb_acc(const cplx (&A)[N], const cplx (&x)[N],
         mulb_acc<N, C + 1>(A, x, o);
     }
 }
+// one row of the product: o[R_] += sum_c A[R_][c] x[c]
+template <int N, int R_, int C = 0>
+__device__ __forceinline__ void mulb_row(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N]) {
+    if constexpr (C < N) {
+        cmac_dpp<C>(o[R_], A[R_], x[C]);
+        mulb_row<N, R_, C + 1>(A, x, o);
+    }
+}
 // every register a DPP read may touch is defined before the statement (the compiler cannot see the DPP read inside the asm); then the wait
 // states a DPP read needs behind a VALU write of its source (2) or of EXEC (5): the compiler pads neither for an asm statement
 template <int N>
@@ -74,6 +82,40 @@ __device__ __forceinline__ void mulb(cplx (&A)[N], const cplx (&x)[N], cplx (&o)
     for (int r = 0; r < N; ++r) o[r] = cmake(0.0, 0.0);
     dpp_guard<N>(A);
     mulb_acc<N>(A, x, o);
+}
+
+// The costate side has m rows (Y = Lambda^dagger is m x n, m <= n state vectors: a two-qutrit gate has m = 4 of n = 9): products whose LEFT operand is such a matrix only
+// form the rows r < m (a wave-uniform branch per row), products that SUM over its rows (Psi Y) only take the lanes c < m.
+template <int N, int R_ = 0>
+__device__ __forceinline__ void mulb_rows_acc(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N], int m) {
+    if constexpr (R_ < N) {
+        if (R_ < m) mulb_row<N, R_>(A, x, o);
+        mulb_rows_acc<N, R_ + 1>(A, x, o, m);
+    }
+}
+template <int N>
+__device__ __forceinline__ void mulb_m(cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N], int m) {       // rows r >= m of A are zero: o[r] = 0 there
+#pragma unroll
+    for (int r = 0; r < N; ++r) o[r] = cmake(0.0, 0.0);
+    dpp_guard<N>(A);
+    mulb_rows_acc<N>(A, x, o, m);
+}
+template <int N, int C = 0>
+__device__ __forceinline__ void mulb_cols_acc(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N], int m) {
+    if constexpr (C < N) {
+        if (C < m) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) cmac_dpp<C>(o[r], A[r], x[C]);
+        }
+        mulb_cols_acc<N, C + 1>(A, x, o, m);
+    }
+}
+template <int N>
+__device__ __forceinline__ void mulb_k(cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N], int m) {       // x[c] = 0 for c >= m (and the lanes c >= m of A hold nothing)
+#pragma unroll
+    for (int r = 0; r < N; ++r) o[r] = cmake(0.0, 0.0);
+    dpp_guard<N>(A);
+    mulb_cols_acc<N>(A, x, o, m);
 }
 
 // sum over the 16 lanes of a row (result in every lane): DPP moves on the VALU (qoc_common.h: dpp_xor)
@@ -328,7 +370,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
     for (int e = 0; e < QE; ++e) { sv_base[e] = 0.0; sv_m[e] = 0.0; sv_v[e] = 0.0; sv_w[e] = 0.0; sv_g[e] = 0.0; }
 #ifdef QOC_SMALL_TIMING
-    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
@@ -533,7 +575,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
                         for (int r = 0; r < N; ++r) Phi[r] = acc[r];
                     } else {
-                        mulb<N>(Y, Ms, acc);
+                        mulb_m<N>(Y, Ms, acc, m);
 #pragma unroll
                         for (int r = 0; r < N; ++r) Y[r] = acc[r];
                     }
@@ -565,6 +607,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     for (int r = 0; r < N; ++r) Phi[r] = acc[r];
                 }
             }
+            QSM_STAMP(8);
             double fval = 0.0, zz2 = 0.0;
             cplx sf[QOC_SMALL_NF], ztau;
             if (grow == 0) {                                                      // tau = 0: inter_vecs[0] = V
@@ -591,6 +634,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     }
                 }
             }
+            QSM_STAMP(9);
             wg_sum2<THREADS>(fval, zz2, misc + M_RED);
             auto fetch_a1 = [&]() {                                               // (after the flags of the exchange that carried the payload)
                 const int glast = (steps - 1) / RL;
@@ -626,6 +670,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             const double resid = (double)(steps + 1) - zz2 / mm;
             reg_state = fval + (has_speed ? d.a_speed * 0.5 * resid * resid : 0.0);
             coef = has_speed ? -d.a_speed * resid * 2.0 / mm : 0.0;
+            QSM_STAMP(10);
             // offsets of the row: O_tau = O_{tau+1} K_tau + S_tau^dagger for 1 <= tau <= steps - 1 (S_N belongs to the terminal costate)
             cplx Oown[N];
 #pragma unroll
@@ -634,7 +679,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             for (int i = L - 1; i >= 0; --i) {
                 const int t = t0 + i;
                 cplx acc[N];
-                mulb<N>(Oown, Kr[i], acc);
+                mulb_m<N>(Oown, Kr[i], acc, m);
 #pragma unroll
                 for (int r = 0; r < N; ++r) Oown[r] = acc[r];
                 if (t >= 1 && t <= steps - 1) {
@@ -643,6 +688,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     add_sources<N>(Oown, sf, VfS, nforb, jj, has_speed, coef, ztau, Wd);
                 }
             }
+            QSM_STAMP(11);
             if (act) {
                 cplx* nd = lnodeO(0, row);
 #pragma unroll
@@ -657,7 +703,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     cplx Ar[N], xl[N], acc[N];
 #pragma unroll
                     for (int r = 0; r < N; ++r) { Ar[r] = r < m ? orn[r * N + jj] : cmake(0.0, 0.0); xl[r] = mln[r * N + jj]; }
-                    mulb<N>(Ar, xl, acc);
+                    mulb_m<N>(Ar, xl, acc, m);
                     cplx* nd = lnodeO(l, row >> l);
 #pragma unroll
                     for (int r = 0; r < N; ++r) { Oown[r] = cadd(Oown[r], acc[r]); if (act && r < m) nd[r * N + j] = Oown[r]; }
@@ -665,6 +711,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             }
             __syncthreads();
             if (multi) {
+                QSM_STAMP(12);
                 // exchange A2: the offsets of the subtrees
                 const double* root = (const double*)lnodeO(LR, 0);
                 double* mine = xS + (size_t)g * sd.xs_stride + 4 + 2 * NN;
@@ -689,7 +736,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                         cplx Ar[N], xl[N], acc[N];
 #pragma unroll
                         for (int r = 0; r < N; ++r) { Ar[r] = r < m ? orn[r * N + jj] : cmake(0.0, 0.0); xl[r] = mln[r * N + jj]; }
-                        mulb<N>(Ar, xl, acc);
+                        mulb_m<N>(Ar, xl, acc, m);
                         cplx* nd = unodeO(l, nd_i);
                         if (act) {
 #pragma unroll
@@ -699,6 +746,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     __syncthreads();
                 }
             }
+            QSM_STAMP(13);
             // terminal costate Y_N = conj(c0 z) W^dagger + S_N^dagger
             {
                 cplx PN[N];
@@ -719,7 +767,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     cplx Ms[N], acc[N];
 #pragma unroll
                     for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
-                    mulb<N>(Y, Ms, acc);
+                    mulb_m<N>(Y, Ms, acc, m);
 #pragma unroll
                     for (int r = 0; r < N; ++r) Y[r] = r < m ? cadd(acc[r], on[r * N + jj]) : acc[r];
                 }
@@ -733,7 +781,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         for (int i = L - 1; i >= 0; --i) {
             const int t = t0 + i, tl = row * L + i;
             cplx Rm[N];
-            mulb<N>(Ps[i], Y, Rm);                                               // Rm[c] (lane a) = (Psi_{t+1} Y_{t+1})[c][a]
+            mulb_k<N>(Ps[i], Y, Rm, m);                                          // Rm[c] (lane a) = (Psi_{t+1} Y_{t+1})[c][a]: a sum over the m state vectors
             if constexpr (HOIST) {                                                 // the first two controls against the register copies, both reductions in flight together
                 cplx q0 = cmake(0.0, 0.0), q1 = cmake(0.0, 0.0);
 #pragma unroll
@@ -761,7 +809,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             }
             if (i > 0) {
                 cplx acc[N];
-                mulb<N>(Y, Kr[i], acc);
+                mulb_m<N>(Y, Kr[i], acc, m);
 #pragma unroll
                 for (int r = 0; r < N; ++r) Y[r] = acc[r];
             }
@@ -879,6 +927,9 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                "walk+forward(+state terms, offsets) %llu, backward %llu, tail to sums(+exchange B) %llu, stop rule+Adam %llu clk\n", N, L, R, (int)SRC, G, sd.iters,
                ck1 - ck0, (double)(rt1 - rt0) / 100.0, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4],
                stamp[6] - stamp[5]);
+        if (SRC) printf("   state-regulariser flow: walk for the start state %llu, forward + state terms %llu, sums (+ exchange A1) %llu, offsets of the row %llu, offset tree up-sweep %llu, "
+                        "exchange A2 + upper offset tree %llu, terminal + walk for the costate %llu clk\n", stamp[8] - stamp[2], stamp[9] - stamp[8], stamp[10] - stamp[9], stamp[11] - stamp[10],
+                        stamp[12] - stamp[11], stamp[13] - stamp[12], stamp[3] - stamp[13]);
     }
 #endif
 
