@@ -68,7 +68,7 @@ def test_random_problem_all_paths(seed):
         raise AssertionError('no well-conditioned draw in 16 attempts from seed %d' % seed)
     bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 * (i + 1) for i in range(B - 1)]
     tried = 0
-    for path, chunks, kernel in ((0, 0, 0), (1, 0, 0), (2, 0, 1), (2, 3, 2), (2, 2, 3), (2, 5, 4), (2, 0, 5), (2, 4, 5), (2, 3, 6), (2, 3, 7), (2, 4, 8), (3, 0, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0)):
+    for path, chunks, kernel in ((0, 0, 0), (1, 0, 0), (2, 0, 1), (2, 3, 2), (2, 2, 3), (2, 5, 4), (2, 0, 5), (2, 4, 5), (2, 3, 6), (2, 3, 7), (2, 4, 8), (3, 0, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0), (5, 0, 0), (5, 3, 0)):
         try:
             eng = make_engine(sp, n_seeds=B, path=path, chunks=chunks, variant=kernel)
         except hip_engine.QocError:
@@ -134,3 +134,79 @@ def test_random_direct_route_one_vector(seed):
     assert expect in kinds, (kinds, n, lossy)
     if not lossy and 3 <= T <= 14:
         assert 'squared' in kinds, (kinds, T)
+
+
+@pytest.mark.parametrize('seed', range(64))
+def test_random_small_path(seed):
+    """The workgroup-resident path (QOC_PATH_SMALL, csrc/qoc_small_kernel.h) on random problems of 2 .. 12 levels: both modes, every regulariser it takes (all but the
+    bandpass), 1 .. 3 control sets, pulses of 1 .. 300 slices over AUTO's / 1 / 2 / 3 / 7 workgroups per control set and 16 / 32 rows per workgroup -- one evaluation
+    against the oracle, then five iterations of the loop inside ONE launch against the oracle's loop (run_session.py:47-69)."""
+    from quantum_optimal_control.core import hip_engine
+    import oracle.grape_oracle as go
+    rng = np.random.default_rng(91_000 + seed)
+    for attempt in range(16):
+        st = bool(rng.integers(0, 2))
+        n = int(rng.integers(2, 13))
+        k = int(rng.integers(1, 6))
+        steps = int(rng.choice([1, 2, 5, 16, 17, 31, 33, 64, 100, 129, 200, 300]))
+        T = int(rng.integers(1, 10))
+        if st:
+            m = int(rng.integers(1, min(n, 4) + 1))
+            c = cases.case_c3(n=n, k=k, steps=steps, taylor=(T, 0), seed=seed + 100 * attempt)
+            vs = [rng.normal(size=n) + 1j * rng.normal(size=n) for _ in range(2 * m)]
+            c['states_concerned_list'] = [v / np.linalg.norm(v) for v in vs[:m]]
+            c['U'] = [v / np.linalg.norm(v) for v in vs[m:]]
+        else:
+            m = int(rng.integers(1, n + 1))
+            c = cases.case_c2(n=n, k=k, steps=steps, m=m, taylor=(T, int(rng.integers(0, 4))), seed=seed + 100 * attempt)
+        c['total_time'] = float(rng.uniform(0.2, 0.8)) * steps / 20.0
+        reg = {}
+        if rng.random() < 0.4:
+            reg['amplitude'] = float(rng.uniform(0.05, 0.5))
+        if rng.random() < 0.4:
+            reg['dwdt'] = float(rng.uniform(0.01, 0.2))
+            if rng.random() < 0.5:
+                reg['d2wdt2'] = float(rng.uniform(0.01, 0.1))
+        if rng.random() < 0.3:
+            reg['envelope'] = float(rng.uniform(0.05, 0.3))
+        if rng.random() < 0.45 and n >= 3:
+            f = rng.choice(n, size=int(rng.integers(1, min(4, n - 1) + 1)), replace=False)
+            reg['forbidden_coeff_list'] = [float(x) for x in rng.uniform(1, 5, size=len(f))]
+            reg['states_forbidden_list'] = [int(x) for x in f]
+        if rng.random() < 0.3:
+            reg['speed_up'] = float(rng.uniform(0.1, 0.8))
+        c['reg_coeffs'] = reg
+        sp = oracle_system(c)
+        us = go.evaluate(sp, sp.base0)['unitary_scale']
+        if np.isfinite(us) and abs(us) <= 1e6:
+            break
+    else:
+        raise AssertionError('no well-conditioned draw in 16 attempts from seed %d' % seed)
+    B = int(rng.choice([1, 2, 3]))
+    bases = [sp.base0] + [2.0 * rng.normal(size=sp.base0.shape) / np.sqrt(sp.steps) + 0.1 * (i + 1) for i in range(B - 1)]
+    tried = 0
+    for groups, rows in ((0, 0), (1, 0), (2, 16), (3, 0), (7, 16), (0, 32)):
+        try:
+            eng = make_engine(sp, n_seeds=B, path=5, chunks=groups, variant=rows)
+        except hip_engine.QocError as exc:
+            assert 'a pulse that fits' in str(exc), exc           # (a pinned workgroup count / row count that has no instance for this pulse)
+            continue
+        what = 'seed %d groups %d rows %d plan %s (n=%d k=%d steps=%d m=%d T=%d s=%d st=%s regs=%s)' % (
+            seed, groups, rows, eng.plan, sp.n, sp.k, sp.steps, sp.m, sp.exp_terms, sp.scaling, sp.state_transfer, sorted(sp.reg_coeffs))
+        try:
+            eng.set_base(np.stack(bases))
+            check_eval(eng, sp, bases)
+            if tried == 0 and sp.steps <= 130:
+                conv = dict(rate=0.02, max_iterations=5, learning_rate_decay=50, conv_target=-1.0, min_grad=-1.0)
+                ref = go.run_adam(sp, conv, base=bases[-1])
+                eng.set_base(np.stack(bases))
+                eng.iterate(eng.adam_params(**conv), 5)
+                eng.sync()
+                np.testing.assert_allclose(eng.get_base()[-1], ref['base'], rtol=0, atol=1e-10)
+            tried += 1
+        except AssertionError as exc:
+            raise AssertionError('%s: %s' % (what, exc))
+        finally:
+            eng.close()
+    # (long pulses of the largest sizes have no instance: their product trees do not fit 160 KB of LDS -- AUTO keeps those on the MFMA path)
+    assert tried >= 1 or (sp.n >= 9 and sp.steps >= 64), (sp.n, sp.steps, sorted(sp.reg_coeffs))
