@@ -25,9 +25,9 @@
 
 // LDS carve of one workgroup, in units of one complex (16 bytes); the same function runs on the host (launch size) and in the kernel.
 struct QocSmallLayout {
-    int hsc, hst, vfs, psi0, wd, wcol, v0, psin, treeM, treeU, treeO, treeOU, qS, wS, misc, xsum, total;
+    int hsc, hst, vfs, psi0, wd, wcol, v0, psin, treeM, treeU, treeO, treeOU, qS, wS, misc, xsum, twS, phS, total;
 };
-__host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, int k, int m, int Gp, bool src) {
+__host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, int k, int m, int Gp, bool src, bool band = false) {
     QocSmallLayout lo;
     const int NN = N * N, RL = R * L;
     int o = 0;
@@ -47,6 +47,8 @@ __host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, 
     lo.wS = o; o += (k * (RL + 4) + 1) / 2;        // sin(base) of the own slices + two halo slices either side (doubles)
     lo.misc = o; o += 64;                          // reductions, scalars, inverse factorials (128 doubles)
     lo.xsum = o; o += Gp > 1 ? 2 * Gp : 0;         // partial sums of the workgroups of the control set (4 doubles each)
+    lo.twS = o; o += band ? RL : 0;                // bandpass regulariser (one workgroup per control set): e^{-2 pi i r / steps}, r < steps
+    lo.phS = o; o += band ? k * RL : 0;            // ... and cnt_f conj(F_f) / |F_f| of the pulse spectrum
     lo.total = o;
     return lo;
 }

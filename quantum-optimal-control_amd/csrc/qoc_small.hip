@@ -47,6 +47,7 @@ double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
     const int LR = ilog2_ceil(R), LG = ilog2_ceil(G);
     double us = share * (L * per_slice + (src ? 4.0 : 2.0) * LR * (prod + 0.1));
     if (G > 1) us += (src ? 4.0 : 2.0) * 1.5 + (src ? 4.0 : 2.0) * LG * (prod + 0.1);
+    if (d.has_band) us += 1.2e-4 * d.k * (double)d.steps * d.steps;      // direct DFT of the pulse and back: 2 k steps^2 terms over the workgroup's four SIMDs
     return 1.45 * (us + 1.5);            // (measured / modelled: 1.4 - 1.5 over n = 2 .. 12, profiles/r06_small_n_latency.txt)
 }
 
@@ -71,10 +72,10 @@ Choice choose(const QocDev& d, bool src, int G_req, int R_req = 0) {
         const int cap = in.R * in.L;
         int G = (d.steps + cap - 1) / cap;
         if (G_req > 0) { if (G > G_req) continue; G = G_req; }
-        if (G > QOC_SMALL_MAXG || (in.single && G > 1)) continue;
+        if (G > QOC_SMALL_MAXG || (in.single && G > 1) || (d.has_band && G > 1)) continue;       // (the bandpass DFT needs the whole pulse in one workgroup)
         if (G > 1 && ((long long)d.Bplan * G > budget || (long long)d.B * G > 2 * budget)) continue;     // (planned batch; and never more resident-or-deadlocked workgroups than CUs)
         const int Gp = 1 << ilog2_ceil(G);
-        const QocSmallLayout lo = qoc_small_layout(N, in.R, in.L, d.k, d.m, Gp, src);
+        const QocSmallLayout lo = qoc_small_layout(N, in.R, in.L, d.k, d.m, Gp, src, d.has_band != 0);
         if ((size_t)lo.total * 16 > 160 * 1024) continue;
         const double us = model_us(d, N, in.R, in.L, G, src);
         if (us < best.us) { best.inst = i; best.G = G; best.us = us; }
@@ -93,7 +94,6 @@ bool qoc_small_supported(const QocDev& d, bool antiherm, int G_req, int R_req, s
     if (d.m > d.n || d.m > 16) return no("m <= n");
     if (d.k > 8) return no("k <= 8");
     if (Teff < 0 || Teff > 30) return no("a Taylor order of at most 30");
-    if (d.has_band) return no("no bandpass regulariser");
     if (d.n_forb > QOC_SMALL_NF) return no("at most 4 forbidden levels");
     if (d.state_transfer && !antiherm) return no("exactly anti-Hermitian generators in state transfer");
     if (choose(d, is_src(d), G_req, R_req).inst < 0)
@@ -121,7 +121,7 @@ int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int
     sd.G = c.G; sd.LG = ilog2_ceil(c.G); sd.Gp = 1 << sd.LG;
     sd.Teff = d.state_transfer ? d.T - 1 : d.T;
     sd.iters = 1;
-    const QocSmallLayout lo = qoc_small_layout(sm.N, sm.R, sm.L, d.k, d.m, sd.Gp, sm.src);
+    const QocSmallLayout lo = qoc_small_layout(sm.N, sm.R, sm.L, d.k, d.m, sd.Gp, sm.src, d.has_band != 0);
     sm.lds_bytes = (size_t)lo.total * 16;
     const int NN2 = 2 * sm.N * sm.N;
     sd.xa_stride = NN2 + 36; sd.xb_stride = 8; sd.xs_stride = 4 + 2 * NN2;

@@ -262,11 +262,12 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     const bool multi = MM && G > 1;
     const bool has_speed = SRC && d.has_speed;
 
-    const QocSmallLayout lo = qoc_small_layout(N, R, L, k, m, sd.Gp, SRC);
+    const QocSmallLayout lo = qoc_small_layout(N, R, L, k, m, sd.Gp, SRC, d.has_band != 0);
     cplx* S = (cplx*)smem;
     cplx* HsC = S + lo.hsc; cplx* HsT = S + lo.hst; cplx* VfS = S + lo.vfs; cplx* Psi0c = S + lo.psi0; cplx* Wd = S + lo.wd;
     cplx* Wcol = S + lo.wcol; cplx* V0c = S + lo.v0; cplx* PsiN = S + lo.psin;
     cplx* treeM = S + lo.treeM; cplx* treeU = S + lo.treeU; cplx* treeO = S + lo.treeO; cplx* treeOU = S + lo.treeOU;
+    cplx* twS = S + lo.twS; cplx* phS = S + lo.phS;
     cplx* qS = S + lo.qS; double* wS = (double*)(S + lo.wS); double* misc = (double*)(S + lo.misc); double* xsum = (double*)(S + lo.xsum);
     auto Wv = [&](int kk, int tl) -> double& { return wS[kk * (RL + 4) + 2 + tl]; };
     // node (level, index) of the two trees: levels below LR live in this workgroup (index relative to its first node of the level)
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         if (tid < 32) { double f = 1.0; for (int i = 2; i <= tid; ++i) f *= (double)i; misc[M_INVF + tid] = 1.0 / f; }
         if (tid < 8) misc[M_MAXA + tid] = tid < k ? d.maxA[tid] : 0.0;
         for (int o = tid; o < k * (RL + 4); o += THREADS) wS[o] = 0.0;
+        if (d.has_band) for (int r = tid; r < steps; r += THREADS) { double sn, cs; sincos(-2.0 * M_PI * (double)r / (double)steps, &sn, &cs); twS[r] = cmake(cs, sn); }
     }
     __syncthreads();
     // the (control, slice) elements of this thread: variable and Adam slots stay in registers for the whole launch
@@ -832,12 +834,58 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             cplx z = SRC ? zfin : cmake(misc[M_Z], misc[M_Z + 1]);
             const double dt = d.dt;
             double reg = 0.0, g2 = 0.0;
+            double dRb[QE];
+#pragma unroll
+            for (int e = 0; e < QE; ++e) dRb[e] = 0.0;
+            if (d.has_band) {
+                // bandpass regulariser (core/regularization_functions.py:47-67) by direct DFT, one workgroup per control set (the whole pulse is in LDS): the thread
+                // that owns (control, slice t) forms the spectrum bin f = t, F_f = sum_t' w_t' e^{-2 pi i f t' / N}; value a sum_f cnt_f |F_f| with cnt_f = how often
+                // the reference's two slices (f < lo; hi <= f < N / 2) contain f; then d/dw_t = a sum_f Re(cnt_f conj(F_f) / |F_f| e^{-2 pi i f t / N})
+                const int half = steps / 2, lo_f = min(max(d.band_lo, 0), steps), hi_f = min(max(d.band_hi, 0), steps), fend = min(max(half, lo_f), steps);
+#pragma unroll
+                for (int e = 0; e < QE; ++e) {
+                    if (e_ok[e]) {
+                        const int kk = e_kk[e], f = e_tl[e];
+                        const int cnt = (f < lo_f ? 1 : 0) + ((f >= hi_f && f < half) ? 1 : 0);
+                        cplx ph = cmake(0.0, 0.0);
+                        if (cnt > 0) {
+                            double fr = 0.0, fi = 0.0;
+                            int r = 0;
+                            for (int t = 0; t < steps; ++t) {
+                                const cplx tw = twS[r];
+                                const double wv = Wv(kk, t);
+                                fr = fma(wv, tw.x, fr); fi = fma(wv, tw.y, fi);
+                                r += f; if (r >= steps) r -= steps;
+                            }
+                            const double mag = sqrt(fr * fr + fi * fi);
+                            reg += d.a_band * (double)cnt * mag;
+                            if (mag > 0.0) ph = cmake((double)cnt * fr / mag, -(double)cnt * fi / mag);
+                        }
+                        phS[kk * RL + f] = ph;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < QE; ++e) {
+                    if (e_ok[e]) {
+                        const int kk = e_kk[e], t = e_tl[e];
+                        double acc = 0.0;
+                        int r = 0;
+                        for (int f = 0; f < fend; ++f) {
+                            const cplx q = phS[kk * RL + f], tw = twS[r];
+                            acc += q.x * tw.x - q.y * tw.y;
+                            r += t; if (r >= steps) r -= steps;
+                        }
+                        dRb[e] = d.a_band * acc;
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < QE; ++e) {
                 if (e_ok[e]) {
                     const int kk = e_kk[e], tl = e_tl[e], t = g * RL + tl;
                     const double wv = Wv(kk, tl), wm1 = Wv(kk, tl - 1), wm2 = Wv(kk, tl - 2), wp1 = Wv(kk, tl + 1), wp2 = Wv(kk, tl + 2);
-                    double dR = 0.0;
+                    double dR = dRb[e];
                     if (d.has_amp) { reg += d.a_amp * 0.5 * wv * wv; dR += d.a_amp * wv; }                  // regularization_functions.py:15-18
                     if (d.has_env) {                                                                        // :21-25
                         const double ev = d.omg[(size_t)kk * steps + t];

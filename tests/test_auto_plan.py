@@ -76,7 +76,7 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
     Teff = T - 1 if state_transfer else T
     s = 0 if state_transfer else s
     src = n_forb > 0 or speed_up
-    if n > 12 or m > n or k > 8 or not (0 <= Teff <= 30) or bandpass or n_forb > 4 or (state_transfer and not hermitian):
+    if n > 12 or m > n or k > 8 or not (0 <= Teff <= 30) or n_forb > 4 or (state_transfer and not hermitian):
         return None
     N = [v for v in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12) if v >= n][0]
     clog2 = lambda v: max(0, (v - 1).bit_length())                                   # noqa: E731
@@ -85,11 +85,12 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
         if Ni != N or (src and not S):
             continue
         G = ceil_div(steps, R * L)
-        if G > 32 or (single and G > 1) or (G > 1 and B * G > 128):
+        if G > 32 or (single and G > 1) or (bandpass and G > 1) or (G > 1 and B * G > 128):
             continue
         Gp, NN, RL = 1 << clog2(G), N * N, R * L
         lds = ((k + 1) * NN + k * NN + (4 * N if src else 0) + 2 * NN + (3 * NN if src else 0) + (2 * R - 1) * NN + (2 * Gp - 1) * NN
-               + ((2 * R - 1 + 2 * Gp - 1) * m * N if src else 0) + k * RL + (k * (RL + 4) + 1) // 2 + 64 + (2 * Gp if Gp > 1 else 0))
+               + ((2 * R - 1 + 2 * Gp - 1) * m * N if src else 0) + k * RL + (k * (RL + 4) + 1) // 2 + 64 + (2 * Gp if Gp > 1 else 0)
+               + ((k + 1) * RL if bandpass else 0))
         if lds * 16 > 160 * 1024:
             continue
         prod = 4.0 * N * N * 5.9 / 2400.0
@@ -98,6 +99,8 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
         us = share * (L * per_slice + (4.0 if src else 2.0) * clog2(R) * (prod + 0.1))
         if G > 1:
             us += (4.0 if src else 2.0) * 1.5 + (4.0 if src else 2.0) * clog2(G) * (prod + 0.1)
+        if bandpass:
+            us += 1.2e-4 * k * steps * steps
         us = 1.45 * (us + 1.5)
         if best is None or us < best[0]:
             best = (us, N, R, L, G)
@@ -353,10 +356,16 @@ def test_auto_plan_small_rows_cover_both_sides():
 
 
 def test_auto_plan_small_excluded_shapes():
-    """A bandpass regulariser, more than four forbidden levels and Taylor orders beyond 30 stay on the other paths."""
+    """A bandpass regulariser on a pulse that needs several workgroups (its DFT wants the whole pulse in one) or whose 2 k steps^2 terms cost more than the other
+    paths, and more than four forbidden levels, stay on the other paths; a bandpass regulariser on a short pulse is taken."""
     c = _problem(4, 2, 64, 3, 5, 2, False, seed=9)
     c['reg_coeffs'] = {'bandpass': 0.1, 'band': [0.5, 2.0]}
-    _run(c, 1, {'path': 'mfma'}, seed=1)
+    assert small_plan(4, 2, 3, 64, 5, 2, 1, bandpass=True) is not None
+    _run(c, 1, {'path': 'small', 'workgroups': 1}, seed=1)
+    c = _problem(4, 2, 700, 3, 5, 2, False, seed=9)
+    c['reg_coeffs'] = {'bandpass': 0.1, 'band': [0.5, 2.0]}
+    assert small_plan(4, 2, 3, 700, 5, 2, 1, bandpass=True) is None
+    _run(c, 1, {'path': 'mfma'}, seed=1, check=False)
     c = _problem(8, 2, 64, 3, 5, 2, False, seed=9)
     c['reg_coeffs'] = {'forbidden_coeff_list': [1.0] * 5, 'states_forbidden_list': [7, 6, 5, 4, 3]}
     _run(c, 1, {'path': 'mfma'}, seed=1)

@@ -175,6 +175,9 @@ def test_random_small_path(seed):
             reg['states_forbidden_list'] = [int(x) for x in f]
         if rng.random() < 0.3:
             reg['speed_up'] = float(rng.uniform(0.1, 0.8))
+        if rng.random() < 0.25 and steps >= 5:
+            reg['bandpass'] = float(rng.uniform(0.05, 0.5))
+            reg['band'] = [float(rng.uniform(0.1, 0.4)) * steps / c['total_time'] / 2, float(rng.uniform(0.5, 0.9)) * steps / c['total_time'] / 2]
         c['reg_coeffs'] = reg
         sp = oracle_system(c)
         us = go.evaluate(sp, sp.base0)['unitary_scale']
@@ -209,4 +212,5 @@ def test_random_small_path(seed):
         finally:
             eng.close()
     # (long pulses of the largest sizes have no instance: their product trees do not fit 160 KB of LDS -- AUTO keeps those on the MFMA path)
-    assert tried >= 1 or (sp.n >= 9 and sp.steps >= 64), (sp.n, sp.steps, sorted(sp.reg_coeffs))
+    assert tried >= 1 or (sp.n >= 9 and sp.steps >= 64) or ('bandpass' in sp.reg_coeffs and sp.steps > (128 if sp.n <= 4 else 64 if sp.n <= 8 else 16)), (
+        sp.n, sp.steps, sorted(sp.reg_coeffs))       # (a bandpass regulariser: the pulse must fit ONE workgroup of the instance)

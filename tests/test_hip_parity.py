@@ -1051,7 +1051,7 @@ def test_plan_seeds_makes_a_shard_bit_identical_to_the_whole_batch():
 
 
 @pytest.mark.parametrize('name', ['c1', 'small_auto_U0', 'dressed_forbidden', 'state_small', 'c3_small', 'unitary_allreg', 'state_transfer_allreg', 'c2_n8'])
-@pytest.mark.parametrize('path', [0, 1], ids=['auto', 'generic'])
+@pytest.mark.parametrize('path', [0, 1, 5], ids=['auto', 'generic', 'workgroup_resident'])
 def test_hip_against_the_reference_graph_vectors(name, path):
     """The HIP engine straight against tests/golden/graph_*.npz -- numbers the reference's OWN graph code produced (lib2to3 copy of
     core/tensorflow_state.py + core/regularization_functions.py run on a TF1 stand-in, tests/golden/make_graph_golden.py), no oracle in
@@ -1060,7 +1060,11 @@ def test_hip_against_the_reference_graph_vectors(name, path):
     c = graph_cases()[name]
     fx = load_golden('graph_%s.npz' % name)
     sp = oracle_system(c)                                   # inputs only (a1-a5 are pinned bit-exactly by sysparams_*.npz)
+    if path == 5 and name == 'c3_small':
+        pytest.skip('not a problem of the workgroup-resident path (n = 16)')
     eng = make_engine(sp, n_seeds=1, path=path)
+    if path == 5 or (path == 0 and name != 'c3_small'):
+        assert eng.plan['path'] == 'small', eng.plan         # n <= 12: AUTO = the workgroup-resident path (csrc/qoc_small_kernel.h) since round 6
     eng.set_base(fx['base0'][None])
     r = eng.evaluate()
     for key in ('loss', 'reg_loss', 'unitary_scale', 'grad_squared'):

@@ -44,6 +44,12 @@ def small_cases():
     c = cases.case_c2(n=12, k=3, steps=19, m=12, taylor=(5, 2), seed=22); c['reg_coeffs'] = {'speed_up': 0.4}
     out.append(('n12_speed_up', c))
     out.append(('T1_no_products', cases.case_c2(n=6, k=2, steps=11, m=3, taylor=(1, 0), seed=23)))
+    # all seven regularisers at once; the bandpass DFT needs the whole pulse in ONE workgroup
+    c = cases.case_c2(n=4, k=2, steps=12, m=3, taylor=(6, 1), seed=2); c['total_time'] = 2.0
+    c['reg_coeffs'] = dict(PULSE_REG, forbidden_coeff_list=[3.0, 2.0], states_forbidden_list=[3, 2], speed_up=0.7, bandpass=0.4, band=[0.5, 2.0])
+    out.append(('unitary_allreg_bandpass', c))
+    c = cases.case_c2(n=3, k=3, steps=101, m=3, taylor=(5, 1), seed=29); c['total_time'] = 10.0; c['reg_coeffs'] = {'bandpass': 0.2, 'band': [0.3, 3.0], 'dwdt': 0.05}
+    out.append(('n3_bandpass_101_slices', c))
     return out
 
 
@@ -57,7 +63,7 @@ def test_small_path_eval_parity(name, c, groups):
     try:
         eng = make_engine(sp, n_seeds=len(bases), path=SMALL, chunks=groups)
     except hip_engine.QocError as err:
-        if (groups in (1, 2) or (groups == 5 and sp.n > 10)) and 'a pulse that fits' in str(err):
+        if (groups in (1, 2) or (groups == 5 and sp.n > 10) or (groups > 1 and 'bandpass' in sp.reg_coeffs)) and 'a pulse that fits' in str(err):
             pytest.skip('the pulse needs more workgroups than pinned (or, n > 10: the trees of this many workgroups more LDS than there is)')
         raise
     assert eng.path == SMALL and eng.plan['path'] == 'small'
