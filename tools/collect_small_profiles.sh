@@ -11,8 +11,10 @@ if [ -x /opt/conda/bin/python3.9 ]; then      # save=True needs h5py: the image'
   echo "# the same under /opt/conda/bin/python3.9 (h5py): save=True with update_step 100" >> $O/grape_walltime.txt
   LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6 /opt/conda/bin/python3.9 -W ignore tools/grape_walltime.py 1000 >> $O/grape_walltime.txt 2>&1
 fi
-if [ -f quantum-optimal-control_amd/lib_timing_a/libqoc_hip.so ]; then
-  for v in a b; do QOC_HIP_LIBRARY=quantum-optimal-control_amd/lib_timing_$v/libqoc_hip.so python tools/small_phase_timing.py 2>&1 | grep -v "iters=2000"; done > $O/small_phase_timing.txt
+# phase stamps: libraries built with -DQOC_SMALL_TIMING, one per translation unit of instances (python tools/build_variant.py timing_<u> qoc_small_<u> -DQOC_SMALL_TIMING)
+if [ -f quantum-optimal-control_amd/lib_timing_a1/libqoc_hip.so ]; then
+  { for v in a1 a b; do QOC_HIP_LIBRARY=quantum-optimal-control_amd/lib_timing_$v/libqoc_hip.so python tools/small_phase_timing.py 2>&1 | grep "iters=200:\|state-regulariser"; done
+    QOC_HIP_LIBRARY=quantum-optimal-control_amd/lib_timing_c/libqoc_hip.so python tools/small_phase_timing_src.py 2>&1 | grep -v "iters=1000"; } > $O/small_phase_timing.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -- python $R/tools/bench_configs.py c1 > /dev/null 2>&1
