@@ -1,4 +1,6 @@
 // qoc_small_a.hip -- instances of k_small_iter (csrc/qoc_small_instances.h, list A); the host side is qoc_small.hip.
+// n <= 4: no statement of these builds has a spill copy in front of its DPP read (tools/dpp_hazard_scan.py checks the objects): no padding
+#define QOC_SMALL_DPP_PAD 0
 #include "qoc_small_kernel.h"
 #include "qoc_small_instances.h"
 #define QOC_SMALL_DEF(N, L, R, S) \

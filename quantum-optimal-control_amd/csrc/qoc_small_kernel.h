@@ -32,42 +32,94 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // ---- the product primitive -----------------------------------------------------------------------------------------------------------
 // o += bcast_C(a) * x:  (a.x, a.y) of lane C of this row of 16 lanes reaches every lane inside the FMA (row_newbcast, the one DPP control
 // double-precision VALU has on gfx90a+); four VOP2 instructions per complex MAC, two accumulator chains interleaved.
+//
+// Hazard: a DPP read needs 2 wait states behind a VALU write of its source, and the compiler pads nothing for an asm statement -- under register pressure it places a
+// copy (v_mov_b64 from a spill register) of the broadcast operand directly in front of a statement (seen in the n = 8 and the state-regulariser builds: wrong gradients).
+// EVERY statement therefore opens with s_nop 1; statements are made of up to sixteen FMAs (four rows of a column step, or four columns of a row step) so that this costs 2 - 3 %.
+// The translation units of the n <= 4 instances define QOC_SMALL_DPP_PAD 0: their builds have no such copies, and tools/dpp_hazard_scan.py (run by
+// tests/test_abi.py on every built object) proves it on the machine code -- a build where that stops being true fails the test instead of the physics.
+#ifndef QOC_SMALL_DPP_PAD
+#define QOC_SMALL_DPP_PAD 1
+#endif
+#if QOC_SMALL_DPP_PAD
+#define QPAD "s_nop 1\n\t"
+#else
+#define QPAD
+#endif
+#define QF(d, a, x, c) "v_fmac_f64_dpp " d ", " a ", " x " row_newbcast:" c " row_mask:0xf bank_mask:0xf\n\t"
 template <int C>
 __device__ __forceinline__ void cmac_dpp(cplx& o, const cplx& a, const cplx& x) {
-    asm volatile("v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, -%3, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+    asm volatile(QPAD QF("%0", "%2", "%4", "%6") QF("%1", "%2", "%5", "%6") QF("%0", "-%3", "%5", "%6") QF("%1", "%3", "%4", "%6")
                  : "+v"(o.x), "+v"(o.y) : "v"(a.x), "v"(a.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+// two rows: o0 += bcast_C(a0) x, o1 += bcast_C(a1) x
+template <int C>
+__device__ __forceinline__ void cmac2_dpp(cplx& o0, cplx& o1, const cplx& a0, const cplx& a1, const cplx& x) {
+    asm volatile(QPAD QF("%0", "%4", "%8", "%10") QF("%1", "%4", "%9", "%10") QF("%2", "%6", "%8", "%10") QF("%3", "%6", "%9", "%10")
+                 QF("%0", "-%5", "%9", "%10") QF("%1", "%5", "%8", "%10") QF("%2", "-%7", "%9", "%10") QF("%3", "%7", "%8", "%10")
+                 : "+v"(o0.x), "+v"(o0.y), "+v"(o1.x), "+v"(o1.y) : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+// three and four rows
+template <int C>
+__device__ __forceinline__ void cmac3_dpp(cplx& o0, cplx& o1, cplx& o2, const cplx& a0, const cplx& a1, const cplx& a2, const cplx& x) {
+    asm volatile(QPAD QF("%0", "%6", "%12", "%14") QF("%1", "%6", "%13", "%14") QF("%2", "%8", "%12", "%14") QF("%3", "%8", "%13", "%14") QF("%4", "%10", "%12", "%14") QF("%5", "%10", "%13", "%14")
+                 QF("%0", "-%7", "%13", "%14") QF("%1", "%7", "%12", "%14") QF("%2", "-%9", "%13", "%14") QF("%3", "%9", "%12", "%14") QF("%4", "-%11", "%13", "%14") QF("%5", "%11", "%12", "%14")
+                 : "+v"(o0.x), "+v"(o0.y), "+v"(o1.x), "+v"(o1.y), "+v"(o2.x), "+v"(o2.y)
+                 : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(a2.x), "v"(a2.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ void cmac4_dpp(cplx& o0, cplx& o1, cplx& o2, cplx& o3, const cplx& a0, const cplx& a1, const cplx& a2, const cplx& a3, const cplx& x) {
+    asm volatile(QPAD QF("%0", "%8", "%16", "%18") QF("%1", "%8", "%17", "%18") QF("%2", "%10", "%16", "%18") QF("%3", "%10", "%17", "%18") QF("%4", "%12", "%16", "%18") QF("%5", "%12", "%17", "%18") QF("%6", "%14", "%16", "%18") QF("%7", "%14", "%17", "%18")
+                 QF("%0", "-%9", "%17", "%18") QF("%1", "%9", "%16", "%18") QF("%2", "-%11", "%17", "%18") QF("%3", "%11", "%16", "%18") QF("%4", "-%13", "%17", "%18") QF("%5", "%13", "%16", "%18") QF("%6", "-%15", "%17", "%18") QF("%7", "%15", "%16", "%18")
+                 : "+v"(o0.x), "+v"(o0.y), "+v"(o1.x), "+v"(o1.y), "+v"(o2.x), "+v"(o2.y), "+v"(o3.x), "+v"(o3.y)
+                 : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(a2.x), "v"(a2.y), "v"(a3.x), "v"(a3.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+// two columns of one row: o += bcast_C0(a) x0 + bcast_{C0+1}(a) x1
+template <int C0>
+__device__ __forceinline__ void cmac_row2(cplx& o, const cplx& a, const cplx& x0, const cplx& x1) {
+    asm volatile(QPAD QF("%0", "%2", "%4", "%8") QF("%1", "%2", "%5", "%8") QF("%0", "-%3", "%5", "%8") QF("%1", "%3", "%4", "%8")
+                 QF("%0", "%2", "%6", "%9") QF("%1", "%2", "%7", "%9") QF("%0", "-%3", "%7", "%9") QF("%1", "%3", "%6", "%9")
+                 : "+v"(o.x), "+v"(o.y) : "v"(a.x), "v"(a.y), "v"(x0.x), "v"(x0.y), "v"(x1.x), "v"(x1.y), "n"(C0), "n"(C0 + 1));
+}
+// four columns of one row
+template <int C0>
+__device__ __forceinline__ void cmac_row4(cplx& o, const cplx& a, const cplx& x0, const cplx& x1, const cplx& x2, const cplx& x3) {
+    asm volatile(QPAD QF("%0", "%2", "%4", "%12") QF("%1", "%2", "%5", "%12") QF("%0", "-%3", "%5", "%12") QF("%1", "%3", "%4", "%12") QF("%0", "%2", "%6", "%13") QF("%1", "%2", "%7", "%13") QF("%0", "-%3", "%7", "%13") QF("%1", "%3", "%6", "%13")
+                 QF("%0", "%2", "%8", "%14") QF("%1", "%2", "%9", "%14") QF("%0", "-%3", "%9", "%14") QF("%1", "%3", "%8", "%14") QF("%0", "%2", "%10", "%15") QF("%1", "%2", "%11", "%15") QF("%0", "-%3", "%11", "%15") QF("%1", "%3", "%10", "%15")
+                 : "+v"(o.x), "+v"(o.y) : "v"(a.x), "v"(a.y), "v"(x0.x), "v"(x0.y), "v"(x1.x), "v"(x1.y), "v"(x2.x), "v"(x2.y), "v"(x3.x), "v"(x3.y),
+                   "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
 }
 // o += conj(bcast_C(a) * x)
 template <int C>
 __device__ __forceinline__ void cmac_dpp_conj(cplx& o, const cplx& a, const cplx& x) {
-    asm volatile("v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %1, -%2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, -%3, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %1, -%3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+    asm volatile(QPAD QF("%0", "%2", "%4", "%6") QF("%1", "-%2", "%5", "%6") QF("%0", "-%3", "%5", "%6") QF("%1", "-%3", "%4", "%6")
                  : "+v"(o.x), "+v"(o.y) : "v"(a.x), "v"(a.y), "v"(x.x), "v"(x.y), "n"(C));
 }
 
+// one column step of the product: o[r] += A[r][C] x[C] for every r
+template <int N, int C, int R0 = 0>
+__device__ __forceinline__ void mulb_col(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N]) {
+    if constexpr (R0 + 4 <= N) { cmac4_dpp<C>(o[R0], o[R0 + 1], o[R0 + 2], o[R0 + 3], A[R0], A[R0 + 1], A[R0 + 2], A[R0 + 3], x[C]); mulb_col<N, C, R0 + 4>(A, x, o); }
+    else if constexpr (R0 + 3 == N) cmac3_dpp<C>(o[R0], o[R0 + 1], o[R0 + 2], A[R0], A[R0 + 1], A[R0 + 2], x[C]);
+    else if constexpr (R0 + 2 == N) cmac2_dpp<C>(o[R0], o[R0 + 1], A[R0], A[R0 + 1], x[C]);
+    else if constexpr (R0 < N) cmac_dpp<C>(o[R0], A[R0], x[C]);
+}
 template <int N, int C = 0>
 __device__ __forceinline__ void mulb_acc(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N]) {
     if constexpr (C < N) {
-#pragma unroll
-        for (int r = 0; r < N; ++r) cmac_dpp<C>(o[r], A[r], x[C]);
+        mulb_col<N, C>(A, x, o);
         mulb_acc<N, C + 1>(A, x, o);
     }
 }
 // one row of the product: o[R_] += sum_c A[R_][c] x[c]
 template <int N, int R_, int C = 0>
 __device__ __forceinline__ void mulb_row(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N]) {
-    if constexpr (C < N) {
-        cmac_dpp<C>(o[R_], A[R_], x[C]);
-        mulb_row<N, R_, C + 1>(A, x, o);
-    }
+    if constexpr (C + 4 <= N) { cmac_row4<C>(o[R_], A[R_], x[C], x[C + 1], x[C + 2], x[C + 3]); mulb_row<N, R_, C + 4>(A, x, o); }
+    else if constexpr (C + 2 <= N) { cmac_row2<C>(o[R_], A[R_], x[C], x[C + 1]); mulb_row<N, R_, C + 2>(A, x, o); }
+    else if constexpr (C < N) cmac_dpp<C>(o[R_], A[R_], x[C]);
 }
-// every register a DPP read may touch is defined before the statement (the compiler cannot see the DPP read inside the asm); then the wait
-// states a DPP read needs behind a VALU write of its source (2) or of EXEC (5): the compiler pads neither for an asm statement
+// every register a DPP read may touch is defined before the product (the compiler cannot see the DPP read inside the asm); then the 5 wait states a DPP read needs behind
+// a write of EXEC (a product may open right behind a divergent branch)
 template <int N>
 __device__ __forceinline__ void dpp_guard(cplx (&A)[N]) {
 #pragma unroll
@@ -103,10 +155,7 @@ __device__ __forceinline__ void mulb_m(cplx (&A)[N], const cplx (&x)[N], cplx (&
 template <int N, int C = 0>
 __device__ __forceinline__ void mulb_cols_acc(const cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N], int m) {
     if constexpr (C < N) {
-        if (C < m) {
-#pragma unroll
-            for (int r = 0; r < N; ++r) cmac_dpp<C>(o[r], A[r], x[C]);
-        }
+        if (C < m) mulb_col<N, C>(A, x, o);
         mulb_cols_acc<N, C + 1>(A, x, o, m);
     }
 }
@@ -118,9 +167,124 @@ __device__ __forceinline__ void mulb_k(cplx (&A)[N], const cplx (&x)[N], cplx (&
     mulb_cols_acc<N>(A, x, o, m);
 }
 
+// ---- split form, 5 <= n <= 8 (half of a row of 16 lanes would idle) ---------------------------------------------------------------------
+// Lanes j and j + 8 of a row both hold column j: lane j (half h = 0) forms the REAL parts of the product's column, lane j + 8 (h = 1) the imaginary parts -- two DPP
+// FMAs per (r, c) instead of four -- and the halves hand each other their part with one row_ror:8 move per double.  A matrix in registers is (mine, other): .x = the
+// part this half forms (h = 0: re, h = 1: im), .y = the other one; the lanes c < 8 that row_newbcast reads are all of half 0, where (mine, other) = (re, im).
+//   re: sum_c a_re x_re - a_im x_im = sum_c a_re mine_c - a_im other_c        im: sum_c a_re x_im + a_im x_re = sum_c a_re mine_c + a_im other_c
+#ifndef QOC_SMALL_SPLIT
+#define QOC_SMALL_SPLIT 1
+#endif
+// p += bcast_C(a.x) x.x, q += bcast_C(a.y) x.y for one, two or four rows of a column step
+template <int C>
+__device__ __forceinline__ void smac1(double& p, double& q, const cplx& a, const cplx& x) {
+    asm volatile(QPAD QF("%0", "%2", "%4", "%6") QF("%1", "%3", "%5", "%6") : "+v"(p), "+v"(q) : "v"(a.x), "v"(a.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ void smac2(double& p0, double& q0, double& p1, double& q1, const cplx& a0, const cplx& a1, const cplx& x) {
+    asm volatile(QPAD QF("%0", "%4", "%8", "%10") QF("%1", "%5", "%9", "%10") QF("%2", "%6", "%8", "%10") QF("%3", "%7", "%9", "%10")
+                 : "+v"(p0), "+v"(q0), "+v"(p1), "+v"(q1) : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ void smac4(double& p0, double& q0, double& p1, double& q1, double& p2, double& q2, double& p3, double& q3,
+                                      const cplx& a0, const cplx& a1, const cplx& a2, const cplx& a3, const cplx& x) {
+    asm volatile(QPAD QF("%0", "%8", "%16", "%18") QF("%1", "%9", "%17", "%18") QF("%2", "%10", "%16", "%18") QF("%3", "%11", "%17", "%18")
+                 QF("%4", "%12", "%16", "%18") QF("%5", "%13", "%17", "%18") QF("%6", "%14", "%16", "%18") QF("%7", "%15", "%17", "%18")
+                 : "+v"(p0), "+v"(q0), "+v"(p1), "+v"(q1), "+v"(p2), "+v"(q2), "+v"(p3), "+v"(q3)
+                 : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(a2.x), "v"(a2.y), "v"(a3.x), "v"(a3.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ void smac3(double& p0, double& q0, double& p1, double& q1, double& p2, double& q2, const cplx& a0, const cplx& a1, const cplx& a2, const cplx& x) {
+    asm volatile(QPAD QF("%0", "%6", "%12", "%14") QF("%1", "%7", "%13", "%14") QF("%2", "%8", "%12", "%14") QF("%3", "%9", "%13", "%14") QF("%4", "%10", "%12", "%14") QF("%5", "%11", "%13", "%14")
+                 : "+v"(p0), "+v"(q0), "+v"(p1), "+v"(q1), "+v"(p2), "+v"(q2) : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(a2.x), "v"(a2.y), "v"(x.x), "v"(x.y), "n"(C));
+}
+// ... for two or four columns of a row step
+template <int C0>
+__device__ __forceinline__ void srow2(double& p, double& q, const cplx& a, const cplx& x0, const cplx& x1) {
+    asm volatile(QPAD QF("%0", "%2", "%4", "%8") QF("%1", "%3", "%5", "%8") QF("%0", "%2", "%6", "%9") QF("%1", "%3", "%7", "%9")
+                 : "+v"(p), "+v"(q) : "v"(a.x), "v"(a.y), "v"(x0.x), "v"(x0.y), "v"(x1.x), "v"(x1.y), "n"(C0), "n"(C0 + 1));
+}
+template <int C0>
+__device__ __forceinline__ void srow4(double& p, double& q, const cplx& a, const cplx& x0, const cplx& x1, const cplx& x2, const cplx& x3) {
+    asm volatile(QPAD QF("%0", "%2", "%4", "%12") QF("%1", "%3", "%5", "%12") QF("%0", "%2", "%6", "%13") QF("%1", "%3", "%7", "%13")
+                 QF("%0", "%2", "%8", "%14") QF("%1", "%3", "%9", "%14") QF("%0", "%2", "%10", "%15") QF("%1", "%3", "%11", "%15")
+                 : "+v"(p), "+v"(q) : "v"(a.x), "v"(a.y), "v"(x0.x), "v"(x0.y), "v"(x1.x), "v"(x1.y), "v"(x2.x), "v"(x2.y), "v"(x3.x), "v"(x3.y),
+                   "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
+}
+template <int N, int C, int R0 = 0>
+__device__ __forceinline__ void smulb_col(const cplx (&A)[N], const cplx (&x)[N], double (&o1)[N], double (&o2)[N]) {
+    if constexpr (R0 + 4 <= N) {
+        smac4<C>(o1[R0], o2[R0], o1[R0 + 1], o2[R0 + 1], o1[R0 + 2], o2[R0 + 2], o1[R0 + 3], o2[R0 + 3], A[R0], A[R0 + 1], A[R0 + 2], A[R0 + 3], x[C]);
+        smulb_col<N, C, R0 + 4>(A, x, o1, o2);
+    } else if constexpr (R0 + 3 == N) smac3<C>(o1[R0], o2[R0], o1[R0 + 1], o2[R0 + 1], o1[R0 + 2], o2[R0 + 2], A[R0], A[R0 + 1], A[R0 + 2], x[C]);
+    else if constexpr (R0 + 2 == N) smac2<C>(o1[R0], o2[R0], o1[R0 + 1], o2[R0 + 1], A[R0], A[R0 + 1], x[C]);
+    else if constexpr (R0 < N) smac1<C>(o1[R0], o2[R0], A[R0], x[C]);
+}
+template <int N, int R_, int C = 0>
+__device__ __forceinline__ void smulb_row(const cplx (&A)[N], const cplx (&x)[N], double (&o1)[N], double (&o2)[N]) {
+    if constexpr (C + 4 <= N) { srow4<C>(o1[R_], o2[R_], A[R_], x[C], x[C + 1], x[C + 2], x[C + 3]); smulb_row<N, R_, C + 4>(A, x, o1, o2); }
+    else if constexpr (C + 2 <= N) { srow2<C>(o1[R_], o2[R_], A[R_], x[C], x[C + 1]); smulb_row<N, R_, C + 2>(A, x, o1, o2); }
+    else if constexpr (C < N) smac1<C>(o1[R_], o2[R_], A[R_], x[C]);
+}
+template <int N, int C = 0>
+__device__ __forceinline__ void smulb_acc(const cplx (&A)[N], const cplx (&x)[N], double (&o1)[N], double (&o2)[N]) {
+    if constexpr (C < N) {
+        smulb_col<N, C>(A, x, o1, o2);
+        smulb_acc<N, C + 1>(A, x, o1, o2);
+    }
+}
+template <int N, int R_ = 0>
+__device__ __forceinline__ void smulb_rows_acc(const cplx (&A)[N], const cplx (&x)[N], double (&o1)[N], double (&o2)[N], int m) {
+    if constexpr (R_ < N) {
+        if (R_ < m) smulb_row<N, R_>(A, x, o1, o2);
+        smulb_rows_acc<N, R_ + 1>(A, x, o1, o2, m);
+    }
+}
+template <int N, int C = 0>
+__device__ __forceinline__ void smulb_cols_acc(const cplx (&A)[N], const cplx (&x)[N], double (&o1)[N], double (&o2)[N], int m) {
+    if constexpr (C < N) {
+        if (C < m) smulb_col<N, C>(A, x, o1, o2);
+        smulb_cols_acc<N, C + 1>(A, x, o1, o2, m);
+    }
+}
+// mine = o1 + sgn o2 (sgn = -1 in half 0, +1 in half 1); other = the partner lane's mine
+template <int N>
+__device__ __forceinline__ void smulb_finish(const double (&o1)[N], const double (&o2)[N], cplx (&o)[N], double sgn) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) o[r].x = fma(sgn, o2[r], o1[r]);
+#pragma unroll
+    for (int r = 0; r < N; ++r) o[r].y = dpp_xor<8>(o[r].x);
+}
+// WHICH 0: full product, 1: rows r < m of A, 2: summation index c < m
+template <int N, int WHICH>
+__device__ __forceinline__ void smulb(cplx (&A)[N], const cplx (&x)[N], cplx (&o)[N], int m, double sgn) {
+    double o1[N], o2[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) { o1[r] = 0.0; o2[r] = 0.0; }
+    dpp_guard<N>(A);
+    if constexpr (WHICH == 0) smulb_acc<N>(A, x, o1, o2);
+    else if constexpr (WHICH == 1) smulb_rows_acc<N>(A, x, o1, o2, m);
+    else smulb_cols_acc<N>(A, x, o1, o2, m);
+    smulb_finish<N>(o1, o2, o, sgn);
+}
+// an element of a matrix in LDS (natural re, im) as (mine, other)
+template <bool SPL>
+__device__ __forceinline__ cplx ldm(const cplx* p, int h) {
+    if constexpr (SPL) { const double* q = (const double*)p; return cmake(q[h], q[1 - h]); }
+    else return *p;
+}
+// (mine, other) <-> (re, im): the same exchange in half 1, nothing in half 0
+__device__ __forceinline__ cplx swp(const cplx& v, int h) { return h ? cmake(v.y, v.x) : v; }
+
 // sum over the 16 lanes of a row (result in every lane): DPP moves on the VALU (qoc_common.h: dpp_xor)
 __device__ __forceinline__ double row_sum16(double v) {
     v += dpp_xor<1>(v); v += dpp_xor<2>(v); v += dpp_xor<4>(v); v += dpp_xor<8>(v);
+    return v;
+}
+
+// ... over the 8 lanes of a half row
+__device__ __forceinline__ double row_sum8(double v) {
+    v += dpp_xor<1>(v); v += dpp_xor<2>(v); v += dpp_xor<4>(v);
     return v;
 }
 
@@ -244,20 +408,53 @@ __device__ __forceinline__ void add_sources(cplx (&Y)[N], cplx (&sf)[QOC_SMALL_N
     }
 }
 
+// the same two on a (mine, other) matrix of the split form: the complex arithmetic per lane runs on (re, im) in both halves
+template <int N, bool SPL>
+__device__ __forceinline__ double state_terms_l(const cplx (&P)[N], const cplx* VfS, const double* faS, int nforb, const cplx* Wcol, int jj,
+                                                bool lane_m, bool want_z, cplx (&sf)[QOC_SMALL_NF], cplx& ztau, int h) {
+    if constexpr (SPL) {
+        cplx Pn[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) Pn[r] = swp(P[r], h);
+        return state_terms<N>(Pn, VfS, faS, nforb, Wcol, jj, lane_m, want_z, sf, ztau);
+    } else return state_terms<N>(P, VfS, faS, nforb, Wcol, jj, lane_m, want_z, sf, ztau);
+}
+template <int N, bool SPL>
+__device__ __forceinline__ void add_sources_l(cplx (&Y)[N], cplx (&sf)[QOC_SMALL_NF], const cplx* VfS, int nforb, int jj, bool has_speed,
+                                              double coef, const cplx& ztau, const cplx* Wd, int h) {
+    if constexpr (SPL) {
+        cplx Sd[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) Sd[r] = cmake(0.0, 0.0);
+        add_sources<N>(Sd, sf, VfS, nforb, jj, has_speed, coef, ztau, Wd);
+#pragma unroll
+        for (int r = 0; r < N; ++r) Y[r] = cadd(Y[r], swp(Sd[r], h));
+    } else add_sources<N>(Y, sf, VfS, nforb, jj, has_speed, coef, ztau, Wd);
+}
+
 // =========================================================================================================================================
 // MM = false: an instance for ONE workgroup per control set -- the exchange code, the deferred stop rule and their live state are compiled out (the 32-row instances of
 // n <= 4 have 256 registers per lane: with the exchanges compiled in they spill in the loop; C1 takes one of these)
+// the three products, in the form of the instance (SPL, sgn, m: locals of the kernel)
+#define MULB(A, x, o) do { if constexpr (SPL) smulb<N, 0>(A, x, o, 0, sgn); else mulb<N>(A, x, o); } while (0)
+#define MULB_M(A, x, o, m_) do { if constexpr (SPL) smulb<N, 1>(A, x, o, m_, sgn); else mulb_m<N>(A, x, o, m_); } while (0)
+#define STATE_TERMS(P, wz) state_terms_l<N, SPL>(P, VfS, misc + M_FA, nforb, Wcol, jj, lane_m, wz, sf, ztau, h)
+#define ADD_SOURCES(Ym, zt) add_sources_l<N, SPL>(Ym, sf, VfS, nforb, jj, has_speed, coef, zt, Wd, h)
+#define MULB_K(A, x, o, m_) do { if constexpr (SPL) smulb<N, 2>(A, x, o, m_, sgn); else mulb_k<N>(A, x, o, m_); } while (0)
 template <int N, int L, int R, bool SRC, bool MM = true>
 __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, QocSmallDev sd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int THREADS = R * 16, RL = R * L, LR = ilog2c(R), NN = N * N;
     constexpr int QE = (8 * RL + THREADS - 1) / THREADS;            // (k, t) elements per thread, k <= 8
-    const int tid = threadIdx.x, row = tid >> 4, j = tid & 15;
+    // split form (5 <= n <= 8): lanes j and j + 8 of the row share column j, half h forms the real (0) / imaginary (1) parts of the products
+    constexpr bool SPL = QOC_SMALL_SPLIT && N >= 5 && N <= 8;
+    const int tid = threadIdx.x, row = tid >> 4, lane16 = tid & 15, j = SPL ? (lane16 & 7) : lane16, h = SPL ? (lane16 >> 3) : 0;
+    const double sgn = h ? 1.0 : -1.0;
     const int G = sd.G, g = blockIdx.x % G, b = blockIdx.x / G;
-    const bool act = j < N;
+    const bool act = j < N, actw = act && h == 0;            // actw: the lane that writes column j to LDS / HBM and counts in sums over the columns
     const int jj = act ? j : N - 1;
     const int n = d.n, m = d.m, k = d.k, steps = d.steps, nforb = SRC ? d.n_forb : 0;
-    const bool lane_m = j < m;
+    const bool lane_m = j < m && h == 0;
     const int grow = g * R + row, t0 = grow * L, LTOT = LR + sd.LG;
     const bool multi = MM && G > 1;
     const bool has_speed = SRC && d.has_speed;
@@ -393,7 +590,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         for (int i = 0; i < L; ++i) {
             const int t = t0 + i;
 #pragma unroll
-            for (int r = 0; r < N; ++r) Kr[i][r] = cmake(r == j ? 1.0 : 0.0, 0.0);
+            for (int r = 0; r < N; ++r) { const double dj = r == j ? 1.0 : 0.0; Kr[i][r] = cmake(h ? 0.0 : dj, h ? dj : 0.0); }
             if (t < steps && sd.Teff >= 1) {
                 cplx A[N], Hn[N], acc[N];
                 const int tl = row * L + i;
@@ -405,13 +602,13 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < N; ++r) A[r] = HsC[r * N + jj];
+                    for (int r = 0; r < N; ++r) A[r] = ldm<SPL>(HsC + r * N + jj, h);
                 }
                 for (int kk = HOIST ? 2 : 0; kk < k; ++kk) {
                     const double u = misc[M_MAXA + kk] * Wv(kk, tl);
                     const cplx* Hk = HsC + (kk + 1) * NN;
 #pragma unroll
-                    for (int r = 0; r < N; ++r) { const cplx h = Hk[r * N + jj]; A[r].x = fma(u, h.x, A[r].x); A[r].y = fma(u, h.y, A[r].y); }
+                    for (int r = 0; r < N; ++r) { const cplx hk = ldm<SPL>(Hk + r * N + jj, h); A[r].x = fma(u, hk.x, A[r].x); A[r].y = fma(u, hk.y, A[r].y); }
                 }
 #pragma unroll
                 for (int r = 0; r < N; ++r) { Hn[r] = A[r]; Kr[i][r] = cadd(Kr[i][r], A[r]); }
@@ -420,13 +617,13 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 for (int ii = 2; ii <= sd.Teff; ++ii) {                          // H_n = H H_n ; matexp += H_n / ii!      tensorflow_state.py:38-41
                     const double f = fnext;
                     fnext = misc[M_INVF + ii + 1];
-                    mulb<N>(A, Hn, acc);
+                    MULB(A, Hn, acc);
 #pragma unroll
                     for (int r = 0; r < N; ++r) { Hn[r] = acc[r]; Kr[i][r].x = fma(acc[r].x, f, Kr[i][r].x); Kr[i][r].y = fma(acc[r].y, f, Kr[i][r].y); }
                 }
 #pragma unroll 1
                 for (int q = 0; q < d.s; ++q) {                                   // squarings                              tensorflow_state.py:43-44
-                    mulb<N>(Kr[i], Kr[i], acc);
+                    MULB(Kr[i], Kr[i], acc);
 #pragma unroll
                     for (int r = 0; r < N; ++r) Kr[i][r] = acc[r];
                 }
@@ -439,11 +636,11 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
         for (int i = 1; i < L; ++i) {
             cplx acc[N];
-            mulb<N>(Kr[i], Mown, acc);
+            MULB(Kr[i], Mown, acc);
 #pragma unroll
             for (int r = 0; r < N; ++r) Mown[r] = acc[r];
         }
-        if (act) {
+        if (actw) {
             cplx* nd = lnode(treeM, 0, row);
 #pragma unroll
             for (int r = 0; r < N; ++r) nd[r * N + j] = Mown[r];
@@ -457,11 +654,11 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 const cplx* rn = lnode(treeM, l - 1, (row >> (l - 1)) + 1);
                 cplx Ar[N], acc[N];
 #pragma unroll
-                for (int r = 0; r < N; ++r) Ar[r] = rn[r * N + jj];
-                mulb<N>(Ar, Mown, acc);
+                for (int r = 0; r < N; ++r) Ar[r] = ldm<SPL>(rn + r * N + jj, h);
+                MULB(Ar, Mown, acc);
                 cplx* nd = lnode(treeM, l, row >> l);
 #pragma unroll
-                for (int r = 0; r < N; ++r) { Mown[r] = acc[r]; if (act) nd[r * N + j] = acc[r]; }
+                for (int r = 0; r < N; ++r) { Mown[r] = acc[r]; if (actw) nd[r * N + j] = acc[r]; }
             }
         }
         __syncthreads();
@@ -472,7 +669,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             const double* root = (const double*)lnode(treeM, LR, 0);
             double* mine = xA + (size_t)g * sd.xa_stride;
             for (int o = tid; o < 2 * NN; o += THREADS) st_sc1(mine + o, root[o]);
-            if (tid < 4 * k) { const int kk = tid >> 2, h = tid & 3; st_sc1(mine + 2 * NN + tid, Wv(kk, h < 2 ? h : RL - 4 + h)); }
+            if (tid < 4 * k) { const int kk = tid >> 2, hh = tid & 3; st_sc1(mine + 2 * NN + tid, Wv(kk, hh < 2 ? hh : RL - 4 + hh)); }
             if (spec && tid == 0) { st_sc1(mine + 2 * NN + 32, sp_reg); st_sc1(mine + 2 * NN + 33, sp_g2); st_sc1(mine + 2 * NN + 34, sp_z.x); st_sc1(mine + 2 * NN + 35, sp_z.y); }
             publish_flag(flags + 4 * g + 0, epoch);
             wait_flags(flags + 0, G, epoch, sd.err);
@@ -481,10 +678,10 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 [&](int o) -> const double* { const int gi = o / (2 * NN); return gi < G ? xA + (size_t)gi * sd.xa_stride + (o - gi * 2 * NN) : nullptr; },
                 [&](int o) { const int w = o % (2 * NN), e = w >> 1; return ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; });   // identity leaves pad the tree
             if (tid < 4 * k) {                                    // halo: the neighbours' controls of this evaluation
-                const int kk = tid >> 2, h = tid & 3;
-                const int src_g = h < 2 ? g - 1 : g + 1, tl = h < 2 ? h - 2 : RL + (h - 2), t = g * RL + tl;
+                const int kk = tid >> 2, hh = tid & 3;
+                const int src_g = hh < 2 ? g - 1 : g + 1, tl = hh < 2 ? hh - 2 : RL + (hh - 2), t = g * RL + tl;
                 if (src_g >= 0 && src_g < G && t >= 0 && t < steps)
-                    Wv(kk, tl) = ld_sc1(xA + (size_t)src_g * sd.xa_stride + 2 * NN + 4 * kk + (h < 2 ? h + 2 : h - 2));
+                    Wv(kk, tl) = ld_sc1(xA + (size_t)src_g * sd.xa_stride + 2 * NN + 4 * kk + (hh < 2 ? hh + 2 : hh - 2));
             }
             __syncthreads();
             if (spec) {                                            // the stop rule of the previous iteration, one exchange late
@@ -512,10 +709,10 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     const cplx* ln = unode(treeU, l - 1, 2 * nd_i);
                     cplx Ar[N], xl[N], acc[N];
 #pragma unroll
-                    for (int r = 0; r < N; ++r) { Ar[r] = rn[r * N + jj]; xl[r] = ln[r * N + jj]; }
-                    mulb<N>(Ar, xl, acc);
+                    for (int r = 0; r < N; ++r) { Ar[r] = ldm<SPL>(rn + r * N + jj, h); xl[r] = ldm<SPL>(ln + r * N + jj, h); }
+                    MULB(Ar, xl, acc);
                     cplx* nd = unode(treeU, l, nd_i);
-                    if (act) {
+                    if (actw) {
 #pragma unroll
                         for (int r = 0; r < N; ++r) nd[r * N + j] = acc[r];
                     }
@@ -538,7 +735,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         // ---- P3 / P4: start state and end costate of the row by a walk from the root; forward and backward sweep over the own slices --------
         cplx Phi[N], Y[N], Ps[L][N];
 #pragma unroll
-        for (int r = 0; r < N; ++r) { Phi[r] = Psi0c[r * N + jj]; Y[r] = Wd[r * N + jj]; }
+        for (int r = 0; r < N; ++r) { Phi[r] = ldm<SPL>(Psi0c + r * N + jj, h); Y[r] = ldm<SPL>(Wd + r * N + jj, h); }
         cplx zfin = cmake(0.0, 0.0);
         double reg_state = 0.0, coef = 0.0;
         if constexpr (!SRC) {
@@ -559,7 +756,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     cplx As[N], xs[N], acc[N];
 #pragma unroll
                     for (int r = 0; r < N; ++r) { As[r] = bit ? Sib[l - 1][r] : Y[r]; xs[r] = bit ? Phi[r] : Sib[l - 1][r]; }
-                    mulb<N>(As, xs, acc);
+                    MULB(As, xs, acc);
 #pragma unroll
                     for (int r = 0; r < N; ++r) { if (bit) Phi[r] = acc[r]; else Y[r] = acc[r]; }
                 }
@@ -570,14 +767,14 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 const cplx* sn = sibling(treeM, treeU, l, bit);
                 cplx Ms[N], acc[N];
 #pragma unroll
-                for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
+                for (int r = 0; r < N; ++r) Ms[r] = ldm<SPL>(sn + r * N + jj, h);
                 if (l >= 3) {                                                     // the four rows of a wave share their ancestors from level 2 up: a uniform branch
                     if (bit) {
-                        mulb<N>(Ms, Phi, acc);
+                        MULB(Ms, Phi, acc);
 #pragma unroll
                         for (int r = 0; r < N; ++r) Phi[r] = acc[r];
                     } else {
-                        mulb_m<N>(Y, Ms, acc, m);
+                        MULB_M(Y, Ms, acc, m);
 #pragma unroll
                         for (int r = 0; r < N; ++r) Y[r] = acc[r];
                     }
@@ -585,14 +782,14 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     cplx As[N], xs[N];
 #pragma unroll
                     for (int r = 0; r < N; ++r) { As[r] = bit ? Ms[r] : Y[r]; xs[r] = bit ? Phi[r] : Ms[r]; }
-                    mulb<N>(As, xs, acc);
+                    MULB(As, xs, acc);
 #pragma unroll
                     for (int r = 0; r < N; ++r) { if (bit) Phi[r] = acc[r]; else Y[r] = acc[r]; }
                 }
             }
 #pragma unroll
             for (int i = 0; i < L; ++i) {
-                if (i == 0) mulb<N>(Kr[0], Phi, Ps[0]); else mulb<N>(Kr[i], Ps[i - 1], Ps[i]);
+                if (i == 0) MULB(Kr[0], Phi, Ps[0]); else MULB(Kr[i], Ps[i - 1], Ps[i]);
             }
         } else {
             // ---- state regularisers: true costate.  Forward first (values, z_tau), then the affine offsets, then the walk for the costate ----
@@ -603,8 +800,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 if (bit) {
                     cplx Ms[N], acc[N];
 #pragma unroll
-                    for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
-                    mulb<N>(Ms, Phi, acc);
+                    for (int r = 0; r < N; ++r) Ms[r] = ldm<SPL>(sn + r * N + jj, h);
+                    MULB(Ms, Phi, acc);
 #pragma unroll
                     for (int r = 0; r < N; ++r) Phi[r] = acc[r];
                 }
@@ -617,19 +814,19 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
                 for (int r = 0; r < N; ++r) P0[r] = V0c[r * N + jj];
                 fval += state_terms<N>(P0, VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
-                if (j == 0) zz2 += ztau.x * ztau.x + ztau.y * ztau.y;
+                if (lane16 == 0) zz2 += ztau.x * ztau.x + ztau.y * ztau.y;
             }
 #pragma unroll
             for (int i = 0; i < L; ++i) {
-                if (i == 0) mulb<N>(Kr[0], Phi, Ps[0]); else mulb<N>(Kr[i], Ps[i - 1], Ps[i]);
+                if (i == 0) MULB(Kr[0], Phi, Ps[0]); else MULB(Kr[i], Ps[i - 1], Ps[i]);
                 const int t = t0 + i;
                 if (t < steps) {                                                  // tau = t + 1
                     const bool last = t == steps - 1;
-                    fval += state_terms<N>(Ps[i], VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed || last, sf, ztau);
-                    if (j == 0 && has_speed) zz2 += ztau.x * ztau.x + ztau.y * ztau.y;
+                    fval += STATE_TERMS(Ps[i], has_speed || last);
+                    if (lane16 == 0 && has_speed) zz2 += ztau.x * ztau.x + ztau.y * ztau.y;
                     if (last) {
-                        if (j == 0) { misc[M_ZN] = ztau.x; misc[M_ZN + 1] = ztau.y; }
-                        if (act) {
+                        if (lane16 == 0) { misc[M_ZN] = ztau.x; misc[M_ZN + 1] = ztau.y; }
+                        if (actw) {
 #pragma unroll
                             for (int r = 0; r < N; ++r) PsiN[r * N + j] = Ps[i][r];
                         }
@@ -681,17 +878,17 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             for (int i = L - 1; i >= 0; --i) {
                 const int t = t0 + i;
                 cplx acc[N];
-                mulb_m<N>(Oown, Kr[i], acc, m);
+                MULB_M(Oown, Kr[i], acc, m);
 #pragma unroll
                 for (int r = 0; r < N; ++r) Oown[r] = acc[r];
                 if (t >= 1 && t <= steps - 1) {
-                    if (i == 0) state_terms<N>(Phi, VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
-                    else state_terms<N>(Ps[i > 0 ? i - 1 : 0], VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
-                    add_sources<N>(Oown, sf, VfS, nforb, jj, has_speed, coef, ztau, Wd);
+                    if (i == 0) STATE_TERMS(Phi, has_speed);
+                    else STATE_TERMS(Ps[i > 0 ? i - 1 : 0], has_speed);
+                    ADD_SOURCES(Oown, ztau);
                 }
             }
             QSM_STAMP(11);
-            if (act) {
+            if (actw) {
                 cplx* nd = lnodeO(0, row);
 #pragma unroll
                 for (int r = 0; r < N; ++r) if (r < m) nd[r * N + j] = Oown[r];
@@ -704,11 +901,11 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     const cplx* mln = lnode(treeM, l - 1, row >> (l - 1));
                     cplx Ar[N], xl[N], acc[N];
 #pragma unroll
-                    for (int r = 0; r < N; ++r) { Ar[r] = r < m ? orn[r * N + jj] : cmake(0.0, 0.0); xl[r] = mln[r * N + jj]; }
-                    mulb_m<N>(Ar, xl, acc, m);
+                    for (int r = 0; r < N; ++r) { Ar[r] = r < m ? ldm<SPL>(orn + r * N + jj, h) : cmake(0.0, 0.0); xl[r] = ldm<SPL>(mln + r * N + jj, h); }
+                    MULB_M(Ar, xl, acc, m);
                     cplx* nd = lnodeO(l, row >> l);
 #pragma unroll
-                    for (int r = 0; r < N; ++r) { Oown[r] = cadd(Oown[r], acc[r]); if (act && r < m) nd[r * N + j] = Oown[r]; }
+                    for (int r = 0; r < N; ++r) { Oown[r] = cadd(Oown[r], acc[r]); if (actw && r < m) nd[r * N + j] = Oown[r]; }
                 }
             }
             __syncthreads();
@@ -737,10 +934,10 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                         const cplx* mln = unode(treeU, l - 1, 2 * nd_i);
                         cplx Ar[N], xl[N], acc[N];
 #pragma unroll
-                        for (int r = 0; r < N; ++r) { Ar[r] = r < m ? orn[r * N + jj] : cmake(0.0, 0.0); xl[r] = mln[r * N + jj]; }
-                        mulb_m<N>(Ar, xl, acc, m);
+                        for (int r = 0; r < N; ++r) { Ar[r] = r < m ? ldm<SPL>(orn + r * N + jj, h) : cmake(0.0, 0.0); xl[r] = ldm<SPL>(mln + r * N + jj, h); }
+                        MULB_M(Ar, xl, acc, m);
                         cplx* nd = unodeO(l, nd_i);
-                        if (act) {
+                        if (actw) {
 #pragma unroll
                             for (int r = 0; r < N; ++r) if (r < m) nd[r * N + j] = cadd(acc[r], oln[r * N + j]);
                         }
@@ -759,6 +956,10 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
                 for (int r = 0; r < N; ++r) Y[r] = cmul(cz, Wd[r * N + jj]);
                 add_sources<N>(Y, sf, VfS, nforb, jj, has_speed, coef, zfin, Wd);
+                if constexpr (SPL) {
+#pragma unroll
+                    for (int r = 0; r < N; ++r) Y[r] = swp(Y[r], h);
+                }
             }
 #pragma unroll 1
             for (int l = LTOT; l >= 1; --l) {
@@ -768,10 +969,10 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     const cplx* on = siblingO(l);
                     cplx Ms[N], acc[N];
 #pragma unroll
-                    for (int r = 0; r < N; ++r) Ms[r] = sn[r * N + jj];
-                    mulb_m<N>(Y, Ms, acc, m);
+                    for (int r = 0; r < N; ++r) Ms[r] = ldm<SPL>(sn + r * N + jj, h);
+                    MULB_M(Y, Ms, acc, m);
 #pragma unroll
-                    for (int r = 0; r < N; ++r) Y[r] = r < m ? cadd(acc[r], on[r * N + jj]) : acc[r];
+                    for (int r = 0; r < N; ++r) Y[r] = r < m ? cadd(acc[r], ldm<SPL>(on + r * N + jj, h)) : acc[r];
                 }
             }
             // (the backward sweep below adds S_t^dagger after each slice)
@@ -783,7 +984,11 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         for (int i = L - 1; i >= 0; --i) {
             const int t = t0 + i, tl = row * L + i;
             cplx Rm[N];
-            mulb_k<N>(Ps[i], Y, Rm, m);                                          // Rm[c] (lane a) = (Psi_{t+1} Y_{t+1})[c][a]: a sum over the m state vectors
+            MULB_K(Ps[i], Y, Rm, m);                                          // Rm[c] (lane a) = (Psi_{t+1} Y_{t+1})[c][a]: a sum over the m state vectors
+            if constexpr (SPL) {                                                   // the contractions below are complex arithmetic per lane: (re, im) in both halves
+#pragma unroll
+                for (int c = 0; c < N; ++c) Rm[c] = swp(Rm[c], h);
+            }
             if constexpr (HOIST) {                                                 // the first two controls against the register copies, both reductions in flight together
                 cplx q0 = cmake(0.0, 0.0), q1 = cmake(0.0, 0.0);
 #pragma unroll
@@ -791,8 +996,20 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 if (!act) { q0 = cmake(0.0, 0.0); q1 = cmake(0.0, 0.0); }
                 q0.x = row_sum16(q0.x); q0.y = row_sum16(q0.y);
                 if (k > 1) { q1.x = row_sum16(q1.x); q1.y = row_sum16(q1.y); }
-                if (j == 0 && t < steps) { qS[tl] = q0; if (k > 1) qS[RL + tl] = q1; }
+                if (lane16 == 0 && t < steps) { qS[tl] = q0; if (k > 1) qS[RL + tl] = q1; }
             }
+            if constexpr (SPL) {                                                   // half h contracts the controls kk = h, h + 2, ...: sums over the 8 lanes of a half
+                for (int k2 = 0; k2 < k; k2 += 2) {
+                    const int kk = k2 + h;
+                    const cplx* Hk = HsT + (kk < k ? kk : 0) * NN;
+                    cplx q = cmake(0.0, 0.0);
+#pragma unroll
+                    for (int c = 0; c < N; ++c) cfma(q, Hk[c * N + jj], Rm[c]);
+                    if (!act) q = cmake(0.0, 0.0);
+                    q.x = row_sum8(q.x); q.y = row_sum8(q.y);
+                    if (j == 0 && kk < k && t < steps) qS[kk * RL + tl] = q;
+                }
+            } else
             for (int kk = HOIST ? 2 : 0; kk < k; ++kk) {
                 const cplx* Hk = HsT + kk * NN;
                 cplx q = cmake(0.0, 0.0);
@@ -805,21 +1022,21 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             if (!SRC && i == L - 1 && row == 0) {                                // z = <W, Psi_N> = tr(Y_tau Psi_tau) at any tau (a workgroup's own copy)
                 cplx dg = cmake(0.0, 0.0);
 #pragma unroll
-                for (int r = 0; r < N; ++r) if (r == j) dg = Rm[r];
+                for (int r = 0; r < N; ++r) if (r == j && h == 0) dg = Rm[r];
                 dg.x = row_sum16(dg.x); dg.y = row_sum16(dg.y);
-                if (j == 0) { misc[M_Z] = dg.x; misc[M_Z + 1] = dg.y; }
+                if (lane16 == 0) { misc[M_Z] = dg.x; misc[M_Z + 1] = dg.y; }
             }
             if (i > 0) {
                 cplx acc[N];
-                mulb_m<N>(Y, Kr[i], acc, m);
+                MULB_M(Y, Kr[i], acc, m);
 #pragma unroll
                 for (int r = 0; r < N; ++r) Y[r] = acc[r];
             }
             if constexpr (SRC) {
                 if (i > 0 && t >= 1 && t <= steps - 1) {                         // (i == 0: Y_{t0} belongs to the previous row's sweep)
                     cplx sf[QOC_SMALL_NF], ztau;
-                    state_terms<N>(Ps[i > 0 ? i - 1 : 0], VfS, misc + M_FA, nforb, Wcol, jj, lane_m, has_speed, sf, ztau);
-                    add_sources<N>(Y, sf, VfS, nforb, jj, has_speed, coef, ztau, Wd);
+                    STATE_TERMS(Ps[i > 0 ? i - 1 : 0], has_speed);
+                    ADD_SOURCES(Y, ztau);
                 }
             }
         }
@@ -998,23 +1215,32 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         cplx Ar[N], Uc[N], X[N];
 #pragma unroll
         for (int r = 0; r < N; ++r) {
-            Ar[r] = root[r * N + jj];
-            Uc[r] = (r < n && j < n) ? d.U0[r * n + j] : cmake(0.0, 0.0);
+            Ar[r] = ldm<SPL>(root + r * N + jj, h);
+            Uc[r] = swp((r < n && j < n) ? d.U0[r * n + j] : cmake(0.0, 0.0), h);
         }
-        mulb<N>(Ar, Uc, X);
+        MULB(Ar, Uc, X);
         double part = 0.0;
+        const bool wr = j < n && h == 0;                                            // (half 0 holds (re, im))
 #pragma unroll
         for (int r = 0; r < N; ++r) {
-            if (r < n && j < n) d.Xfinal[(size_t)b * n * n + r * n + j] = X[r];
-            const double sx = row_sum16(j < n ? X[r].x : 0.0), sy = row_sum16(j < n ? X[r].y : 0.0);
+            if (r < n && wr) d.Xfinal[(size_t)b * n * n + r * n + j] = X[r];
+            const double sx = row_sum16(wr ? X[r].x : 0.0), sy = row_sum16(wr ? X[r].y : 0.0);
             if (r < n) part += sx * sx + sy * sy;
         }
-        if (j == 0) { d.uscale[b] = part / (double)n; sd.final_valid[b] = 1; }
+        if (lane16 == 0) { d.uscale[b] = part / (double)n; sd.final_valid[b] = 1; }
     }
     if (g == 0 && tid == 0) {
         d.loss[b] = out_loss; d.reg_loss[b] = out_reg; d.g2[b] = out_g2; d.reg_state[b] = out_regstate; d.zfin[b] = out_z;
         if (ap.mode != 0) { d.iters[b] = it_count; d.adam_t[b] = adam_t; if (done_now) d.done[b] = 1; }
     }
 }
+
+#undef QF
+#undef QPAD
+#undef MULB
+#undef MULB_M
+#undef MULB_K
+#undef STATE_TERMS
+#undef ADD_SOURCES
 
 }  // namespace qsm

@@ -91,3 +91,19 @@ def test_plan_limits_header_is_the_single_source_of_autos_numbers():
     for name in lim:
         used = any(('QOC_PLAN_' + name) in open(os.path.join(csrc, f)).read() for f in ('qoc_engine.hip', 'qoc_mfma_backward.hip', 'qoc_small.hip'))
         assert used, 'QOC_PLAN_%s is defined but no engine source uses it' % name
+
+
+def test_no_dpp_read_hazard_in_the_built_device_code():
+    """The fp64 products written as `v_fmac_f64_dpp` inline assembly (csrc/qoc_small_kernel.h, csrc/qoc_gemm_chain_dpp.h) need two wait states behind a VALU write of
+    their DPP source; the compiler pads none for an asm statement and, under register pressure, places spill copies right in front of one (round 6: wrong gradients of
+    one n = 8 build).  tools/dpp_hazard_scan.py disassembles the gfx950 code of every built object and must find no such pair."""
+    import glob
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objs = sorted(glob.glob(os.path.join(root, 'quantum-optimal-control_amd', 'build', '*.o')))
+    if not objs or not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('no built objects (python -c "import __graft_entry__ as g; g.build()") or no llvm-objdump')
+    spec = importlib.util.spec_from_file_location('dpp_hazard_scan', os.path.join(root, 'tools', 'dpp_hazard_scan.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(objs) == 0
