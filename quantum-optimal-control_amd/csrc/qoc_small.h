@@ -23,13 +23,17 @@
 #define QOC_SMALL_MAXG 32       // workgroups per control set
 #define QOC_SMALL_WG_BUDGET 128 // control sets x workgroups per control set that may spin on each other (all must be resident: 256 CUs)
 
+// Distance between the nodes of the product trees, in complex numbers.  (n = 4, 8, 12 put the nodes on the 256-byte grid of the LDS banks; 64 bytes of padding per node
+// were measured and changed nothing -- profiles/EXPERIMENTS.md, round 6 -- so the nodes are dense.)
+__host__ __device__ constexpr int qoc_small_node(int N) { return N * N; }
+
 // LDS carve of one workgroup, in units of one complex (16 bytes); the same function runs on the host (launch size) and in the kernel.
 struct QocSmallLayout {
     int hsc, hst, vfs, psi0, wd, wcol, v0, psin, treeM, treeU, treeO, treeOU, qS, wS, misc, xsum, twS, phS, total;
 };
 __host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, int k, int m, int Gp, bool src, bool band = false) {
     QocSmallLayout lo;
-    const int NN = N * N, RL = R * L;
+    const int NN = N * N, RL = R * L, NP = qoc_small_node(N);
     int o = 0;
     lo.hsc = o; o += (k + 1) * NN;                 // generators / 2^s, row-major (lane j reads [r][j])
     lo.hst = o; o += k * NN;                       // control Hamiltonians transposed (lane a reads [c][a] = H_k[a][c])
@@ -39,8 +43,10 @@ __host__ __device__ inline QocSmallLayout qoc_small_layout(int N, int R, int L, 
     lo.wcol = o; o += src ? NN : 0;                // W, [r][j]
     lo.v0 = o; o += src ? NN : 0;                  // V = inter_vecs[0]
     lo.psin = o; o += src ? NN : 0;                // Psi_N of this evaluation
-    lo.treeM = o; o += (2 * R - 1) * NN;           // product tree of the rows of this workgroup
-    lo.treeU = o; o += (2 * Gp - 1) * NN;          // ... of the workgroups of the control set (leaves: their subtree roots)
+    lo.treeM = o; o += (2 * R - 1) * NP;           // product tree of the rows of this workgroup
+    // ... of the workgroups of the control set (leaves: their subtree roots).  Without a state regulariser the levels above the leaves are two ping-pong buffers of the
+    // range reduction instead (Gp / 2 + 2 and Gp / 4 + 2 nodes)
+    lo.treeU = o; o += (src || Gp == 1 ? 2 * Gp - 1 : Gp + Gp / 2 + Gp / 4 + 4) * NP;
     lo.treeO = o; o += src ? (2 * R - 1) * m * N : 0;   // offsets of the affine costate recursion, same shape; m x N nodes (rows j' < m of Y)
     lo.treeOU = o; o += src ? (2 * Gp - 1) * m * N : 0;
     lo.qS = o; o += k * RL;                        // <Lambda_{t+1}, H_k Psi_{t+1}> of the own slices

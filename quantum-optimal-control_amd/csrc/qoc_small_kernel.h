@@ -320,8 +320,8 @@ __device__ __forceinline__ void wait_flags(unsigned* flags /* stride 4 words */,
 
 // count doubles from the exchange buffers into LDS, sixteen write-through loads in flight per thread (one at a time they cost a fabric round trip each);
 // src(o) = the global address of element o, or nullptr for a pad element of value pad(o)
-template <int THREADS, class SRC, class PAD>
-__device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD pad) {
+template <int THREADS, class SRC, class PAD, class DST>
+__device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD pad, DST at) {
     for (int o0 = threadIdx.x; o0 < count; o0 += 16 * THREADS) {
         double v[16];
 #pragma unroll
@@ -331,9 +331,11 @@ __device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD p
             if (o < count) { const double* a = src(o); v[u] = a ? ld_sc1(a) : pad(o); }
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int o = o0 + u * THREADS; if (o < count) dst[o] = v[u]; }
+        for (int u = 0; u < 16; ++u) { const int o = o0 + u * THREADS; if (o < count) dst[at(o)] = v[u]; }
     }
 }
+template <int THREADS, class SRC, class PAD>
+__device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD pad) { fetch_sc1<THREADS>(dst, count, src, pad, [](int o) { return o; }); }
 
 template <int THREADS>
 __device__ __forceinline__ void wg_sum2(double& a, double& b, double* red /* 2 x waves doubles */) {
@@ -445,6 +447,7 @@ template <int N, int L, int R, bool SRC, bool MM = true>
 __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, QocSmallDev sd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int THREADS = R * 16, RL = R * L, LR = ilog2c(R), NN = N * N;
+    constexpr int NP = qoc_small_node(N);                           // distance between the nodes of the product trees (qoc_small.h)
     constexpr int QE = (8 * RL + THREADS - 1) / THREADS;            // (k, t) elements per thread, k <= 8
     // split form (5 <= n <= 8): lanes j and j + 8 of the row share column j, half h forms the real (0) / imaginary (1) parts of the products
     constexpr bool SPL = QOC_SMALL_SPLIT && N >= 5 && N <= 8;
@@ -468,8 +471,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     cplx* qS = S + lo.qS; double* wS = (double*)(S + lo.wS); double* misc = (double*)(S + lo.misc); double* xsum = (double*)(S + lo.xsum);
     auto Wv = [&](int kk, int tl) -> double& { return wS[kk * (RL + 4) + 2 + tl]; };
     // node (level, index) of the two trees: levels below LR live in this workgroup (index relative to its first node of the level)
-    auto lnode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * R - (2 * R >> l)) + i) * NN; };
-    auto unode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * sd.Gp - (2 * sd.Gp >> l)) + i) * NN; };
+    auto lnode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * R - (2 * R >> l)) + i) * NP; };
+    auto unode = [&](cplx* base, int l, int i) -> cplx* { return base + (size_t)((2 * sd.Gp - (2 * sd.Gp >> l)) + i) * NP; };
     // the offsets of the affine costate recursion are m x N (rows j' < m of Y): their nodes are that small
     const int MN = m * N;
     auto lnodeO = [&](int l, int i) -> cplx* { return treeO + (size_t)((2 * R - (2 * R >> l)) + i) * MN; };
@@ -662,6 +665,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             }
         }
         __syncthreads();
+        QSM_STAMP(14);
+        const cplx* rangeP = nullptr;                              // several workgroups, no state regulariser: start state and end costate of THIS workgroup (below)
         if (multi) {
             // exchange A: the subtree product of every workgroup of the control set + the halo controls of the neighbours.  Two buffers, by the parity of
             // the iteration: with the stop rule deferred nothing else separates a fast workgroup's next publication from a slow one's reads of this one
@@ -673,10 +678,12 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             if (spec && tid == 0) { st_sc1(mine + 2 * NN + 32, sp_reg); st_sc1(mine + 2 * NN + 33, sp_g2); st_sc1(mine + 2 * NN + 34, sp_z.x); st_sc1(mine + 2 * NN + 35, sp_z.y); }
             publish_flag(flags + 4 * g + 0, epoch);
             wait_flags(flags + 0, G, epoch, sd.err);
+            QSM_STAMP(15);
             if (spec) fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xA + (size_t)(o >> 2) * sd.xa_stride + 2 * NN + 32 + (o & 3); }, [](int) { return 0.0; });
             fetch_sc1<THREADS>((double*)unode(treeU, 0, 0), sd.Gp * 2 * NN,
                 [&](int o) -> const double* { const int gi = o / (2 * NN); return gi < G ? xA + (size_t)gi * sd.xa_stride + (o - gi * 2 * NN) : nullptr; },
-                [&](int o) { const int w = o % (2 * NN), e = w >> 1; return ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; });   // identity leaves pad the tree
+                [&](int o) { const int w = o % (2 * NN), e = w >> 1; return ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; },     // identity leaves pad the tree
+                [&](int o) { const int gi = o / (2 * NN); return gi * 2 * NP + (o - gi * 2 * NN); });
             if (tid < 4 * k) {                                    // halo: the neighbours' controls of this evaluation
                 const int kk = tid >> 2, hh = tid & 3;
                 const int src_g = hh < 2 ? g - 1 : g + 1, tl = hh < 2 ? hh - 2 : RL + (hh - 2), t = g * RL + tl;
@@ -684,6 +691,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     Wv(kk, tl) = ld_sc1(xA + (size_t)src_g * sd.xa_stride + 2 * NN + 4 * kk + (hh < 2 ? hh + 2 : hh - 2));
             }
             __syncthreads();
+            QSM_STAMP(7);
             if (spec) {                                            // the stop rule of the previous iteration, one exchange late
                 double reg = 0.0, g2 = 0.0;
                 for (int gi = 0; gi < G; ++gi) { reg += xsum[4 * gi]; g2 += xsum[4 * gi + 1]; }
@@ -702,22 +710,66 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 spec = false;
                 __syncthreads();                                   // (xsum is written again by the next exchange)
             }
+            if constexpr (SRC) {
 #pragma unroll 1
-            for (int l = 1; l <= sd.LG; ++l) {
-                for (int nd_i = row; nd_i < (sd.Gp >> l); nd_i += R) {
-                    const cplx* rn = unode(treeU, l - 1, 2 * nd_i + 1);
-                    const cplx* ln = unode(treeU, l - 1, 2 * nd_i);
-                    cplx Ar[N], xl[N], acc[N];
+                for (int l = 1; l <= sd.LG; ++l) {
+                    for (int nd_i = row; nd_i < (sd.Gp >> l); nd_i += R) {
+                        const cplx* rn = unode(treeU, l - 1, 2 * nd_i + 1);
+                        const cplx* ln = unode(treeU, l - 1, 2 * nd_i);
+                        cplx Ar[N], xl[N], acc[N];
 #pragma unroll
-                    for (int r = 0; r < N; ++r) { Ar[r] = ldm<SPL>(rn + r * N + jj, h); xl[r] = ldm<SPL>(ln + r * N + jj, h); }
-                    MULB(Ar, xl, acc);
-                    cplx* nd = unode(treeU, l, nd_i);
-                    if (actw) {
+                        for (int r = 0; r < N; ++r) { Ar[r] = ldm<SPL>(rn + r * N + jj, h); xl[r] = ldm<SPL>(ln + r * N + jj, h); }
+                        MULB(Ar, xl, acc);
+                        cplx* nd = unode(treeU, l, nd_i);
+                        if (actw) {
 #pragma unroll
-                        for (int r = 0; r < N; ++r) nd[r * N + j] = acc[r];
+                            for (int r = 0; r < N; ++r) nd[r * N + j] = acc[r];
+                        }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
+            } else {
+                // z-free costate: this workgroup needs ONE start state and ONE end costate, i.e. the products of two RANGES of the subtree roots -- (Psi_0, M_0 .. M_{g-1}) and
+                // (M_{g+1} .. M_{G-1}, W^dagger) in time order.  Both are reduced pairwise (later times on the left, an odd last element passes through), at most
+                // Gp / 2 + 1 pairs per level over the R rows: ceil(log2(max(g + 1, G - g))) <= LG dependent products instead of the LG of a tree plus the LG of a walk down it.
+                int ca = g + 1, cb = G - g;
+                // (offsets into the LDS carve as 32-bit integers: the address arithmetic of a level is otherwise half as long as its product)
+                const int offP = lo.treeU + sd.Gp * NP, offQ = offP + (sd.Gp / 2 + 2) * NP;
+                int cur = -1, nxt = offP;
+#pragma unroll 1
+                while (ca > 1 || cb > 1) {
+                    const int na = (ca + 1) >> 1, nb = (cb + 1) >> 1;
+                    for (int w = row; w < na + nb; w += R) {
+                        const bool pre = w < na;
+                        const int i = pre ? w : w - na, c = pre ? ca : cb;
+                        int o0, o1;
+                        if (cur >= 0) { o0 = cur + (pre ? 2 * i : ca + 2 * i) * NP; o1 = o0 + NP; }
+                        else if (pre) { o0 = i == 0 ? lo.psi0 : lo.treeU + (2 * i - 1) * NP; o1 = lo.treeU + 2 * i * NP; }
+                        else { o0 = 2 * i == c - 1 ? lo.wd : lo.treeU + (g + 1 + 2 * i) * NP; o1 = 2 * i + 1 == c - 1 ? lo.wd : o0 + NP; }
+                        const cplx* e0 = S + o0 + jj;
+                        cplx xl[N], acc[N];
+#pragma unroll
+                        for (int r = 0; r < N; ++r) xl[r] = ldm<SPL>(e0 + r * N, h);
+                        if (2 * i + 1 < c) {
+                            const cplx* e1 = S + o1 + jj;
+                            cplx Ar[N];
+#pragma unroll
+                            for (int r = 0; r < N; ++r) Ar[r] = ldm<SPL>(e1 + r * N, h);
+                            MULB(Ar, xl, acc);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < N; ++r) acc[r] = xl[r];
+                        }
+                        if (actw) {
+                            cplx* nd = S + nxt + w * NP + j;
+#pragma unroll
+                            for (int r = 0; r < N; ++r) nd[r * N] = acc[r];
+                        }
+                    }
+                    __syncthreads();
+                    ca = na; cb = nb; cur = nxt; nxt = (nxt == offP) ? offQ : offP;
+                }
+                rangeP = S + cur;                                    // [0]: (M_{g-1} .. M_0) Psi_0, [1]: W^dagger (M_{G-1} .. M_{g+1})
             }
         }
         QSM_STAMP(2);
@@ -735,7 +787,10 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
         // ---- P3 / P4: start state and end costate of the row by a walk from the root; forward and backward sweep over the own slices --------
         cplx Phi[N], Y[N], Ps[L][N];
 #pragma unroll
-        for (int r = 0; r < N; ++r) { Phi[r] = ldm<SPL>(Psi0c + r * N + jj, h); Y[r] = ldm<SPL>(Wd + r * N + jj, h); }
+        for (int r = 0; r < N; ++r) {
+            Phi[r] = ldm<SPL>((rangeP ? rangeP : Psi0c) + r * N + jj, h);
+            Y[r] = ldm<SPL>((rangeP ? rangeP + NP : Wd) + r * N + jj, h);
+        }
         cplx zfin = cmake(0.0, 0.0);
         double reg_state = 0.0, coef = 0.0;
         if constexpr (!SRC) {
@@ -762,7 +817,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
             } else
 #pragma unroll 1
-            for (int l = LTOT; l >= 1; --l) {
+            for (int l = multi ? LR : LTOT; l >= 1; --l) {                      // (several workgroups: the levels above LR are in rangeP already)
                 int bit;
                 const cplx* sn = sibling(treeM, treeU, l, bit);
                 cplx Ms[N], acc[N];
@@ -1192,6 +1247,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                "walk+forward(+state terms, offsets) %llu, backward %llu, tail to sums(+exchange B) %llu, stop rule+Adam %llu clk\n", N, L, R, (int)SRC, G, sd.iters,
                ck1 - ck0, (double)(rt1 - rt0) / 100.0, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4],
                stamp[6] - stamp[5]);
+        if (sd.G > 1) printf("   exchange A: local up-sweep %llu, payload stores + drain + flag + wait for all flags %llu, fetch of the payloads %llu, upper sweep %llu clk\n",
+                             stamp[14] - stamp[1], stamp[15] - stamp[14], stamp[7] - stamp[15], stamp[2] - stamp[7]);
         if (SRC) printf("   state-regulariser flow: walk for the start state %llu, forward + state terms %llu, sums (+ exchange A1) %llu, offsets of the row %llu, offset tree up-sweep %llu, "
                         "exchange A2 + upper offset tree %llu, terminal + walk for the costate %llu clk\n", stamp[8] - stamp[2], stamp[9] - stamp[8], stamp[10] - stamp[9], stamp[11] - stamp[10],
                         stamp[12] - stamp[11], stamp[13] - stamp[12], stamp[3] - stamp[13]);
@@ -1210,8 +1267,34 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     }
     // unitary mode: final_state = (product of all propagators) U0 is one product away from the root of the tree, unitary_scale = (1/n) sum_c |sum_a X[c][a]|^2 a row
     // reduction away from that (core/tensorflow_state.py:204-227): formed here, so that a poll of the progress line needs no second pass over the pulse
-    if (!d.state_transfer && tree_is_last && g == 0 && row == 0) {
-        const cplx* root = multi ? unode(treeU, sd.LG, 0) : lnode(treeM, LR, 0);
+    const cplx* root = lnode(treeM, LR, 0);
+    const bool want_final = !d.state_transfer && tree_is_last && g == 0;
+    if (want_final && multi) {
+        if constexpr (SRC) root = unode(treeU, sd.LG, 0);
+        else {                                                      // (the iterations reduce ranges, not the tree: the product of ALL subtree roots once per launch, by every row of workgroup 0)
+            cplx* bufs[2] = { treeU + (size_t)sd.Gp * NP, treeU + (size_t)(sd.Gp + sd.Gp / 2 + 2) * NP };
+            const cplx* cur = unode(treeU, 0, 0);
+            int which = 0;
+            for (int c = sd.Gp; c > 1; c >>= 1) {
+                cplx* nxt = bufs[which];
+                for (int w = row; w < (c >> 1); w += R) {
+                    const cplx* e0 = cur + (size_t)(2 * w) * NP;
+                    cplx Ar[N], xl[N], acc[N];
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { xl[r] = ldm<SPL>(e0 + r * N + jj, h); Ar[r] = ldm<SPL>(e0 + NP + r * N + jj, h); }
+                    MULB(Ar, xl, acc);
+                    if (actw) {
+#pragma unroll
+                        for (int r = 0; r < N; ++r) nxt[(size_t)w * NP + r * N + j] = acc[r];
+                    }
+                }
+                __syncthreads();
+                cur = nxt; which ^= 1;
+            }
+            root = cur;
+        }
+    }
+    if (want_final && row == 0) {
         cplx Ar[N], Uc[N], X[N];
 #pragma unroll
         for (int r = 0; r < N; ++r) {

@@ -88,7 +88,8 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
         if G > 32 or (single and G > 1) or (bandpass and G > 1) or (G > 1 and B * G > 128):
             continue
         Gp, NN, RL = 1 << clog2(G), N * N, R * L
-        lds = ((k + 1) * NN + k * NN + (4 * N if src else 0) + 2 * NN + (3 * NN if src else 0) + (2 * R - 1) * NN + (2 * Gp - 1) * NN
+        NP = NN                                                # qoc_small_node(N)
+        lds = ((k + 1) * NN + k * NN + (4 * N if src else 0) + 2 * NN + (3 * NN if src else 0) + (2 * R - 1) * NP + ((2 * Gp - 1) if (src or Gp == 1) else (Gp + Gp // 2 + Gp // 4 + 4)) * NP
                + ((2 * R - 1 + 2 * Gp - 1) * m * N if src else 0) + k * RL + (k * (RL + 4) + 1) // 2 + 64 + (2 * Gp if Gp > 1 else 0)
                + ((k + 1) * RL if bandpass else 0))
         if lds * 16 > 160 * 1024:
