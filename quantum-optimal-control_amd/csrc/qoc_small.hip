@@ -41,8 +41,9 @@ int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // ~1.5 us per exchange between workgroups): only used to rank the (L, G) candidates of one problem and for AUTO's threshold
 double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
     const int Teff = d.state_transfer ? d.T - 1 : d.T;
-    // (n <= 4: a slice is a few hundred instructions between LDS round trips -- a second wave per SIMD hides them instead of competing: C1 9.1 us on 32 rows, 10.4 on 16)
-    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? (R >= 32 ? 1.15 : 0.9) : (R <= 16 ? 1.0 : R / 16.0);
+    // (n = 2: a slice is a few hundred instructions between LDS round trips -- a second wave per SIMD hides them instead of competing: C1 8.4 us on 32 rows, 9.3 on 16;
+    // n = 3, 4: the two waves do compete, and the 32-row builds spill -- n = 4 x 40 slices: 17.9 us on 32 rows, 13.6 on 16, 12.2 on 4 workgroups of 16)
+    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? (R >= 32 ? (N <= 2 ? 1.15 : 1.7) : 0.9) : (R <= 16 ? 1.0 : R / 16.0);
     const double per_slice = ((Teff > 1 ? Teff - 1 : 0) + d.s + (src ? 6.0 : 4.0)) * prod + 0.15;
     const int LR = ilog2_ceil(R), LG = ilog2_ceil(G);
     double us = share * (L * per_slice + (src ? 4.0 : 2.0) * LR * (prod + 0.1));

@@ -95,7 +95,7 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
         if lds * 16 > 160 * 1024:
             continue
         prod = 4.0 * N * N * 5.9 / 2400.0
-        share = (1.15 if R >= 32 else 0.9) if N <= 4 else max(1.0, R / 16.0)
+        share = ((1.15 if N <= 2 else 1.7) if R >= 32 else 0.9) if N <= 4 else max(1.0, R / 16.0)
         per_slice = (max(Teff - 1, 0) + s + (6.0 if src else 4.0)) * prod + 0.15
         us = share * (L * per_slice + (4.0 if src else 2.0) * clog2(R) * (prod + 0.1))
         if G > 1:
