@@ -964,8 +964,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
             }
             __syncthreads();
+            QSM_STAMP(12);
             if (multi) {
-                QSM_STAMP(12);
                 // exchange A2: the offsets of the subtrees
                 const double* root = (const double*)lnodeO(LR, 0);
                 double* mine = xS + (size_t)g * sd.xs_stride + 4 + 2 * NN;

@@ -1,6 +1,8 @@
 """Randomised differential test: random small problems (mode, sizes, Taylor order, regularisers, seed count) evaluated
 by every engine path that accepts them, each compared with the NumPy oracle.  Seeds are fixed, so a failure reproduces.
 Sizes stay small enough for the oracle to take milliseconds; the structured full-size checks live in test_hip_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,7 +138,7 @@ def test_random_direct_route_one_vector(seed):
         assert 'squared' in kinds, (kinds, T)
 
 
-@pytest.mark.parametrize('seed', range(64))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('QOC_FUZZ_SMALL', '64'))))        # (QOC_FUZZ_SMALL=512: the long run after a change of the product primitive)
 def test_random_small_path(seed):
     """The workgroup-resident path (QOC_PATH_SMALL, csrc/qoc_small_kernel.h) on random problems of 2 .. 12 levels: both modes, every regulariser it takes (all but the
     bandpass), 1 .. 3 control sets, pulses of 1 .. 300 slices over AUTO's / 1 / 2 / 3 / 7 workgroups per control set and 16 / 32 rows per workgroup -- one evaluation
@@ -212,5 +214,6 @@ def test_random_small_path(seed):
         finally:
             eng.close()
     # (long pulses of the largest sizes have no instance: their product trees do not fit 160 KB of LDS -- AUTO keeps those on the MFMA path)
-    assert tried >= 1 or (sp.n >= 9 and sp.steps >= 64) or ('bandpass' in sp.reg_coeffs and sp.steps > (128 if sp.n <= 4 else 64 if sp.n <= 8 else 16)), (
+    src = 'forbidden_coeff_list' in sp.reg_coeffs or 'speed_up' in sp.reg_coeffs      # (n > 10 with a state regulariser: two trees of 2304-byte nodes, <= ~30 slices)
+    assert tried >= 1 or (sp.n >= 9 and sp.steps >= 64) or (sp.n >= 11 and src and sp.steps > 30) or ('bandpass' in sp.reg_coeffs and sp.steps > (128 if sp.n <= 4 else 32 if sp.n <= 8 else 16)), (
         sp.n, sp.steps, sorted(sp.reg_coeffs))       # (a bandpass regulariser: the pulse must fit ONE workgroup of the instance)

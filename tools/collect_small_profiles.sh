@@ -13,7 +13,7 @@ if [ -x /opt/conda/bin/python3.9 ]; then      # save=True needs h5py: the image'
 fi
 # phase stamps: libraries built with -DQOC_SMALL_TIMING, one per translation unit of instances (python tools/build_variant.py timing_<u> qoc_small_<u> -DQOC_SMALL_TIMING)
 if [ -f quantum-optimal-control_amd/lib_timing_a1/libqoc_hip.so ]; then
-  { for v in a1 a b; do QOC_HIP_LIBRARY=quantum-optimal-control_amd/lib_timing_$v/libqoc_hip.so python tools/small_phase_timing.py 2>&1 | grep "iters=200:\|state-regulariser"; done
+  { for v in a1 a b; do QOC_HIP_LIBRARY=quantum-optimal-control_amd/lib_timing_$v/libqoc_hip.so python tools/small_phase_timing.py 2>&1 | grep "iters=200:\|state-regulariser\|exchange A:"; done
     QOC_HIP_LIBRARY=quantum-optimal-control_amd/lib_timing_c/libqoc_hip.so python tools/small_phase_timing_src.py 2>&1 | grep -v "iters=1000"; } > $O/small_phase_timing.txt
 fi
 cd /tmp && export TMPDIR=/tmp

@@ -24,12 +24,17 @@ def run(name, c, seeds=1, groups=0, rows=0):
     eng.close()
 
 
-run('C1', cases.case_c1())
-run('C1 rows=16', cases.case_c1(), rows=16)
-run('C1 x64', cases.case_c1(), 64)
-for n in (4, 8):
-    run('n=%d x 500' % n, cases.case_c2(n=n, k=4, steps=500, m=min(8, n), taylor=(5, 3), seed=2))
-run('n=8 x 500, 16 workgroups', cases.case_c2(n=8, k=4, steps=500, m=8, taylor=(5, 3), seed=2), groups=16)
-c = cases.case_c2(n=9, k=4, steps=300, m=4, taylor=(5, 3), seed=2)
-c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [8, 5]}
-run('two qutrits + forbidden', c)
+def main():
+    run('C1', cases.case_c1())
+    run('C1 rows=16', cases.case_c1(), rows=16)
+    run('C1 x64', cases.case_c1(), 64)
+    for n in (4, 8):
+        run('n=%d x 500' % n, cases.case_c2(n=n, k=4, steps=500, m=min(8, n), taylor=(5, 3), seed=2))
+    run('n=8 x 500, 16 workgroups', cases.case_c2(n=8, k=4, steps=500, m=8, taylor=(5, 3), seed=2), groups=16)
+    c = cases.case_c2(n=9, k=4, steps=300, m=4, taylor=(5, 3), seed=2)
+    c['reg_coeffs'] = {'dwdt': 1e-3, 'forbidden_coeff_list': [10.0, 10.0], 'states_forbidden_list': [8, 5]}
+    run('two qutrits + forbidden', c)
+
+
+if __name__ == '__main__':
+    main()
