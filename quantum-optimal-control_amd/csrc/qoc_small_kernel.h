@@ -282,6 +282,15 @@ __device__ __forceinline__ double row_sum16(double v) {
     return v;
 }
 
+// sum over the first lanes of a row that can hold data of an N-column matrix (result in those lanes; the others must hold zero): 1 .. 4 DPP steps
+template <int N>
+__device__ __forceinline__ double row_sum_n(double v) {
+    v += dpp_xor<1>(v);
+    if constexpr (N > 2) v += dpp_xor<2>(v);
+    if constexpr (N > 4) v += dpp_xor<4>(v);
+    if constexpr (N > 8) v += dpp_xor<8>(v);
+    return v;
+}
 // ... over the 8 lanes of a half row
 __device__ __forceinline__ double row_sum8(double v) {
     v += dpp_xor<1>(v); v += dpp_xor<2>(v); v += dpp_xor<4>(v);
@@ -518,19 +527,19 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
     }
     __syncthreads();
     // the (control, slice) elements of this thread: variable and Adam slots stay in registers for the whole launch
-    double e_base[QE], e_m[QE], e_v[QE], e_w[QE], e_g[QE];
+    double e_base[QE], e_m[QE], e_v[QE], e_w[QE], e_g[QE], e_c[QE];      // e_w = sin(base), e_c = cos(base) (the chain rule of the tail): ONE sincos per step
     int e_kk[QE], e_tl[QE];
     bool e_ok[QE];
 #pragma unroll
     for (int e = 0; e < QE; ++e) {
         const int o = tid + e * THREADS, kk = o / RL, tl = o - kk * RL, t = g * RL + tl;
         e_kk[e] = kk; e_tl[e] = tl; e_ok[e] = kk < k && t < steps;
-        e_base[e] = 0.0; e_m[e] = 0.0; e_v[e] = 0.0; e_w[e] = 0.0; e_g[e] = 0.0;
+        e_base[e] = 0.0; e_m[e] = 0.0; e_v[e] = 0.0; e_w[e] = 0.0; e_g[e] = 0.0; e_c[e] = 1.0;
         if (e_ok[e]) {
             const size_t go = ((size_t)b * k + kk) * steps + t;
             e_base[e] = d.base[go];
             if (ap.mode != 0) { e_m[e] = d.adam_m[go]; e_v[e] = d.adam_v[go]; }
-            e_w[e] = sin(e_base[e]);
+            sincos(e_base[e], &e_w[e], &e_c[e]);
             Wv(kk, tl) = e_w[e];
         }
     }
@@ -1049,8 +1058,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
                 for (int c = 0; c < N; ++c) { cfma(q0, T0r[c], Rm[c]); cfma(q1, T1r[c], Rm[c]); }
                 if (!act) { q0 = cmake(0.0, 0.0); q1 = cmake(0.0, 0.0); }
-                q0.x = row_sum16(q0.x); q0.y = row_sum16(q0.y);
-                if (k > 1) { q1.x = row_sum16(q1.x); q1.y = row_sum16(q1.y); }
+                q0.x = row_sum_n<N>(q0.x); q0.y = row_sum_n<N>(q0.y);
+                if (k > 1) { q1.x = row_sum_n<N>(q1.x); q1.y = row_sum_n<N>(q1.y); }
                 if (lane16 == 0 && t < steps) { qS[tl] = q0; if (k > 1) qS[RL + tl] = q1; }
             }
             if constexpr (SPL) {                                                   // half h contracts the controls kk = h, h + 2, ...: sums over the 8 lanes of a half
@@ -1071,14 +1080,14 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
                 for (int c = 0; c < N; ++c) cfma(q, Hk[c * N + jj], Rm[c]);
                 if (!act) q = cmake(0.0, 0.0);
-                q.x = row_sum16(q.x); q.y = row_sum16(q.y);
+                q.x = row_sum_n<N>(q.x); q.y = row_sum_n<N>(q.y);
                 if (j == 0 && t < steps) qS[kk * RL + tl] = q;
             }
             if (!SRC && i == L - 1 && row == 0) {                                // z = <W, Psi_N> = tr(Y_tau Psi_tau) at any tau (a workgroup's own copy)
                 cplx dg = cmake(0.0, 0.0);
 #pragma unroll
                 for (int r = 0; r < N; ++r) if (r == j && h == 0) dg = Rm[r];
-                dg.x = row_sum16(dg.x); dg.y = row_sum16(dg.y);
+                dg.x = row_sum_n<N>(dg.x); dg.y = row_sum_n<N>(dg.y);
                 if (lane16 == 0) { misc[M_Z] = dg.x; misc[M_Z + 1] = dg.y; }
             }
             if (i > 0) {
@@ -1181,7 +1190,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     }
                     const cplx q = qS[kk * RL + tl];
                     const double dLdu = SRC ? q.x : (c0 * z.x) * q.x + (c0 * z.y) * q.y;                    // Re(conj(c0 z) q')
-                    const double gv = cos(e_base[e]) * (misc[M_MAXA + kk] * dLdu + dR);                     // tensorflow_state.py:176-178
+                    const double gv = e_c[e] * (misc[M_MAXA + kk] * dLdu + dR);                     // tensorflow_state.py:176-178
                     e_g[e] = gv; g2 += gv * gv;
                 }
             }
@@ -1233,7 +1242,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                     const double vv = b2 * e_v[e] + (1.0 - b2) * gv * gv;
                     e_m[e] = mv; e_v[e] = vv;
                     e_base[e] = e_base[e] - lr_t * mv / (sqrt(vv) + eps);
-                    if (more) { e_w[e] = sin(e_base[e]); Wv(e_kk[e], e_tl[e]) = e_w[e]; }
+                    if (more) { sincos(e_base[e], &e_w[e], &e_c[e]); Wv(e_kk[e], e_tl[e]) = e_w[e]; }
                 }
             }
             __syncthreads();
