@@ -15,7 +15,7 @@
     extern template __global__ void qsm::k_small_iter<N, L, R, false, false>(QocDev, QocAdamDev, QocSmallDev); \
     extern template __global__ void qsm::k_small_iter<N, L, R, true, false>(QocDev, QocAdamDev, QocSmallDev);
 QOC_SMALL_INSTANCES_A(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_B(QOC_SMALL_DECL) QOC_SMALL_INSTANCES_C(QOC_SMALL_DECL)
-QOC_SMALL_INSTANCES_A1(QOC_SMALL_DECL1)
+QOC_SMALL_INSTANCES_A1(QOC_SMALL_DECL1) QOC_SMALL_INSTANCES_B1(QOC_SMALL_DECL1)
 
 namespace {
 
@@ -26,7 +26,7 @@ struct Instance { int N, L, R; small_kernel_t fn[2]; bool ok[2]; bool lds_opted[
 #define QOC_SMALL_ROW(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, true>, S ? qsm::k_small_iter<N, L, R, true, true> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, false },
 // (one-workgroup builds: a row of their own -- `single` -- that choose() takes for G = 1 only)
 #define QOC_SMALL_ROW1(N, L, R, S) { N, L, R, { qsm::k_small_iter<N, L, R, false, false>, S ? qsm::k_small_iter<N, L, R, true, false> : (small_kernel_t) nullptr }, { true, S != 0 }, { false, false }, true },
-Instance g_inst[] = { QOC_SMALL_INSTANCES_A1(QOC_SMALL_ROW1) QOC_SMALL_INSTANCES_A(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_B(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_C(QOC_SMALL_ROW) };
+Instance g_inst[] = { QOC_SMALL_INSTANCES_A1(QOC_SMALL_ROW1) QOC_SMALL_INSTANCES_B1(QOC_SMALL_ROW1) QOC_SMALL_INSTANCES_A(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_B(QOC_SMALL_ROW) QOC_SMALL_INSTANCES_C(QOC_SMALL_ROW) };
 constexpr int N_INST = sizeof(g_inst) / sizeof(g_inst[0]);
 
 int padded_n(int n) {

@@ -14,6 +14,9 @@
 #define QOC_SMALL_INSTANCES_B(X) \
     X(5, 1, 16, 1) X(5, 2, 16, 1) X(5, 4, 16, 1) X(6, 1, 16, 1) X(6, 2, 16, 1) X(6, 4, 16, 1) X(7, 1, 16, 1) X(7, 2, 16, 1) X(7, 4, 16, 0) \
     X(8, 1, 16, 1) X(8, 2, 16, 1) X(8, 4, 16, 0)
+// ... and their builds for ONE workgroup per control set (pulses of up to 64 slices)
+#define QOC_SMALL_INSTANCES_B1(X) \
+    X(5, 2, 16, 1) X(5, 4, 16, 1) X(6, 2, 16, 1) X(6, 4, 16, 1) X(7, 2, 16, 1) X(7, 4, 16, 1) X(8, 2, 16, 1) X(8, 4, 16, 1)
 // 8 < n <= 12; n > 10: a product tree of 16 rows (x 2 with the offsets of a state regulariser) does not always fit 160 KB beside the Hamiltonians: 8 rows.
 // (n = 13 .. 16 stay on the MFMA path: a column-per-lane instance of 16 levels needs more than the 512 registers of a wave, and a 16 x 16 MFMA tile has no padding there)
 #define QOC_SMALL_INSTANCES_C(X) \

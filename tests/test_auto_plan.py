@@ -59,10 +59,10 @@ def _small_instances():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'quantum-optimal-control_amd', 'csrc', 'qoc_small_instances.h')
     text = open(path).read()
     out = []
-    for name in ('A1', 'A', 'B', 'C'):                    # the order of the engine's table; list A1 = builds for ONE workgroup per control set
+    for name in ('A1', 'B1', 'A', 'B', 'C'):                    # the order of the engine's table; list A1 = builds for ONE workgroup per control set
         body = text[text.index('#define QOC_SMALL_INSTANCES_%s(X)' % name):]
         body = body[:body.index('\n//') if '\n//' in body else len(body)]
-        out += [tuple(int(v) for v in mt.groups()) + (name == 'A1',) for mt in re.finditer(r'X\((\d+), (\d+), (\d+), ([01])\)', body)]
+        out += [tuple(int(v) for v in mt.groups()) + (name in ('A1', 'B1'),) for mt in re.finditer(r'X\((\d+), (\d+), (\d+), ([01])\)', body)]
     assert len(out) >= 30
     return out
 
