@@ -107,3 +107,22 @@ def test_no_dpp_read_hazard_in_the_built_device_code():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(objs) == 0
+
+
+def test_dpp_hazard_scan_recognises_the_patterns_it_guards_against():
+    """The scanner on hand-written disassembly: a spill copy right in front of a DPP read, the same behind s_nop 1, an EXEC write four / five slots before."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('dpp_hazard_scan', os.path.join(root, 'tools', 'dpp_hazard_scan.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fma = '\tv_fmac_f64_dpp v[10:11], v[30:31], v[40:41] row_newbcast:1 row_mask:0xf bank_mask:0xf // 0000: 0\n'
+    head = '0000000000001000 <kernel_a>:\n'
+    assert mod.scan(head + '\tv_mov_b64_e32 v[30:31], v[200:201]\n' + fma) == (1, [('kernel_a', 'v_mov_b64_e32', fma.split('//')[0].strip())])
+    assert mod.scan(head + '\tv_accvgpr_read_b32 v31, a5\n\tv_add_f64 v[2:3], v[4:5], v[6:7]\n' + fma)[1] != []          # one instruction in between: still one wait state short
+    assert mod.scan(head + '\tv_mov_b64_e32 v[30:31], v[200:201]\n\ts_nop 1\n' + fma) == (1, [])
+    assert mod.scan(head + '\tv_mov_b64_e32 v[32:33], v[200:201]\n' + fma) == (1, [])                                      # another register
+    four = '\tv_add_f64 v[2:3], v[4:5], v[6:7]\n' * 4
+    assert mod.scan(head + '\ts_and_saveexec_b64 s[0:1], vcc\n' + four + fma)[1] != []
+    assert mod.scan(head + '\ts_and_saveexec_b64 s[0:1], vcc\n\ts_nop 4\n' + fma) == (1, [])
+    assert mod.scan(head + '\ts_mov_b64 exec, s[0:1]\n' + four + '\tv_add_f64 v[2:3], v[4:5], v[6:7]\n' + fma) == (1, [])
