@@ -44,7 +44,9 @@ double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
     // (n = 2: a slice is a few hundred instructions between LDS round trips -- a second wave per SIMD hides them instead of competing: C1 8.4 us on 32 rows, 9.3 on 16;
     // n = 3, 4: the two waves do compete, and the 32-row builds spill -- n = 4 x 40 slices: 17.9 us on 32 rows, 13.6 on 16, 12.2 on 4 workgroups of 16)
     const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? (R >= 32 ? (N <= 2 ? 1.15 : 1.7) : 0.9) : (R <= 16 ? 1.0 : R / 16.0);
-    const double per_slice = ((Teff > 1 ? Teff - 1 : 0) + d.s + (src ? 6.0 : 4.0)) * prod + 0.15;
+    // (state regularisers: besides two more products per slice, the element-wise state terms and sources of three passes -- what a slice of a SMALL system mostly
+    // costs then: a qutrit with a forbidden level, 100 slices: 29 us on one workgroup x 8 slices per row, 22 on 7 workgroups x 1)
+    const double per_slice = ((Teff > 1 ? Teff - 1 : 0) + d.s + (src ? 6.0 : 4.0)) * prod + 0.15 + (src ? (N <= 4 ? 0.6 : N <= 8 ? 0.3 : 0.0) : 0.0);
     const int LR = ilog2_ceil(R), LG = ilog2_ceil(G);
     double us = share * (L * per_slice + (src ? 4.0 : 2.0) * LR * (prod + 0.1));
     if (G > 1) us += (src ? 4.0 : 2.0) * 1.5 + (src ? 4.0 : 2.0) * LG * (prod + 0.1);

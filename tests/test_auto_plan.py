@@ -96,7 +96,7 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
             continue
         prod = 4.0 * N * N * 5.9 / 2400.0
         share = ((1.15 if N <= 2 else 1.7) if R >= 32 else 0.9) if N <= 4 else max(1.0, R / 16.0)
-        per_slice = (max(Teff - 1, 0) + s + (6.0 if src else 4.0)) * prod + 0.15
+        per_slice = (max(Teff - 1, 0) + s + (6.0 if src else 4.0)) * prod + 0.15 + ((0.6 if N <= 4 else 0.3 if N <= 8 else 0.0) if src else 0.0)
         us = share * (L * per_slice + (4.0 if src else 2.0) * clog2(R) * (prod + 0.1))
         if G > 1:
             us += (4.0 if src else 2.0) * 1.5 + (4.0 if src else 2.0) * clog2(G) * (prod + 0.1)
