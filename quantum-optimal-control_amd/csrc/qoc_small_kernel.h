@@ -346,6 +346,43 @@ __device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD p
 template <int THREADS, class SRC, class PAD>
 __device__ __forceinline__ void fetch_sc1(double* dst, int count, SRC src, PAD pad) { fetch_sc1<THREADS>(dst, count, src, pad, [](int o) { return o; }); }
 
+// The same for the big payloads (the subtree roots of all workgroups: 32 KB at n = 8) with 16-byte loads, eight in flight per thread: `pairs` complex numbers, src(p) = the
+// 16-byte aligned global address of pair p or nullptr for a pad pair of value pad(p).  One asm statement holds the loads AND their s_waitcnt: the compiler does not track
+// the arrival of a load it did not issue, so nothing may touch the destination registers in between.
+typedef double qsm_d2 __attribute__((ext_vector_type(2)));
+template <int THREADS, class SRC, class PAD>
+__device__ __forceinline__ void fetch_sc1_pairs(cplx* dst, int pairs, SRC src, PAD pad, const cplx* any_valid) {
+    for (int p0 = threadIdx.x; p0 < pairs; p0 += 8 * THREADS) {
+        const cplx* a[8];
+        bool real[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * THREADS;
+            const cplx* q = p < pairs ? src(p) : nullptr;
+            real[u] = q != nullptr;
+            a[u] = q ? q : any_valid;
+        }
+        qsm_d2 v0, v1, v2, v3, v4, v5, v6, v7;
+        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                     "global_load_dwordx4 %1, %9, off sc1\n\t"
+                     "global_load_dwordx4 %2, %10, off sc1\n\t"
+                     "global_load_dwordx4 %3, %11, off sc1\n\t"
+                     "global_load_dwordx4 %4, %12, off sc1\n\t"
+                     "global_load_dwordx4 %5, %13, off sc1\n\t"
+                     "global_load_dwordx4 %6, %14, off sc1\n\t"
+                     "global_load_dwordx4 %7, %15, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+        const qsm_d2 v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * THREADS;
+            if (p < pairs) dst[p] = real[u] ? cmake(v[u].x, v[u].y) : pad(p);
+        }
+    }
+}
+
 template <int THREADS>
 __device__ __forceinline__ void wg_sum2(double& a, double& b, double* red /* 2 x waves doubles */) {
 #pragma unroll
@@ -689,10 +726,11 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             wait_flags(flags + 0, G, epoch, sd.err);
             QSM_STAMP(15);
             if (spec) fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xA + (size_t)(o >> 2) * sd.xa_stride + 2 * NN + 32 + (o & 3); }, [](int) { return 0.0; });
-            fetch_sc1<THREADS>((double*)unode(treeU, 0, 0), sd.Gp * 2 * NN,
-                [&](int o) -> const double* { const int gi = o / (2 * NN); return gi < G ? xA + (size_t)gi * sd.xa_stride + (o - gi * 2 * NN) : nullptr; },
-                [&](int o) { const int w = o % (2 * NN), e = w >> 1; return ((w & 1) == 0 && (e / N) == (e % N)) ? 1.0 : 0.0; },     // identity leaves pad the tree
-                [&](int o) { const int gi = o / (2 * NN); return gi * 2 * NP + (o - gi * 2 * NN); });
+            static_assert(NP == NN, "the leaves are fetched as one dense array");
+            fetch_sc1_pairs<THREADS>(unode(treeU, 0, 0), sd.Gp * NN,
+                [&](int p) -> const cplx* { const int gi = p / NN; return gi < G ? (const cplx*)(xA + (size_t)gi * sd.xa_stride) + (p - gi * NN) : nullptr; },
+                [&](int p) { const int e = p % NN; return cmake((e / N) == (e % N) ? 1.0 : 0.0, 0.0); },                               // identity leaves pad the tree
+                (const cplx*)xA);
             if (tid < 4 * k) {                                    // halo: the neighbours' controls of this evaluation
                 const int kk = tid >> 2, hh = tid & 3;
                 const int src_g = hh < 2 ? g - 1 : g + 1, tl = hh < 2 ? hh - 2 : RL + (hh - 2), t = g * RL + tl;
