@@ -12,7 +12,9 @@
 // row_newbcast:c -- A[r][c] reaches all lanes of the row from lane c's register r inside the FMA, so neither operand passes through LDS.  The
 // chain over the rows is a product TREE in LDS (log-depth up-sweep, then a barrier-free walk from the root down to each row's start state and
 // end costate); a pulse that does not fit one workgroup takes G workgroups per control set, which hand their subtree products and partial
-// sums to each other through write-through (sc1) stores, one flag per workgroup and epoch (cdna_hip_programming.md, Guideline 16).
+// sums to each other through write-through (sc1) stores, one flag per workgroup and epoch (cdna_hip_programming.md, Guideline 16), and then
+// reduce the two ranges of subtree products they need (start state, end costate) instead of a common upper tree.  5 <= n <= 8: lanes j and j + 8
+// of a row share column j and form the real / imaginary parts of a product (2 n^2 FMAs per lane instead of 4 n^2).
 #pragma once
 #include <string>
 #include <vector>

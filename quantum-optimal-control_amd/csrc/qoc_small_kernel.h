@@ -5,7 +5,7 @@
 //   K_t = (sum_{j<=T} A^j / j!)^(2^s), A = H_t / 2^s    core/tensorflow_state.py:25-46    (state transfer: sum_{j<T} B^j / j!, :77-97)
 //   chain, inter vectors, fidelity                      core/tensorflow_state.py:204-242, 282-340
 //   first-order gradient Re<Lambda_{t+1}, H_k Psi_{t+1}> core/tensorflow_state.py:49-65 (:100-133 in state transfer)
-//   regularisers                                        core/regularization_functions.py:15-45, 69-95 (no bandpass on this path)
+//   regularisers                                        core/regularization_functions.py:15-95 (the bandpass, :47-67, by a direct DFT when the pulse fits ONE workgroup)
 //   grad_squared, TF1 Adam                              core/tensorflow_state.py:342-356
 //   stop rule, learning-rate schedule                   core/run_session.py:47-69
 //
