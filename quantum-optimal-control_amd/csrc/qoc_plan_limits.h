@@ -49,6 +49,8 @@
 #define QOC_PLAN_CHUNKS_MAX_NT2 64
 #define QOC_PLAN_CHUNKS_MAX 32
 // ---- workgroup-resident path (QOC_PATH_SMALL, n <= 16): taken while the modelled iteration time and the planned batch stay below ------------
-#define QOC_PLAN_SMALL_MAX_MODEL_US 45      // microseconds per iteration by qoc_small.hip: model_us (the other paths: 42 - 65)   (r06_small_n_latency.txt)
+#define QOC_PLAN_SMALL_MAX_MODEL_US 52      // microseconds per iteration by qoc_small.hip: model_us (the other paths: 42 - 67 up to 500 slices)   (r06_small_n_latency.txt)
+#define QOC_PLAN_SMALL_MODEL_US_BASE 36     // ... or, for long pulses, 0.9 x what the latency mode of the MFMA path costs: 40 us + 0.04 us per slice
+#define QOC_PLAN_SMALL_MODEL_NS_PER_SLICE 36    //     (n = 8 / 9 x 1000 slices: 83 / 89 us there, 32 / 49 here)
 #define QOC_PLAN_SMALL_MAX_MODEL_US_SRC 85  // ... with a state regulariser (the other paths: 80 - 120)
 #define QOC_PLAN_SMALL_MAX_SETS 256         // control sets (one workgroup each when the pulse fits one)

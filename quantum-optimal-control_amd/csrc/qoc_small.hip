@@ -43,13 +43,14 @@ double model_us(const QocDev& d, int N, int R, int L, int G, bool src) {
     const int Teff = d.state_transfer ? d.T - 1 : d.T;
     // (n = 2: a slice is a few hundred instructions between LDS round trips -- a second wave per SIMD hides them instead of competing: C1 8.4 us on 32 rows, 9.3 on 16;
     // n = 3, 4: the two waves do compete, and the 32-row builds spill -- n = 4 x 40 slices: 17.9 us on 32 rows, 13.6 on 16, 12.2 on 4 workgroups of 16)
-    const double prod = 4.0 * N * N * 5.9 / 2400.0, share = N <= 4 ? (R >= 32 ? (N <= 2 ? 1.15 : 1.7) : 0.9) : (R <= 16 ? 1.0 : R / 16.0);
+    // (5 <= n <= 8: the split form -- 2 n^2 DPP FMAs per lane, the hand-over and the padding: 0.65 of the 4 n^2 form, measured)
+    const double prod = (N >= 5 && N <= 8 ? 2.6 : 4.0) * N * N * 5.9 / 2400.0, share = N <= 4 ? (R >= 32 ? (N <= 2 ? 1.15 : 1.7) : 0.9) : (R <= 16 ? 1.0 : R / 16.0);
     // (state regularisers: besides two more products per slice, the element-wise state terms and sources of three passes -- what a slice of a SMALL system mostly
     // costs then: a qutrit with a forbidden level, 100 slices: 29 us on one workgroup x 8 slices per row, 22 on 7 workgroups x 1)
     const double per_slice = ((Teff > 1 ? Teff - 1 : 0) + d.s + (src ? 6.0 : 4.0)) * prod + 0.15 + (src ? (N <= 4 ? 0.6 : N <= 8 ? 0.3 : 0.0) : 0.0);
     const int LR = ilog2_ceil(R), LG = ilog2_ceil(G);
     double us = share * (L * per_slice + (src ? 4.0 : 2.0) * LR * (prod + 0.1));
-    if (G > 1) us += (src ? 4.0 : 2.0) * 1.5 + (src ? 4.0 : 2.0) * LG * (prod + 0.1);
+    if (G > 1) us += (src ? 4.0 : 2.0) * 1.5 + (src ? 4.0 : 1.0) * LG * (prod + 0.1);        // (no state regulariser: range reduction, half the levels of tree + walk)
     if (d.has_band) us += 1.2e-4 * d.k * (double)d.steps * d.steps;      // direct DFT of the pulse and back: 2 k steps^2 terms over the workgroup's four SIMDs
     return 1.45 * (us + 1.5);            // (measured / modelled: 1.4 - 1.5 over n = 2 .. 12, profiles/r06_small_n_latency.txt)
 }
@@ -109,7 +110,9 @@ bool qoc_small_auto(const QocDev& d, bool antiherm) {
     const Choice c = choose(d, is_src(d), 0);
     // one or a few control sets: the other paths cost >= 42 us per iteration whatever n (profiles/r04_latency_sizes.txt); batches of small
     // systems: the MFMA batch kernels pad to 16 x 16 tiles (C1 x 64: 78 us)
-    return c.us <= (is_src(d) ? QOC_PLAN_SMALL_MAX_MODEL_US_SRC : QOC_PLAN_SMALL_MAX_MODEL_US) && d.Bplan <= QOC_PLAN_SMALL_MAX_SETS;
+    const double long_pulse = QOC_PLAN_SMALL_MODEL_US_BASE + 1e-3 * QOC_PLAN_SMALL_MODEL_NS_PER_SLICE * d.steps;
+    const double limit = is_src(d) ? QOC_PLAN_SMALL_MAX_MODEL_US_SRC : (long_pulse > QOC_PLAN_SMALL_MAX_MODEL_US ? long_pulse : QOC_PLAN_SMALL_MAX_MODEL_US);
+    return c.us <= limit && d.Bplan <= QOC_PLAN_SMALL_MAX_SETS;
 }
 
 int qoc_small_setup(QocSmall& sm, const QocDev& d, bool antiherm, int G_req, int R_req, std::vector<void*>& allocs, std::string& msg) {

@@ -94,18 +94,19 @@ def small_plan(n, k, m, steps, T, s, B, state_transfer=False, n_forb=0, speed_up
                + ((k + 1) * RL if bandpass else 0))
         if lds * 16 > 160 * 1024:
             continue
-        prod = 4.0 * N * N * 5.9 / 2400.0
+        prod = (2.6 if 5 <= N <= 8 else 4.0) * N * N * 5.9 / 2400.0
         share = ((1.15 if N <= 2 else 1.7) if R >= 32 else 0.9) if N <= 4 else max(1.0, R / 16.0)
         per_slice = (max(Teff - 1, 0) + s + (6.0 if src else 4.0)) * prod + 0.15 + ((0.6 if N <= 4 else 0.3 if N <= 8 else 0.0) if src else 0.0)
         us = share * (L * per_slice + (4.0 if src else 2.0) * clog2(R) * (prod + 0.1))
         if G > 1:
-            us += (4.0 if src else 2.0) * 1.5 + (4.0 if src else 2.0) * clog2(G) * (prod + 0.1)
+            us += (4.0 if src else 2.0) * 1.5 + (4.0 if src else 1.0) * clog2(G) * (prod + 0.1)
         if bandpass:
             us += 1.2e-4 * k * steps * steps
         us = 1.45 * (us + 1.5)
         if best is None or us < best[0]:
             best = (us, N, R, L, G)
-    if best is None or best[0] > (LIM['SMALL_MAX_MODEL_US_SRC'] if src else LIM['SMALL_MAX_MODEL_US']) or B > LIM['SMALL_MAX_SETS']:
+    limit = LIM['SMALL_MAX_MODEL_US_SRC'] if src else max(LIM['SMALL_MAX_MODEL_US'], LIM['SMALL_MODEL_US_BASE'] + 1e-3 * LIM['SMALL_MODEL_NS_PER_SLICE'] * steps)
+    if best is None or best[0] > limit or B > LIM['SMALL_MAX_SETS']:
         return None
     return {'path': 'small', 'n_pad': best[1], 'rows': best[2], 'slices_per_row': best[3], 'workgroups': best[4], 'state_sources': 1 if src else 0}
 
@@ -340,7 +341,8 @@ def test_auto_plan_state_transfer_long_pulses(n, k, m, B, steps, reg):
 SMALL_ROWS = [(2, 1, 2, 100, 1, False), (2, 1, 2, 100, 64, False), (2, 1, 2, 100, 256, False), (2, 1, 2, 100, 257, False), (4, 2, 4, 200, 1, False), (4, 2, 4, 200, 16, True),
               (8, 4, 8, 500, 1, False), (8, 4, 8, 500, 4, False), (8, 4, 8, 500, 5, False), (8, 4, 8, 100, 16, False), (8, 4, 8, 100, 64, False), (9, 4, 4, 300, 1, True),
               (12, 3, 8, 100, 1, False), (12, 3, 8, 400, 1, False), (13, 3, 8, 100, 1, False), (10, 2, 5, 64, 2, True), (10, 2, 5, 700, 1, True), (6, 8, 6, 130, 3, False),
-              (5, 2, 2, 1100, 1, False), (3, 1, 3, 4000, 1, False), (3, 1, 3, 4200, 1, False)]
+              (5, 2, 2, 1100, 1, False), (3, 1, 3, 4000, 1, False), (3, 1, 3, 4200, 1, False),
+              (8, 4, 8, 1000, 1, False), (9, 4, 8, 1000, 1, False), (10, 4, 8, 500, 1, False), (10, 4, 8, 100, 1, False), (12, 4, 8, 50, 1, False)]      # long pulses: the limit grows with the slices
 
 
 @pytest.mark.parametrize('n,k,m,steps,B,reg', SMALL_ROWS, ids=['n%d_k%d_m%d_%dslices_B%d%s' % (r[0], r[1], r[2], r[3], r[4], '_forb' if r[5] else '') for r in SMALL_ROWS])
