@@ -62,6 +62,8 @@ struct qoc_engine {
     cplx* expm_scratch = nullptr;
     int expm_grid = 0;
     cplx* seed_scratch = nullptr;
+    double* fin_part = nullptr;      // [B][fin_S + 2][2] partial sums of the split tail (k_finish_split_a / _b: control sets of 4097 .. 8192 (k, t) elements)
+    int fin_S = 0;
     // mfma path
     QocMfma mf;
     QocGemm gm;
@@ -338,8 +340,21 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
             hipLaunchKernelGGL(k_band_gradient, dim3((unsigned)(g2 > 8192 ? 8192 : g2)), dim3(256), 0, e->stream, d);
         }
         // seeds of 4097 .. 8192 (k, t) elements (C3: 6 x 1000) keep their Adam slots in registers too: eight elements per thread
+        // ... or, since round 6, spread over fin_S workgroups in two launches: one control set of 6000 elements is bound by the fp64 sin / cos / sqrt / divide of the
+        // ONE compute unit k_finish_t runs it on (C3, one trajectory: 32.5 us; profiles/r06_kernel_stats_c3_single_trajectory.txt)
         const bool wide = d.k * d.steps > 4 * 1024 && d.k * d.steps <= 8 * 1024;
-        if (plain && wide) hipLaunchKernelGGL((k_finish_t<true, 8>), dim3(d.B), fb, 0, e->stream, d, ap);
+        const bool split = wide && e->fin_part;
+        if (split) {
+            const dim3 sg((unsigned)e->fin_S, (unsigned)d.B);
+            if (plain) {
+                hipLaunchKernelGGL(k_finish_split_a<true>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
+                hipLaunchKernelGGL(k_finish_split_b<true>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
+            } else {
+                hipLaunchKernelGGL(k_finish_split_a<false>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
+                hipLaunchKernelGGL(k_finish_split_b<false>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
+            }
+        }
+        else if (plain && wide) hipLaunchKernelGGL((k_finish_t<true, 8>), dim3(d.B), fb, 0, e->stream, d, ap);
         else if (plain) hipLaunchKernelGGL(k_finish_t<true>, dim3(d.B), fb, 0, e->stream, d, ap);
         else if (wide) hipLaunchKernelGGL((k_finish_t<false, 8>), dim3(d.B), fb, 0, e->stream, d, ap);
         else hipLaunchKernelGGL(k_finish_t<false>, dim3(d.B), fb, 0, e->stream, d, ap);
@@ -544,6 +559,10 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     ALLOC(d.base, B * ks); ALLOC(d.adam_m, B * ks); ALLOC(d.adam_v, B * ks);
     ALLOC(d.adam_t, (size_t)B); ALLOC(d.iters, (size_t)B); ALLOC(d.done, (size_t)B);
     ALLOC(d.w, B * ks); ALLOC(d.u, B * ks); ALLOC(d.w2, B * ks); ALLOC(d.u2, B * ks); ALLOC(d.dLdu, B * ks); ALLOC(d.grad, B * ks);
+    if (ks > 4 * 1024 && ks <= 8 * 1024 && !qoc_exp_is("QOC_FINISH_SPLIT", 0)) {      // (the tail of such control sets runs over fin_S workgroups each; the switch: A/B runs)
+        e->fin_S = (int)((ks + 255) / 256);
+        ALLOC(e->fin_part, (size_t)B * (e->fin_S + 2) * 2);
+    }
     ALLOC(d.inter, (size_t)B * (steps + 1) * nm);
     ALLOC(d.Xfinal, (size_t)B * nn);
     ALLOC(d.ztau, (size_t)B * (steps + 1));

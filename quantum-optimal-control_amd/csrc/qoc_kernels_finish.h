@@ -40,8 +40,11 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red /* 
 // trajectory this single-workgroup kernel is bound by its instruction fetch and its chain of global round trips, not by arithmetic)
 // (a __device__ body: the latency mode of the MFMA path runs it in the last workgroup of its gradient kernel, qoc_mfma_latency.h)
 // LEVEL: 0 = no pulse regulariser (PLAIN), 1 = the local ones (amplitude, envelope, dwdt, d2wdt2) but no bandpass DFT, 2 = all.
-template <int LEVEL, int QFE = QF_E>
-__device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */) {
+// SPLIT (one control set of many elements -- C3: 6 x 1000 -- is bound by the fp64 sin / cos / sqrt / divide of ONE compute unit: 34 us): 1 = part A, S workgroups
+// per control set form the gradient elements and their partial sums (`part`: [B][S + 2][2] doubles, the last two rows a snapshot of the counters part B must not
+// read while its first workgroup updates them); 2 = part B, every workgroup sums the partials in the same order, takes the stop rule, updates its own elements.
+template <int LEVEL, int QFE = QF_E, int SPLIT = 0>
+__device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */, double* part = nullptr) {
     // no implicit contraction into FMAs in here: the three flavours (and the fused / separate launches of the latency mode) must round
     // alike -- with a regulariser of weight zero they are bit-identical -- and which a*b + c the compiler contracts depends on the code
     // around it (an edit of the bandpass loops flipped one in the Adam update).  Every fma() below is written out.
@@ -52,14 +55,17 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     const double* dLdu = d.dLdu + (size_t)b * ks;
     double* base = d.base + (size_t)b * ks;
     double* grad = d.grad + (size_t)b * ks;
-    const int it0 = d.iters[b];
-    const int was_done = d.done[b];
+    // the elements of this thread: tid, tid + tn, ... (one workgroup: its threads; split: the threads of the S workgroups of the control set)
+    const int tid = SPLIT ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (int)threadIdx.x, tn = SPLIT ? (int)(gridDim.x * blockDim.x) : (int)blockDim.x;
+    double* const pb = SPLIT ? part + (size_t)b * (gridDim.x + 2) * 2 : nullptr;
+    const int it0 = SPLIT == 2 ? (int)pb[2 * gridDim.x] : d.iters[b];
+    const int was_done = SPLIT == 2 ? (int)pb[2 * gridDim.x + 1] : d.done[b];
     const double dt = d.dt;
     const double loss = d.loss[b], reg_state_v = d.reg_state[b];
-    const int adam_t0 = d.adam_t[b];
+    const int adam_t0 = SPLIT == 2 ? (int)pb[2 * gridDim.x + 2] : d.adam_t[b];
     double* am = d.adam_m + (size_t)b * ks;
     double* av = d.adam_v + (size_t)b * ks;
-    const bool in_regs = ks <= QFE * (int)blockDim.x;             // every element of this thread fits its register file
+    const bool in_regs = SPLIT == 0 && ks <= QFE * (int)blockDim.x;      // every element of this thread fits its register file
     double g_r[QFE], m_r[QFE], v_r[QFE], b_r[QFE];
     if (in_regs && ap.mode != 0) {
 #pragma unroll
@@ -77,10 +83,12 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     const double lr_t = lr_next * sqrt(1.0 - pow(b2, (double)(adam_t0 + 1))) / (1.0 - pow(b1, (double)(adam_t0 + 1)));
 
     double reg = 0.0;
+    double g2 = 0.0;
+    if constexpr (SPLIT != 2) {
     // ---- values that are not sums over (k,t) elements --------------------------------------------------------
     if (!PLAIN && d.has_dwdt) {                                                            // :28-35
         double acc = 0.0;
-        for (int o = threadIdx.x; o < d.k * (steps + 3); o += blockDim.x) {
+        for (int o = tid; o < d.k * (steps + 3); o += tn) {
             const int kk = o / (steps + 3), i = o - kk * (steps + 3);
             const double* wk = w + (size_t)kk * steps;
             const double dd = (padded_w(wk, steps, i + 1) - padded_w(wk, steps, i)) / dt;
@@ -90,7 +98,7 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     }
     if (!PLAIN && d.has_d2wdt2) {                                                          // :38-45
         double acc = 0.0;
-        for (int o = threadIdx.x; o < d.k * (steps + 2); o += blockDim.x) {
+        for (int o = tid; o < d.k * (steps + 2); o += tn) {
             const int kk = o / (steps + 2), i = o - kk * (steps + 2);
             const double* wk = w + (size_t)kk * steps;
             const double e = (padded_w(wk, steps, i + 2) - 2.0 * padded_w(wk, steps, i + 1) + padded_w(wk, steps, i)) / (dt * dt);
@@ -101,13 +109,12 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     if (BAND && d.has_band) {                                                              // :47-67: sum of cnt |F_f| (k_band_spectrum)
         double acc = 0.0;
         const double* bm = d.band_mag + (size_t)b * ks;
-        for (int o = threadIdx.x; o < ks; o += blockDim.x) acc += bm[o];
+        for (int o = tid; o < ks; o += tn) acc += bm[o];
         reg += d.a_band * acc;
     }
 
     // ---- per-element: remaining values, d reg / d w, chain rule -------------------------------------------------
-    double g2 = 0.0;
-    for (int o = threadIdx.x; o < ks; o += blockDim.x) {
+    for (int o = tid; o < ks; o += tn) {
         const int kk = o / steps, t = o - kk * steps;
         const double* wk = w + (size_t)kk * steps;
         const double wv = wk[t];
@@ -143,8 +150,20 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
         }
     }
     block_sum2(reg, g2, red);
+    }
+    if constexpr (SPLIT == 1) {
+        if (threadIdx.x == 0) {
+            pb[2 * blockIdx.x] = reg; pb[2 * blockIdx.x + 1] = g2;
+            if (blockIdx.x == 0) { pb[2 * gridDim.x] = (double)it0; pb[2 * gridDim.x + 1] = (double)was_done; pb[2 * gridDim.x + 2] = (double)adam_t0; }
+        }
+        return;
+    }
+    if constexpr (SPLIT == 2) {
+        for (unsigned i = 0; i < gridDim.x; ++i) { reg += pb[2 * i]; g2 += pb[2 * i + 1]; }
+    }
+    const bool writer = threadIdx.x == 0 && (SPLIT == 0 || blockIdx.x == 0);      // the one thread of the control set that stores its scalars
     g2 *= 0.5;                                                                   // sum of tf.nn.l2_loss
-    if (threadIdx.x == 0) {
+    if (writer) {
         d.reg_loss[b] = loss + reg_state_v + reg;
         d.g2[b] = g2;
     }
@@ -153,17 +172,17 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
     // controls of the next evaluation (u2 / w2; the engine swaps them in instead of launching k_controls): a seed that does not move keeps its own
     auto keep_controls = [&]() {
         if (!d.u2) return;
-        for (int o = threadIdx.x; o < ks; o += blockDim.x) { d.w2[(size_t)b * ks + o] = w[o]; d.u2[(size_t)b * ks + o] = d.u[(size_t)b * ks + o]; }
+        for (int o = tid; o < ks; o += tn) { d.w2[(size_t)b * ks + o] = w[o]; d.u2[(size_t)b * ks + o] = d.u[(size_t)b * ks + o]; }
     };
     if (ap.mode == 1) {                                                          // run_session.py:56-66
         if (was_done) { keep_controls(); return; }
         const bool end = (loss < ap.conv_target) || (g2 < ap.min_grad) || (it0 >= ap.max_iterations);
         if (end) {
-            if (threadIdx.x == 0) d.done[b] = 1;
+            if (writer) d.done[b] = 1;
             keep_controls();
             return;
         }
-        if (threadIdx.x == 0) d.iters[b] = it0 + 1;                              // update_and_save :92
+        if (writer) d.iters[b] = it0 + 1;                                        // update_and_save :92
     }
     const int tstep = adam_t0 + 1;
     if (in_regs) {
@@ -181,7 +200,7 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
             }
         }
     } else {
-        for (int o = threadIdx.x; o < ks; o += blockDim.x) {
+        for (int o = tid; o < ks; o += tn) {
             const double g = grad[o];
             const double mm = b1 * am[o] + (1.0 - b1) * g;
             const double vv = b2 * av[o] + (1.0 - b2) * g * g;
@@ -191,11 +210,23 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
             if (d.u2) { const double wn = sin(bn); d.w2[(size_t)b * ks + o] = wn; d.u2[(size_t)b * ks + o] = d.maxA[o / steps] * wn; }
         }
     }
-    if (threadIdx.x == 0) d.adam_t[b] = tstep;
+    if (writer) d.adam_t[b] = tstep;
 }
 
 template <bool PLAIN, int QFE = QF_E>
 __global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
     __shared__ double red[34];
     finish_body<PLAIN ? 0 : 2, QFE>(d, ap, blockIdx.x, red);
+}
+
+// one control set of 4097 .. 8192 elements per iteration (a single C3 trajectory): the two halves of finish_body over S workgroups per control set (grid: S x B)
+template <bool PLAIN>
+__global__ void __launch_bounds__(256) k_finish_split_a(QocDev d, QocAdamDev ap, double* part) {
+    __shared__ double red[34];
+    finish_body<PLAIN ? 0 : 2, QF_E, 1>(d, ap, blockIdx.y, red, part);
+}
+template <bool PLAIN>
+__global__ void __launch_bounds__(256) k_finish_split_b(QocDev d, QocAdamDev ap, double* part) {
+    __shared__ double red[34];
+    finish_body<PLAIN ? 0 : 2, QF_E, 2>(d, ap, blockIdx.y, red, part);
 }
