@@ -346,11 +346,14 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         const bool split = wide && e->fin_part;
         if (split) {
             const dim3 sg((unsigned)e->fin_S, (unsigned)d.B);
+            // (GEMM path, persistent chains: the wide gradient product left per-tile partial dots -- qoc_gemm_backward skipped its reduce launch, part A sums them)
+            QocGradPartial gp{nullptr, 0, 0, 0};
+            if (e->path == QOC_PATH_GEMM && e->gm.reduce_in_tail) gp = QocGradPartial{e->gm.partial, e->gm.N / 32, e->gm.ldW, e->gm.MV};
             if (plain) {
-                hipLaunchKernelGGL(k_finish_split_a<true>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
+                hipLaunchKernelGGL(k_finish_split_a<true>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part, gp);
                 hipLaunchKernelGGL(k_finish_split_b<true>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
             } else {
-                hipLaunchKernelGGL(k_finish_split_a<false>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
+                hipLaunchKernelGGL(k_finish_split_a<false>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part, gp);
                 hipLaunchKernelGGL(k_finish_split_b<false>, sg, dim3(256), 0, e->stream, d, ap, e->fin_part);
             }
         }
@@ -765,6 +768,7 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
         if (rc) return bail(fail(rc, "qoc_create: %s", msg.c_str()));
         if (!qoc_gemm_lds_opt_in()) return bail(fail(QOC_ERR_HIP, "qoc_create: cannot reserve LDS for the GEMM-path kernels"));
         e->chunks = e->gm.NC;
+        e->gm.reduce_in_tail = e->gm.persistent && e->fin_part != nullptr && e->skip_mask == 0;      // (the split tail sums the gradient partials: one launch less)
         if (e->gm.ts_G > 0) {
             std::string why;
             if (!qoc_gemm_ts_supported(e->gm, d, e->gm.ts_G, why))

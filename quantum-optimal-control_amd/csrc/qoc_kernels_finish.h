@@ -43,8 +43,12 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red /* 
 // SPLIT (one control set of many elements -- C3: 6 x 1000 -- is bound by the fp64 sin / cos / sqrt / divide of ONE compute unit: 34 us): 1 = part A, S workgroups
 // per control set form the gradient elements and their partial sums (`part`: [B][S + 2][2] doubles, the last two rows a snapshot of the counters part B must not
 // read while its first workgroup updates them); 2 = part B, every workgroup sums the partials in the same order, takes the stop rule, updates its own elements.
+// gp (part A only): dL/du of an element still lies as per-tile partial dots of the wide gradient product (GEMM path, k_gemm_grad_reduce_wide's input) -- summed
+// here, in that kernel's order, and stored to dLdu: one launch less in front of the tail
+struct QocGradPartial { const double* partial; int tiles_m, ldW, MV; };
 template <int LEVEL, int QFE = QF_E, int SPLIT = 0>
-__device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */, double* part = nullptr) {
+__device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& ap, const int b, double* red /* 34 doubles of LDS */, double* part = nullptr,
+                                            const QocGradPartial* gp = nullptr) {
     // no implicit contraction into FMAs in here: the three flavours (and the fused / separate launches of the latency mode) must round
     // alike -- with a regulariser of weight zero they are bit-identical -- and which a*b + c the compiler contracts depends on the code
     // around it (an edit of the bandpass loops flipped one in the Adam update).  Every fma() below is written out.
@@ -140,7 +144,15 @@ __device__ __forceinline__ void finish_body(const QocDev& d, const QocAdamDev& a
         }
         if (BAND && d.has_band) dR += d.a_band * d.band_dR[(size_t)b * ks + o];                            // (k_band_gradient)
         const double bv = base[o];
-        const double g = cos(bv) * (d.maxA[kk] * dLdu[o] + dR);
+        double dl;
+        if (SPLIT == 1 && gp && gp->partial) {
+            const double* pp = gp->partial + ((size_t)b * d.k + kk) * gp->tiles_m * (size_t)gp->ldW + (size_t)t * gp->MV;
+            dl = 0.0;
+            for (int i = 0; i < gp->tiles_m; ++i)
+                for (int jv = 0; jv < gp->MV; ++jv) dl += pp[(size_t)i * gp->ldW + jv];
+            d.dLdu[(size_t)b * ks + o] = dl;
+        } else dl = dLdu[o];
+        const double g = cos(bv) * (d.maxA[kk] * dl + dR);
         grad[o] = g;
         g2 += g * g;
         if (in_regs) {
@@ -221,9 +233,9 @@ __global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
 
 // one control set of 4097 .. 8192 elements per iteration (a single C3 trajectory): the two halves of finish_body over S workgroups per control set (grid: S x B)
 template <bool PLAIN>
-__global__ void __launch_bounds__(256) k_finish_split_a(QocDev d, QocAdamDev ap, double* part) {
+__global__ void __launch_bounds__(256) k_finish_split_a(QocDev d, QocAdamDev ap, double* part, QocGradPartial gp) {
     __shared__ double red[34];
-    finish_body<PLAIN ? 0 : 2, QF_E, 1>(d, ap, blockIdx.y, red, part);
+    finish_body<PLAIN ? 0 : 2, QF_E, 1>(d, ap, blockIdx.y, red, part, &gp);
 }
 template <bool PLAIN>
 __global__ void __launch_bounds__(256) k_finish_split_b(QocDev d, QocAdamDev ap, double* part) {

@@ -380,6 +380,7 @@ struct QocGemm {
     double plan_scale = 1.0;
     bool direct = false;      // state transfer as Taylor mat-vec chains on the assembled generators (one chunk, no propagators)
     bool persistent = false;  // N <= 64, m <= 8: thin chains run as persistent VALU kernels instead of one launch per step
+    bool reduce_in_tail = false;  // ... and the engine's split tail (k_finish_split_a) sums the per-tile gradient partials itself: no k_gemm_grad_reduce_wide launch
     cplx* HsP = nullptr;      // [k+1][N][N]
     cplx* HsPT = nullptr;     // dpp_chain: the same stack transposed -- k_gemm_assemble_rows then writes the generators column-major
     // dpp_chain with a state regulariser (forward chain alone in its launch): the generators of the slices from asm_split on are assembled
@@ -1253,7 +1254,7 @@ static inline void qoc_gemm_backward(QocGemm& gm, const QocDev& d, hipStream_t s
     }
     if (gm.persistent) {
         qoc_gemm_wide_gradient(gm, d, s, 0, gm.ldW);
-        hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, N / 32,
+        if (!gm.reduce_in_tail) hipLaunchKernelGGL(k_gemm_grad_reduce_wide, dim3(gemm_grid((size_t)d.B * d.steps * d.k)), dim3(256), 0, s, d, gm.partial, N / 32,
             gm.ldW, gm.MV);
         return;
     }
