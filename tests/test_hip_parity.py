@@ -518,6 +518,46 @@ def test_adam_loop_parity_and_stop_rules():
     eng.close()
 
 
+@pytest.mark.parametrize('regs', [0, 1, 2], ids=['plain', 'pulse_regularisers', 'with_bandpass'])
+def test_adam_loop_of_a_wide_pulse_over_several_workgroups(regs):
+    """A control set of 4097 .. 8192 (control, slice) elements: the regulariser / Adam tail runs as two launches over ceil(elements / 256) workgroups
+    (k_finish_split_a / _b, csrc/qoc_kernels_finish.h) -- gradient elements + partial sums, then every workgroup sums the partials, takes the stop rule of
+    run_session.py:56-66 and updates its own elements.  max_iterations stop, and conv_target stops of two control sets at different iterations inside a burst."""
+    c = cases.case_c2(n=3, k=5, steps=1000, m=2, taylor=(4, 1), seed=41)
+    c['total_time'] = 20.0
+    if regs:
+        c['reg_coeffs'] = {'amplitude': 0.02, 'dwdt': 0.001, 'd2wdt2': 1e-5, 'envelope': 0.01}
+        if regs == 2:
+            c['reg_coeffs'].update(bandpass=0.01, band=[0.5, 5.0])
+    sp = oracle_system(c)
+    assert 4096 < sp.k * sp.steps <= 8192
+    conv = dict(rate=0.02, max_iterations=6, learning_rate_decay=50, conv_target=-1.0, min_grad=-1.0)
+    ref = go.run_adam(sp, conv)
+    eng = make_engine(sp, n_seeds=1, path=1)
+    eng.set_base(sp.base0[None])
+    check_eval(eng, sp, [sp.base0])
+    eng.set_base(sp.base0[None])
+    its = eng.run_adam(eng.adam_params(poll_every=4, **conv))
+    assert its[0] == ref['iterations'] == 6
+    np.testing.assert_allclose(eng.get_base()[0], ref['base'], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(eng.get_uks()[0], ref['uks'], rtol=0, atol=1e-10)
+    s = eng.scalars()
+    assert abs(s['loss'][0] - ref['loss']) < 1e-10 and abs(s['reg_loss'][0] - ref['reg_loss']) < 1e-10
+    eng.close()
+    hist = go.run_adam(sp, dict(conv, max_iterations=12))                       # a target two control sets reach at different iterations
+    base_b = sp.base0 + 0.05
+    conv2 = dict(rate=0.02, max_iterations=12, learning_rate_decay=50, conv_target=float(hist['loss']) * 1.02 + 1e-3, min_grad=-1.0)
+    ref_a, ref_b = go.run_adam(sp, conv2), go.run_adam(sp, conv2, base=base_b)
+    eng = make_engine(sp, n_seeds=2, path=1)
+    eng.set_base(np.stack([sp.base0, base_b]))
+    its = eng.run_adam(eng.adam_params(poll_every=5, **conv2))
+    assert list(its) == [ref_a['iterations'], ref_b['iterations']]
+    np.testing.assert_allclose(eng.get_base()[0], ref_a['base'], atol=1e-10)
+    np.testing.assert_allclose(eng.get_base()[1], ref_b['base'], atol=1e-10)
+    np.testing.assert_allclose(eng.get_uks()[1], ref_b['uks'], atol=1e-10)
+    eng.close()
+
+
 def test_explicit_adam_step_matches_tf1_adam():
     sp = oracle_system(cases.case_small_auto())
     eng = make_engine(sp, path=1)
