@@ -383,6 +383,24 @@ __device__ __forceinline__ void fetch_sc1_pairs(cplx* dst, int pairs, SRC src, P
     }
 }
 
+// The partial sums xs[4 gi], xs[4 gi + 1] of the G <= 32 workgroups of a control set, summed by every wave for itself: lane gi takes workgroup gi, a DPP tree over each
+// row of 16 lanes, the two rows through readlane.  The same tree in every wave of every workgroup of the set: their copies of the sums are bit-identical (the stop rule
+// must fall the same way everywhere), and a tree costs 0.3 k cycles where the loop over gi cost 2.7 k per iteration.
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ void sum_groups2(const double* xs, int G, double& a, double& b) {
+    static_assert(QOC_SMALL_MAXG <= 32, "two rows of 16 lanes");
+    const int l = threadIdx.x & 63;
+    double va = l < G ? xs[4 * l] : 0.0, vb = l < G ? xs[4 * l + 1] : 0.0;
+    va += dpp_xor<1>(va); vb += dpp_xor<1>(vb);
+    va += dpp_xor<2>(va); vb += dpp_xor<2>(vb);
+    va += dpp_xor<4>(va); vb += dpp_xor<4>(vb);
+    va += dpp_xor<8>(va); vb += dpp_xor<8>(vb);
+    a = lane_value(va, 0) + lane_value(va, 16);
+    b = lane_value(vb, 0) + lane_value(vb, 16);
+}
+
 template <int THREADS>
 __device__ __forceinline__ void wg_sum2(double& a, double& b, double* red /* 2 x waves doubles */) {
 #pragma unroll
@@ -618,7 +636,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
 #pragma unroll
     for (int e = 0; e < QE; ++e) { sv_base[e] = 0.0; sv_m[e] = 0.0; sv_v[e] = 0.0; sv_w[e] = 0.0; sv_g[e] = 0.0; }
 #ifdef QOC_SMALL_TIMING
-    unsigned long long stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
@@ -741,7 +759,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
             QSM_STAMP(7);
             if (spec) {                                            // the stop rule of the previous iteration, one exchange late
                 double reg = 0.0, g2 = 0.0;
-                for (int gi = 0; gi < G; ++gi) { reg += xsum[4 * gi]; g2 += xsum[4 * gi + 1]; }
+                sum_groups2(xsum, G, reg, g2);
                 g2 *= 0.5;
                 const cplx z = cmake(xsum[2], xsum[3]);
                 const double loss = 1.0 - (z.x * z.x + z.y * z.y) / mm;
@@ -757,6 +775,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 spec = false;
                 __syncthreads();                                   // (xsum is written again by the next exchange)
             }
+            QSM_STAMP(16);
             if constexpr (SRC) {
 #pragma unroll 1
                 for (int l = 1; l <= sd.LG; ++l) {
@@ -946,7 +965,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 }
                 __syncthreads();
                 fval = 0.0; zz2 = 0.0;
-                for (int gi = 0; gi < G; ++gi) { fval += xsum[4 * gi]; zz2 += xsum[4 * gi + 1]; }
+                sum_groups2(xsum, G, fval, zz2);
                 if (tid == 0) { misc[M_ZN] = xsum[4 * glast + 2]; misc[M_ZN + 1] = xsum[4 * glast + 3]; }
                 __syncthreads();
             };
@@ -1249,7 +1268,7 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                 fetch_sc1<THREADS>(xsum, 4 * G, [&](int o) -> const double* { return xB + (size_t)(o >> 2) * sd.xb_stride + (o & 3); }, [](int) { return 0.0; });
                 __syncthreads();
                 reg = 0.0; g2 = 0.0;
-                for (int gi = 0; gi < G; ++gi) { reg += xsum[4 * gi]; g2 += xsum[4 * gi + 1]; }
+                sum_groups2(xsum, G, reg, g2);
                 z = cmake(xsum[2], xsum[3]);
             }
             QSM_STAMP(5);
@@ -1294,8 +1313,8 @@ __global__ void __launch_bounds__(R * 16) k_small_iter(QocDev d, QocAdamDev ap, 
                "walk+forward(+state terms, offsets) %llu, backward %llu, tail to sums(+exchange B) %llu, stop rule+Adam %llu clk\n", N, L, R, (int)SRC, G, sd.iters,
                ck1 - ck0, (double)(rt1 - rt0) / 100.0, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4],
                stamp[6] - stamp[5]);
-        if (sd.G > 1) printf("   exchange A: local up-sweep %llu, payload stores + drain + flag + wait for all flags %llu, fetch of the payloads %llu, upper sweep %llu clk\n",
-                             stamp[14] - stamp[1], stamp[15] - stamp[14], stamp[7] - stamp[15], stamp[2] - stamp[7]);
+        if (sd.G > 1) printf("   exchange A: local up-sweep %llu, payload stores + drain + flag + wait for all flags %llu, fetch of the payloads %llu, deferred stop rule %llu, upper sweep / range reduction %llu clk\n",
+                             stamp[14] - stamp[1], stamp[15] - stamp[14], stamp[7] - stamp[15], stamp[16] - stamp[7], stamp[2] - stamp[16]);
         if (SRC) printf("   state-regulariser flow: walk for the start state %llu, forward + state terms %llu, sums (+ exchange A1) %llu, offsets of the row %llu, offset tree up-sweep %llu, "
                         "exchange A2 + upper offset tree %llu, terminal + walk for the costate %llu clk\n", stamp[8] - stamp[2], stamp[9] - stamp[8], stamp[10] - stamp[9], stamp[11] - stamp[10],
                         stamp[12] - stamp[11], stamp[13] - stamp[12], stamp[3] - stamp[13]);
