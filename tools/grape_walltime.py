@@ -108,4 +108,4 @@ report('C2 (n=32, k=4, 500 slices, m=8)', cases.case_c2(), 73.0)
 c3 = cases.case_c3()
 report('C3 state transfer (n=64, k=6, 1000 slices, dwdt + forbidden)', c3, 397.0)
 c8 = cases.case_c2(n=8, k=4, steps=500, m=8, taylor=(5, 3), seed=2)
-report('two transmons (n=8, k=4, 500 slices)', c8, 26.2)
+report('two transmons (n=8, k=4, 500 slices)', c8, 24.5)
