@@ -343,7 +343,7 @@ static int enqueue_iteration(qoc_engine* e, const QocAdamDev& ap) {
         // ... or, since round 6, spread over fin_S workgroups in two launches: one control set of 6000 elements is bound by the fp64 sin / cos / sqrt / divide of the
         // ONE compute unit k_finish_t runs it on (C3, one trajectory: 32.5 us; profiles/r06_kernel_stats_c3_single_trajectory.txt)
         const bool wide = d.k * d.steps > 4 * 1024 && d.k * d.steps <= 8 * 1024;
-        const bool split = wide && e->fin_part;
+        const bool split = d.k * d.steps > 4 * 1024 && e->fin_part;
         if (split) {
             const dim3 sg((unsigned)e->fin_S, (unsigned)d.B);
             // (GEMM path, persistent chains: the wide gradient product left per-tile partial dots -- qoc_gemm_backward skipped its reduce launch, part A sums them)
@@ -562,8 +562,9 @@ int qoc_create(const qoc_config* cfg, const double* Hs, const double* U0, const 
     ALLOC(d.base, B * ks); ALLOC(d.adam_m, B * ks); ALLOC(d.adam_v, B * ks);
     ALLOC(d.adam_t, (size_t)B); ALLOC(d.iters, (size_t)B); ALLOC(d.done, (size_t)B);
     ALLOC(d.w, B * ks); ALLOC(d.u, B * ks); ALLOC(d.w2, B * ks); ALLOC(d.u2, B * ks); ALLOC(d.dLdu, B * ks); ALLOC(d.grad, B * ks);
-    if (ks > 4 * 1024 && ks <= 8 * 1024 && !qoc_exp_is("QOC_FINISH_SPLIT", 0)) {      // (the tail of such control sets runs over fin_S workgroups each; the switch: A/B runs)
+    if (ks > 4 * 1024 && !qoc_exp_is("QOC_FINISH_SPLIT", 0)) {      // (the tail of such control sets runs over fin_S workgroups each; the switch: A/B runs)
         e->fin_S = (int)((ks + 255) / 256);
+        if (e->fin_S > 64) e->fin_S = 64;                          // (longer pulses: several elements per thread)
         ALLOC(e->fin_part, (size_t)B * (e->fin_S + 2) * 2);
     }
     ALLOC(d.inter, (size_t)B * (steps + 1) * nm);

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(1024) k_finish_t(QocDev d, QocAdamDev ap) {
     finish_body<PLAIN ? 0 : 2, QFE>(d, ap, blockIdx.x, red);
 }
 
-// one control set of 4097 .. 8192 elements per iteration (a single C3 trajectory): the two halves of finish_body over S workgroups per control set (grid: S x B)
+// control sets of more than 4096 elements (a single C3 trajectory: 6000): the two halves of finish_body over S workgroups per control set (grid: S x B)
 template <bool PLAIN>
 __global__ void __launch_bounds__(256) k_finish_split_a(QocDev d, QocAdamDev ap, double* part, QocGradPartial gp) {
     __shared__ double red[34];
